@@ -1,0 +1,151 @@
+"""Shared test helpers: configurations, the seeded weight-perturbation recipe,
+the two scalar losses of SURVEY.md 8-D, and tolerance checks.  Used by tests/, bench.py and
+tests/golden/make_golden.py (where it is applied to the *reference* model)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "deep-turbulence_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# model kwargs + private keys (_in_hw: low-fidelity H,W ; _up: cglow_upscale == output/input size ratio)
+CFG_TINY = dict(in_features=2, out_features=2, enc_blocks=[2, 2], glow_blocks=[3, 3], cond_features=4,
+                cglow_upscale=2, growth_rate=4, init_features=8, rec_features=4, _in_hw=(8, 8), _up=2)
+CFG_TINY3 = dict(in_features=3, out_features=3, enc_blocks=[1, 2, 2], glow_blocks=[2, 3, 1], cond_features=5,
+                 cglow_upscale=2, growth_rate=4, init_features=8, rec_features=6, _in_hw=(8, 16), _up=2)
+# BASELINE.json configs[0]: cylinder-wake, 32x32x2 -> 64x64x2, L=3, K=16 (CPU plumbing case)
+CFG1 = dict(in_features=2, out_features=2, enc_blocks=[4, 4, 4], glow_blocks=[16, 16, 16], cond_features=32,
+            cglow_upscale=2, growth_rate=4, init_features=16, rec_features=64, _in_hw=(32, 32), _up=2)
+# configs[1]: cylinder 64x64 -> 128x128, 3 levels
+CFG2 = dict(in_features=3, out_features=3, enc_blocks=[4, 4, 4], glow_blocks=[16, 16, 16], cond_features=32,
+            cglow_upscale=2, growth_rate=4, init_features=16, rec_features=64, _in_hw=(64, 64), _up=2)
+# configs[2]: backward-facing step 128x256x4, 4 levels
+CFG3 = dict(in_features=4, out_features=4, enc_blocks=[4, 4, 4, 4], glow_blocks=[16, 16, 16, 16], cond_features=32,
+            cglow_upscale=2, growth_rate=4, init_features=16, rec_features=64, _in_hw=(64, 128), _up=2)
+# metric config M / configs[3]: 256x256x4, 4 levels
+CFG_M = dict(in_features=4, out_features=4, enc_blocks=[4, 4, 4, 4], glow_blocks=[16, 16, 16, 16], cond_features=32,
+             cglow_upscale=2, growth_rate=4, init_features=16, rec_features=64, _in_hw=(128, 128), _up=2)
+# configs[4]: synthetic 512x512x4, 5 levels
+CFG5 = dict(in_features=4, out_features=4, enc_blocks=[4, 4, 4, 4, 4], glow_blocks=[16, 16, 16, 16, 16],
+            cond_features=32, cglow_upscale=2, growth_rate=4, init_features=16, rec_features=64,
+            _in_hw=(256, 256), _up=2)
+
+
+def build_kwargs(cfg):
+    return {k: v for k, v in cfg.items() if not k.startswith("_")}
+
+
+def seed_all(seed):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+
+
+def _perturb_kind(name):
+    if ".zero_conv.conv." in name or ".conv2d.conv." in name:
+        return 0
+    if name.endswith(".scale") or name.endswith(".norm.weight") or name.endswith(".norm.bias"):
+        return 1
+    if name.endswith(".l") or name.endswith(".u") or name.endswith(".log_s"):
+        return 2
+    return None
+
+
+def perturb_(model, seed, s_zero, s_norm, s_lu):
+    """Seeded, order-dependent perturbation that makes the freshly initialised (identity) flow a
+    well-conditioned non-identity one.  Works on any nn.Module whose parameter names follow the
+    reference schema; walks named_parameters() in registration order."""
+    g = torch.Generator().manual_seed(seed)
+    scales = (s_zero, s_norm, s_lu)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            kind = _perturb_kind("." + name)
+            if kind is None:
+                continue
+            p.add_((scales[kind] * torch.randn(p.shape, generator=g)).to(p.device, p.dtype))
+    return model
+
+
+def loss_forward(logp, y):
+    """x->z direction: -mean(log p) / (noc*H*W)  (SURVEY.md 8-D)."""
+    return -logp.mean() / float(y.shape[1] * y.shape[2] * y.shape[3])
+
+
+def loss_reverse(y, logdet):
+    """generative direction: mean(y^2) + mean(logdet) / (noc*H*W)  (SURVEY.md 8-D)."""
+    return (y ** 2).mean() + logdet.mean() / float(y.shape[1] * y.shape[2] * y.shape[3])
+
+
+def tensor_checksums(sd):
+    out = {}
+    for k, v in sd.items():
+        t = torch.as_tensor(v).double()
+        out[k] = float(t.sum() + 3.0 * t.abs().sum())
+    return out
+
+
+def load_npz(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def states_from(d, prefix, L, device="cpu"):
+    return [(torch.from_numpy(d["%s%d.h" % (prefix, i)]).to(device), torch.from_numpy(d["%s%d.c" % (prefix, i)]).to(device))
+            for i in range(L)]
+
+
+# ---- stated tolerances (10x the reference's own fp32-vs-fp64 noise floor) ----
+FIELD_ATOL, FIELD_RTOL = 2e-4, 1e-4
+LOGDET_RTOL = 1e-5
+STATE_ATOL = 1e-5
+GRAD_GLOBAL_REL_L2 = 5e-4
+GRAD_TENSOR_REL_MAX = 1e-2
+
+
+def assert_field(a, b, what="field", atol=FIELD_ATOL, rtol=FIELD_RTOL):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, "%s shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    assert bool((err <= bound).all()), "%s: max abs err %.3e (max |ref| %.3e)" % (what, err.max().item(), b.abs().max().item())
+
+
+def assert_logdet(a, b, what="logdet", rtol=LOGDET_RTOL, atol=1e-4):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, "%s shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    err = (a - b).abs()
+    assert bool((err <= atol + rtol * b.abs()).all()), "%s: %s vs %s" % (what, a.flatten()[:4].tolist(), b.flatten()[:4].tolist())
+
+
+def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_tol=GRAD_TENSOR_REL_MAX, skip=()):
+    """got/ref: name -> tensor.  Global relative L2 and worst per-tensor relative max."""
+    num = den = 0.0
+    worst, worst_k = 0.0, None
+    for k, r in ref.items():
+        if any(s in k for s in skip):
+            continue
+        assert k in got and got[k] is not None, "%s: missing gradient for %s" % (what, k)
+        g = torch.as_tensor(got[k]).detach().cpu().double().reshape(-1)
+        r = torch.as_tensor(r).detach().cpu().double().reshape(-1)
+        assert g.shape == r.shape, "%s: %s shape" % (what, k)
+        num += float(((g - r) ** 2).sum())
+        den += float((r ** 2).sum())
+        scale = float(r.abs().max())
+        if scale > 0:
+            rel = float((g - r).abs().max()) / scale
+            if rel > worst:
+                worst, worst_k = rel, k
+    glob = (num / max(den, 1e-300)) ** 0.5
+    assert glob <= global_tol, "%s: global rel-L2 %.3e > %.1e (worst tensor %s %.3e)" % (what, glob, global_tol, worst_k, worst)
+    assert worst <= tensor_tol, "%s: tensor %s rel-max %.3e > %.1e" % (what, worst_k, worst, tensor_tol)
+    return glob, worst

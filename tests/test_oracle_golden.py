@@ -1,0 +1,155 @@
+"""Pin the CPU oracle (oracle/tmglow_oracle.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import common as C
+from oracle import tmglow_oracle as O
+
+
+def _P(d, prefix="sd.", dtype=None):
+    return O.params_from_state_dict({k: torch.from_numpy(v) for k, v in C.sub(d, prefix).items()}, dtype=dtype)
+
+
+def _grads(P):
+    return {k: v.grad for k, v in P.items() if v.requires_grad and v.grad is not None}
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_model.npz", C.CFG_TINY), ("tiny3_model.npz", C.CFG_TINY3)])
+def test_model_forward_and_reverse_match_reference(name, cfg):
+    d = C.load_npz(name)
+    L = len(cfg["glow_blocks"])
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"])
+    h_in = C.states_from(d, "h_in.", L)
+    P = _P(d)
+    z, logp, h_out, eps = O.tmglow_forward(P, cfg, x, y, h_in, return_eps=True)
+    C.assert_field(z, d["fwd.z"], "z")
+    C.assert_logdet(logp, d["fwd.logp"], "logp")
+    for i in range(L):
+        C.assert_field(h_out[i][0], d["fwd.h_out.%d.h" % i], "h_out", atol=C.STATE_ATOL)
+        C.assert_field(h_out[i][1], d["fwd.h_out.%d.c" % i], "c_out", atol=C.STATE_ATOL)
+    for i in range(L + 1):
+        C.assert_field(eps[i], d["fwd.eps.%d" % i], "eps%d" % i)
+    loss = C.loss_forward(logp, y)
+    assert abs(loss.item() - float(d["fwd.loss"])) <= 1e-5 * abs(float(d["fwd.loss"])) + 1e-6
+    loss.backward()
+    C.assert_grads(_grads(P), C.sub(d, "fwd.grad."), "fwd grads")
+
+    P = _P(d)
+    eps_in = [torch.from_numpy(d["fwd.eps.%d" % i]) for i in range(L + 1)]
+    yr, logdet, h_out2 = O.tmglow_reconstruct(P, cfg, x, h_in, eps_in)
+    C.assert_field(yr, d["rev.y"], "y_rec")
+    C.assert_logdet(logdet, d["rev.logdet"], "logdet")
+    for i in range(L):
+        C.assert_field(h_out2[i][0], d["rev.h_out.%d.h" % i], "h_out", atol=C.STATE_ATOL)
+        C.assert_field(h_out2[i][1], d["rev.h_out.%d.c" % i], "c_out", atol=C.STATE_ATOL)
+    lr = C.loss_reverse(yr, logdet)
+    lr.backward()
+    C.assert_grads(_grads(P), C.sub(d, "rev.grad."), "rev grads")
+    # the reference's own self-test property: forward -> reconstruct is the identity
+    assert float((yr.detach() - y).abs().max()) < 5e-4
+
+
+def test_lstm_state_seeding_matches_reference():
+    d = C.load_npz("tiny_model.npz")
+    st = O.init_lstm_states(C.CFG_TINY, torch.arange(2), [16, 16])
+    for i, (h, c) in enumerate(st):
+        assert np.array_equal(h.numpy(), d["h_in.%d.h" % i])
+        assert np.array_equal(c.numpy(), d["h_in.%d.c" % i])
+
+
+def test_flow_level_matches_reference():
+    d = C.load_npz("modules.npz")
+    sd = {"glow.flow_blocks.0." + k: torch.from_numpy(v) for k, v in C.sub(d, "level.sd.").items()}
+    P = O.params_from_state_dict(sd)
+    x = torch.from_numpy(d["level.x"]).requires_grad_(True)
+    cond = torch.from_numpy(d["level.cond"]).requires_grad_(True)
+    h = torch.from_numpy(d["level.h"]).requires_grad_(True)
+    c = torch.from_numpy(d["level.c"]).requires_grad_(True)
+    z, ld, st, eps = O.flow_level_forward(P, 0, 3, x, cond, (h, c), True)
+    C.assert_field(z, d["level.fwd.z"], atol=2e-5)
+    C.assert_logdet(ld, d["level.fwd.logdet"])
+    C.assert_field(st[0], d["level.fwd.h_out"], atol=C.STATE_ATOL)
+    C.assert_field(st[1], d["level.fwd.c_out"], atol=C.STATE_ATOL)
+    C.assert_field(eps, d["level.fwd.eps"], atol=2e-5)
+    loss = (z * torch.from_numpy(d["level.wz"])).sum() + ld.sum() * 0.01 + (st[0] * torch.from_numpy(d["level.wh"])).sum() \
+        + (st[1] * torch.from_numpy(d["level.wc"])).sum()
+    loss.backward()
+    got = {k[len("glow.flow_blocks.0."):]: v for k, v in _grads(P).items()}
+    got.update({"@dx": x.grad, "@dcond": cond.grad, "@dh": h.grad, "@dc": c.grad})
+    ref = C.sub(d, "level.fwd.grad.")
+    ref.update({"@dx": d["level.fwd.dx"], "@dcond": d["level.fwd.dcond"], "@dh": d["level.fwd.dh"], "@dc": d["level.fwd.dc"]})
+    C.assert_grads(got, ref, "level fwd grads")
+
+    P = O.params_from_state_dict(sd)
+    for t in (cond, h, c):
+        t.grad = None
+    zin = torch.from_numpy(d["level.fwd.z"]).requires_grad_(True)
+    xr, ldr, st2 = O.flow_level_reverse(P, 0, 3, zin, cond, (h, c), torch.from_numpy(d["level.fwd.eps"]))
+    C.assert_field(xr, d["level.rev.x"], atol=2e-5)
+    C.assert_logdet(ldr, d["level.rev.logdet"])
+    loss = (xr * torch.from_numpy(d["level.wx"])).sum() + ldr.sum() * 0.01 + (st2[0] * torch.from_numpy(d["level.wh"])).sum() \
+        + (st2[1] * torch.from_numpy(d["level.wc"])).sum()
+    loss.backward()
+    got = {k[len("glow.flow_blocks.0."):]: v for k, v in _grads(P).items()}
+    got.update({"@dz": zin.grad, "@dcond": cond.grad, "@dh": h.grad, "@dc": c.grad})
+    ref = C.sub(d, "level.rev.grad.")
+    ref.update({"@dz": d["level.rev.dz"], "@dcond": d["level.rev.dcond"], "@dh": d["level.rev.dh"], "@dc": d["level.rev.dc"]})
+    C.assert_grads(got, ref, "level rev grads")
+
+
+def test_plain_1x1_and_glow_squeeze_match_reference():
+    d = C.load_npz("modules.npz")
+    for ts in (1, 0):
+        tag = "plain1x1.ts%d." % ts
+        w, x = torch.from_numpy(d[tag + "weight"]), torch.from_numpy(d[tag + "x"])
+        y, ld = O.invconv_plain(w, x, False, bool(ts))
+        C.assert_field(y, d[tag + "fwd.y"], atol=1e-5)
+        assert abs(ld.item() - float(d[tag + "fwd.logdet"])) < 1e-4
+        y, ld = O.invconv_plain(w, x, True, bool(ts))
+        C.assert_field(y, d[tag + "rev.y"], atol=1e-5)
+        assert abs(ld.item() - float(d[tag + "rev.logdet"])) < 1e-4
+    x = torch.from_numpy(d["squeeze.x"])
+    y = O.glow_squeeze(x)
+    assert np.array_equal(y.numpy(), d["squeeze.y"])
+    assert np.array_equal(O.glow_unsqueeze(y).numpy(), d["squeeze.x"])
+
+
+def test_checker_squeeze_roundtrip_and_order():
+    x = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    y = O.checker_squeeze(x)
+    assert y.shape == (2, 12, 2, 3)
+    assert torch.equal(y[:, 3:6], x[:, :, 1::2, 0::2]) and torch.equal(y[:, 9:12], x[:, :, 0::2, 1::2])
+    assert torch.equal(O.checker_unsqueeze(y), x)
+
+
+def test_training_loop_capture_matches_reference():
+    """A16: three optimizer steps of the trainer's inner loop, eps injected through reconstruct()."""
+    d = C.load_npz("tiny_train.npz")
+    cfg = C.CFG_TINY
+    L = len(cfg["glow_blocks"])
+    P = _P(d)
+    params = list(O.trainable(P).values())
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    seeds = torch.from_numpy(d["seeds"])
+    a_key = O.init_lstm_states(cfg, seeds, [16, 16])
+    a0 = [(h.clone(), c.clone()) for h, c in a_key]
+    xs = torch.from_numpy(d["xs"])
+    for a in range(xs.shape[0]):
+        opt.zero_grad()
+        loss = 0.0
+        for t in range(xs.shape[1]):
+            eps = [torch.from_numpy(d["eps.%d.%d.%d" % (a, t, i)]) for i in range(L + 1)]
+            y, logp, a0 = O.tmglow_reconstruct(P, cfg, xs[a, t], a0, eps)
+            loss = loss + C.loss_reverse(y, logp)
+            tol = 1.0 + 4.0 * a  # later steps inherit Adam's sign-like amplification of fp32 noise
+            C.assert_field(y, d["step%d.t%d.y" % (a, t)], "y", atol=C.FIELD_ATOL * tol, rtol=C.FIELD_RTOL * tol)
+            C.assert_logdet(logp, d["step%d.t%d.logp" % (a, t)], rtol=C.LOGDET_RTOL * 10 * tol)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(params, float(d["max_grad_norm"]))
+        opt.step()
+        assert abs(loss.item() - float(d["step%d.loss" % a])) < 2e-4 * tol
+        assert abs(float(gn) - float(d["step%d.gradnorm" % a])) < 2e-3 * float(d["step%d.gradnorm" % a]) * tol
+        C.assert_field(P[str(d["log_s_key"])], d["step%d.log_s" % a], "log_s", atol=2e-5 * tol)
+        a0 = [(0.5 * h.detach() + 0.5 * hk, 0.5 * c.detach() + 0.5 * ck) for (h, c), (hk, ck) in zip(a0, a_key)]
