@@ -1,0 +1,134 @@
+// Shared device helpers for the TM-Glow gfx950 kernels.  fp32, NHWC activations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TMG_MAX_IN_SEG 3
+#define TMG_MAX_OUT_SEG 3
+
+// A "segment" is a channel range [off, off+n) of an NHWC tensor whose pixels are `stride` floats
+// apart.  Several segments side by side stand for the channel concatenation the reference builds
+// with torch.cat (flowAffine.py:74, convLSTM.py:72,151, denseBlock.py:152) without materialising it.
+struct TmgSeg {
+    const float* p;
+    int stride;
+    int off;
+    int n;
+};
+struct TmgOSeg {
+    float* p;
+    int stride;
+    int off;
+    int n;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float out_scale_of(const float* kappa) {
+    if (!kappa) return 1.0f;
+    float k = *kappa;
+    k = fminf(fmaxf(k, -4.0f), 1.3862943611198906f);
+    return expf(k);
+}
+
+
+// 4 consecutive (concatenated) input channels c..c+3 of pixel (b,iy,ix), after padding rule,
+// optional affine and optional ReLU.
+template <typename P>
+__device__ __forceinline__ float4 load_in4(const P& p, int b, int iy, int ix, int c) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.pad_rep) {
+        iy = min(max(iy, 0), p.Hin - 1);
+        ix = min(max(ix, 0), p.Win - 1);
+    } else if (iy < 0 || iy >= p.Hin || ix < 0 || ix >= p.Win) {
+        return v;
+    }
+    if (c >= p.Cin) return v;
+    const size_t pix = ((size_t)b * p.Hin + iy) * p.Win + ix;
+    if (p.vec4) {
+        int cl = c;
+        const TmgSeg* s = &p.in[0];
+        if (cl >= s->n) {
+            cl -= s->n;
+            s = &p.in[1];
+            if (cl >= s->n) {
+                cl -= s->n;
+                s = &p.in[2];
+            }
+        }
+        v = *reinterpret_cast<const float4*>(s->p + pix * s->stride + s->off + cl);
+    } else {
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int cl = c + e;
+            float x = 0.f;
+            if (cl < p.Cin) {
+                const TmgSeg* s = &p.in[0];
+                if (cl >= s->n) {
+                    cl -= s->n;
+                    s = &p.in[1];
+                    if (cl >= s->n) {
+                        cl -= s->n;
+                        s = &p.in[2];
+                    }
+                }
+                x = s->p[pix * s->stride + s->off + cl];
+            }
+            t[e] = x;
+        }
+        v = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    if (p.in_scale) {
+        float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < p.Cin) f[e] = f[e] * p.in_scale[c + e] + p.in_shift[c + e];
+    }
+    if (p.relu_in) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+    }
+    return v;
+}
+
+// Stage channels [c0, c0+kch) of the (PH x PW) input patch whose top-left input pixel is (iy0, ix0).
+template <typename P>
+__device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int iy0, int ix0, int PH, int PW, int c0,
+                                            int kch, int CS) {
+    const int k4 = kch >> 2;
+    const int items = PH * PW * k4;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int pix = it / k4;
+        const int c4 = it - pix * k4;
+        const int py = pix / PW;
+        const int px = pix - py * PW;
+        const float4 v = load_in4(p, b, iy0 + py, ix0 + px, c0 + 4 * c4);
+        *reinterpret_cast<float4*>(lds + pix * CS + 4 * c4) = v;
+    }
+}
+
+
+#define TMG_CHECK_LAUNCH()                          \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)

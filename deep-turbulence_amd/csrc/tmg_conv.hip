@@ -1,0 +1,642 @@
+// Implicit-GEMM convolution for gfx950 on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// One kernel family serves every dense contraction on the TM-Glow hot path:
+//   * Conv2dZeros 3x3 with replicate padding           (reference flowUtils.py:246-247)
+//   * ConvLSTM gate conv and residual out-conv 3x3     (reference convLSTM.py:72-74, :150-152)
+//   * the encoder's 3x3 / stride-2 convs               (reference tmGlow.py:88-95,148-156,180-182)
+//   * the invertible 1x1 channel mix (ksize = 1)       (reference glowConv.py:193-194, :219-220)
+//   * every input-gradient of the above (same kernel, transposed + flipped packed weights)
+// plus the weight-gradient kernel (contraction over pixels) and the weight packer.
+//
+// Layout: activations NHWC fp32.  GEMM view: M = output pixels of a TH x TW tile, N = output
+// channels, K = taps x input channels.  The input patch (tile + halo) is staged through LDS once per
+// channel chunk with padding / ReLU / per-channel affine applied on the way in; A fragments come from
+// LDS with ds_read_b128 (4 k-steps per read), B fragments come straight from the L2-resident packed
+// weights with 16-byte global loads (4 k-steps per load).  fp32 MFMA issues one 16x16x4 tile per 32
+// cycles per SIMD, so the kernel is matrix-pipe bound by construction and LDS traffic is negligible.
+#include "tmg_common.h"
+
+struct ConvP {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg;
+    int vec4;  // every segment offset / width / stride is a multiple of 4 -> float4 staging
+    int B, Hin, Win, Hout, Wout;
+    int ksize, stride;
+    int Cin, Cin_pad, Cout, Cout_pad;
+    const float* wpk;       // [taps][Cin_pad/16][Cout_pad][16]
+    const float* bias;      // [Cout] or null
+    const float* kappa;     // device scalar: output multiplied by exp(clamp(kappa,-4,ln4)); null -> 1
+    const float* in_scale;  // optional per-input-channel affine applied before ReLU (BatchNorm fold)
+    const float* in_shift;
+    int relu_in, pad_rep, relu_out, accumulate;
+    TmgOSeg out[TMG_MAX_OUT_SEG];
+    int nout;
+    int TW_log2, TH;
+    int KCH;  // channels staged per LDS chunk (multiple of 16)
+    int tiles_x, tiles_y;
+};
+
+// MT m-tiles (16 px each) x NTW n-tiles (16 ch each) per wave; WM x WN waves per block (WM*WN == 4).
+template <int MT, int NTW, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int li = lane & 15, q = lane >> 4;
+    constexpr int MBLK = 16 * MT * WM;
+
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = MBLK >> TWl;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int s = p.stride, halo = p.ksize >> 1;
+    const int PW = s * (TW - 1) + 1 + 2 * halo, PH = s * (TH - 1) + 1 + 2 * halo;
+    const int iy0 = s * oy0 - halo, ix0 = s * ox0 - halo;
+    const int ntaps = p.ksize * p.ksize;
+    const int KB = p.Cin_pad >> 4;
+
+    const int ntile0 = (blockIdx.y * WN + wn) * NTW;  // first n-tile of this wave
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS base (in floats, without the chunk's channel stride applied) of each m-tile
+    int mrow[MT], mcol[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wm * MT + i) * 16 + li;
+        mrow[i] = (m >> TWl) * s;
+        mcol[i] = (m & (TW - 1)) * s;
+    }
+    const int ntiles_total = p.Cout_pad >> 4;
+
+    for (int c0 = 0; c0 < p.Cin_pad; c0 += p.KCH) {
+        const int kch = min(p.KCH, p.Cin_pad - c0);
+        const int CS = kch + 8;
+        __syncthreads();
+        stage_patch(p, lds, b, iy0, ix0, PH, PW, c0, kch, CS);
+        __syncthreads();
+        const int kbn = kch >> 4;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
+            const float* wtap = p.wpk + ((size_t)(tap * KB + (c0 >> 4)) * p.Cout_pad) * 16;
+            for (int kb = 0; kb < kbn; ++kb) {
+                float4 bf[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int nt = ntile0 + j;
+                    if (nt < ntiles_total)
+                        bf[j] = *reinterpret_cast<const float4*>(wtap + ((size_t)kb * p.Cout_pad + nt * 16 + li) * 16 + 4 * q);
+                    else
+                        bf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float4 af[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const float4*>(lds + ((mrow[i] + tyy) * PW + mcol[i] + txx) * CS + kb * 16 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // epilogue: C/D map of the 16x16 tile: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel)
+    const float osc = out_scale_of(p.kappa);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = (ntile0 + j) * 16 + li;
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        int nl = n;
+        const TmgOSeg* os = &p.out[0];
+        if (nl >= os->n) {
+            nl -= os->n;
+            os = &p.out[1];
+            if (nl >= os->n) {
+                nl -= os->n;
+                os = &p.out[2];
+            }
+        }
+        float* obase = os->p + os->off + nl;
+        const int ostride = os->stride;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (wm * MT + i) * 16 + q * 4 + r;
+                const int oy = oy0 + (m >> TWl), ox = ox0 + (m & (TW - 1));
+                if (oy < p.Hout && ox < p.Wout) {
+                    float v = (acc[i][j][r] + bv) * osc;
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    float* dst = obase + (((size_t)b * p.Hout + oy) * p.Wout + ox) * ostride;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][ci][tap] (+)= scale * sum_p in(p*s + tap)[ci] * dy(p)[co]
+// GEMM view: M = input channels (per tap), N = output channels, K = pixels.
+// ---------------------------------------------------------------------------------------------
+struct WgradP {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg;
+    int vec4;
+    int B, Hin, Win, Hout, Wout;
+    int ksize, stride;
+    int Cin, Cin_pad, Cout;
+    const float* in_scale;
+    const float* in_shift;
+    int relu_in, pad_rep;
+    TmgSeg dy;  // n == Cout
+    int dy_vec4;
+    float* dW;     // [Cout][Cin][ksize*ksize], accumulated with atomics (caller zeroes)
+    float* dbias;  // [Cout] or null, accumulated with atomics
+    const float* kappa;
+    int TW_log2, TH;  // pixel tile (TH*TW == 64)
+    int tiles_x, tiles_y, ntiles;
+    int CITG;  // input-channel tiles (of 16) handled per block group (grid.z walks the groups)
+};
+
+template <int NP, int NCO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int MPIX = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = MPIX >> TWl;
+    const int s = p.stride, halo = p.ksize >> 1, ntaps = p.ksize * p.ksize;
+    const int PW = s * (TW - 1) + 1 + 2 * halo, PH = s * (TH - 1) + 1 + 2 * halo;
+    const int cit0 = blockIdx.z * p.CITG;
+    const int citn = min(p.CITG, (p.Cin_pad >> 4) - cit0);
+    const int kch = citn * 16, CS = kch + 4;
+    const int co0 = blockIdx.y * NCO * 16;
+    constexpr int DS = NCO * 16 + 4;
+    float* ldy = lds + PH * PW * CS;
+
+    const int npairs = ntaps * citn;
+    f32x4 acc[NP][NCO];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int n = 0; n < NCO; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    // which pixel of a 4-pixel k-step this lane feeds, as (row, col) deltas inside the tile
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        const int b = t / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        stage_patch(p, lds, b, s * oy0 - halo, s * ox0 - halo, PH, PW, cit0 * 16, kch, CS);
+        // dy tile: MPIX pixels x NCO*16 channels (zero outside the image / beyond Cout)
+        for (int it = tid; it < MPIX * NCO * 4; it += 256) {
+            const int m = it / (NCO * 4), c4 = it - m * (NCO * 4);
+            const int oy = oy0 + (m >> TWl), ox = ox0 + (m & (TW - 1));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < p.Hout && ox < p.Wout) {
+                const float* src = p.dy.p + (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.dy.stride + p.dy.off;
+                const int c = co0 + 4 * c4;
+                if (p.dy_vec4 && c + 3 < p.Cout) {
+                    v = *reinterpret_cast<const float4*>(src + c);
+                } else {
+                    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < p.Cout) f[e] = src[c + e];
+                }
+            }
+            *reinterpret_cast<float4*>(ldy + m * DS + 4 * c4) = v;
+        }
+        __syncthreads();
+        if (p.dbias && blockIdx.z == 0 && tid < NCO * 16) {
+            float sacc = 0.f;
+            for (int m = 0; m < MPIX; ++m) sacc += ldy[m * DS + tid];
+            bsum += sacc;
+        }
+        for (int ks = 0; ks < MPIX / 4; ++ks) {
+            const int m = ks * 4 + q;
+            const int prow = (m >> TWl) * s, pcol = (m & (TW - 1)) * s;
+            float bfr[NCO];
+#pragma unroll
+            for (int n = 0; n < NCO; ++n) bfr[n] = ldy[m * DS + n * 16 + li];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int pid = wave + 4 * j;
+                if (pid < npairs) {
+                    const int tap = pid / citn, cit = pid - tap * citn;
+                    const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
+                    const float a = lds[((prow + tyy) * PW + pcol + txx) * CS + cit * 16 + li];
+#pragma unroll
+                    for (int n = 0; n < NCO; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[n], acc[j][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float osc = out_scale_of(p.kappa);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int pid = wave + 4 * j;
+        if (pid >= npairs) continue;
+        const int tap = pid / citn, cit = pid - tap * citn;
+#pragma unroll
+        for (int n = 0; n < NCO; ++n) {
+            const int co = co0 + n * 16 + li;
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = (cit0 + cit) * 16 + q * 4 + r;
+                if (ci < p.Cin) atomicAdd(p.dW + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[j][n][r] * osc);
+            }
+        }
+    }
+    if (p.dbias && blockIdx.z == 0 && tid < NCO * 16 && co0 + tid < p.Cout) atomicAdd(p.dbias + co0 + tid, bsum * osc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packer: torch layout W[Cout][Cin][k][k]  ->  wpk[tap][Cin_pad/16][Cout_pad][16]
+// mode 0: forward operand.   mode 1: input-gradient operand (roles of Cin/Cout swapped, taps flipped):
+//         wpk[tap][co/16][ci][co%16] = W[co][ci][ntaps-1-tap]
+// ---------------------------------------------------------------------------------------------
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin, int ntaps,
+                                 int Kpad, int Npad, int mode) {
+    const size_t total = (size_t)ntaps * Kpad * Npad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c16 = i & 15;
+        size_t r = i >> 4;
+        const int n = r % Npad;
+        r /= Npad;
+        const int kb = r % (Kpad >> 4);
+        const int tap = r / (Kpad >> 4);
+        const int k = kb * 16 + c16;
+        float v = 0.f;
+        if (mode == 0) {
+            if (k < Cin && n < Cout) v = w[((size_t)n * Cin + k) * ntaps + tap];
+        } else {
+            if (k < Cout && n < Cin) v = w[((size_t)k * Cin + n) * ntaps + (ntaps - 1 - tap)];
+        }
+        wpk[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Replicate-padding input-gradient fix-up.  The main kernel computes the gradient w.r.t. the
+// in-image part of the padded input; the ring of padded pixels folds onto the border pixels:
+//   dx(q) += sum over ring pixels rho with clamp(rho) == q of sum_tap W_tap^T dy(rho - tap + 1)
+// Output channel set / segments as in the main kernel.  One thread per (border pixel, out channel).
+// ---------------------------------------------------------------------------------------------
+struct BorderP {
+    const float* dy;  // [B,H,W] x Cdy, stride/off
+    int dy_stride, dy_off, Cdy;
+    const float* w;  // torch layout W[Cdy][Cx][3][3]
+    int Cx;
+    const float* kappa;
+    int B, H, W;
+    TmgOSeg out[TMG_MAX_OUT_SEG];
+    int nborder;  // border pixels per image
+};
+
+__device__ __forceinline__ void border_pixel(int idx, int H, int W, int* y, int* x) {
+    // enumerate the image border: top row, bottom row, then left/right columns without corners
+    if (idx < W) { *y = 0; *x = idx; return; }
+    idx -= W;
+    if (H > 1) {
+        if (idx < W) { *y = H - 1; *x = idx; return; }
+        idx -= W;
+    }
+    const int rows = H - 2;
+    if (idx < rows) { *y = 1 + idx; *x = 0; return; }
+    idx -= rows;
+    *y = 1 + idx; *x = W - 1;
+}
+
+__global__ void conv_rep_border_fix_kernel(BorderP p) {
+    const size_t total = (size_t)p.B * p.nborder * p.Cx;
+    const float osc = out_scale_of(p.kappa);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = i % p.Cx;
+        size_t r = i / p.Cx;
+        const int bi = r % p.nborder;
+        const int b = r / p.nborder;
+        int qy, qx;
+        border_pixel(bi, p.H, p.W, &qy, &qx);
+        float acc = 0.f;
+        // ring pixels that clamp onto (qy,qx): rho = (qy+dy, qx+dx) with dy,dx in {-1,0,1}, outside the image
+        for (int dyy = -1; dyy <= 1; ++dyy) {
+            const int ry = qy + dyy;
+            if (dyy != 0 && !((dyy < 0 && qy == 0) || (dyy > 0 && qy == p.H - 1))) continue;
+            for (int dxx = -1; dxx <= 1; ++dxx) {
+                const int rx = qx + dxx;
+                if (dxx != 0 && !((dxx < 0 && qx == 0) || (dxx > 0 && qx == p.W - 1))) continue;
+                if (dyy == 0 && dxx == 0) continue;
+                const bool outside = (ry < 0 || ry >= p.H || rx < 0 || rx >= p.W);
+                if (!outside) continue;
+                // forward: y(pp) uses padded pixel rho = pp + (ky-1, kx-1)  ->  pp = rho - (ky-1, kx-1)
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int py = ry - (ky - 1);
+                    if (py < 0 || py >= p.H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int px = rx - (kx - 1);
+                        if (px < 0 || px >= p.W) continue;
+                        const float* d = p.dy + (((size_t)b * p.H + py) * p.W + px) * p.dy_stride + p.dy_off;
+                        const float* wp = p.w + (size_t)ci * 9 + ky * 3 + kx;
+                        float sacc = 0.f;
+                        for (int co = 0; co < p.Cdy; ++co) sacc += d[co] * wp[(size_t)co * p.Cx * 9];
+                        acc += sacc;
+                    }
+                }
+            }
+        }
+        int nl = ci;
+        const TmgOSeg* os = &p.out[0];
+        if (nl >= os->n) {
+            nl -= os->n;
+            os = &p.out[1];
+            if (nl >= os->n) {
+                nl -= os->n;
+                os = &p.out[2];
+            }
+        }
+        float* dst = os->p + (((size_t)b * p.H + qy) * p.W + qx) * os->stride + os->off + nl;
+        *dst += acc * osc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic direct input-gradient (any stride) for the encoder's two stride-2 convs (tiny FLOPs).
+// dx[b,iy,ix,ci] = sum_{ky,kx,co : iy+pad-ky = s*oy, ix+pad-kx = s*ox} W[co][ci][ky][kx] * dy[b,oy,ox,co]
+// ---------------------------------------------------------------------------------------------
+__global__ void conv_dgrad_direct_kernel(const float* __restrict__ dy, int dy_stride, int dy_off, const float* __restrict__ w,
+                                         float* __restrict__ dx, int dx_stride, int dx_off, int B, int Hin, int Win, int Hout,
+                                         int Wout, int Cin, int Cout, int ksize, int stride, int accumulate) {
+    const int pad = ksize >> 1;
+    const size_t total = (size_t)B * Hin * Win * Cin;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = i % Cin;
+        size_t r = i / Cin;
+        const int ix = r % Win;
+        r /= Win;
+        const int iy = r % Hin;
+        const int b = r / Hin;
+        float acc = 0.f;
+        for (int ky = 0; ky < ksize; ++ky) {
+            const int ny = iy + pad - ky;
+            if (ny < 0 || ny % stride) continue;
+            const int oy = ny / stride;
+            if (oy >= Hout) continue;
+            for (int kx = 0; kx < ksize; ++kx) {
+                const int nx = ix + pad - kx;
+                if (nx < 0 || nx % stride) continue;
+                const int ox = nx / stride;
+                if (ox >= Wout) continue;
+                const float* d = dy + (((size_t)b * Hout + oy) * Wout + ox) * dy_stride + dy_off;
+                const float* wp = w + ((size_t)ci * ksize + ky) * ksize + kx;
+                for (int co = 0; co < Cout; ++co) acc += d[co] * wp[(size_t)co * Cin * ksize * ksize];
+            }
+        }
+        float* dst = dx + (((size_t)b * Hin + iy) * Win + ix) * dx_stride + dx_off + ci;
+        *dst = accumulate ? (*dst + acc) : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int ilog2_ceil(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+template <int MT, int NTW, int WM, int WN>
+static int launch_conv(const ConvP& p, int gy, size_t lds_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, NTW, WM, WN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.B * p.tiles_x * p.tiles_y, gy, 1);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NTW, WM, WN>), grid, dim3(256), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+static void fill_segs(TmgSeg* dst, const void* const* ptrs, const int64_t* desc, int n, int* vec4) {
+    for (int i = 0; i < TMG_MAX_IN_SEG; ++i) dst[i] = TmgSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        dst[i].p = (const float*)ptrs[i];
+        dst[i].stride = (int)desc[3 * i + 0];
+        dst[i].off = (int)desc[3 * i + 1];
+        dst[i].n = (int)desc[3 * i + 2];
+        if ((dst[i].stride | dst[i].off | dst[i].n) & 3) *vec4 = 0;
+        if (((uintptr_t)ptrs[i]) & 15) *vec4 = 0;
+    }
+}
+
+extern "C" int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t ksize, int64_t mode, hipStream_t st) {
+    const int ntaps = (int)(ksize * ksize);
+    const int K = mode == 0 ? (int)Cin : (int)Cout, N = mode == 0 ? (int)Cout : (int)Cin;
+    const int Kpad = (K + 15) & ~15, Npad = (N + 15) & ~15;
+    const size_t total = (size_t)ntaps * Kpad * Npad;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (float*)wpk, (int)Cout, (int)Cin, ntaps, Kpad, Npad, (int)mode);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep,relu_out,accumulate]
+extern "C" int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* wpk, const void* bias,
+                            const void* kappa, const void* in_scale, const void* in_shift, void* const* out_ptrs,
+                            const int64_t* out_desc, int64_t nout, const int64_t* dims, hipStream_t st) {
+    ConvP p;
+    p.nseg = (int)nseg;
+    p.vec4 = 1;
+    fill_segs(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Hout = (int)dims[3]; p.Wout = (int)dims[4];
+    p.ksize = (int)dims[5]; p.stride = (int)dims[6]; p.Cin = (int)dims[7]; p.Cout = (int)dims[8];
+    p.relu_in = (int)dims[9]; p.pad_rep = (int)dims[10]; p.relu_out = (int)dims[11]; p.accumulate = (int)dims[12];
+    if (p.ksize != 1 && p.ksize != 3) return -2;
+    int csum = 0;
+    for (int i = 0; i < p.nseg; ++i) csum += p.in[i].n;
+    if (csum != p.Cin || p.nseg < 1 || p.nseg > TMG_MAX_IN_SEG || nout < 1 || nout > TMG_MAX_OUT_SEG) return -3;
+    p.Cin_pad = (p.Cin + 15) & ~15;
+    p.Cout_pad = (p.Cout + 15) & ~15;
+    p.wpk = (const float*)wpk; p.bias = (const float*)bias; p.kappa = (const float*)kappa;
+    p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
+    p.nout = (int)nout;
+    int osum = 0;
+    for (int i = 0; i < TMG_MAX_OUT_SEG; ++i) p.out[i] = TmgOSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < p.nout; ++i) {
+        p.out[i] = TmgOSeg{(float*)out_ptrs[i], (int)out_desc[3 * i], (int)out_desc[3 * i + 1], (int)out_desc[3 * i + 2]};
+        osum += p.out[i].n;
+    }
+    if (osum != p.Cout) return -4;
+
+    // tile configuration
+    const int ntt = p.Cout_pad >> 4;
+    int WM, WN, NTW;
+    if (ntt <= 4) { WM = 4; WN = 1; NTW = ntt; }
+    else if (ntt <= 6) { WM = 2; WN = 2; NTW = 3; }
+    else if (ntt <= 8) { WM = 2; WN = 2; NTW = 4; }
+    else if (ntt <= 12) { WM = 1; WN = 4; NTW = 3; }
+    else { WM = 1; WN = 4; NTW = 4; }
+    const int gy = (ntt + WN * NTW - 1) / (WN * NTW);
+    const int MBLK = 64 * WM;
+    int twl = ilog2_ceil(p.Wout);
+    if (twl > 5) twl = 5;
+    if (twl < 2) twl = 2;
+    // keep the tile no taller than needed when the image is small
+    while (twl < 5 && (MBLK >> twl) > p.Hout && (1 << twl) < p.Wout) ++twl;
+    p.TW_log2 = twl;
+    const int TW = 1 << twl;
+    p.TH = MBLK >> twl;
+    if (p.TH < 1) return -5;
+    p.tiles_x = (p.Wout + TW - 1) / TW;
+    p.tiles_y = (p.Hout + p.TH - 1) / p.TH;
+    const int halo = p.ksize >> 1;
+    const int PW = p.stride * (TW - 1) + 1 + 2 * halo, PH = p.stride * (p.TH - 1) + 1 + 2 * halo;
+    int kch = (int)(65536 / (4 * (size_t)PH * PW)) - 8;
+    kch &= ~15;
+    if (kch < 16) kch = 16;
+    if (kch > p.Cin_pad) kch = p.Cin_pad;
+    p.KCH = kch;
+    const size_t lds_bytes = (size_t)PH * PW * (kch + 8) * 4;
+    if (lds_bytes > 160 * 1024) return -6;
+
+#define TMG_CONV_CASE(MT_, NTW_, WM_, WN_) \
+    if (NTW == NTW_ && WM == WM_ && WN == WN_) return launch_conv<MT_, NTW_, WM_, WN_>(p, gy, lds_bytes, st);
+    TMG_CONV_CASE(4, 1, 4, 1)
+    TMG_CONV_CASE(4, 2, 4, 1)
+    TMG_CONV_CASE(4, 3, 4, 1)
+    TMG_CONV_CASE(4, 4, 4, 1)
+    TMG_CONV_CASE(4, 3, 2, 2)
+    TMG_CONV_CASE(4, 4, 2, 2)
+    TMG_CONV_CASE(4, 3, 1, 4)
+    TMG_CONV_CASE(4, 4, 1, 4)
+#undef TMG_CONV_CASE
+    return -7;
+}
+
+template <int NP, int NCO>
+static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NP, NCO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO>), grid, dim3(256), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep]; dy_desc: [stride, off]
+// dW (and dbias) must be zero-initialised by the caller (or hold a value to accumulate onto).
+extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
+                              const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias,
+                              const void* kappa, const int64_t* dims, hipStream_t st) {
+    WgradP p;
+    p.nseg = (int)nseg;
+    p.vec4 = 1;
+    fill_segs(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Hout = (int)dims[3]; p.Wout = (int)dims[4];
+    p.ksize = (int)dims[5]; p.stride = (int)dims[6]; p.Cin = (int)dims[7]; p.Cout = (int)dims[8];
+    p.relu_in = (int)dims[9]; p.pad_rep = (int)dims[10];
+    if (p.ksize != 1 && p.ksize != 3) return -2;
+    p.Cin_pad = (p.Cin + 15) & ~15;
+    p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
+    p.dy = TmgSeg{(const float*)dy, (int)dy_desc[0], (int)dy_desc[1], p.Cout};
+    p.dy_vec4 = (((p.dy.stride | p.dy.off) & 3) == 0) && ((((uintptr_t)dy) & 15) == 0);
+    p.dW = (float*)dW; p.dbias = (float*)dbias; p.kappa = (const float*)kappa;
+    int twl = ilog2_ceil(p.Wout);
+    if (twl > 5) twl = 5;
+    if (twl < 1) twl = 1;
+    p.TW_log2 = twl;
+    const int TW = 1 << twl;
+    p.TH = 64 >> twl;
+    p.tiles_x = (p.Wout + TW - 1) / TW;
+    p.tiles_y = (p.Hout + p.TH - 1) / p.TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const int cit = p.Cin_pad >> 4, ntaps = p.ksize * p.ksize;
+    // pairs per wave NP = ceil(ntaps*CITG/4) must be <= 16 (3x3: CITG <= 7) ; 1x1: CITG <= 64 -> cap at 16 tiles for LDS
+    int citg_max = (16 * 4) / ntaps;
+    if (citg_max > 16) citg_max = 16;
+    const int ngroups = (cit + citg_max - 1) / citg_max;
+    p.CITG = (cit + ngroups - 1) / ngroups;
+    const int np = (ntaps * p.CITG + 3) / 4;
+    const int cot = (p.Cout + 15) >> 4;
+    int NCO;
+    if (np <= 8) NCO = cot >= 4 ? 4 : (cot >= 2 ? 2 : 1);
+    else NCO = cot >= 2 ? 2 : 1;
+    const int gy = (cot + NCO - 1) / NCO;
+    const int halo = p.ksize >> 1;
+    const int PW = p.stride * (TW - 1) + 1 + 2 * halo, PH = p.stride * (p.TH - 1) + 1 + 2 * halo;
+    const size_t lds_bytes = ((size_t)PH * PW * (p.CITG * 16 + 4) + 64 * (NCO * 16 + 4)) * 4;
+    if (lds_bytes > 160 * 1024) return -6;
+    int gx = p.ntiles;
+    const int target = 2048 / (gy * ngroups) > 0 ? 2048 / (gy * ngroups) : 1;
+    if (gx > target) gx = target;
+    dim3 grid(gx, gy, ngroups);
+#define TMG_WG_CASE(NP_, NCO_) \
+    if (np <= NP_ && NCO == NCO_) return launch_wgrad<NP_, NCO_>(p, grid, lds_bytes, st);
+    TMG_WG_CASE(8, 1)
+    TMG_WG_CASE(8, 2)
+    TMG_WG_CASE(8, 4)
+    TMG_WG_CASE(16, 1)
+    TMG_WG_CASE(16, 2)
+#undef TMG_WG_CASE
+    return -7;
+}
+
+// Replicate-padding fold for the 3x3 input gradient (see conv_rep_border_fix_kernel).
+// dims: [B,H,W,Cdy,Cx]; dy_desc: [stride, off]
+extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, const void* w, const void* kappa,
+                                       void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims,
+                                       hipStream_t st) {
+    BorderP p;
+    p.dy = (const float*)dy; p.dy_stride = (int)dy_desc[0]; p.dy_off = (int)dy_desc[1];
+    p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.Cdy = (int)dims[3]; p.Cx = (int)dims[4];
+    p.w = (const float*)w; p.kappa = (const float*)kappa;
+    for (int i = 0; i < TMG_MAX_OUT_SEG; ++i) p.out[i] = TmgOSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < (int)nout; ++i)
+        p.out[i] = TmgOSeg{(float*)out_ptrs[i], (int)out_desc[3 * i], (int)out_desc[3 * i + 1], (int)out_desc[3 * i + 2]};
+    if (p.H == 1 && p.W == 1) p.nborder = 1;
+    else if (p.H == 1) p.nborder = p.W;
+    else p.nborder = 2 * p.W + (p.W > 1 ? 2 : 1) * (p.H - 2);
+    const size_t total = (size_t)p.B * p.nborder * p.Cx;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_rep_border_fix_kernel, dim3(blocks), dim3(256), 0, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [B,Hin,Win,Hout,Wout,Cin,Cout,ksize,stride,accumulate]; dy_desc/dx_desc: [stride, off]
+extern "C" int tmg_conv_dgrad_direct(const void* dy, const int64_t* dy_desc, const void* w, void* dx, const int64_t* dx_desc,
+                                     const int64_t* dims, hipStream_t st) {
+    const size_t total = (size_t)dims[0] * dims[1] * dims[2] * dims[5];
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(conv_dgrad_direct_kernel, dim3(blocks), dim3(256), 0, st, (const float*)dy, (int)dy_desc[0], (int)dy_desc[1],
+                       (const float*)w, (float*)dx, (int)dx_desc[0], (int)dx_desc[1], (int)dims[0], (int)dims[1], (int)dims[2],
+                       (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7], (int)dims[8], (int)dims[9]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,813 @@
+// Bandwidth-bound kernels of the TM-Glow hot path (gfx950, fp32, NHWC):
+//   affine coupling apply + per-sample log-det and its backward   (reference flowAffine.py:76-83, :102-109)
+//   ConvLSTM gate pointwise and its backward                      (reference convLSTM.py:76-83)
+//   diagonal-Gaussian split prior: log-prob / eps / sample / bwd  (reference flowUtils.py:176-209, :274-275, :307-334)
+//   checker squeeze / un-squeeze                                  (reference flowUtils.py:114-122, :137-145)
+//   bilinear align_corners up-sampling and its adjoint            (reference misc.py:34-35)
+//   BatchNorm batch moments and backward                          (reference denseBlock.py:49)
+//   the growth-1 dense layers of the coupling network (C_out = 1) (reference denseBlock.py:135-138)
+//   masked gradient scatter (ReLU masks + channel-concat adjoint)
+// Every tensor argument is (pointer, pixel stride in floats, channel offset) so channel slices of
+// wider NHWC buffers are addressed in place.
+#include "tmg_common.h"
+
+#define LN5 1.6094379124341003f
+#define LOG2PI 1.8378770664093453f
+
+static inline int grid_for(size_t n, int cap = 4096) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// affine coupling
+// ---------------------------------------------------------------------------------------------
+// hh: [npix][C] interleaved (shift_j, r_j).  x2 -> y2 over C/2 channels.  logdet[b] += sum 2*softsign(r).
+__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ hh, int hs, int ho, const float* x2, int xs,
+                                                           int xo, float* y2, int ys, int yo, float* __restrict__ rsave,
+                                                           float* __restrict__ logdet, int pix_per_img, int Ch, int reverse) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * pix_per_img;
+    const size_t total = (size_t)pix_per_img * Ch;
+    float ld = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = base + i / Ch;
+        const int j = i % Ch;
+        const float2 h2 = *reinterpret_cast<const float2*>(hh + pix * hs + ho + 2 * j);
+        const float r = h2.y;
+        const float sg = 2.f * r / (1.f + fabsf(r));
+        const float xv = x2[pix * xs + xo + j];
+        float out;
+        if (reverse) out = xv * expf(-sg) - h2.x;
+        else out = (xv + h2.x) * expf(sg);
+        y2[pix * ys + yo + j] = out;
+        if (rsave) rsave[pix * Ch + j] = r;
+        ld += sg;
+    }
+    const float tot = block_sum_256(ld, red);
+    if (threadIdx.x == 0) atomicAdd(logdet + b, tot);
+}
+
+// gout: grad w.r.t. op output half; yref: forward -> op OUTPUT y2, reverse -> op INPUT y2.
+// gin: grad w.r.t. op input half; dhh: [npix][C] interleaved (da, dr).  g: per-sample grad on logdet.
+__global__ void affine_bwd_kernel(const float* gout, int gs, int go, const float* __restrict__ yref, int rs_, int ro,
+                                  const float* __restrict__ rsave, const float* __restrict__ g, float* gin, int is, int io,
+                                  float* __restrict__ dhh, int ds, int dof, int pix_per_img, int Ch, size_t npix, int reverse) {
+    const size_t total = npix * Ch;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / Ch;
+        const int j = i % Ch;
+        const int b = (int)(pix / pix_per_img);
+        const float r = rsave[pix * Ch + j];
+        const float den = 1.f + fabsf(r);
+        const float sg = 2.f * r / den;
+        const float go_ = gout[pix * gs + go + j];
+        const float yv = yref[pix * rs_ + ro + j];
+        const float gb = g ? g[b] : 0.f;
+        float gi, da, dsg;
+        if (reverse) {
+            const float inv = expf(-sg);
+            gi = go_ * inv;
+            da = -go_;
+            dsg = -2.f * go_ * (yv * inv) + 2.f * gb;
+        } else {
+            const float sc = expf(sg);
+            gi = go_ * sc;
+            da = gi;
+            dsg = 2.f * go_ * yv + 2.f * gb;
+        }
+        gin[pix * is + io + j] = gi;
+        *reinterpret_cast<float2*>(dhh + pix * ds + dof + 2 * j) = make_float2(da, dsg / (den * den));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvLSTM pointwise.  gates: [npix][4R] pre-activation in the order i,f,o,g; overwritten with the
+// activated gates (kept for backward).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void lstm_pointwise_fwd_kernel(float* __restrict__ gates, const float* __restrict__ c_prev, int cps, int cpo,
+                                          float* __restrict__ c_next, float* __restrict__ h_next, int R, size_t npix) {
+    const size_t total = npix * R;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / R;
+        const int j = i % R;
+        float* gp = gates + pix * 4 * R + j;
+        const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[R]), go = sigmoidf_(gp[2 * R]), gg = tanhf(gp[3 * R]);
+        const float cp = c_prev ? c_prev[pix * cps + cpo + j] : 0.f;
+        const float cn = gf * cp + gi * gg;
+        gp[0] = gi; gp[R] = gf; gp[2 * R] = go; gp[3 * R] = gg;
+        c_next[pix * R + j] = cn;
+        h_next[pix * R + j] = go * tanhf(cn);
+    }
+}
+
+// acts (activated gates) are overwritten in place by the pre-activation gradients.
+__global__ void lstm_pointwise_bwd_kernel(float* __restrict__ acts, const float* __restrict__ c_prev, int cps, int cpo,
+                                          const float* __restrict__ c_next, const float* __restrict__ dh,
+                                          const float* __restrict__ dc_in, float* __restrict__ dc_prev, int R, size_t npix) {
+    const size_t total = npix * R;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / R;
+        const int j = i % R;
+        float* gp = acts + pix * 4 * R + j;
+        const float gi = gp[0], gf = gp[R], go = gp[2 * R], gg = gp[3 * R];
+        const float cp = c_prev ? c_prev[pix * cps + cpo + j] : 0.f;
+        const float tc = tanhf(c_next[pix * R + j]);
+        const float dhv = dh ? dh[pix * R + j] : 0.f;
+        const float dc = (dc_in ? dc_in[pix * R + j] : 0.f) + dhv * go * (1.f - tc * tc);
+        gp[0] = dc * gg * gi * (1.f - gi);
+        gp[R] = dc * cp * gf * (1.f - gf);
+        gp[2 * R] = dhv * tc * go * (1.f - go);
+        gp[3 * R] = dc * gi * (1.f - gg * gg);
+        dc_prev[pix * R + j] = dc * gf;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal Gaussian.  hz: [npix][2*Ch] = (mean | log-std) halves.  mean clipped to [mlo,mhi] when
+// clip_mean (split prior: hardtanh(-2, ln5) hits both halves), log-std clipped to [slo, shi].
+// mode 0 (x->z): given z2: logp[b] += sum -0.5(ln2pi + 2 lsd + (z2-mean)^2 e^{-2 lsd}); eps out optional.
+// mode 1 (z->x): given eps: z2 = mean + e^{lsd} eps (written), logp[b] += sum -0.5(ln2pi + 2 lsd + eps^2).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gauss_fwd_kernel(const float* __restrict__ hz, int hs, int ho, const float* zin, int zs,
+                                                        int zo, float* zout, int os, int oo, float* __restrict__ logp,
+                                                        int pix_per_img, int Ch, int mode, int clip_mean, float mlo, float mhi,
+                                                        float slo, float shi) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * pix_per_img;
+    const size_t total = (size_t)pix_per_img * Ch;
+    float lp = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = base + i / Ch;
+        const int j = i % Ch;
+        float mean = hz[pix * hs + ho + j];
+        float lsd = hz[pix * hs + ho + Ch + j];
+        if (clip_mean) mean = fminf(fmaxf(mean, mlo), mhi);
+        lsd = fminf(fmaxf(lsd, slo), shi);
+        const float v = zin[pix * zs + zo + j];
+        if (mode == 0) {
+            const float e = (v - mean) * expf(-lsd);
+            lp += -0.5f * (LOG2PI + 2.f * lsd + e * e);
+            if (zout) zout[pix * os + oo + j] = e;
+        } else {
+            lp += -0.5f * (LOG2PI + 2.f * lsd + v * v);
+            zout[pix * os + oo + j] = mean + expf(lsd) * v;
+        }
+    }
+    const float tot = block_sum_256(lp, red);
+    if (threadIdx.x == 0) atomicAdd(logp + b, tot);
+}
+
+// mode 0: inputs z2 (zin), g[b]; outputs dz2 (dzout, optional) and dhz (grad w.r.t. raw hz, clip masks applied).
+// mode 1: inputs eps (zin), dz2 (dzin: grad w.r.t. sampled z2), g[b]; outputs dhz.
+__global__ void gauss_bwd_kernel(const float* __restrict__ hz, int hs, int ho, const float* zin, int zs, int zo,
+                                 const float* dzin, int dis, int dio, const float* __restrict__ g, float* dzout, int dos,
+                                 int doo, float* __restrict__ dhz, int ds, int dof, int pix_per_img, int Ch, size_t npix,
+                                 int mode, int clip_mean, float mlo, float mhi, float slo, float shi) {
+    const size_t total = npix * Ch;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / Ch;
+        const int j = i % Ch;
+        const int b = (int)(pix / pix_per_img);
+        const float mraw = hz[pix * hs + ho + j], sraw = hz[pix * hs + ho + Ch + j];
+        float mean = mraw, lsd = fminf(fmaxf(sraw, slo), shi);
+        bool mpass = true;
+        if (clip_mean) {
+            mean = fminf(fmaxf(mraw, mlo), mhi);
+            mpass = (mraw > mlo) && (mraw < mhi);
+        }
+        const bool spass = (sraw > slo) && (sraw < shi);
+        const float gb = g ? g[b] : 0.f;
+        const float v = zin[pix * zs + zo + j];
+        float dmean, dlsd;
+        if (mode == 0) {
+            const float il = expf(-lsd);
+            const float e = (v - mean) * il;
+            dmean = gb * e * il;
+            dlsd = gb * (e * e - 1.f);
+            float dz = -gb * e * il;
+            if (dzin) dz += dzin[pix * dis + dio + j];
+            if (dzout) dzout[pix * dos + doo + j] = dz;
+        } else {
+            const float dz = dzin ? dzin[pix * dis + dio + j] : 0.f;
+            dmean = dz;
+            dlsd = dz * expf(lsd) * v - gb;
+        }
+        dhz[pix * ds + dof + j] = mpass ? dmean : 0.f;
+        dhz[pix * ds + dof + Ch + j] = spass ? dlsd : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// checker squeeze: big [B,2h,2w,C] <-> small [B,h,w,4C]; block k takes (row,col) offset (0,0),(1,0),(1,1),(0,1)
+// ---------------------------------------------------------------------------------------------
+__global__ void checker_kernel(const float* __restrict__ src, int ss, int so, float* __restrict__ dst, int ds, int dof, int B,
+                               int h, int w, int C, int to_small) {
+    const size_t total = (size_t)B * h * w * 4 * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % (4 * C);
+        size_t r = i / (4 * C);
+        const int x = r % w;
+        r /= w;
+        const int y = r % h;
+        const int b = r / h;
+        const int k = c4 / C, c = c4 - k * C;
+        const int ry = (k == 1 || k == 2) ? 1 : 0, rx = (k >= 2) ? 1 : 0;
+        const size_t bigpix = ((size_t)b * 2 * h + 2 * y + ry) * (2 * w) + 2 * x + rx;
+        const size_t smallpix = ((size_t)b * h + y) * w + x;
+        if (to_small) dst[smallpix * ds + dof + c4] = src[bigpix * ss + so + c];
+        else dst[bigpix * ds + dof + c] = src[smallpix * ss + so + c4];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear up-sampling, align_corners = True
+// ---------------------------------------------------------------------------------------------
+__global__ void upsample_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int hi, int wi, int ho, int wo,
+                                    int C) {
+    const float ry = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.f;
+    const float rx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.f;
+    const size_t total = (size_t)B * ho * wo * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        size_t r = i / C;
+        const int ox = r % wo;
+        r /= wo;
+        const int oy = r % ho;
+        const int b = r / ho;
+        const float sy = ry * oy, sx = rx * ox;
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = min(y0, hi - 1);
+        x0 = min(x0, wi - 1);
+        const int y1 = min(y0 + 1, hi - 1), x1 = min(x0 + 1, wi - 1);
+        const float fy = sy - y0, fx = sx - x0;
+        const float* sb = src + (size_t)b * hi * wi * C + c;
+        const float v00 = sb[((size_t)y0 * wi + x0) * C], v01 = sb[((size_t)y0 * wi + x1) * C];
+        const float v10 = sb[((size_t)y1 * wi + x0) * C], v11 = sb[((size_t)y1 * wi + x1) * C];
+        dst[i] = (1.f - fy) * ((1.f - fx) * v00 + fx * v01) + fy * ((1.f - fx) * v10 + fx * v11);
+    }
+}
+
+// adjoint as a gather: each low-res element sums the hat-function weights of the outputs that touch it
+__global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int hi, int wi, int ho, int wo,
+                                    int C) {
+    const float ry = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.f;
+    const float rx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.f;
+    const size_t total = (size_t)B * hi * wi * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        size_t r = i / C;
+        const int ix = r % wi;
+        r /= wi;
+        const int iy = r % hi;
+        const int b = r / hi;
+        // outputs oy with source coordinate in (iy-1, iy+1)
+        int oy_lo = 0, oy_hi = ho - 1, ox_lo = 0, ox_hi = wo - 1;
+        if (ry > 0.f) {
+            oy_lo = max(0, (int)floorf((iy - 1) / ry) - 1);
+            oy_hi = min(ho - 1, (int)ceilf((iy + 1) / ry) + 1);
+        }
+        if (rx > 0.f) {
+            ox_lo = max(0, (int)floorf((ix - 1) / rx) - 1);
+            ox_hi = min(wo - 1, (int)ceilf((ix + 1) / rx) + 1);
+        }
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            const float sy = ry * oy;
+            int y0 = min((int)sy, hi - 1);
+            const int y1 = min(y0 + 1, hi - 1);
+            const float fy = sy - y0;
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - fy;
+            if (y1 == iy) wy += fy;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const float sx = rx * ox;
+                int x0 = min((int)sx, wi - 1);
+                const int x1 = min(x0 + 1, wi - 1);
+                const float fx = sx - x0;
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - fx;
+                if (x1 == ix) wx += fx;
+                if (wx == 0.f) continue;
+                acc += wy * wx * dout[(((size_t)b * ho + oy) * wo + ox) * C + c];
+            }
+        }
+        din[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel reductions over pixels (BatchNorm moments and backward sums)
+//   mode 0: s0 += sum (x - shift_c),          s1 += sum (x - shift_c)^2
+//   mode 1: du = g * [x*a_c + b_c > 0];  xhat = (x - mean_c) * rstd_c;  s0 += sum du, s1 += sum du * xhat
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, int xs, int xo, const float* __restrict__ g,
+                                                          int gs, int go, const float* __restrict__ v0, const float* __restrict__ v1,
+                                                          const float* __restrict__ v2, const float* __restrict__ v3,
+                                                          float* __restrict__ s0, float* __restrict__ s1, size_t npix, int C,
+                                                          int mode) {
+    __shared__ float l0[256], l1[256];
+    const int tid = threadIdx.x;
+    const int lanes = 256 / C > 0 ? 256 / C : 1;  // pixel lanes per block (C <= 256)
+    const int c = tid % C, pl = tid / C;
+    float a0 = 0.f, a1 = 0.f;
+    if (pl < lanes) {
+        for (size_t pix = blockIdx.x * (size_t)lanes + pl; pix < npix; pix += (size_t)gridDim.x * lanes) {
+            const float xv = x[pix * xs + xo + c];
+            if (mode == 0) {
+                const float d = xv - (v0 ? v0[c] : 0.f);
+                a0 += d;
+                a1 += d * d;
+            } else {
+                const float u = xv * v0[c] + v1[c];
+                const float du = u > 0.f ? g[pix * gs + go + c] : 0.f;
+                a0 += du;
+                a1 += du * (xv - v2[c]) * v3[c];
+            }
+        }
+    }
+    l0[tid] = a0;
+    l1[tid] = a1;
+    __syncthreads();
+    if (tid < C) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int k = 0; k < lanes; ++k) {
+            t0 += l0[k * C + tid];
+            t1 += l1[k * C + tid];
+        }
+        atomicAdd(s0 + tid, t0);
+        atomicAdd(s1 + tid, t1);
+    }
+}
+
+// BatchNorm(+ReLU) input gradient:  u = x*a_c + b_c,  du = g*[u>0],
+//   dx = gamma_c * rstd_c * (du - m0_c - xhat * m1_c)     (m0 = mean du, m1 = mean du*xhat)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int xs, int xo, const float* __restrict__ g, int gs, int go,
+                                    const float* __restrict__ a, const float* __restrict__ bsh, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ m0,
+                                    const float* __restrict__ m1, float* __restrict__ dx, int ds, int dof, size_t npix, int C,
+                                    int accumulate) {
+    const size_t total = npix * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C;
+        const int c = i % C;
+        const float xv = x[pix * xs + xo + c];
+        const float u = xv * a[c] + bsh[c];
+        const float du = u > 0.f ? g[pix * gs + go + c] : 0.f;
+        const float xh = (xv - mean[c]) * rstd[c];
+        const float v = gamma[c] * rstd[c] * (du - m0[c] - xh * m1[c]);
+        float* d = dx + pix * ds + dof + c;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// masked gradient scatter: dst[c] (+)= src[c] * [ref[c] > 0] (+ add[c])   over n channels
+// ---------------------------------------------------------------------------------------------
+__global__ void masked_add_kernel(const float* __restrict__ src, int ss, int so, const float* __restrict__ ref, int rs_, int ro,
+                                  const float* __restrict__ add, int as, int ao, float* dst, int ds, int dof, size_t npix, int n,
+                                  int accumulate) {
+    const size_t total = npix * n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / n;
+        const int c = i % n;
+        float v = src ? src[pix * ss + so + c] : 0.f;
+        if (ref && !(ref[pix * rs_ + ro + c] > 0.f)) v = 0.f;
+        if (add) v += add[pix * as + ao + c];
+        float* d = dst + pix * ds + dof + c;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// growth-1 dense layer (C_out = 1): out[p] = sum_{tap,ci} w[ci][tap] * relu(in(p+tap))[ci], zero pad.
+// Vector-ALU kernel: one pixel per thread over a 256-pixel tile, input patch through LDS in chunks.
+// ---------------------------------------------------------------------------------------------
+struct C1P {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg, vec4;
+    int B, Hin, Win;
+    int Cin;
+    const float* in_scale;
+    const float* in_shift;
+    int relu_in, pad_rep;
+    const float* w;  // [Cin][9]
+    float* out; int out_stride, out_off;
+    int TW_log2, tiles_x, tiles_y, KCH;
+};
+
+__global__ __launch_bounds__(256) void c1_fwd_kernel(C1P p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = 256 >> TWl;
+    const int PW = TW + 2, PH = TH + 2;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int row = tid >> TWl, col = tid & (TW - 1);
+    const int Cpad = (p.Cin + 3) & ~3;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < Cpad; c0 += p.KCH) {
+        const int kch = min(p.KCH, Cpad - c0);
+        const int CS = kch + 4;
+        float* lw = lds + PH * PW * CS;  // [9][kch]
+        __syncthreads();
+        stage_patch(p, lds, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
+        for (int i = tid; i < 9 * kch; i += 256) {
+            const int tap = i / kch, c = i - tap * kch;
+            lw[i] = (c0 + c < p.Cin) ? p.w[(size_t)(c0 + c) * 9 + tap] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tyy = tap / 3, txx = tap - tyy * 3;
+            const float* pp = lds + ((row + tyy) * PW + col + txx) * CS;
+            const float* wp = lw + tap * kch;
+            for (int c = 0; c < kch; c += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(pp + c);
+                const float4 w4 = *reinterpret_cast<const float4*>(wp + c);
+                acc += a.x * w4.x + a.y * w4.y + a.z * w4.z + a.w * w4.w;
+            }
+        }
+    }
+    const int oy = oy0 + row, ox = ox0 + col;
+    if (oy < p.Hin && ox < p.Win) p.out[(((size_t)b * p.Hin + oy) * p.Win + ox) * p.out_stride + p.out_off] = acc;
+}
+
+// Backward of the C_out = 1 layer.  ddm(p) = dd(p) * [dref(p) > 0]  (dref null -> no mask)
+//   G[p][ci]  += sum_tap w[ci][tap] * ddm(p - tap + 1)          (raw gradient w.r.t. the ReLU'd input)
+//   dW[ci][tap] += sum_p relu(in(p + tap - 1))[ci] * ddm(p)
+struct C1BP {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg, vec4;
+    int B, Hin, Win;
+    int Cin;
+    const float* in_scale;
+    const float* in_shift;
+    int relu_in, pad_rep;
+    const float* w;   // [Cin][9]
+    float* dW;        // [Cin][9] atomically accumulated
+    const float* dd; int dd_stride, dd_off;
+    const float* dref; int dref_stride, dref_off;
+    TmgOSeg g[TMG_MAX_OUT_SEG];  // gradient destinations for input channels (accumulated, +=)
+    int TW_log2, tiles_x, tiles_y, ntiles, KCH;
+};
+
+__global__ __launch_bounds__(256) void c1_bwd_kernel(C1BP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = 256 >> TWl;
+    const int PW = TW + 2, PH = TH + 2;
+    const int row = tid >> TWl, col = tid & (TW - 1);
+    const int Cpad = (p.Cin + 3) & ~3;
+    const int nchunks = (Cpad + p.KCH - 1) / p.KCH;
+    float* ldd = lds;                       // [PH*PW] masked dd with halo 1 (zero outside the image)
+    float* lw = ldd + ((PH * PW + 3) & ~3); // [9][KCH]
+    float* lin = lw + 9 * p.KCH;            // [PH*PW][CS]
+    // weight-gradient accumulators: this thread owns outputs o = tid + 256*k of the chunk's kch*9 products
+    float wacc[2][8];  // [k][chunk]  (kch*9 <= 512 -> KCH <= 56 ; nchunks <= 8)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wacc[k][c] = 0.f;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        const int b = t / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        for (int i = tid; i < PH * PW; i += 256) {
+            const int py = i / PW, px = i - py * PW;
+            const int y = oy0 - 1 + py, x = ox0 - 1 + px;
+            float v = 0.f;
+            if (y >= 0 && y < p.Hin && x >= 0 && x < p.Win) {
+                const size_t pix = ((size_t)b * p.Hin + y) * p.Win + x;
+                v = p.dd[pix * p.dd_stride + p.dd_off];
+                if (p.dref && !(p.dref[pix * p.dref_stride + p.dref_off] > 0.f)) v = 0.f;
+            }
+            ldd[i] = v;
+        }
+        __syncthreads();
+        float dnb[9];  // ddm(p - tap + 1): tap (ky,kx) reads patch (row + 2 - ky, col + 2 - kx)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            dnb[tap] = ldd[(row + 2 - ky) * PW + col + 2 - kx];
+        }
+        const int oy = oy0 + row, ox = ox0 + col;
+        const bool inside = oy < p.Hin && ox < p.Win;
+        const size_t opix = ((size_t)b * p.Hin + oy) * p.Win + ox;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            if (ch >= nchunks) break;
+            const int c0 = ch * p.KCH;
+            const int kch = min(p.KCH, Cpad - c0);
+            const int CS = kch + 4;
+            __syncthreads();
+            stage_patch(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
+            for (int i = tid; i < 9 * kch; i += 256) {
+                const int tap = i / kch, c = i - tap * kch;
+                lw[i] = (c0 + c < p.Cin) ? p.w[(size_t)(c0 + c) * 9 + tap] : 0.f;
+            }
+            __syncthreads();
+            // (a) input gradient for this pixel, channels of the chunk
+            if (inside) {
+                for (int c = 0; c < kch; ++c) {
+                    const int ci = c0 + c;
+                    if (ci >= p.Cin) break;
+                    float v = 0.f;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) v += lw[tap * kch + c] * dnb[tap];
+                    int nl = ci;
+                    const TmgOSeg* os = &p.g[0];
+                    if (nl >= os->n) {
+                        nl -= os->n;
+                        os = &p.g[1];
+                        if (nl >= os->n) {
+                            nl -= os->n;
+                            os = &p.g[2];
+                        }
+                    }
+                    float* d = os->p + opix * os->stride + os->off + nl;
+                    *d += v;
+                }
+            }
+            // (b) weight gradient: outputs (c, tap) of the chunk spread over the threads
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int o = tid + 256 * k;
+                if (o < kch * 9) {
+                    const int tap = o / kch, c = o - tap * kch;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    float sacc = 0.f;
+                    for (int r = 0; r < TH; ++r) {
+                        const float* ip = lin + ((r + ky) * PW + kx) * CS + c;
+                        const float* dp = ldd + (r + 1) * PW + 1;
+                        for (int cc = 0; cc < TW; ++cc) sacc += ip[cc * CS] * dp[cc];
+                    }
+                    wacc[k][ch] += sacc;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        if (ch >= nchunks) break;
+        const int c0 = ch * p.KCH;
+        const int kch = min(p.KCH, Cpad - c0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int o = tid + 256 * k;
+            if (o < kch * 9) {
+                const int tap = o / kch, c = o - tap * kch;
+                if (c0 + c < p.Cin) atomicAdd(p.dW + (size_t)(c0 + c) * 9 + tap, wacc[k][ch]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+// dims: [B, pix_per_img, Ch, reverse]; each *_d = [stride, off]
+extern "C" int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2,
+                                const int64_t* y_d, void* rsave, void* logdet, const int64_t* dims, hipStream_t st) {
+    const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
+    const size_t per = (size_t)ppi * Ch;
+    int gx = (int)((per + 255) / 256);
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)hh, (int)hh_d[0], (int)hh_d[1],
+                       (const float*)x2, (int)x_d[0], (int)x_d[1], (float*)y2, (int)y_d[0], (int)y_d[1], (float*)rsave, (float*)logdet,
+                       ppi, Ch, (int)dims[3]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tmg_affine_bwd(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
+                              const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d, const int64_t* dims,
+                              hipStream_t st) {
+    const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
+    const size_t npix = (size_t)B * ppi;
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid_for(npix * Ch)), dim3(256), 0, st, (const float*)gout, (int)go_d[0], (int)go_d[1],
+                       (const float*)yref, (int)yr_d[0], (int)yr_d[1], (const float*)rsave, (const float*)g, (float*)gin, (int)gi_d[0],
+                       (int)gi_d[1], (float*)dhh, (int)dh_d[0], (int)dh_d[1], ppi, Ch, npix, (int)dims[3]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [npix, R]; cprev_d = [stride, off]
+extern "C" int tmg_lstm_pointwise_fwd(void* gates, const void* c_prev, const int64_t* cprev_d, void* c_next, void* h_next,
+                                      const int64_t* dims, hipStream_t st) {
+    const size_t npix = (size_t)dims[0];
+    const int R = (int)dims[1];
+    hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (float*)gates, (const float*)c_prev,
+                       (int)cprev_d[0], (int)cprev_d[1], (float*)c_next, (float*)h_next, R, npix);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tmg_lstm_pointwise_bwd(void* acts, const void* c_prev, const int64_t* cprev_d, const void* c_next, const void* dh,
+                                      const void* dc_in, void* dc_prev, const int64_t* dims, hipStream_t st) {
+    const size_t npix = (size_t)dims[0];
+    const int R = (int)dims[1];
+    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (float*)acts, (const float*)c_prev,
+                       (int)cprev_d[0], (int)cprev_d[1], (const float*)c_next, (const float*)dh, (const float*)dc_in, (float*)dc_prev, R,
+                       npix);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [B, pix_per_img, Ch, mode, clip_mean]; fl: [mlo, mhi, slo, shi]
+extern "C" int tmg_gauss_fwd(const void* hz, const int64_t* hz_d, const void* zin, const int64_t* zi_d, void* zout,
+                             const int64_t* zo_d, void* logp, const int64_t* dims, const float* fl, hipStream_t st) {
+    const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
+    const size_t per = (size_t)ppi * Ch;
+    int gx = (int)((per + 255) / 256);
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gauss_fwd_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)hz, (int)hz_d[0], (int)hz_d[1], (const float*)zin,
+                       (int)zi_d[0], (int)zi_d[1], (float*)zout, (int)zo_d[0], (int)zo_d[1], (float*)logp, ppi, Ch, (int)dims[3],
+                       (int)dims[4], fl[0], fl[1], fl[2], fl[3]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tmg_gauss_bwd(const void* hz, const int64_t* hz_d, const void* zin, const int64_t* zi_d, const void* dzin,
+                             const int64_t* dzi_d, const void* g, void* dzout, const int64_t* dzo_d, void* dhz, const int64_t* dh_d,
+                             const int64_t* dims, const float* fl, hipStream_t st) {
+    const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
+    const size_t npix = (size_t)B * ppi;
+    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(grid_for(npix * Ch)), dim3(256), 0, st, (const float*)hz, (int)hz_d[0], (int)hz_d[1],
+                       (const float*)zin, (int)zi_d[0], (int)zi_d[1], (const float*)dzin, (int)dzi_d[0], (int)dzi_d[1], (const float*)g,
+                       (float*)dzout, (int)dzo_d[0], (int)dzo_d[1], (float*)dhz, (int)dh_d[0], (int)dh_d[1], ppi, Ch, npix, (int)dims[3],
+                       (int)dims[4], fl[0], fl[1], fl[2], fl[3]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [B, h, w, C, to_small]  (h, w: the SMALL spatial size; C: channels of the big tensor)
+extern "C" int tmg_checker(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, hipStream_t st) {
+    const size_t total = (size_t)dims[0] * dims[1] * dims[2] * 4 * dims[3];
+    hipLaunchKernelGGL(checker_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)src, (int)s_d[0], (int)s_d[1], (float*)dst,
+                       (int)d_d[0], (int)d_d[1], (int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [B, hi, wi, ho, wo, C]; dense NHWC tensors
+extern "C" int tmg_upsample_fwd(const void* src, void* dst, const int64_t* dims, hipStream_t st) {
+    const size_t total = (size_t)dims[0] * dims[3] * dims[4] * dims[5];
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)src, (float*)dst, (int)dims[0],
+                       (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tmg_upsample_bwd(const void* dout, void* din, const int64_t* dims, hipStream_t st) {
+    const size_t total = (size_t)dims[0] * dims[1] * dims[2] * dims[5];
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)dout, (float*)din, (int)dims[0],
+                       (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [npix, C, mode]; s0/s1 accumulate (caller zeroes); C <= 256
+extern "C" int tmg_chan_reduce(const void* x, const int64_t* x_d, const void* g, const int64_t* g_d, const void* v0, const void* v1,
+                               const void* v2, const void* v3, void* s0, void* s1, const int64_t* dims, hipStream_t st) {
+    const size_t npix = (size_t)dims[0];
+    const int C = (int)dims[1];
+    if (C > 256 || C < 1) return -2;
+    const int lanes = 256 / C;
+    size_t blocks = (npix + lanes - 1) / lanes;
+    blocks = (blocks + 31) / 32;  // >= 32 pixels per lane
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(chan_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (int)x_d[0], (int)x_d[1],
+                       (const float*)g, g ? (int)g_d[0] : 0, g ? (int)g_d[1] : 0, (const float*)v0, (const float*)v1, (const float*)v2,
+                       (const float*)v3, (float*)s0, (float*)s1, npix, C, (int)dims[2]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [npix, C, accumulate]
+extern "C" int tmg_bn_bwd_apply(const void* x, const int64_t* x_d, const void* g, const int64_t* g_d, const void* a, const void* bsh,
+                                const void* mean, const void* rstd, const void* gamma, const void* m0, const void* m1, void* dx,
+                                const int64_t* dx_d, const int64_t* dims, hipStream_t st) {
+    const size_t npix = (size_t)dims[0];
+    const int C = (int)dims[1];
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, st, (const float*)x, (int)x_d[0], (int)x_d[1],
+                       (const float*)g, (int)g_d[0], (int)g_d[1], (const float*)a, (const float*)bsh, (const float*)mean,
+                       (const float*)rstd, (const float*)gamma, (const float*)m0, (const float*)m1, (float*)dx, (int)dx_d[0],
+                       (int)dx_d[1], npix, C, (int)dims[2]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [npix, n, accumulate]; src/ref/add may be null
+extern "C" int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const int64_t* r_d, const void* add,
+                              const int64_t* a_d, void* dst, const int64_t* d_d, const int64_t* dims, hipStream_t st) {
+    const size_t npix = (size_t)dims[0];
+    const int n = (int)dims[1];
+    hipLaunchKernelGGL(masked_add_kernel, dim3(grid_for(npix * n)), dim3(256), 0, st, (const float*)src, src ? (int)s_d[0] : 0,
+                       src ? (int)s_d[1] : 0, (const float*)ref, ref ? (int)r_d[0] : 0, ref ? (int)r_d[1] : 0, (const float*)add,
+                       add ? (int)a_d[0] : 0, add ? (int)a_d[1] : 0, (float*)dst, (int)d_d[0], (int)d_d[1], npix, n, (int)dims[2]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+static void fill_segs_pw(TmgSeg* dst, const void* const* ptrs, const int64_t* desc, int n, int* vec4) {
+    for (int i = 0; i < TMG_MAX_IN_SEG; ++i) dst[i] = TmgSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        dst[i] = TmgSeg{(const float*)ptrs[i], (int)desc[3 * i], (int)desc[3 * i + 1], (int)desc[3 * i + 2]};
+        if ((dst[i].stride | dst[i].off | dst[i].n) & 3) *vec4 = 0;
+        if (((uintptr_t)ptrs[i]) & 15) *vec4 = 0;
+    }
+}
+
+static int c1_tile(int W, int H, int* twl) {
+    int l = 0;
+    while ((1 << l) < W) ++l;
+    if (l > 5) l = 5;
+    if (l < 2) l = 2;
+    *twl = l;
+    (void)H;
+    return 0;
+}
+
+// dims: [B,H,W,Cin,relu_in]; out_d = [stride, off]
+extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out,
+                          const int64_t* out_d, const int64_t* dims, hipStream_t st) {
+    C1P p;
+    p.nseg = (int)nseg;
+    p.vec4 = 1;
+    fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.relu_in = (int)dims[4];
+    if (p.Cin & 3) p.vec4 = 0;
+    p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
+    p.w = (const float*)w; p.out = (float*)out; p.out_stride = (int)out_d[0]; p.out_off = (int)out_d[1];
+    c1_tile(p.Win, p.Hin, &p.TW_log2);
+    const int TW = 1 << p.TW_log2, TH = 256 >> p.TW_log2;
+    p.tiles_x = (p.Win + TW - 1) / TW;
+    p.tiles_y = (p.Hin + TH - 1) / TH;
+    const int Cpad = (p.Cin + 3) & ~3;
+    p.KCH = Cpad < 32 ? Cpad : 32;
+    const size_t lds_bytes = ((size_t)(TH + 2) * (TW + 2) * (p.KCH + 4) + 9 * p.KCH) * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(c1_fwd_kernel, dim3(p.B * p.tiles_x * p.tiles_y), dim3(256), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [B,H,W,Cin,relu_in]; dd_d/dref_d = [stride, off]; g segments accumulate (+=); dW accumulates atomically
+extern "C" int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* dW, const void* dd,
+                          const int64_t* dd_d, const void* dref, const int64_t* dref_d, void* const* g_ptrs, const int64_t* g_desc,
+                          int64_t ng, const int64_t* dims, hipStream_t st) {
+    C1BP p;
+    p.nseg = (int)nseg;
+    p.vec4 = 1;
+    fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.relu_in = (int)dims[4];
+    if (p.Cin & 3) p.vec4 = 0;
+    p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
+    p.w = (const float*)w; p.dW = (float*)dW;
+    p.dd = (const float*)dd; p.dd_stride = (int)dd_d[0]; p.dd_off = (int)dd_d[1];
+    p.dref = (const float*)dref; p.dref_stride = dref ? (int)dref_d[0] : 0; p.dref_off = dref ? (int)dref_d[1] : 0;
+    for (int i = 0; i < TMG_MAX_OUT_SEG; ++i) p.g[i] = TmgOSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < (int)ng; ++i)
+        p.g[i] = TmgOSeg{(float*)g_ptrs[i], (int)g_desc[3 * i], (int)g_desc[3 * i + 1], (int)g_desc[3 * i + 2]};
+    c1_tile(p.Win, p.Hin, &p.TW_log2);
+    const int TW = 1 << p.TW_log2, TH = 256 >> p.TW_log2;
+    p.tiles_x = (p.Win + TW - 1) / TW;
+    p.tiles_y = (p.Hin + TH - 1) / TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const int Cpad = (p.Cin + 3) & ~3;
+    p.KCH = Cpad < 32 ? Cpad : 32;
+    if ((Cpad + p.KCH - 1) / p.KCH > 8) return -2;  // Cin <= 256
+    const int PP = (TH + 2) * (TW + 2);
+    const size_t lds_bytes = ((size_t)((PP + 3) & ~3) + 9 * p.KCH + (size_t)PP * (p.KCH + 4)) * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    int gx = p.ntiles < 1024 ? p.ntiles : 1024;
+    hipLaunchKernelGGL(c1_bwd_kernel, dim3(gx), dim3(256), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,81 @@
+"""Conditional affine coupling layers on the HIP path.  API mirror of the reference's
+nn/modules/flowAffine.py (AffineCouplingLayer :20-109, LSTMAffineCouplingLayer :111-236)."""
+import torch
+import torch.nn as nn
+
+import tmg_hip as H
+import tmg_ops as ops
+from nn.modules.convLSTM import ResidLSTMBlock
+from nn.modules.denseBlock import NoNormDenseBlock
+from nn.modules.flowUtils import Conv2dZeros
+
+
+def _channels(in_features, cond_features):
+    if in_features % 2 == 0:
+        return in_features // 2 + cond_features, in_features
+    # odd channel counts (reference :43-46) never occur in TMGlow: squeezed widths are multiples of 4
+    raise NotImplementedError("odd channel counts are not on the TM-Glow path (reference flowAffine.py:43-46)")
+
+
+class AffineCouplingLayer(nn.Module):
+    """h = ZeroConv(relu(Dense2(cat(x1, cond)))); x2 <- (x2 + h_even) * exp(2 softsign(h_odd))
+    (forward, reference :73-83) or x2 / s - shift (reverse, :98-109); log-det has the same sign both ways.
+
+    The channel concatenations are never materialised: the conv kernels read x1, cond and the two
+    growth channels as separate segments, with the ReLU applied on the way into LDS."""
+
+    def __init__(self, in_features, cond_features):
+        super().__init__()
+        in_channels, out_channels = _channels(in_features, cond_features)
+        self.coupling_nn = nn.Sequential()
+        self.coupling_nn.add_module('dense_block', NoNormDenseBlock(2, in_channels, growth_rate=1, drop_rate=0., bottleneck=False))
+        self.coupling_nn.add_module('zero_conv', Conv2dZeros(in_channels + 2, out_channels))
+
+    def run(self, xn, condn, reverse):
+        ch = xn.shape[3] // 2
+        t = self.coupling_nn.dense_block.run([xn[..., :ch], condn])
+        if len(t) > 3:
+            t = t[:2] + [torch.cat(t[2:], 3)]
+        hh = self.coupling_nn.zero_conv.run(t, relu_in=True)
+        return ops.AffineFn.apply(hh, xn, reverse)
+
+    def forward(self, x, cond):
+        y, ld = self.run(H.nhwc(x), H.nhwc(cond), False)
+        return H.nchw(y), ld
+
+    def reverse(self, y, cond):
+        x, ld = self.run(H.nhwc(y), H.nhwc(cond), True)
+        return H.nchw(x), ld
+
+
+class LSTMAffineCouplingLayer(nn.Module):
+    """As AffineCouplingLayer with a residual ConvLSTM block in front of the dense layers
+    (reference :161-236).  Returns (y, logdet, (h_next, c_next))."""
+
+    def __init__(self, in_features, cond_features, rec_features):
+        super().__init__()
+        in_channels, out_channels = _channels(in_features, cond_features)
+        self.resid_lstm = ResidLSTMBlock(in_channels, rec_features, in_channels, kernel_size=(3, 3))
+        self.dense_nn = nn.Sequential()
+        self.dense_nn.add_module('dense_block', NoNormDenseBlock(2, in_channels, growth_rate=1, drop_rate=0., bottleneck=False))
+        self.out_conv = nn.Sequential()
+        self.out_conv.add_module('zero_conv', Conv2dZeros(in_channels + 2, out_channels))
+
+    def run(self, xn, condn, state, reverse):
+        ch = xn.shape[3] // 2
+        out, h_next, c_next = self.resid_lstm.run([xn[..., :ch], condn], state)
+        t = self.dense_nn.dense_block.run([out])
+        hh = self.out_conv.zero_conv.run(t, relu_in=True)
+        y, ld = ops.AffineFn.apply(hh, xn, reverse)
+        return y, ld, (h_next, c_next)
+
+    def _call(self, x, cond, rec_states, reverse):
+        st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
+        y, ld, (h, c) = self.run(H.nhwc(x), H.nhwc(cond), st, reverse)
+        return H.nchw(y), ld, (H.nchw(h), H.nchw(c))
+
+    def forward(self, x, cond, rec_states=None):
+        return self._call(x, cond, rec_states, False)
+
+    def reverse(self, y, cond, rec_states=None):
+        return self._call(y, cond, rec_states, True)

@@ -1,0 +1,220 @@
+"""Flow blocks on the HIP path.  API mirror of the reference's nn/modules/flowLSTMBlock.py
+(AffineCouplingBlock :24-86, UnNormedAffineCouplingBlock :88-146, LSTMCouplingBlock :148-218,
+LSTMFLowBlock :220-361)."""
+import torch
+import torch.nn as nn
+
+import tmg_hip as H
+import tmg_ops as ops
+from nn.modules.actNorm import ActNorm
+from nn.modules.flowAffine import AffineCouplingLayer, LSTMAffineCouplingLayer
+from nn.modules.flowUtils import CheckerSqueeze, Split, Squeeze
+from nn.modules.glowConv import InvertibleConv1x1, InvertibleConv1x1LU
+
+
+def _make_conv(in_features, train_sampling, LUdecompose):
+    cls = InvertibleConv1x1LU if LUdecompose else InvertibleConv1x1
+    return cls(in_features, train_sampling=train_sampling)
+
+
+class _BlockBase(nn.Module):
+    """Shared mechanics of the three block kinds: the ActNorm (if any) and the invertible 1x1 conv are
+    ONE channel-mix launch.  Forward order is norm -> conv:  W (a*x + b) = (W diag a) x + W b;
+    reverse order is conv -> norm^-1:  (W y - b) / a = (diag(1/a) W) y - b/a.  The O(C^2) folding of
+    the parameters is ordinary torch autograd, the [B,H,W,C] contraction is the MFMA 1x1 kernel."""
+
+    def _mix_params(self, reverse):
+        norm = getattr(self, 'norm', None)
+        if isinstance(self.conv, InvertibleConv1x1LU):
+            W = self.conv.matrix(reverse)
+        else:
+            W = self.conv._matrix((not reverse) if self.conv.train_sampling else reverse)
+        if norm is None:
+            return W, None
+        s, t = norm.folded(reverse)
+        if reverse:
+            return s.unsqueeze(1) * W, t
+        return W * s.unsqueeze(0), W @ t
+
+    def _mix_logdet(self, xn):
+        hw = xn.shape[1] * xn.shape[2]
+        if isinstance(self.conv, InvertibleConv1x1LU):
+            ld = self.conv.log_s.sum() * hw
+            ld = -ld if self.conv.train_sampling else ld
+        else:
+            raise NotImplementedError("TMGlow always builds LU blocks (tmGlow.py:366); plain blocks run via the stand-alone modules")
+        norm = getattr(self, 'norm', None)
+        if norm is not None:
+            ld = ld + norm.weight.abs().log().sum() * hw
+        return ld
+
+    def _mix(self, xn, reverse):
+        W, b = self._mix_params(reverse)
+        c = W.shape[0]
+        return ops.conv([xn], W.reshape(c, c, 1, 1), b, ksize=1)
+
+
+class AffineCouplingBlock(_BlockBase):
+    def __init__(self, in_features, cond_features, train_sampling=True, LUdecompose=False):
+        super().__init__()
+        self.norm = ActNorm(in_features)
+        self.conv = _make_conv(in_features, train_sampling, LUdecompose)
+        self.coupling = AffineCouplingLayer(in_features, cond_features)
+
+    def run(self, xn, condn, reverse):
+        if not isinstance(self.conv, InvertibleConv1x1LU):
+            return _run_unfused(self, xn, condn, None, reverse)[:2]
+        if reverse:
+            t, ld = self.coupling.run(xn, condn, True)
+            return self._mix(t, True), ld + self._mix_logdet(xn)
+        y, ld = self.coupling.run(self._mix(xn, False), condn, False)
+        return y, ld + self._mix_logdet(xn)
+
+    def forward(self, x, cond):
+        y, ld = self.run(H.nhwc(x), H.nhwc(cond), False)
+        return H.nchw(y), ld
+
+    def reverse(self, y, cond):
+        x, ld = self.run(H.nhwc(y), H.nhwc(cond), True)
+        return H.nchw(x), ld
+
+
+class UnNormedAffineCouplingBlock(AffineCouplingBlock):
+    """First block of every level: no ActNorm (reference :101-146)."""
+
+    def __init__(self, in_features, cond_features, train_sampling=True, LUdecompose=False):
+        nn.Module.__init__(self)
+        self.conv = _make_conv(in_features, train_sampling, LUdecompose)
+        self.coupling = AffineCouplingLayer(in_features, cond_features)
+
+
+class LSTMCouplingBlock(_BlockBase):
+    """Last block of every level (reference :148-218).  `norm2` is dead in the reference (:170, never
+    called); it is kept so the state_dict matches, and it never receives a gradient."""
+
+    def __init__(self, in_features, cond_features, rec_features, train_sampling=True, LUdecompose=False):
+        super().__init__()
+        self.norm = ActNorm(in_features)
+        self.norm2 = ActNorm(in_features)
+        self.conv = _make_conv(in_features, train_sampling, LUdecompose)
+        self.coupling = LSTMAffineCouplingLayer(in_features, cond_features, rec_features)
+
+    def run(self, xn, condn, state, reverse):
+        if not isinstance(self.conv, InvertibleConv1x1LU):
+            return _run_unfused(self, xn, condn, state, reverse)
+        if reverse:
+            t, ld, st = self.coupling.run(xn, condn, state, True)
+            return self._mix(t, True), ld + self._mix_logdet(xn), st
+        y, ld, st = self.coupling.run(self._mix(xn, False), condn, state, False)
+        return y, ld + self._mix_logdet(xn), st
+
+    def _call(self, x, cond, rec_states, reverse):
+        st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
+        y, ld, (h, c) = self.run(H.nhwc(x), H.nhwc(cond), st, reverse)
+        return H.nchw(y), ld, (H.nchw(h), H.nchw(c))
+
+    def forward(self, x, cond, rec_states=None):
+        return self._call(x, cond, rec_states, False)
+
+    def reverse(self, y, cond, rec_states=None):
+        return self._call(y, cond, rec_states, True)
+
+
+def _run_unfused(block, xn, condn, state, reverse):
+    """Blocks built with the plain (non-LU) 1x1 conv: chain the stand-alone modules."""
+    is_lstm = isinstance(block, LSTMCouplingBlock)
+    norm = getattr(block, 'norm', None)
+    x = H.nchw(xn)
+    cond = H.nchw(condn)
+    st_out = None
+    if reverse:
+        if is_lstm:
+            st = None if state is None else (H.nchw(state[0]), H.nchw(state[1]))
+            x, ld, st_out = block.coupling.reverse(x, cond, st)
+        else:
+            x, ld = block.coupling.reverse(x, cond)
+        x, ld2 = block.conv.reverse(x)
+        ld = ld + ld2
+        if norm is not None:
+            x, ld3 = norm.reverse(x)
+            ld = ld + ld3
+    else:
+        ld = 0.
+        if norm is not None:
+            x, ld = norm(x)
+        x, ld2 = block.conv(x)
+        ld = ld + ld2
+        if is_lstm:
+            st = None if state is None else (H.nchw(state[0]), H.nchw(state[1]))
+            x, ld3, st_out = block.coupling(x, cond, st)
+        else:
+            x, ld3 = block.coupling(x, cond)
+        ld = ld + ld3
+    if st_out is not None:
+        st_out = (H.nhwc(st_out[0]), H.nhwc(st_out[1]))
+    return H.nhwc(x), ld, st_out
+
+
+class LSTMFLowBlock(nn.Module):
+    """One flow level: squeeze -> K coupling blocks (first un-normed, last LSTM) -> split
+    (reference :220-361).  Module names `revlayers.affine_layer{i}` as in the reference."""
+
+    def __init__(self, in_features, cond_features, rec_features, n_layers, factor=2, LUdecompose=True, train_sampling=False,
+                 do_split=True, squeeze_type=0):
+        super().__init__()
+        self.do_split = do_split
+        self.n_layers = n_layers
+        self.squeeze = CheckerSqueeze(factor) if squeeze_type == 0 else Squeeze(factor)
+        in_features = in_features * factor ** 2
+        self.revlayers = nn.Sequential()
+        for i in range(n_layers - 1):
+            cls = UnNormedAffineCouplingBlock if i == 0 else AffineCouplingBlock
+            self.revlayers.add_module('affine_layer{}'.format(i + 1),
+                                      cls(in_features, cond_features, LUdecompose=LUdecompose, train_sampling=train_sampling))
+        self.revlayers.add_module('affine_layer{}'.format(n_layers),
+                                  LSTMCouplingBlock(in_features, cond_features, rec_features, LUdecompose=LUdecompose,
+                                                    train_sampling=train_sampling))
+        if do_split:
+            self.split = Split(in_features)
+
+    def _squeeze_nhwc(self, xn, to_small):
+        if isinstance(self.squeeze, CheckerSqueeze):
+            return ops.CheckerFn.apply(xn, to_small)
+        x = H.nchw(xn)
+        return H.nhwc(self.squeeze(x) if to_small else self.squeeze.reverse(x))
+
+    def forward(self, x, cond, rec_states, return_eps=False):
+        xn, condn = self._squeeze_nhwc(H.nhwc(x), True), H.nhwc(cond)
+        st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
+        layers = list(self.revlayers._modules.values())
+        logdet = 0.
+        out_states = []
+        for i, layer in enumerate(layers):
+            if i == self.n_layers - 1:
+                xn, dld, so = layer.run(xn, condn, st, False)
+                out_states = (H.nchw(so[0]), H.nchw(so[1]))
+            else:
+                xn, dld = layer.run(xn, condn, False)
+            logdet = logdet + dld
+        if self.do_split:
+            z1, lp, eps = self.split(H.nchw(xn), return_eps=return_eps)
+            return z1, logdet + lp, out_states, eps
+        return H.nchw(xn), logdet, out_states, None
+
+    def reverse(self, y, cond, rec_states, eps=None):
+        logdet = 0.
+        out_states = []
+        if self.do_split:
+            y, lp = self.split.reverse(y, eps)
+            logdet = logdet + lp
+        yn, condn = H.nhwc(y), H.nhwc(cond)
+        st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
+        layers = list(self.revlayers._modules.values())
+        for i in range(len(layers) - 1, -1, -1):
+            if i == self.n_layers - 1:
+                yn, dld, so = layers[i].run(yn, condn, st, True)
+                out_states = (H.nchw(so[0]), H.nchw(so[1]))
+            else:
+                yn, dld = layers[i].run(yn, condn, True)
+            logdet = logdet + dld
+        return H.nchw(self._squeeze_nhwc(yn, False)), logdet, out_states

@@ -1,0 +1,175 @@
+"""TM-Glow on the MI355X HIP path.  API mirror of the reference's nn/tmGlow.py
+(Encoder :26-186, LSTMCFlowDecoder :188-303, TMGlow :305-509): same constructor signatures, method
+names, return structures and state_dict keys, so `main.py` can import this package in place of the
+reference's `nn` (put `deep-turbulence_amd/` on sys.path instead of `tmglow/`).
+
+Tensors cross this API as logical NCHW fp32 (any strides); internally everything is NHWC and every
+numerical operation is a kernel of libtmglow_hip.so -- there is no eager / CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+import tmg_hip as H
+import tmg_ops as ops
+from nn.modules.denseBlock import DenseBlock
+from nn.modules.flowLSTMBlock import LSTMFLowBlock
+from nn.modules.flowUtils import GaussianDiag
+from nn.modules.misc import UpsamplingLinear
+
+
+def _conv3(cin, cout, stride):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False, padding_mode='zeros')
+
+
+class Encoder(nn.Module):
+    """Dense conditioning encoder (reference :53-129).  Produces one conditioning map per flow level
+    plus the (mean, log-std) map of the deepest latent, each bilinearly up-sampled by `cglow_upscale`."""
+
+    def __init__(self, in_features, enc_block_layers, growth_rate=4, init_features=48, output_features=8, cond_features=8,
+                 cglow_upscale=1, bn_size=8, drop_rate=0., bottleneck=False):
+        super().__init__()
+        self.first_encoder = nn.Sequential()
+        self.first_encoder.add_module('In_conv', _conv3(in_features, init_features // 2, 1))
+        self.first_encoder.add_module('In_conv3', _conv3(init_features // 2, init_features, 2))
+        blocks, cond_convs = [], []
+        self.num_feat = init_features
+        for i, num_layers in enumerate(enc_block_layers):
+            block = nn.Sequential()
+            if i > 0:
+                trans = nn.Sequential()
+                trans.add_module('conv1', _conv3(self.num_feat, self.num_feat // 2, 2))
+                if drop_rate > 0:
+                    raise NotImplementedError("dropout is not on the TM-Glow path")
+                block.add_module('encode_conv{}'.format(i), trans)
+                self.num_feat = self.num_feat // 2
+            block.add_module('encode_dense_block{}'.format(i),
+                             DenseBlock(num_layers=num_layers, in_features=self.num_feat, bn_size=bn_size, growth_rate=growth_rate,
+                                        drop_rate=drop_rate, bottleneck=bottleneck))
+            blocks.append(block)
+            self.num_feat = self.num_feat + num_layers * growth_rate
+            cond_convs.append(nn.Sequential(_conv3(self.num_feat, cond_features, 1)))
+        self.out_conv = nn.Sequential(_conv3(self.num_feat, 2 * output_features, 1))
+        self.enc_up_scale = UpsamplingLinear(scale_factor=cglow_upscale)
+        self.encoding_blocks = nn.ModuleList(blocks)
+        self.cond_convs = nn.ModuleList(cond_convs)
+
+    def run(self, xn):
+        """NHWC in, NHWC out: (latent map, [conditioning map per level])."""
+        fe = self.first_encoder
+        out = ops.conv([xn], fe.In_conv.weight)
+        out = ops.conv([out], fe.In_conv3.weight, stride=2, relu_in=True)
+        up = self.enc_up_scale.scale_factor
+        c_out = []
+        for i, block in enumerate(self.encoding_blocks):
+            mods = list(block._modules.values())
+            if i > 0:
+                out = ops.conv([out], mods[0].conv1.weight, stride=2, relu_in=True)
+            out = mods[-1].run(out)
+            c0 = ops.conv([out], self.cond_convs[i][0].weight)
+            c_out.append(ops.UpsampleFn.apply(c0, up))
+        z = ops.UpsampleFn.apply(ops.conv([out], self.out_conv[0].weight), up)
+        return z, c_out
+
+    def forward(self, x):
+        z, c_out = self.run(H.nhwc(x))
+        return H.nchw(z), [H.nchw(c) for c in c_out]
+
+
+class LSTMCFlowDecoder(nn.Module):
+    """Stack of flow levels (reference :210-303)."""
+
+    def __init__(self, in_features, glow_block_layers, cond_features=8, rec_features=8, squeeze_factor=2, conv_ksize=3,
+                 LUdecompose=False, train_sampling=True, squeeze_type=0):
+        super().__init__()
+        self.flow_blocks = nn.ModuleList()
+        self.num_feat = in_features
+        for num_layers in glow_block_layers:
+            self.flow_blocks.append(LSTMFLowBlock(self.num_feat, cond_features, rec_features, num_layers, LUdecompose=LUdecompose,
+                                                  train_sampling=train_sampling, do_split=True, squeeze_type=squeeze_type))
+            self.num_feat = (self.num_feat * squeeze_factor ** 2) // 2
+
+    def forward(self, x, c_in, h_in, return_eps=False):
+        assert (len(c_in) == len(self.flow_blocks)), 'List of conditions need to be same length as flow blocks.'
+        z, log_det, eps, s_out = x, 0, [], []
+        for i, flow_block in enumerate(self.flow_blocks):
+            z, ld, s0, eps0 = flow_block.forward(z, c_in[i], None if h_in is None else h_in[i], return_eps)
+            log_det = log_det + ld
+            eps.append(eps0)
+            s_out.append(s0)
+        return z, log_det, s_out, eps
+
+    def reverse(self, z, c_in, h_in, eps):
+        assert (len(c_in) == len(self.flow_blocks)), 'List of conditions need to be same length as flow blocks.'
+        x, log_det, s_out = z, 0, []
+        for i in range(len(self.flow_blocks) - 1, -1, -1):
+            x, ld, s0 = self.flow_blocks[i].reverse(x, c_in[i], None if h_in is None else h_in[i], eps[i])
+            log_det = log_det + ld
+            s_out.insert(0, s0)
+        return x, log_det, s_out
+
+
+class TMGlow(nn.Module):
+    """Transient multi-fidelity Glow (reference :336-509)."""
+
+    def __init__(self, in_features, out_features, enc_blocks, glow_blocks, cond_features=8, cglow_upscale=1, growth_rate=4,
+                 init_features=48, rec_features=8, bn_size=8, drop_rate=0, bottleneck=False):
+        super().__init__()
+        self.glow_blocks = glow_blocks
+        self.rec_features = rec_features
+        enc_out_features = out_features * (2 ** len(glow_blocks))
+        self.encoder = Encoder(in_features, enc_block_layers=enc_blocks, growth_rate=growth_rate, init_features=init_features,
+                               output_features=enc_out_features, cond_features=cond_features, cglow_upscale=cglow_upscale,
+                               bn_size=bn_size, drop_rate=drop_rate, bottleneck=bottleneck)
+        self.glow = LSTMCFlowDecoder(out_features, glow_block_layers=glow_blocks, cond_features=cond_features,
+                                     rec_features=rec_features, squeeze_factor=2, LUdecompose=True, train_sampling=True,
+                                     squeeze_type=0)
+        for name in ("in_mu", "in_std", "out_mu", "out_std"):
+            self.register_buffer(name, torch.zeros(3))
+        print('Total number of parameters: {}'.format(self._num_parameters()))
+
+    def _prior(self, x):
+        z_out, c_out = self.encoder.forward(x)
+        cmean, clog_stddev = z_out.chunk(2, 1)
+        return GaussianDiag(cmean, clog_stddev), c_out
+
+    def forward(self, x, y, h_in=None, return_eps=False):
+        """x -> z.  Returns (z, log_prior + log_det [B], h_out, eps | None) (reference :378-414)."""
+        cprior, c_out = self._prior(x)
+        z, log_det, h_out, eps = self.glow.forward(y, c_out, h_in, return_eps=return_eps)
+        log_prior, eps0 = cprior.log_prob(z, return_eps=return_eps)
+        if return_eps:
+            eps.append(eps0)  # deepest latent noise, from the clamped log-std (reference :407 + flowUtils.py:163)
+        else:
+            eps = None
+        return z, log_prior + log_det, h_out, eps
+
+    def sample(self, x, h_in=None):
+        """Conditional generation with freshly drawn latents; no top-prior term in the log-det (reference :417-440)."""
+        cprior, c_out = self._prior(x)
+        z_samp = cprior.sample()
+        eps = [None for _ in range(len(self.glow_blocks))]
+        return self.glow.reverse(z_samp, c_out, h_in, eps)
+
+    def reconstruct(self, x, h_in, eps):
+        """Generation from given latents, eps[-1] being the deepest (reference :442-467)."""
+        cprior, c_out = self._prior(x)
+        z_samp = cprior.sample(eps[-1])
+        return self.glow.reverse(z_samp, c_out, h_in, eps[:-1])
+
+    def _num_parameters(self):
+        return sum(p.numel() for p in self.parameters())
+
+    def initLSTMStates(self, seeds, input_dim):
+        """Per (level, sample) a fresh CPU generator with the sample's seed: hidden ~ U[-1,1], cell ~ N(0,1)
+        (reference :481-509).  Host RNG by construction, then one copy to the model's device."""
+        device = next(self.parameters()).device
+        states = []
+        for i in range(len(self.glow_blocks)):
+            hs, cs = [], []
+            for j in range(seeds.size(0)):
+                gen = torch.Generator().manual_seed(int(seeds[j].item()))
+                dims = [1, self.rec_features, input_dim[0] // (2 ** (i + 1)), input_dim[1] // (2 ** (i + 1))]
+                hs.append(2 * torch.rand(dims, generator=gen) - 1)
+                cs.append(torch.randn(dims, generator=gen))
+            states.append((torch.cat(hs, dim=0).to(device), torch.cat(cs, dim=0).to(device)))
+        return states

@@ -1,0 +1,284 @@
+"""ctypes binding of libtmglow_hip.so (C ABI: include/tmglow_hip.h) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and autograd
+bookkeeping.  Every numerical operation of the hot path is a kernel of the shared library.  There is
+no CPU or eager fallback: calling an op without the library, or with a tensor that is not a
+contiguous-NHWC fp32 CUDA/HIP tensor, raises.
+
+Internal tensor convention: activations are torch tensors of shape [B, H, W, C] (NHWC, contiguous)
+or channel-slice views of such tensors.  `seg(t)` turns one into the (pointer, stride, offset, n)
+descriptor the library expects.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtmglow_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip"]
+_lib = None
+
+c_i64 = ctypes.c_int64
+c_vp = ctypes.c_void_p
+
+EXPORTS = [
+    "tmg_conv_pack", "tmg_conv_fwd", "tmg_conv_wgrad", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
+    "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
+    "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
+    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd",
+]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into libtmglow_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "tmg_common.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(os.path.dirname(_HERE), "include")] + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libtmglow_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                               "There is no fallback path." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def _stream():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(code, name):
+    if code != 0:
+        raise RuntimeError("%s failed with code %d" % (name, code))
+
+
+def _ptr(t):
+    return c_vp(t.data_ptr()) if t is not None else c_vp(0)
+
+
+def check_act(t):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError("TM-Glow HIP ops need fp32 tensors on a HIP device (got %s on %s); there is no CPU path"
+                           % (t.dtype, t.device))
+
+
+def seg(t):
+    """(ptr, pixel stride, channel offset folded into ptr => 0, n) of an NHWC tensor or channel-slice view."""
+    check_act(t)
+    B, H, W, C = t.shape
+    s = t.stride()
+    ps = s[2] if W > 1 else (s[1] // W if H > 1 else (s[0] // (H * W) if B > 1 else C))
+    ok = s[3] == 1 or C == 1
+    if W > 1:
+        ok = ok and (H == 1 or s[1] == W * ps) and (B == 1 or s[0] == H * W * ps)
+    if not ok or ps < C:
+        raise RuntimeError("tensor is not an NHWC channel-slice: shape %s strides %s" % (tuple(t.shape), s))
+    return (t.data_ptr(), int(ps), 0, int(C))
+
+
+def nhwc(x):
+    """API tensor [B,C,H,W] (any strides) -> internal [B,H,W,C] contiguous (free if channels_last)."""
+    check_act(x)
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    """internal [B,H,W,C] -> API-shaped [B,C,H,W] view (channels_last strides)."""
+    return t.permute(0, 3, 1, 2)
+
+
+def _segs(tensors):
+    d = [seg(t) for t in tensors]
+    ptrs = (c_vp * len(d))(*[x[0] for x in d])
+    desc = (c_i64 * (3 * len(d)))(*[v for x in d for v in (x[1], x[2], x[3])])
+    return ptrs, desc, len(d)
+
+
+def _d2(t):
+    s = seg(t)
+    return (c_i64 * 2)(s[1], 0)
+
+
+def _i64(*v):
+    return (c_i64 * len(v))(*[int(x) for x in v])
+
+
+# ------------------------------------------------------------------------------------------------
+# dense contractions
+# ------------------------------------------------------------------------------------------------
+def conv_pack(w, mode):
+    """w: torch layout [Cout, Cin, k, k] -> packed MFMA operand (see tmg_conv_pack)."""
+    check_act(w)
+    w = w.contiguous()
+    Cout, Cin, k, _ = w.shape
+    K, N = (Cin, Cout) if mode == 0 else (Cout, Cin)
+    Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
+    wpk = torch.empty(k * k * Kp * Np, device=w.device, dtype=torch.float32)
+    _chk(lib().tmg_conv_pack(_ptr(w), _ptr(wpk), c_i64(Cout), c_i64(Cin), c_i64(k), c_i64(mode), _stream()), "tmg_conv_pack")
+    return wpk
+
+
+def conv_fwd(inputs, wpk, Cout, ksize, stride, outs, bias=None, kappa=None, in_scale=None, in_shift=None, relu_in=False,
+             pad_rep=False, relu_out=False, accumulate=False):
+    """inputs / outs: lists of NHWC tensors (or channel-slice views) forming the channel concatenation."""
+    B, Hin, Win, _ = inputs[0].shape
+    Hout, Wout = outs[0].shape[1], outs[0].shape[2]
+    ip, idesc, n_in = _segs(inputs)
+    op, odesc, n_out = _segs(outs)
+    Cin = sum(t.shape[3] for t in inputs)
+    assert sum(t.shape[3] for t in outs) == Cout
+    dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep, relu_out, accumulate)
+    _chk(lib().tmg_conv_fwd(ip, idesc, c_i64(n_in), _ptr(wpk), _ptr(bias), _ptr(kappa), _ptr(in_scale), _ptr(in_shift), op, odesc,
+                            c_i64(n_out), dims, _stream()), "tmg_conv_fwd")
+
+
+def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, in_shift=None, relu_in=False, pad_rep=False):
+    B, Hin, Win, _ = inputs[0].shape
+    _, Hout, Wout, Cout = dy.shape
+    ip, idesc, n_in = _segs(inputs)
+    Cin = sum(t.shape[3] for t in inputs)
+    dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep)
+    _chk(lib().tmg_conv_wgrad(ip, idesc, c_i64(n_in), _ptr(in_scale), _ptr(in_shift), _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
+                              _ptr(kappa), dims, _stream()), "tmg_conv_wgrad")
+
+
+def conv_rep_border_fix(dy, w, outs, kappa=None):
+    B, H, W, Cdy = dy.shape
+    op, odesc, n_out = _segs(outs)
+    Cx = sum(t.shape[3] for t in outs)
+    _chk(lib().tmg_conv_rep_border_fix(_ptr(dy), _d2(dy), _ptr(w), _ptr(kappa), op, odesc, c_i64(n_out), _i64(B, H, W, Cdy, Cx),
+                                       _stream()), "tmg_conv_rep_border_fix")
+
+
+def conv_dgrad_direct(dy, w, dx, ksize, stride, accumulate=False):
+    B, Hin, Win, Cin = dx.shape
+    _, Hout, Wout, Cout = dy.shape
+    _chk(lib().tmg_conv_dgrad_direct(_ptr(dy), _d2(dy), _ptr(w), _ptr(dx), _d2(dx),
+                                     _i64(B, Hin, Win, Hout, Wout, Cin, Cout, ksize, stride, accumulate), _stream()),
+         "tmg_conv_dgrad_direct")
+
+
+# ------------------------------------------------------------------------------------------------
+# bandwidth-bound ops
+# ------------------------------------------------------------------------------------------------
+def affine_apply(hh, x2, y2, rsave, logdet, reverse):
+    B, H, W, Ch = x2.shape
+    _chk(lib().tmg_affine_apply(_ptr(hh), _d2(hh), _ptr(x2), _d2(x2), _ptr(y2), _d2(y2), _ptr(rsave), _ptr(logdet),
+                                _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_apply")
+
+
+def affine_bwd(gout, yref, rsave, g, gin, dhh, reverse):
+    B, H, W, Ch = gout.shape
+    _chk(lib().tmg_affine_bwd(_ptr(gout), _d2(gout), _ptr(yref), _d2(yref), _ptr(rsave), _ptr(g), _ptr(gin), _d2(gin), _ptr(dhh),
+                              _d2(dhh), _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_bwd")
+
+
+def lstm_pointwise_fwd(gates, c_prev, c_next, h_next):
+    B, H, W, R4 = gates.shape
+    cd = _d2(c_prev) if c_prev is not None else _i64(0, 0)
+    _chk(lib().tmg_lstm_pointwise_fwd(_ptr(gates), _ptr(c_prev), cd, _ptr(c_next), _ptr(h_next), _i64(B * H * W, R4 // 4), _stream()),
+         "tmg_lstm_pointwise_fwd")
+
+
+def lstm_pointwise_bwd(acts, c_prev, c_next, dh, dc_in, dc_prev):
+    B, H, W, R4 = acts.shape
+    cd = _d2(c_prev) if c_prev is not None else _i64(0, 0)
+    _chk(lib().tmg_lstm_pointwise_bwd(_ptr(acts), _ptr(c_prev), cd, _ptr(c_next), _ptr(dh), _ptr(dc_in), _ptr(dc_prev),
+                                      _i64(B * H * W, R4 // 4), _stream()), "tmg_lstm_pointwise_bwd")
+
+
+def _fl(vals):
+    return (ctypes.c_float * 4)(*vals)
+
+
+def gauss_fwd(hz, zin, zout, logp, mode, clip_mean, limits):
+    B, H, W, Ch = zin.shape
+    zo = _d2(zout) if zout is not None else _i64(0, 0)
+    _chk(lib().tmg_gauss_fwd(_ptr(hz), _d2(hz), _ptr(zin), _d2(zin), _ptr(zout), zo, _ptr(logp), _i64(B, H * W, Ch, mode, clip_mean),
+                             _fl(limits), _stream()), "tmg_gauss_fwd")
+
+
+def gauss_bwd(hz, zin, dzin, g, dzout, dhz, mode, clip_mean, limits):
+    B, H, W, Ch = zin.shape
+    di = _d2(dzin) if dzin is not None else _i64(0, 0)
+    do = _d2(dzout) if dzout is not None else _i64(0, 0)
+    _chk(lib().tmg_gauss_bwd(_ptr(hz), _d2(hz), _ptr(zin), _d2(zin), _ptr(dzin), di, _ptr(g), _ptr(dzout), do, _ptr(dhz), _d2(dhz),
+                             _i64(B, H * W, Ch, mode, clip_mean), _fl(limits), _stream()), "tmg_gauss_bwd")
+
+
+def checker(src, dst, to_small):
+    if to_small:
+        B, h, w, _ = dst.shape
+        C = src.shape[3]
+    else:
+        B, h, w, _ = src.shape
+        C = dst.shape[3]
+    _chk(lib().tmg_checker(_ptr(src), _d2(src), _ptr(dst), _d2(dst), _i64(B, h, w, C, to_small), _stream()), "tmg_checker")
+
+
+def upsample_fwd(src, dst):
+    B, hi, wi, C = src.shape
+    _, ho, wo, _ = dst.shape
+    assert src.is_contiguous() and dst.is_contiguous()
+    _chk(lib().tmg_upsample_fwd(_ptr(src), _ptr(dst), _i64(B, hi, wi, ho, wo, C), _stream()), "tmg_upsample_fwd")
+
+
+def upsample_bwd(dout, din):
+    B, hi, wi, C = din.shape
+    _, ho, wo, _ = dout.shape
+    assert dout.is_contiguous() and din.is_contiguous()
+    _chk(lib().tmg_upsample_bwd(_ptr(dout), _ptr(din), _i64(B, hi, wi, ho, wo, C), _stream()), "tmg_upsample_bwd")
+
+
+def chan_reduce(x, g, v0, v1, v2, v3, s0, s1, mode):
+    B, H, W, C = x.shape
+    gd = _d2(g) if g is not None else _i64(0, 0)
+    _chk(lib().tmg_chan_reduce(_ptr(x), _d2(x), _ptr(g), gd, _ptr(v0), _ptr(v1), _ptr(v2), _ptr(v3), _ptr(s0), _ptr(s1),
+                               _i64(B * H * W, C, mode), _stream()), "tmg_chan_reduce")
+
+
+def bn_bwd_apply(x, g, a, bsh, mean, rstd, gamma, m0, m1, dx, accumulate):
+    B, H, W, C = x.shape
+    _chk(lib().tmg_bn_bwd_apply(_ptr(x), _d2(x), _ptr(g), _d2(g), _ptr(a), _ptr(bsh), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(m0),
+                                _ptr(m1), _ptr(dx), _d2(dx), _i64(B * H * W, C, accumulate), _stream()), "tmg_bn_bwd_apply")
+
+
+def masked_add(dst, src=None, ref=None, add=None, accumulate=False):
+    B, H, W, n = dst.shape
+    z = _i64(0, 0)
+    _chk(lib().tmg_masked_add(_ptr(src), _d2(src) if src is not None else z, _ptr(ref), _d2(ref) if ref is not None else z, _ptr(add),
+                              _d2(add) if add is not None else z, _ptr(dst), _d2(dst), _i64(B * H * W, n, accumulate), _stream()),
+         "tmg_masked_add")
+
+
+def c1_fwd(inputs, w, out, relu_in=True):
+    B, H, W, _ = inputs[0].shape
+    ip, idesc, n_in = _segs(inputs)
+    Cin = sum(t.shape[3] for t in inputs)
+    _chk(lib().tmg_c1_fwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(out), _d2(out), _i64(B, H, W, Cin, relu_in), _stream()), "tmg_c1_fwd")
+
+
+def c1_bwd(inputs, w, dW, dd, dref, gsegs, relu_in=True):
+    B, H, W, _ = inputs[0].shape
+    ip, idesc, n_in = _segs(inputs)
+    gp, gdesc, ng = _segs(gsegs)
+    Cin = sum(t.shape[3] for t in inputs)
+    rd = _d2(dref) if dref is not None else _i64(0, 0)
+    _chk(lib().tmg_c1_bwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(dW), _ptr(dd), _d2(dd), _ptr(dref), rd, gp, gdesc, c_i64(ng),
+                          _i64(B, H, W, Cin, relu_in), _stream()), "tmg_c1_bwd")

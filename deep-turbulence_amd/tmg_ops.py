@@ -1,0 +1,304 @@
+"""torch.autograd glue over the HIP kernels: one Function per primitive of the TM-Glow hot path.
+
+Forward and backward of every Function are kernel launches from tmg_hip (libtmglow_hip.so); torch
+only provides tensors, the stream and the autograd tape.  Gradients w.r.t. tiny parameter tensors
+that are pure bookkeeping (e.g. d(kappa) from <W,dW>+<b,db>) are a handful of scalar torch ops.
+
+All activations are NHWC ([B,H,W,C] contiguous, or channel-slice views of such tensors).
+"""
+import math
+
+import torch
+
+import tmg_hip as H
+
+LOG5 = math.log(5.0)
+LOG4 = math.log(4.0)
+SPLIT_LIMITS = (-2.0, LOG5, -2.0, LOG5)      # hardtanh(-2, ln5) on both halves (flowUtils.py:262,274)
+TOP_LIMITS = (0.0, 0.0, -10.0, LOG5)         # only the log-std is clamped (flowUtils.py:163)
+
+
+def _out_hw(h, w, stride):
+    return (h - 1) // stride + 1, (w - 1) // stride + 1
+
+
+class ConvFn(torch.autograd.Function):
+    """y = [relu]((conv_k(pad(act(cat(inputs))), W) + b) * exp(clamp(kappa)))   (see tmg_conv_fwd)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, kappa, opts, *inputs):
+        ksize, stride, relu_in, pad_rep, relu_out = opts
+        inputs = tuple(t if t.stride(3) == 1 else t.contiguous() for t in inputs)
+        B, Hin, Win, _ = inputs[0].shape
+        Cout = weight.shape[0]
+        Ho, Wo = _out_hw(Hin, Win, stride)
+        out = torch.empty((B, Ho, Wo, Cout), device=weight.device, dtype=torch.float32)
+        wpk = H.conv_pack(weight, 0)
+        H.conv_fwd(list(inputs), wpk, Cout, ksize, stride, [out], bias=bias, kappa=kappa, relu_in=relu_in, pad_rep=pad_rep,
+                   relu_out=relu_out)
+        ctx.opts = opts
+        ctx.n_in = len(inputs)
+        ctx.has_bias = bias is not None
+        ctx.has_kappa = kappa is not None
+        ctx.save_for_backward(weight, bias, kappa, out if relu_out else None, *inputs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ksize, stride, relu_in, pad_rep, relu_out = ctx.opts
+        weight, bias, kappa, out = ctx.saved_tensors[:4]
+        inputs = ctx.saved_tensors[4:]
+        dout = dout.contiguous()
+        if relu_out:
+            dy = torch.empty_like(dout)
+            H.masked_add(dy, src=dout, ref=out)
+        else:
+            dy = dout
+        dW = db = dk = None
+        if ctx.needs_input_grad[0] or ctx.has_kappa:
+            dW = torch.zeros_like(weight)
+            db = torch.zeros_like(bias) if ctx.has_bias else None
+            H.conv_wgrad(list(inputs), dy, dW, db, ksize, stride, kappa=kappa, relu_in=relu_in, pad_rep=pad_rep)
+            if ctx.has_kappa:
+                dk = (weight * dW).sum()
+                if ctx.has_bias:
+                    dk = dk + (bias * db).sum()
+                inside = ((kappa >= -4.0) & (kappa <= LOG4)).to(dk.dtype)
+                dk = (dk * inside).reshape(kappa.shape)
+        dins = [None] * ctx.n_in
+        if any(ctx.needs_input_grad[4:]):
+            dins = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in inputs]
+            if stride == 1:
+                wpk_t = H.conv_pack(weight, 1)
+                cin = sum(t.shape[3] for t in inputs)
+                H.conv_fwd([dy], wpk_t, cin, ksize, 1, dins, kappa=kappa)
+                if pad_rep and ksize == 3:
+                    H.conv_rep_border_fix(dy, weight, dins, kappa=kappa)
+            else:
+                assert ctx.n_in == 1 and not ctx.has_kappa and not pad_rep
+                H.conv_dgrad_direct(dy, weight, dins[0], ksize, stride)
+            if relu_in:
+                for d, t in zip(dins, inputs):
+                    H.masked_add(d, src=d, ref=t)
+        return (dW, db, dk, None) + tuple(dins)
+
+
+def conv(inputs, weight, bias=None, kappa=None, ksize=3, stride=1, relu_in=False, pad_rep=False, relu_out=False):
+    return ConvFn.apply(weight, bias, kappa, (ksize, stride, relu_in, pad_rep, relu_out), *inputs)
+
+
+class BNReLUConvFn(torch.autograd.Function):
+    """y = conv3x3(relu(batchnorm(x)))  -- the encoder's dense layer (denseBlock.py:49-53), with the
+    normalisation folded into the conv's input staging as a per-channel affine."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, mean, var, eps, training):
+        # mean / var: batch moments (training) or running moments (eval), computed by the caller
+        x = x if x.stride(3) == 1 else x.contiguous()
+        rstd = torch.rsqrt(var + eps)
+        a = gamma * rstd
+        bsh = beta - mean * a
+        B, Hh, Ww, _ = x.shape
+        Cout = weight.shape[0]
+        out = torch.empty((B, Hh, Ww, Cout), device=x.device, dtype=torch.float32)
+        wpk = H.conv_pack(weight, 0)
+        H.conv_fwd([x], wpk, Cout, 3, 1, [out], in_scale=a, in_shift=bsh, relu_in=True)
+        ctx.training = training
+        ctx.save_for_backward(x, gamma, weight, mean, rstd, a, bsh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, weight, mean, rstd, a, bsh = ctx.saved_tensors
+        dy = dout.contiguous()
+        B, Hh, Ww, C = x.shape
+        n = B * Hh * Ww
+        dW = torch.zeros_like(weight)
+        H.conv_wgrad([x], dy, dW, None, 3, 1, in_scale=a, in_shift=bsh, relu_in=True)
+        wpk_t = H.conv_pack(weight, 1)
+        G = torch.empty((B, Hh, Ww, C), device=x.device, dtype=torch.float32)
+        H.conv_fwd([dy], wpk_t, C, 3, 1, [G])
+        s0 = torch.zeros(C, device=x.device)
+        s1 = torch.zeros(C, device=x.device)
+        H.chan_reduce(x, G, a, bsh, mean, rstd, s0, s1, 1)
+        dgamma, dbeta = s1, s0
+        dx = torch.empty((B, Hh, Ww, C), device=x.device, dtype=torch.float32)
+        if ctx.training:
+            H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, s0 / n, s1 / n, dx, False)
+        else:
+            z = torch.zeros_like(s0)
+            H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, z, z, dx, False)
+        return dx, dgamma, dbeta, dW, None, None, None, None
+
+
+def batch_moments(x):
+    """Two-pass per-channel mean / biased variance over (B,H,W) of an NHWC tensor or channel-slice view."""
+    B, Hh, Ww, C = x.shape
+    n = B * Hh * Ww
+    s0 = torch.zeros(C, device=x.device)
+    s1 = torch.zeros(C, device=x.device)
+    H.chan_reduce(x, None, None, None, None, None, s0, s1, 0)
+    mean = s0 / n
+    s0b = torch.zeros(C, device=x.device)
+    s1b = torch.zeros(C, device=x.device)
+    H.chan_reduce(x, None, mean, None, None, None, s0b, s1b, 0)
+    return mean, s1b / n, n
+
+
+class AffineFn(torch.autograd.Function):
+    """Affine coupling on the second channel half + per-sample log-det (flowAffine.py:76-83 / :102-109)."""
+
+    @staticmethod
+    def forward(ctx, hh, x, reverse):
+        x = x if x.stride(3) == 1 else x.contiguous()
+        hh = hh.contiguous()
+        B, Hh, Ww, C = x.shape
+        ch = C // 2
+        y = torch.empty((B, Hh, Ww, C), device=x.device, dtype=torch.float32)
+        H.masked_add(y[..., :ch], src=x[..., :ch])
+        r = torch.empty((B, Hh, Ww, ch), device=x.device, dtype=torch.float32)
+        logdet = torch.zeros(B, device=x.device, dtype=torch.float32)
+        H.affine_apply(hh, x[..., ch:], y[..., ch:], r, logdet, reverse)
+        ctx.reverse = reverse
+        ctx.save_for_backward(r, x if reverse else y)
+        return y, logdet
+
+    @staticmethod
+    def backward(ctx, dy, dld):
+        r, ref = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Hh, Ww, C = dy.shape
+        ch = C // 2
+        dx = torch.empty_like(dy)
+        H.masked_add(dx[..., :ch], src=dy[..., :ch])
+        dhh = torch.empty((B, Hh, Ww, C), device=dy.device, dtype=torch.float32)
+        g = dld.contiguous() if dld is not None else None
+        H.affine_bwd(dy[..., ch:], ref[..., ch:], r, g, dx[..., ch:], dhh, ctx.reverse)
+        return dhh, dx, None
+
+
+class LSTMPointwiseFn(torch.autograd.Function):
+    """Gate activations and state update of the ConvLSTM cell (convLSTM.py:76-83)."""
+
+    @staticmethod
+    def forward(ctx, gates, c_prev):
+        acts = gates.contiguous().clone()
+        B, Hh, Ww, R4 = acts.shape
+        R = R4 // 4
+        if c_prev is not None and c_prev.stride(3) != 1:
+            c_prev = c_prev.contiguous()
+        c_next = torch.empty((B, Hh, Ww, R), device=acts.device, dtype=torch.float32)
+        h_next = torch.empty((B, Hh, Ww, R), device=acts.device, dtype=torch.float32)
+        H.lstm_pointwise_fwd(acts, c_prev, c_next, h_next)
+        ctx.has_c = c_prev is not None
+        ctx.save_for_backward(acts, c_prev, c_next)
+        return h_next, c_next
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        acts, c_prev, c_next = ctx.saved_tensors
+        dg = acts.clone()
+        dc_prev = torch.empty_like(c_next)
+        H.lstm_pointwise_bwd(dg, c_prev, c_next, dh.contiguous() if dh is not None else None,
+                             dc.contiguous() if dc is not None else None, dc_prev)
+        return dg, (dc_prev if ctx.has_c else None)
+
+
+class GaussLogpFn(torch.autograd.Function):
+    """log N(z2; mean, exp(lsd)) summed per sample, and eps = (z2-mean)/exp(lsd)  (flowUtils.py:176-192, :311)."""
+
+    @staticmethod
+    def forward(ctx, hz, z2, clip_mean, limits, want_eps):
+        hz = hz.contiguous()
+        z2 = z2 if z2.stride(3) == 1 else z2.contiguous()
+        B = z2.shape[0]
+        logp = torch.zeros(B, device=z2.device, dtype=torch.float32)
+        eps = torch.empty(z2.shape, device=z2.device, dtype=torch.float32) if want_eps else None
+        H.gauss_fwd(hz, z2, eps, logp, 0, clip_mean, limits)
+        ctx.cfg = (clip_mean, limits)
+        ctx.save_for_backward(hz, z2)
+        ctx.mark_non_differentiable(*([eps] if want_eps else []))
+        return logp, eps
+
+    @staticmethod
+    def backward(ctx, g, _geps):
+        hz, z2 = ctx.saved_tensors
+        clip_mean, limits = ctx.cfg
+        dz2 = torch.empty(z2.shape, device=z2.device, dtype=torch.float32)
+        dhz = torch.empty_like(hz)
+        H.gauss_bwd(hz, z2, None, g.contiguous(), dz2, dhz, 0, clip_mean, limits)
+        return dhz, dz2, None, None, None
+
+
+class GaussSampleFn(torch.autograd.Function):
+    """z2 = mean + exp(lsd)*eps and its log-prob (flowUtils.py:194-209, :331-334)."""
+
+    @staticmethod
+    def forward(ctx, hz, eps, clip_mean, limits):
+        hz = hz.contiguous()
+        eps = eps.contiguous()
+        B = eps.shape[0]
+        logp = torch.zeros(B, device=eps.device, dtype=torch.float32)
+        z2 = torch.empty(eps.shape, device=eps.device, dtype=torch.float32)
+        H.gauss_fwd(hz, eps, z2, logp, 1, clip_mean, limits)
+        ctx.cfg = (clip_mean, limits)
+        ctx.save_for_backward(hz, eps)
+        return z2, logp
+
+    @staticmethod
+    def backward(ctx, dz2, g):
+        hz, eps = ctx.saved_tensors
+        clip_mean, limits = ctx.cfg
+        dhz = torch.empty_like(hz)
+        H.gauss_bwd(hz, eps, dz2.contiguous() if dz2 is not None else None, g.contiguous() if g is not None else None, None, dhz, 1,
+                    clip_mean, limits)
+        return dhz, None, None, None
+
+
+class CheckerFn(torch.autograd.Function):
+    """Checker squeeze (to_small) / un-squeeze (flowUtils.py:99-145)."""
+
+    @staticmethod
+    def forward(ctx, x, to_small):
+        x = x if x.stride(3) == 1 else x.contiguous()
+        B, Hh, Ww, C = x.shape
+        if to_small:
+            assert Hh % 2 == 0 and Ww % 2 == 0
+            y = torch.empty((B, Hh // 2, Ww // 2, 4 * C), device=x.device, dtype=torch.float32)
+        else:
+            assert C >= 4 and C % 4 == 0
+            y = torch.empty((B, Hh * 2, Ww * 2, C // 4), device=x.device, dtype=torch.float32)
+        H.checker(x, y, to_small)
+        ctx.to_small = to_small
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, Hh, Ww, C = dy.shape
+        if ctx.to_small:
+            dx = torch.empty((B, Hh * 2, Ww * 2, C // 4), device=dy.device, dtype=torch.float32)
+        else:
+            dx = torch.empty((B, Hh // 2, Ww // 2, 4 * C), device=dy.device, dtype=torch.float32)
+        H.checker(dy, dx, not ctx.to_small)
+        return dx, None
+
+
+class UpsampleFn(torch.autograd.Function):
+    """Bilinear align_corners=True up-sampling by an integer factor (misc.py:34-35)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        B, Hh, Ww, C = x.shape
+        ho, wo = int(math.floor(Hh * scale)), int(math.floor(Ww * scale))
+        y = torch.empty((B, ho, wo, C), device=x.device, dtype=torch.float32)
+        H.upsample_fwd(x, y)
+        ctx.in_shape = (B, Hh, Ww, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.in_shape, device=dy.device, dtype=torch.float32)
+        H.upsample_bwd(dy.contiguous(), dx)
+        return dx, None

@@ -1,0 +1,127 @@
+/* tmglow_hip.h -- C ABI of libtmglow_hip.so: the gfx950 (MI355X) kernels behind the TM-Glow
+ * invertible hot path.  Plain pointers and sizes only: device pointers are owned by the caller
+ * (PyTorch's caching allocator in the shipped host code), nothing here allocates or synchronises,
+ * every launch goes to the HIP stream passed in.  Return value: 0 on success, a positive
+ * hipError_t if the launch failed, a negative value for a rejected argument.
+ *
+ * The reference (zabaras/deep-turbulence, pure Python / PyTorch) has no FFI of its own; each
+ * entry point below replaces the stock torch-op call sites cited next to it (paths relative to
+ * /root/reference/tmglow/nn/).  INTEGRATION.md shows the ctypes binding the host side uses.
+ *
+ * Conventions
+ *   - activations: fp32, NHWC.  A tensor argument is (pointer, d = {pixel stride in floats,
+ *     channel offset}) so a channel slice of a wider buffer is addressed in place.
+ *   - "segments": a list of (pointer, {stride, offset, nchannels}) that together stand for the
+ *     channel concatenation torch.cat would build (flowAffine.py:74, convLSTM.py:72,151,
+ *     denseBlock.py:152); at most TMG_MAX_IN_SEG inputs / TMG_MAX_OUT_SEG outputs.
+ *   - `dims` arrays are host int64; their layout is documented per function.
+ */
+#ifndef TMGLOW_HIP_H
+#define TMGLOW_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef TMG_MAX_IN_SEG
+#define TMG_MAX_IN_SEG 3
+#define TMG_MAX_OUT_SEG 3
+#endif
+
+typedef struct ihipStream_t* tmg_stream_t; /* == hipStream_t */
+
+/* ---- dense contractions on the fp32 matrix cores (tmg_conv.hip) -------------------------------- */
+
+/* Re-layout torch weights W[Cout][Cin][k][k] into the MFMA operand order
+ * wpk[k*k][Kpad/16][Npad][16].  mode 0: forward operand (K=Cin, N=Cout).  mode 1: input-gradient
+ * operand (K=Cout, N=Cin, taps flipped).  wpk must hold k*k*Kpad*Npad floats (Kpad, Npad = K, N
+ * rounded up to 16). */
+int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t ksize, int64_t mode, tmg_stream_t st);
+
+/* out = [relu]( (conv_k(pad(act(in)); wpk) + bias) * exp(clamp(kappa,-4,ln4)) ), ksize 1 or 3,
+ * stride 1 or 2, zero or replicate padding, act = optional per-channel affine then optional ReLU.
+ * Replaces F.conv2d at flowUtils.py:246-247 (Conv2dZeros), convLSTM.py:74 and :152, glowConv.py:194
+ * and :220 (1x1), tmGlow.py:88-95,148-156,180-182 (encoder) and, with mode-1 packed weights, the
+ * autograd input-gradient of each.
+ * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate,relu_out,accumulate} */
+int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* wpk, const void* bias,
+                 const void* kappa, const void* in_scale, const void* in_shift, void* const* out_ptrs,
+                 const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
+
+/* dW[Cout][Cin][k][k] += scale * sum_pixels act(in)(p*s+tap) (x) dy(p) ; dbias += scale * sum dy.
+ * (float atomics: caller zero-fills.)  Replaces the autograd weight-gradient of the convs above.
+ * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate}; dy_desc = {stride, off} */
+int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
+                   const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, const void* kappa,
+                   const int64_t* dims, tmg_stream_t st);
+
+/* Adds the contribution of the replicate-padded ring to the border pixels of a 3x3 input gradient
+ * (adjoint of F.pad(mode='replicate'), flowUtils.py:246).  dims = {B,H,W,Cdy,Cx}; w in torch layout. */
+int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, const void* w, const void* kappa, void* const* out_ptrs,
+                            const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
+
+/* Direct input gradient for strided convs (encoder stride-2 convs, tmGlow.py:154-156,180-182).
+ * dims = {B,Hin,Win,Hout,Wout,Cin,Cout,ksize,stride,accumulate} */
+int tmg_conv_dgrad_direct(const void* dy, const int64_t* dy_desc, const void* w, void* dx, const int64_t* dx_desc,
+                          const int64_t* dims, tmg_stream_t st);
+
+/* ---- bandwidth-bound kernels (tmg_pointwise.hip) ------------------------------------------------ */
+
+/* Affine coupling apply + per-sample log-det (flowAffine.py:76-83 forward, :102-109 reverse).
+ * hh = coupling-network output, channels interleaved (shift, r).  logdet[b] += sum 2*softsign(r).
+ * dims = {B, pixels per image, C/2, reverse} */
+int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2, const int64_t* y_d,
+                     void* rsave, void* logdet, const int64_t* dims, tmg_stream_t st);
+int tmg_affine_bwd(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
+                   const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d, const int64_t* dims,
+                   tmg_stream_t st);
+
+/* ConvLSTM gates (convLSTM.py:76-83): gates [npix][4R] in order i,f,o,g are activated in place.
+ * dims = {npix, R} */
+int tmg_lstm_pointwise_fwd(void* gates, const void* c_prev, const int64_t* cprev_d, void* c_next, void* h_next,
+                           const int64_t* dims, tmg_stream_t st);
+int tmg_lstm_pointwise_bwd(void* acts, const void* c_prev, const int64_t* cprev_d, const void* c_next, const void* dh,
+                           const void* dc_in, void* dc_prev, const int64_t* dims, tmg_stream_t st);
+
+/* Diagonal Gaussian prior (flowUtils.py:176-209,274-275,307-334; top prior tmGlow.py:399-412).
+ * dims = {B, pixels per image, Ch, mode(0: log-prob of z2 [+eps out], 1: sample from eps), clip_mean}
+ * fl   = {mean_lo, mean_hi, logstd_lo, logstd_hi} */
+int tmg_gauss_fwd(const void* hz, const int64_t* hz_d, const void* zin, const int64_t* zi_d, void* zout, const int64_t* zo_d,
+                  void* logp, const int64_t* dims, const float* fl, tmg_stream_t st);
+int tmg_gauss_bwd(const void* hz, const int64_t* hz_d, const void* zin, const int64_t* zi_d, const void* dzin,
+                  const int64_t* dzi_d, const void* g, void* dzout, const int64_t* dzo_d, void* dhz, const int64_t* dh_d,
+                  const int64_t* dims, const float* fl, tmg_stream_t st);
+
+/* Checker squeeze / un-squeeze (flowUtils.py:114-122,137-145). dims = {B,h,w,C,to_small} */
+int tmg_checker(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, tmg_stream_t st);
+
+/* Bilinear align_corners=True resize (misc.py:34-35) and its adjoint. dims = {B,hi,wi,ho,wo,C} */
+int tmg_upsample_fwd(const void* src, void* dst, const int64_t* dims, tmg_stream_t st);
+int tmg_upsample_bwd(const void* dout, void* din, const int64_t* dims, tmg_stream_t st);
+
+/* Per-channel sums over pixels: BatchNorm batch moments (mode 0) and backward sums (mode 1)
+ * (nn.BatchNorm2d at denseBlock.py:49).  dims = {npix, C, mode} */
+int tmg_chan_reduce(const void* x, const int64_t* x_d, const void* g, const int64_t* g_d, const void* v0, const void* v1,
+                    const void* v2, const void* v3, void* s0, void* s1, const int64_t* dims, tmg_stream_t st);
+int tmg_bn_bwd_apply(const void* x, const int64_t* x_d, const void* g, const int64_t* g_d, const void* a, const void* bsh,
+                     const void* mean, const void* rstd, const void* gamma, const void* m0, const void* m1, void* dx,
+                     const int64_t* dx_d, const int64_t* dims, tmg_stream_t st);
+
+/* dst (+)= src * [ref > 0] + add  over n channels: ReLU-mask / concat adjoints. dims = {npix,n,accumulate} */
+int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const int64_t* r_d, const void* add,
+                   const int64_t* a_d, void* dst, const int64_t* d_d, const int64_t* dims, tmg_stream_t st);
+
+/* Growth-1 dense layer of the coupling network, C_out = 1 (denseBlock.py:135-138), forward and
+ * backward (input gradient accumulated into g segments, weight gradient accumulated atomically).
+ * dims = {B,H,W,Cin,relu_in} */
+int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out, const int64_t* out_d,
+               const int64_t* dims, tmg_stream_t st);
+int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* dW, const void* dd,
+               const int64_t* dd_d, const void* dref, const int64_t* dref_d, void* const* g_ptrs, const int64_t* g_desc,
+               int64_t ng, const int64_t* dims, tmg_stream_t st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMGLOW_HIP_H */

@@ -1,0 +1,278 @@
+"""GPU parity of every HIP primitive against a plain PyTorch fp32/fp64 CPU reference of the same op.
+Runs through the C ABI (ctypes -> libtmglow_hip.so)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import common as C  # noqa: F401  (sets sys.path)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def _back(t):
+    return t.detach().cpu().permute(0, 3, 1, 2)
+
+
+def _close(a, b, tol=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, "%s: max err %.3e (scale %.2e)" % (what, err, scale)
+
+
+CONV_CASES = [
+    # (B, H, W, seg channels, Cout, k, stride, relu_in, pad_rep, bias, kappa, relu_out)
+    (2, 8, 8, [6], 5, 3, 1, False, False, False, False, False),
+    (2, 16, 12, [4, 8, 4], 16, 3, 1, True, True, True, True, False),
+    (1, 9, 7, [3, 5, 2], 7, 3, 1, True, True, True, True, False),
+    (2, 32, 32, [8, 32, 4], 16, 3, 1, True, True, True, True, False),
+    (2, 16, 16, [16, 32, 64], 256, 3, 1, False, False, True, False, False),
+    (2, 16, 16, [20, 64], 40, 3, 1, False, False, True, False, True),
+    (2, 8, 8, [64, 32, 4], 128, 3, 1, True, True, True, True, False),
+    (2, 16, 16, [8], 16, 3, 2, True, False, False, False, False),
+    (3, 10, 6, [5], 9, 3, 2, True, False, False, False, False),
+    (2, 16, 16, [16], 16, 1, 1, False, False, True, False, False),
+    (2, 8, 12, [6, 6], 12, 1, 1, False, False, True, False, False),
+    (1, 4, 4, [128], 128, 1, 1, False, False, False, False, False),
+    (2, 12, 20, [24], 96, 3, 1, False, False, True, False, False),
+    (1, 6, 6, [160], 96, 3, 1, False, False, True, False, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_and_grads(case):
+    import tmg_ops as ops
+    B, Hh, Ww, segs, Cout, k, stride, relu_in, pad_rep, has_b, has_k, relu_out = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    xs = [torch.randn(B, c, Hh, Ww, generator=g) for c in segs]
+    w = 0.2 * torch.randn(Cout, sum(segs), k, k, generator=g)
+    b = 0.3 * torch.randn(Cout, generator=g) if has_b else None
+    kap = torch.tensor([[[[0.3]]]]) if has_k else None
+    # ---- reference (fp64 on CPU)
+    xr = [t.double().requires_grad_(True) for t in xs]
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if has_b else None
+    kr = kap.double().requires_grad_(True) if has_k else None
+    t = torch.cat(xr, 1)
+    if relu_in:
+        t = F.relu(t)
+    if k == 3:
+        t = F.pad(t, (1, 1, 1, 1), mode="replicate" if pad_rep else "constant")
+    yr = F.conv2d(t, wr, br, stride=stride)
+    if has_k:
+        yr = yr * torch.exp(torch.clamp(kr, -4.0, math.log(4.0)))
+    if relu_out:
+        yr = F.relu(yr)
+    gy = torch.randn(yr.shape, generator=g).double()
+    (yr * gy).sum().backward()
+    # ---- HIP
+    xd = [_nhwc(t_).requires_grad_(True) for t_ in xs]
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if has_b else None
+    kd = kap.to(DEV).requires_grad_(True) if has_k else None
+    y = ops.conv(xd, wd, bd, kappa=kd, ksize=k, stride=stride, relu_in=relu_in, pad_rep=pad_rep, relu_out=relu_out)
+    _close(_back(y), yr, what="conv out")
+    (y * _nhwc(gy.float())).sum().backward()
+    _close(wd.grad, wr.grad, tol=5e-5, what="dW")
+    if has_b:
+        _close(bd.grad, br.grad, tol=5e-5, what="db")
+    if has_k:
+        _close(kd.grad, kr.grad, tol=1e-4, what="dkappa")
+    for a, r in zip(xd, xr):
+        _close(_back(a.grad), r.grad, tol=5e-5, what="dx")
+
+
+def test_conv_on_channel_slice_views():
+    """Segments that are channel slices of wider NHWC buffers (the no-concat path)."""
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(2, 10, 12, 16, generator=g)  # NHWC
+    cond = torch.randn(2, 10, 12, 8, generator=g)
+    w = 0.2 * torch.randn(12, 16, 3, 3, generator=g)
+    bigd, condd = big.to(DEV), cond.to(DEV)
+    y = ops.conv([bigd[..., :8], condd], w.to(DEV), relu_in=True)
+    ref = F.conv2d(F.relu(torch.cat([big[..., :8], cond], 3).permute(0, 3, 1, 2)), w, padding=1)
+    _close(_back(y), ref, what="sliced conv")
+
+
+def test_bn_relu_conv():
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 12, 10, 14, generator=g) * 2 + 0.5
+    gamma, beta = 1 + 0.3 * torch.randn(12, generator=g), 0.2 * torch.randn(12, generator=g)
+    w = 0.2 * torch.randn(4, 12, 3, 3, generator=g)
+    xr, gr, br, wr = (t.double().requires_grad_(True) for t in (x, gamma, beta, w))
+    yr = F.conv2d(F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), wr, padding=1)
+    gy = torch.randn(yr.shape, generator=g).double()
+    (yr * gy).sum().backward()
+    xd = _nhwc(x).requires_grad_(True)
+    gd, bd, wd = (t.to(DEV).requires_grad_(True) for t in (gamma, beta, w))
+    mean, var, n = ops.batch_moments(xd.detach())
+    _close(mean, x.double().mean((0, 2, 3)), what="bn mean")
+    _close(var, x.double().var((0, 2, 3), unbiased=False), what="bn var")
+    y = ops.BNReLUConvFn.apply(xd, gd, bd, wd, mean, var, 1e-5, True)
+    _close(_back(y), yr, what="bnreluconv")
+    (y * _nhwc(gy.float())).sum().backward()
+    _close(_back(xd.grad), xr.grad, tol=1e-4, what="bn dx")
+    _close(gd.grad, gr.grad, tol=1e-4, what="dgamma")
+    _close(bd.grad, br.grad, tol=1e-4, what="dbeta")
+    _close(wd.grad, wr.grad, tol=1e-4, what="bn dW")
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_affine(reverse):
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(7)
+    B, C_, Hh, Ww = 3, 12, 6, 10
+    x = torch.randn(B, C_, Hh, Ww, generator=g)
+    hh = torch.randn(B, C_, Hh, Ww, generator=g)
+    xr, hr = x.double().requires_grad_(True), hh.double().requires_grad_(True)
+    x1, x2 = xr.chunk(2, 1)
+    shift, scale = hr[:, 0::2], torch.exp(2 * F.softsign(hr[:, 1::2]))
+    o2 = x2 / scale - shift if reverse else (x2 + shift) * scale
+    yr = torch.cat([x1, o2], 1)
+    ldr = scale.abs().log().reshape(B, -1).sum(1)
+    gy, gl = torch.randn(yr.shape, generator=g).double(), torch.randn(B, generator=g).double()
+    ((yr * gy).sum() + (ldr * gl).sum()).backward()
+    xd, hd = _nhwc(x).requires_grad_(True), _nhwc(hh).requires_grad_(True)
+    y, ld = ops.AffineFn.apply(hd, xd, reverse)
+    _close(_back(y), yr, what="affine y")
+    _close(ld, ldr, what="affine logdet")
+    ((y * _nhwc(gy.float())).sum() + (ld * gl.float().to(DEV)).sum()).backward()
+    _close(_back(xd.grad), xr.grad, what="affine dx")
+    _close(_back(hd.grad), hr.grad, what="affine dh")
+
+
+@pytest.mark.parametrize("with_c", [True, False])
+def test_lstm_pointwise(with_c):
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(9)
+    B, R, Hh, Ww = 2, 6, 5, 7
+    gates = torch.randn(B, 4 * R, Hh, Ww, generator=g)
+    c = torch.randn(B, R, Hh, Ww, generator=g)
+    gr = gates.double().requires_grad_(True)
+    cr = c.double().requires_grad_(True)
+    i, f, o, gg = torch.split(gr, R, 1)
+    cn = torch.sigmoid(f) * (cr if with_c else 0) + torch.sigmoid(i) * torch.tanh(gg)
+    hn = torch.sigmoid(o) * torch.tanh(cn)
+    w1, w2 = torch.randn(hn.shape, generator=g).double(), torch.randn(hn.shape, generator=g).double()
+    ((hn * w1).sum() + (cn * w2).sum()).backward()
+    gd = _nhwc(gates).requires_grad_(True)
+    cd = _nhwc(c).requires_grad_(True) if with_c else None
+    h2, c2 = ops.LSTMPointwiseFn.apply(gd, cd)
+    _close(_back(h2), hn, what="h")
+    _close(_back(c2), cn, what="c")
+    ((h2 * _nhwc(w1.float())).sum() + (c2 * _nhwc(w2.float())).sum()).backward()
+    _close(_back(gd.grad), gr.grad, what="dgates")
+    if with_c:
+        _close(_back(cd.grad), cr.grad, what="dc_prev")
+
+
+@pytest.mark.parametrize("clip", [1, 0])
+def test_gauss_logp_and_sample(clip):
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(11)
+    B, Ch, Hh, Ww = 3, 5, 4, 6
+    hz = 1.5 * torch.randn(B, 2 * Ch, Hh, Ww, generator=g)
+    z2 = torch.randn(B, Ch, Hh, Ww, generator=g)
+    limits = ops.SPLIT_LIMITS if clip else ops.TOP_LIMITS
+
+    def prior(h):
+        if clip:
+            h = F.hardtanh(h, -2.0, math.log(5.0))
+        m, s = h.chunk(2, 1)
+        return m, s.clamp(-10.0, math.log(5.0))
+
+    hr, zr = hz.double().requires_grad_(True), z2.double().requires_grad_(True)
+    m, s = prior(hr)
+    lp = (-0.5 * (math.log(2 * math.pi) + 2 * s + (zr - m) ** 2 / torch.exp(2 * s))).reshape(B, -1).sum(1)
+    epsr = (zr - m) / torch.exp(s)
+    gl = torch.randn(B, generator=g).double()
+    (lp * gl).sum().backward()
+    hd, zd = _nhwc(hz).requires_grad_(True), _nhwc(z2).requires_grad_(True)
+    logp, eps = ops.GaussLogpFn.apply(hd, zd, clip, limits, True)
+    _close(logp, lp, what="logp")
+    _close(_back(eps), epsr, what="eps")
+    (logp * gl.float().to(DEV)).sum().backward()
+    _close(_back(hd.grad), hr.grad, what="dhz")
+    _close(_back(zd.grad), zr.grad, what="dz2")
+    # sample direction
+    hr2 = hz.double().requires_grad_(True)
+    m, s = prior(hr2)
+    e = torch.randn(B, Ch, Hh, Ww, generator=g)
+    zs = m + torch.exp(s) * e.double()
+    lps = (-0.5 * (math.log(2 * math.pi) + 2 * s + (zs - m) ** 2 / torch.exp(2 * s))).reshape(B, -1).sum(1)
+    gz = torch.randn(zs.shape, generator=g).double()
+    ((zs * gz).sum() + (lps * gl).sum()).backward()
+    hd2 = _nhwc(hz).requires_grad_(True)
+    z_, lp_ = ops.GaussSampleFn.apply(hd2, _nhwc(e), clip, limits)
+    _close(_back(z_), zs, what="sample z")
+    _close(lp_, lps, what="sample logp")
+    ((z_ * _nhwc(gz.float())).sum() + (lp_ * gl.float().to(DEV)).sum()).backward()
+    _close(_back(hd2.grad), hr2.grad, what="sample dhz")
+
+
+def test_checker_and_upsample():
+    import tmg_ops as ops
+    from oracle import tmglow_oracle as O
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 3, 8, 12, generator=g)
+    xd = _nhwc(x).requires_grad_(True)
+    y = ops.CheckerFn.apply(xd, True)
+    ref = O.checker_squeeze(x)
+    assert torch.equal(_back(y), ref)
+    gy = torch.randn(ref.shape, generator=g)
+    (y * _nhwc(gy)).sum().backward()
+    assert torch.equal(_back(xd.grad), O.checker_unsqueeze(gy))
+    back = ops.CheckerFn.apply(y.detach(), False)
+    assert torch.equal(_back(back), x)
+    for (h, w, sc) in [(5, 7, 2), (8, 8, 2), (3, 4, 4), (1, 6, 2)]:
+        x = torch.randn(2, 4, h, w, generator=g)
+        xr = x.double().requires_grad_(True)
+        yr = F.interpolate(xr, scale_factor=sc, mode="bilinear", align_corners=True)
+        gy = torch.randn(yr.shape, generator=g).double()
+        (yr * gy).sum().backward()
+        xd = _nhwc(x).requires_grad_(True)
+        y = ops.UpsampleFn.apply(xd, sc)
+        _close(_back(y), yr, what="upsample")
+        (y * _nhwc(gy.float())).sum().backward()
+        _close(_back(xd.grad), xr.grad, what="upsample bwd")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, [8, 32]), (1, 7, 9, [6, 5]), (2, 32, 32, [8, 32, 4]), (2, 12, 12, [40])])
+def test_c1_forward_and_backward(shape):
+    import tmg_hip as Hh_
+    B, Hh, Ww, segs = shape
+    g = torch.Generator().manual_seed(17)
+    xs = [torch.randn(B, c, Hh, Ww, generator=g) for c in segs]
+    cin = sum(segs)
+    w = 0.2 * torch.randn(1, cin, 3, 3, generator=g)
+    xr = [t.double().requires_grad_(True) for t in xs]
+    wr = w.double().requires_grad_(True)
+    act = F.relu(torch.cat(xr, 1))
+    act.retain_grad()
+    yr = F.conv2d(act, wr, padding=1)
+    dref = torch.randn(yr.shape, generator=g).double()       # pre-activation of the produced channel
+    dd = torch.randn(yr.shape, generator=g).double()
+    (yr * (dd * (dref > 0))).sum().backward()
+    xd = [_nhwc(t) for t in xs]
+    wd = w.to(DEV).reshape(cin, 9).contiguous()
+    out = torch.zeros(B, Hh, Ww, 4, device=DEV)
+    Hh_.c1_fwd(xd, wd, out[..., 1:2], relu_in=True)
+    _close(out[..., 1].cpu(), yr[:, 0], what="c1 fwd")
+    assert float(out[..., 0].abs().max()) == 0 and float(out[..., 2:].abs().max()) == 0
+    dW = torch.zeros(cin, 9, device=DEV)
+    gs = [torch.zeros_like(t) for t in xd]
+    ddn, drn = _nhwc(dd.float()), _nhwc(dref.float())
+    Hh_.c1_bwd(xd, wd, dW, ddn, drn, gs, relu_in=True)
+    _close(dW.cpu().reshape(1, cin, 3, 3), wr.grad, tol=5e-5, what="c1 dW")
+    got = torch.cat([_back(t) for t in gs], 1)
+    _close(got, act.grad, tol=5e-5, what="c1 raw input grad")

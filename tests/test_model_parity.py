@@ -1,0 +1,188 @@
+"""GPU parity of the assembled TM-Glow HIP path against the golden fixtures (outputs of the reference
+itself) and against the CPU oracle, through the drop-in module API."""
+import numpy as np
+import pytest
+import torch
+
+import common as C
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(cfg, sd):
+    from nn.tmGlow import TMGlow
+    m = TMGlow(**C.build_kwargs(cfg))
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).train()
+
+
+def _grads(m):
+    return {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_model.npz", C.CFG_TINY), ("tiny3_model.npz", C.CFG_TINY3)])
+def test_forward_reverse_and_grads_match_reference(name, cfg):
+    d = C.load_npz(name)
+    L = len(cfg["glow_blocks"])
+    sd = {k: torch.from_numpy(v) for k, v in C.sub(d, "sd.").items()}
+    m = _model(cfg, sd)
+    x, y = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["y"]).to(DEV)
+    h_in = C.states_from(d, "h_in.", L, DEV)
+    z, logp, h_out, eps = m.forward(x, y, h_in, return_eps=True)
+    assert z.shape == tuple(d["fwd.z"].shape)
+    C.assert_field(z, d["fwd.z"], "z")
+    C.assert_logdet(logp, d["fwd.logp"], "logp")
+    for i in range(L):
+        C.assert_field(h_out[i][0], d["fwd.h_out.%d.h" % i], "h_out", atol=C.STATE_ATOL)
+        C.assert_field(h_out[i][1], d["fwd.h_out.%d.c" % i], "c_out", atol=C.STATE_ATOL)
+    for i in range(L + 1):
+        C.assert_field(eps[i], d["fwd.eps.%d" % i], "eps%d" % i)
+    C.loss_forward(logp, y).backward()
+    C.assert_grads(_grads(m), C.sub(d, "fwd.grad."), "fwd grads")
+
+    m = _model(cfg, sd)
+    eps_in = [torch.from_numpy(d["fwd.eps.%d" % i]).to(DEV) for i in range(L + 1)]
+    yr, logdet, h_out2 = m.reconstruct(x, h_in, eps_in)
+    C.assert_field(yr, d["rev.y"], "y_rec")
+    C.assert_logdet(logdet, d["rev.logdet"], "logdet")
+    for i in range(L):
+        C.assert_field(h_out2[i][0], d["rev.h_out.%d.h" % i], "h_out", atol=C.STATE_ATOL)
+        C.assert_field(h_out2[i][1], d["rev.h_out.%d.c" % i], "c_out", atol=C.STATE_ATOL)
+    C.loss_reverse(yr, logdet).backward()
+    C.assert_grads(_grads(m), C.sub(d, "rev.grad."), "rev grads")
+    # dead parameters of the reference stay dead
+    assert all(p.grad is None for k, p in m.named_parameters() if ".norm2." in k)
+    # invertibility (the reference's own self-test property)
+    assert float((yr.detach() - y).abs().max()) < 5e-4
+
+
+def test_cfg1_seeded_model_matches_reference():
+    """BASELINE configs[0] widths (L=3, K=16, Cc=32, R=64): weights are re-created from the seeds and the
+    perturbation recipe, checked by checksum against the reference's, then outputs are compared."""
+    from nn.tmGlow import TMGlow
+    d = C.load_npz("cfg1_model.npz")
+    cfg = C.CFG1
+    L = 3
+    C.seed_all(12345)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, 0.004, 0.02, 0.004)
+    cs = C.tensor_checksums(m.state_dict())
+    for k, v in zip(d["sd_checksum_keys"], d["sd_checksum_vals"]):
+        assert abs(cs[str(k)] - v) <= 1e-6 * abs(v) + 1e-9, k
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(DEV).train()
+    x, y = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["y"]).to(DEV)
+    B = x.shape[0]
+    h_in = m.initLSTMStates(torch.arange(B), [y.shape[2], y.shape[3]])
+    z, logp, h_out, eps = m.forward(x, y, h_in, return_eps=True)
+    C.assert_field(z, d["fwd.z"], "z")
+    C.assert_logdet(logp, d["fwd.logp"], "logp")
+    C.loss_forward(logp, y).backward()
+    gn = {k: float(p.grad.double().norm()) for k, p in m.named_parameters() if p.grad is not None}
+    for k, v in zip(d["fwd.gradnorm_keys"], d["fwd.gradnorm_vals"]):
+        assert abs(gn[str(k)] - v) <= 1e-2 * v + 1e-7, (k, gn[str(k)], v)
+    m.load_state_dict(sd0)
+    m.zero_grad()
+    yr, logdet, _ = m.reconstruct(x, h_in, [e.detach() for e in eps])
+    C.assert_field(yr, d["rev.y"], "y_rec")
+    C.assert_logdet(logdet, d["rev.logdet"], "logdet")
+    C.loss_reverse(yr, logdet).backward()
+    gn = {k: float(p.grad.double().norm()) for k, p in m.named_parameters() if p.grad is not None}
+    for k, v in zip(d["rev.gradnorm_keys"], d["rev.gradnorm_vals"]):
+        assert abs(gn[str(k)] - v) <= 1e-2 * v + 1e-7, (k, gn[str(k)], v)
+
+
+def test_flow_level_module_matches_reference():
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+    d = C.load_npz("modules.npz")
+    blk = LSTMFLowBlock(2, 3, 5, 3, LUdecompose=True, train_sampling=True, do_split=True, squeeze_type=0)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in C.sub(d, "level.sd.").items()}, strict=True)
+    blk.to(DEV)
+    t = lambda k: torch.from_numpy(d[k]).to(DEV)  # noqa: E731
+    x, cond, h, c = (t(k).requires_grad_(True) for k in ("level.x", "level.cond", "level.h", "level.c"))
+    z, ld, st, eps = blk.forward(x, cond, (h, c), return_eps=True)
+    C.assert_field(z, d["level.fwd.z"], atol=2e-5)
+    C.assert_logdet(ld, d["level.fwd.logdet"])
+    C.assert_field(eps, d["level.fwd.eps"], atol=2e-5)
+    loss = (z * t("level.wz")).sum() + ld.sum() * 0.01 + (st[0] * t("level.wh")).sum() + (st[1] * t("level.wc")).sum()
+    loss.backward()
+    got = {k: p.grad for k, p in blk.named_parameters() if p.grad is not None}
+    got.update({"@dx": x.grad, "@dcond": cond.grad, "@dh": h.grad, "@dc": c.grad})
+    ref = C.sub(d, "level.fwd.grad.")
+    ref.update({"@dx": d["level.fwd.dx"], "@dcond": d["level.fwd.dcond"], "@dh": d["level.fwd.dh"], "@dc": d["level.fwd.dc"]})
+    C.assert_grads(got, ref, "level fwd grads")
+    blk.zero_grad()
+    for v in (cond, h, c):
+        v.grad = None
+    zin = t("level.fwd.z").requires_grad_(True)
+    xr, ldr, st2 = blk.reverse(zin, cond, (h, c), eps=t("level.fwd.eps"))
+    C.assert_field(xr, d["level.rev.x"], atol=2e-5)
+    C.assert_logdet(ldr, d["level.rev.logdet"])
+    loss = (xr * t("level.wx")).sum() + ldr.sum() * 0.01 + (st2[0] * t("level.wh")).sum() + (st2[1] * t("level.wc")).sum()
+    loss.backward()
+    got = {k: p.grad for k, p in blk.named_parameters() if p.grad is not None}
+    got.update({"@dz": zin.grad, "@dcond": cond.grad, "@dh": h.grad, "@dc": c.grad})
+    ref = C.sub(d, "level.rev.grad.")
+    ref.update({"@dz": d["level.rev.dz"], "@dcond": d["level.rev.dcond"], "@dh": d["level.rev.dh"], "@dc": d["level.rev.dc"]})
+    C.assert_grads(got, ref, "level rev grads")
+
+
+def test_standalone_primitives_match_oracle():
+    """ActNorm, InvertibleConv1x1LU, plain InvertibleConv1x1, Conv2dZeros, CheckerSqueeze, Squeeze stand-alone."""
+    from nn.modules.actNorm import ActNorm
+    from nn.modules.glowConv import InvertibleConv1x1, InvertibleConv1x1LU
+    from nn.modules.flowUtils import Conv2dZeros, Squeeze
+    from oracle import tmglow_oracle as O
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 8, 6, 10, generator=g)
+    an = ActNorm(8)
+    with torch.no_grad():
+        an.weight.add_(0.3 * torch.randn(8, 1, 1, generator=g))
+        an.bias.add_(0.3 * torch.randn(8, 1, 1, generator=g))
+    P = {"weight": an.weight.detach().clone(), "bias": an.bias.detach().clone()}
+    an.to(DEV)
+    for rev in (False, True):
+        y, ld = (an.reverse if rev else an.forward)(x.to(DEV))
+        yo, ldo = O.actnorm(P, "", x, rev)
+        C.assert_field(y, yo, atol=1e-5)
+        assert abs(float(ld) - float(ldo)) < 1e-3
+    C.seed_all(5)
+    lu = InvertibleConv1x1LU(8)
+    P = {k: v.detach().clone() for k, v in lu.state_dict().items()}
+    lu.to(DEV)
+    for rev in (False, True):
+        y, ld = (lu.reverse if rev else lu.forward)(x.to(DEV))
+        yo, ldo = O.invconv_lu(P, "", x, rev)
+        C.assert_field(y, yo, atol=1e-5)
+        assert abs(float(ld) - float(ldo)) < 1e-3
+    d = C.load_npz("modules.npz")
+    for ts in (1, 0):
+        tag = "plain1x1.ts%d." % ts
+        pl = InvertibleConv1x1(6, train_sampling=bool(ts))
+        with torch.no_grad():
+            pl.weight.copy_(torch.from_numpy(d[tag + "weight"]))
+        pl.to(DEV)
+        xx = torch.from_numpy(d[tag + "x"]).to(DEV)
+        y, ld = pl.forward(xx)
+        C.assert_field(y, d[tag + "fwd.y"], atol=1e-5)
+        assert abs(float(ld) - float(d[tag + "fwd.logdet"])) < 1e-3
+        y, ld = pl.reverse(xx)
+        C.assert_field(y, d[tag + "rev.y"], atol=1e-5)
+    zc = Conv2dZeros(8, 6)
+    with torch.no_grad():
+        zc.conv.weight.copy_(0.2 * torch.randn(6, 8, 3, 3, generator=g))
+        zc.conv.bias.copy_(0.2 * torch.randn(6, generator=g))
+        zc.scale.fill_(0.4)
+    P = {k: v.detach().clone() for k, v in zc.state_dict().items()}
+    zc.to(DEV)
+    C.assert_field(zc(x.to(DEV)), O.zero_conv(P, "", x), atol=1e-5)
+    sq = Squeeze(2)
+    xs = torch.from_numpy(d["squeeze.x"])
+    assert np.array_equal(sq(xs).numpy(), d["squeeze.y"]) and np.array_equal(sq.reverse(sq(xs)).numpy(), d["squeeze.x"])
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from nn.modules.flowUtils import Conv2dZeros
+    with pytest.raises(RuntimeError):
+        Conv2dZeros(4, 4)(torch.randn(1, 4, 4, 4))
