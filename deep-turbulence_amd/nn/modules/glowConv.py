@@ -8,6 +8,45 @@ import tmg_hip as H
 import tmg_ops as ops
 
 
+class _TriInv(torch.autograd.Function):
+    """Inverse of a triangular [C,C] parameter matrix.  Forward is one triangular solve against I;
+    backward is the closed form dA = -X^T G X^T as two tiny matmuls (ROCm's solve_triangular
+    backward gave wrong gradients on gfx950, matmul does not)."""
+
+    @staticmethod
+    def forward(ctx, a, upper):
+        eye = torch.eye(a.shape[0], device=a.device, dtype=a.dtype)
+        x = torch.linalg.solve_triangular(a.detach(), eye, upper=upper)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        xt = x.t()
+        return -(xt @ g @ xt), None
+
+
+def _host_inverse_fp64(w):
+    """General inverse for the plain (non-LU) variant, which is off the TM-Glow path: done on the host in
+    fp64 as the reference does (glowConv.py:58), gradient by the closed form."""
+    return _HostInv.apply(w)
+
+
+class _HostInv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        x = torch.inverse(w.detach().double().cpu()).float().to(w.device)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        xt = x.t()
+        return -(xt @ g @ xt)
+
+
 def _mix(x, w, bias=None):
     c = w.shape[0]
     return H.nchw(ops.conv([H.nhwc(x)], w.reshape(c, c, 1, 1), bias, ksize=1))
@@ -27,14 +66,15 @@ class InvertibleConv1x1(nn.Module):
         self.weight = nn.Parameter(torch.Tensor(w_init))
 
     def _matrix(self, inverse):
-        return torch.inverse(self.weight.double()).float() if inverse else self.weight
+        return _host_inverse_fp64(self.weight) if inverse else self.weight
 
     def log_determinant(self, x, W):
         h, w = x.shape[2:]
-        det = torch.det(W.to(torch.float64)).to(torch.float32)
+        # O(C^3) scalar bookkeeping on the host in fp64, as the reference (glowConv.py:98-101)
+        det = torch.det(W.detach().to(torch.float64).cpu()).to(torch.float32)
         if det.item() == 0:
             det = det + 1e-6
-        return h * w * det.abs().log()
+        return (h * w * det.abs().log()).to(W.device)
 
     def forward(self, x):
         W = self._matrix(self.train_sampling)
@@ -86,8 +126,11 @@ class InvertibleConv1x1LU(nn.Module):
         return self.p @ (lower @ upper)
 
     def inv_weight(self):
+        """W^-1 = U^-1 L^-1 P^-1 (reference glowConv.py:171-174).  The reference takes three general
+        `inverse()`s; the factors are triangular and P is a permutation, so two triangular inverses times
+        P^T give the same matrix (to fp32 rounding) without a pivoted GPU factorisation."""
         lower, upper = self._factors()
-        return torch.inverse(upper) @ (torch.inverse(lower) @ torch.inverse(self.p))
+        return _TriInv.apply(upper, True) @ (_TriInv.apply(lower, False) @ self.p.t())
 
     def matrix(self, reverse):
         """Effective channel-mix matrix of the requested direction."""

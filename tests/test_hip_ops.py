@@ -51,7 +51,7 @@ CONV_CASES = [
 def test_conv_forward_and_grads(case):
     import tmg_ops as ops
     B, Hh, Ww, segs, Cout, k, stride, relu_in, pad_rep, has_b, has_k, relu_out = case
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(sum(segs) * 7 + Cout + Hh)
     xs = [torch.randn(B, c, Hh, Ww, generator=g) for c in segs]
     w = 0.2 * torch.randn(Cout, sum(segs), k, k, generator=g)
     b = 0.3 * torch.randn(Cout, generator=g) if has_b else None
