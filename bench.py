@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- flow-field samples/s through the full TM-Glow generative step on MI355X.
+
+One *step* = one batch through one time-step of `TMGlow.sample` (the direction main.py trains through)
+-> scalar loss mean(y^2) + mean(logdet)/(noc*H*W) -> backward -> [gradient all-reduce] -> Adam(amsgrad).
+Workload at N=1: the metric configuration of BASELINE.json (256x256x4 output, 4 flow levels, K=16,
+64 samples per GPU).  `value` = global samples / s with inputs resident in HBM.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+The JSON line also carries
+  roofline:     the dominant kernel's algorithmic TFLOP/s (HIP events on the launch stream, live in the
+                timed region) against the fp32 matrix peak of gfx950 (157.3 TFLOP/s)
+  cpu_baseline: the CPU oracle (oracle/tmglow_oracle.py, a port of the reference's torch-CPU path) timed on
+                this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+import common as C  # noqa: E402
+
+CONFIGS = {"M": C.CFG_M, "cfg1": C.CFG1, "cfg2": C.CFG2, "cfg3": C.CFG3, "cfg5": C.CFG5, "tiny": C.CFG_TINY}
+DEFAULT_BATCH = {"M": 64, "cfg1": 8, "cfg2": 32, "cfg3": 64, "cfg5": 64, "tiny": 2}
+GFLOP_PER_SAMPLE = {"M": 63.72, "cfg1": 2.81, "cfg2": 12.95, "cfg3": 31.86, "cfg5": 267.45}  # SURVEY 8-D, fwd+bwd
+PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+
+
+def build_model(cfg, device):
+    from nn.tmGlow import TMGlow
+    C.seed_all(12345)
+    model = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(model, 7, 0.004, 0.02, 0.004)
+    return model.to(device).train()
+
+
+def cpu_baseline(cfg, name, budget_s=25.0):
+    """The oracle on the host cores: sample direction + backward + Adam on a bounded sample of the workload."""
+    from oracle import tmglow_oracle as O
+    from nn.tmGlow import TMGlow
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    C.seed_all(12345)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, 0.004, 0.02, 0.004)
+    P = O.params_from_state_dict(m.state_dict())
+    del m
+    params = list(O.trainable(P).values())
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    Hin, Win = cfg["_in_hw"]
+    up = cfg["_up"]
+    B = 2
+    L = len(cfg["glow_blocks"])
+    g = torch.Generator().manual_seed(12345)
+    x = torch.randn(B, cfg["in_features"], Hin, Win, generator=g)
+    st = O.init_lstm_states(cfg, torch.arange(B), [Hin * up, Win * up])
+
+    def step():
+        opt.zero_grad()
+        y, ld, _ = O.tmglow_sample(P, cfg, x, st)
+        C.loss_reverse(y, ld).backward()
+        opt.step()
+
+    t0 = time.time()
+    step()  # warm-up (allocator, thread pool)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 + warm) < budget_s * 0.6:
+        step()
+        n += 1
+        if n >= 20:
+            break
+    dt = time.time() - t0
+    return {"value": B * n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "config %s at batch %d, %d timed step(s) after 1 warm-up, torch CPU fp32, sample()+backward+Adam" % (name, B, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="M", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP-event timing")
+    args = ap.parse_args()
+
+    import tmg_dist
+    import tmg_hip
+    rank, world, local = tmg_dist.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU product path"
+    tmg_hip.lib()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = CONFIGS[args.config]
+    B = args.batch or DEFAULT_BATCH[args.config]
+    model = build_model(cfg, dev)
+    tmg_dist.broadcast_parameters(model)
+    bucket = tmg_dist.GradBucket(model.parameters()) if world > 1 else None
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    Hin, Win = cfg["_in_hw"]
+    up = cfg["_up"]
+    g = torch.Generator().manual_seed(12345 + rank)
+    x = torch.randn(B, cfg["in_features"], Hin, Win, generator=g).to(dev)
+    states = model.initLSTMStates(torch.arange(B) + rank * B, [Hin * up, Win * up])
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y, ld, _ = model.sample(x, states)
+        loss = C.loss_reverse(y, ld)
+        loss.backward()
+        if bucket is not None:
+            bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_events:
+        tmg_hip.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if not args.no_events:
+        tmg_hip.prof_enable(False) if False else None
+        prof = tmg_hip.prof_collect()
+        tmg_hip.prof_enable(False)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        return
+    value = B * world * args.steps / dt
+    roof = None
+    if prof:
+        name, (cnt, ms, fl) = max(prof.items(), key=lambda kv: kv[1][1])
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TF, 4), "traffic": None, "launches": cnt,
+                "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2), "time_share_of_step": round(ms * 1e-3 / dt, 4),
+                "all_contraction_kernels": {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
+                                            for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+        if args.config in GFLOP_PER_SAMPLE:
+            e2e = value / world * GFLOP_PER_SAMPLE[args.config] / 1e3
+            roof["end_to_end_tflops_per_gpu"] = round(e2e, 2)
+            roof["end_to_end_frac"] = round(e2e / PEAK_FP32_MFMA_TF, 4)
+    out = {"metric": "flow-field samples/sec (fwd+log-det+bwd), 64x256x256x4" if args.config == "M" else "flow-field samples/sec (fwd+log-det+bwd)",
+           "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "tmglow %s: sample()+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
+               args.config, Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
+               "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss)},
+           "roofline": roof}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, args.config)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

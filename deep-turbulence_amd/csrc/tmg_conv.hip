@@ -420,6 +420,46 @@ __global__ void conv_dgrad_direct_kernel(const float* __restrict__ dy, int dy_st
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+#include <vector>
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline line).
+struct ProfRec { hipEvent_t a, b; int kid; double flops; };
+static std::vector<ProfRec> g_prof;
+static int g_prof_on = 0;
+static const char* const g_prof_names[] = {
+    "conv_mfma_kernel<4,1,4,1>", "conv_mfma_kernel<4,2,4,1>", "conv_mfma_kernel<4,3,4,1>", "conv_mfma_kernel<4,4,4,1>",
+    "conv_mfma_kernel<4,3,2,2>", "conv_mfma_kernel<4,4,2,2>", "conv_mfma_kernel<4,3,1,4>", "conv_mfma_kernel<4,4,1,4>",
+    "conv_wgrad_kernel<8,1>", "conv_wgrad_kernel<8,2>", "conv_wgrad_kernel<8,4>", "conv_wgrad_kernel<16,1>", "conv_wgrad_kernel<16,2>"};
+#define TMG_NPROF 13
+
+struct ProfScope {
+    ProfRec r; bool on; hipStream_t st;
+    ProfScope(int kid, double flops, hipStream_t s) : on(g_prof_on != 0 && g_prof.size() < 400000), st(s) {
+        if (on) { r.kid = kid; r.flops = flops; (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, st); }
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); } }
+};
+
+extern "C" int tmg_prof_enable(int64_t on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = (int)on;
+    return 0;
+}
+
+// out[kid*3 + {0,1,2}] = {launch count, total ms, total algorithmic flops}; returns number of kernel ids
+extern "C" int tmg_prof_collect(double* out, int64_t nk) {
+    for (int i = 0; i < (int)nk * 3; ++i) out[i] = 0.0;
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        if (r.kid < nk) { out[r.kid * 3] += 1.0; out[r.kid * 3 + 1] += ms; out[r.kid * 3 + 2] += r.flops; }
+    }
+    return TMG_NPROF;
+}
+
+extern "C" const char* tmg_prof_name(int64_t kid) { return (kid >= 0 && kid < TMG_NPROF) ? g_prof_names[kid] : ""; }
+
 static inline int ilog2_ceil(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -435,6 +475,8 @@ static int launch_conv(const ConvP& p, int gy, size_t lds_bytes, hipStream_t st)
         attr_set = true;
     }
     dim3 grid(p.B * p.tiles_x * p.tiles_y, gy, 1);
+    const int kid = (WM == 4 ? NTW - 1 : (WM == 2 ? NTW + 1 : NTW + 3));
+    ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NTW, WM, WN>), grid, dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
@@ -544,6 +586,8 @@ static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_
                             160 * 1024);
         attr_set = true;
     }
+    const int kid = 8 + (NP == 8 ? (NCO == 1 ? 0 : (NCO == 2 ? 1 : 2)) : (NCO == 1 ? 3 : 4));
+    ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO>), grid, dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;

@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_fwd", "tmg_conv_wgrad", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd",
+    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_prof_enable", "tmg_prof_collect",
 ]
 
 
@@ -57,6 +57,24 @@ def lib():
         for name in EXPORTS:
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
+
+
+def prof_enable(on):
+    lib().tmg_prof_enable(c_i64(1 if on else 0))
+
+
+def prof_collect():
+    """{kernel name: (launches, total ms, total algorithmic flops)} of the event-timed contraction kernels."""
+    l = lib()
+    l.tmg_prof_name.restype = ctypes.c_char_p
+    nk = 32
+    buf = (ctypes.c_double * (3 * nk))()
+    n = l.tmg_prof_collect(buf, c_i64(nk))
+    out = {}
+    for k in range(n):
+        if buf[3 * k] > 0:
+            out[l.tmg_prof_name(c_i64(k)).decode()] = (int(buf[3 * k]), buf[3 * k + 1], buf[3 * k + 2])
+    return out
 
 
 def _stream():

@@ -66,6 +66,12 @@ int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, const void* 
 int tmg_conv_dgrad_direct(const void* dy, const int64_t* dy_desc, const void* w, void* dx, const int64_t* dx_desc,
                           const int64_t* dims, tmg_stream_t st);
 
+/* Optional per-launch HIP-event timing of the contraction kernels on their launch stream (used by
+ * bench.py's roofline line).  enable(1) clears and starts recording, enable(0) stops.
+ * collect: out[kid*3+{0,1,2}] = {launches, total ms, total algorithmic flops}; returns #kernel ids. */
+int tmg_prof_enable(int64_t on);
+int tmg_prof_collect(double* out, int64_t nk);
+
 /* ---- bandwidth-bound kernels (tmg_pointwise.hip) ------------------------------------------------ */
 
 /* Affine coupling apply + per-sample log-det (flowAffine.py:76-83 forward, :102-109 reverse).
