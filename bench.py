@@ -44,12 +44,12 @@ def build_model(cfg, device):
     return model.to(device).train()
 
 
-def cpu_baseline(cfg, name, budget_s=25.0):
-    """The oracle on the host cores: sample direction + backward + Adam on a bounded sample of the workload."""
+def _cpu_baseline_worker(name, threads, B, max_steps, budget_s):
+    """Runs in a child process: the oracle on `threads` host threads."""
     from oracle import tmglow_oracle as O
     from nn.tmGlow import TMGlow
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cfg = CONFIGS[name]
+    torch.set_num_threads(threads)
     C.seed_all(12345)
     m = TMGlow(**C.build_kwargs(cfg))
     C.perturb_(m, 7, 0.004, 0.02, 0.004)
@@ -59,8 +59,6 @@ def cpu_baseline(cfg, name, budget_s=25.0):
     opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-8, amsgrad=True)
     Hin, Win = cfg["_in_hw"]
     up = cfg["_up"]
-    B = 2
-    L = len(cfg["glow_blocks"])
     g = torch.Generator().manual_seed(12345)
     x = torch.randn(B, cfg["in_features"], Hin, Win, generator=g)
     st = O.init_lstm_states(cfg, torch.arange(B), [Hin * up, Win * up])
@@ -71,18 +69,32 @@ def cpu_baseline(cfg, name, budget_s=25.0):
         C.loss_reverse(y, ld).backward()
         opt.step()
 
-    t0 = time.time()
     step()  # warm-up (allocator, thread pool)
-    warm = time.time() - t0
     n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t0 + warm) < budget_s * 0.6:
+    while n < max_steps and (n == 0 or time.time() - t0 < budget_s):
         step()
         n += 1
-        if n >= 20:
-            break
     dt = time.time() - t0
-    return {"value": B * n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "config %s at batch %d, %d timed step(s) after 1 warm-up, torch CPU fp32, sample()+backward+Adam" % (name, B, n)}
+    print(json.dumps({"value": B * n / dt, "steps": n, "batch": B, "threads": threads}))
+
+
+def cpu_baseline(name, hard_timeout_s=240):
+    """The CPU oracle (a port of the reference's torch-CPU path) on this box's host cores, on a bounded
+    sample of the same workload: sample() + backward + Adam.  Runs in a child process under a hard timeout;
+    thread count capped at 32 (more threads are slower on these small convolutions)."""
+    import subprocess
+    threads = max(1, min(32, os.cpu_count() or 1))
+    B = 2 if name in ("M", "cfg3", "cfg5") else DEFAULT_BATCH[name]
+    code = "import bench; bench._cpu_baseline_worker(%r, %d, %d, 4, 20.0)" % (name, threads, B)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=hard_timeout_s)
+        res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"value": round(res["value"], 4), "unit": "samples/s", "cores": threads, "kind": "port",
+                "sample": "config %s at batch %d, %d timed step(s) after 1 warm-up, torch CPU fp32 oracle, sample()+backward+Adam"
+                          % (name, res["batch"], res["steps"])}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "failed: %s" % type(e).__name__}
 
 
 def main():
@@ -143,7 +155,6 @@ def main():
     dt = time.perf_counter() - t0
     prof = {}
     if not args.no_events:
-        tmg_hip.prof_enable(False) if False else None
         prof = tmg_hip.prof_collect()
         tmg_hip.prof_enable(False)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -175,7 +186,7 @@ def main():
                "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss)},
            "roofline": roof}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, args.config)
+        out["cpu_baseline"] = cpu_baseline(args.config)
     print(json.dumps(out))
 
 
