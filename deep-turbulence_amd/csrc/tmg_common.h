@@ -61,18 +61,21 @@ __device__ __forceinline__ float4 load_in4(const P& p, int b, int iy, int ix, in
     }
     if (c >= p.Cin) return v;
     const size_t pix = ((size_t)b * p.Hin + iy) * p.Win + ix;
+    // segment lookup by value (no pointer into the kernel-argument struct: keeps it out of scratch)
+    const int n0 = p.in[0].n, n1 = p.in[1].n;
     if (p.vec4) {
         int cl = c;
-        const TmgSeg* s = &p.in[0];
-        if (cl >= s->n) {
-            cl -= s->n;
-            s = &p.in[1];
-            if (cl >= s->n) {
-                cl -= s->n;
-                s = &p.in[2];
+        const float* sp = p.in[0].p;
+        int ss = p.in[0].stride, so = p.in[0].off;
+        if (cl >= n0) {
+            cl -= n0;
+            sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+            if (cl >= n1) {
+                cl -= n1;
+                sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
             }
         }
-        v = *reinterpret_cast<const float4*>(s->p + pix * s->stride + s->off + cl);
+        v = *reinterpret_cast<const float4*>(sp + pix * ss + so + cl);
     } else {
         float t[4];
 #pragma unroll
@@ -80,16 +83,17 @@ __device__ __forceinline__ float4 load_in4(const P& p, int b, int iy, int ix, in
             int cl = c + e;
             float x = 0.f;
             if (cl < p.Cin) {
-                const TmgSeg* s = &p.in[0];
-                if (cl >= s->n) {
-                    cl -= s->n;
-                    s = &p.in[1];
-                    if (cl >= s->n) {
-                        cl -= s->n;
-                        s = &p.in[2];
+                const float* sp = p.in[0].p;
+                int ss = p.in[0].stride, so = p.in[0].off;
+                if (cl >= n0) {
+                    cl -= n0;
+                    sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+                    if (cl >= n1) {
+                        cl -= n1;
+                        sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
                     }
                 }
-                x = s->p[pix * s->stride + s->off + cl];
+                x = sp[pix * ss + so + cl];
             }
             t[e] = x;
         }
@@ -126,6 +130,16 @@ __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int i
     }
 }
 
+
+// Select the output segment holding concatenated channel `nl` BY VALUE (taking a pointer into the
+// kernel-argument struct would push the whole struct into scratch memory).
+#define TMG_PICK_OSEG(ARR, NL_, PTR_, STRIDE_, OFF_)                                                      \
+    float* PTR_ = ARR[0].p;                                                                               \
+    int STRIDE_ = ARR[0].stride, OFF_ = ARR[0].off;                                                       \
+    if (NL_ >= ARR[0].n) {                                                                                \
+        NL_ -= ARR[0].n; PTR_ = ARR[1].p; STRIDE_ = ARR[1].stride; OFF_ = ARR[1].off;                     \
+        if (NL_ >= ARR[1].n) { NL_ -= ARR[1].n; PTR_ = ARR[2].p; STRIDE_ = ARR[2].stride; OFF_ = ARR[2].off; } \
+    }
 
 #define TMG_CHECK_LAUNCH()                          \
     do {                                            \

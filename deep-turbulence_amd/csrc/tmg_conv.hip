@@ -82,33 +82,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
         stage_patch(p, lds, b, iy0, ix0, PH, PW, c0, kch, CS);
         __syncthreads();
         const int kbn = kch >> 4;
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
-            const float* wtap = p.wpk + ((size_t)(tap * KB + (c0 >> 4)) * p.Cout_pad) * 16;
-            for (int kb = 0; kb < kbn; ++kb) {
-                float4 bf[NTW];
+        // flattened (tap, kb) loop with the next iteration's B fragments (L2-resident packed weights) prefetched
+        // into registers while the current iteration's MFMAs issue
+        const size_t tap_stride = (size_t)KB * p.Cout_pad * 16, kb_stride = (size_t)p.Cout_pad * 16;
+        const float* wlane = p.wpk + ((size_t)(c0 >> 4) * p.Cout_pad + li) * 16 + 4 * q;
+        float4 bnext[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int nt = ntile0 + j;
+            bnext[j] = (nt < ntiles_total) ? *reinterpret_cast<const float4*>(wlane + (size_t)nt * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        int tap = 0, kb = 0, tyy = 0, txx = 0;
+        const int niter = ntaps * kbn;
+        for (int it = 0; it < niter; ++it) {
+            float4 bf[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) bf[j] = bnext[j];
+            float4 af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const float4*>(lds + ((mrow[i] + tyy) * PW + mcol[i] + txx) * CS + kb * 16 + 4 * q);
+            // advance (tap, kb) and prefetch
+            ++kb;
+            if (kb == kbn) {
+                kb = 0;
+                ++tap;
+                ++txx;
+                if (txx == p.ksize) {
+                    txx = 0;
+                    ++tyy;
+                }
+            }
+            if (it + 1 < niter) {
+                const float* wn = wlane + tap * tap_stride + kb * kb_stride;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     const int nt = ntile0 + j;
-                    if (nt < ntiles_total)
-                        bf[j] = *reinterpret_cast<const float4*>(wtap + ((size_t)kb * p.Cout_pad + nt * 16 + li) * 16 + 4 * q);
-                    else
-                        bf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (nt < ntiles_total) bnext[j] = *reinterpret_cast<const float4*>(wn + (size_t)nt * 256);
                 }
-                float4 af[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    af[i] = *reinterpret_cast<const float4*>(lds + ((mrow[i] + tyy) * PW + mcol[i] + txx) * CS + kb * 16 + 4 * q);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                    }
             }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
         }
     }
 
@@ -120,17 +141,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
         if (n >= p.Cout) continue;
         const float bv = p.bias ? p.bias[n] : 0.f;
         int nl = n;
-        const TmgOSeg* os = &p.out[0];
-        if (nl >= os->n) {
-            nl -= os->n;
-            os = &p.out[1];
-            if (nl >= os->n) {
-                nl -= os->n;
-                os = &p.out[2];
+        float* op_ = p.out[0].p;
+        int ostride = p.out[0].stride, ooff = p.out[0].off;
+        if (nl >= p.out[0].n) {
+            nl -= p.out[0].n;
+            op_ = p.out[1].p; ostride = p.out[1].stride; ooff = p.out[1].off;
+            if (nl >= p.out[1].n) {
+                nl -= p.out[1].n;
+                op_ = p.out[2].p; ostride = p.out[2].stride; ooff = p.out[2].off;
             }
         }
-        float* obase = os->p + os->off + nl;
-        const int ostride = os->stride;
+        float* obase = op_ + ooff + nl;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -167,6 +188,7 @@ struct WgradP {
     int dy_vec4;
     float* dW;     // [Cout][Cin][ksize*ksize], accumulated with atomics (caller zeroes)
     float* dbias;  // [Cout] or null, accumulated with atomics
+    float* ws;     // optional partial-sum slabs (see conv_wgrad_reduce_kernel); null -> direct atomics
     const float* kappa;
     int TW_log2, TH;  // pixel tile (TH*TW == 64)
     int tiles_x, tiles_y, ntiles;
@@ -196,8 +218,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int n = 0; n < NCO; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
+    // LDS offset of each (tap, input-channel tile) pair owned by this wave, hoisted out of the pixel loop
+    int aoff[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int pid = min(wave + 4 * j, npairs - 1);
+        const int tap = pid / citn, cit = pid - tap * citn;
+        const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
+        aoff[j] = (tyy * PW + txx) * CS + cit * 16;
+    }
 
-    // which pixel of a 4-pixel k-step this lane feeds, as (row, col) deltas inside the tile
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         int t = tile;
         const int tx = t % p.tiles_x;
@@ -232,24 +262,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
             for (int m = 0; m < MPIX; ++m) sacc += ldy[m * DS + tid];
             bsum += sacc;
         }
+#pragma unroll 2
         for (int ks = 0; ks < MPIX / 4; ++ks) {
             const int m = ks * 4 + q;
-            const int prow = (m >> TWl) * s, pcol = (m & (TW - 1)) * s;
+            const float* abase = lds + (((m >> TWl) * s) * PW + (m & (TW - 1)) * s) * CS + li;
             float bfr[NCO];
 #pragma unroll
             for (int n = 0; n < NCO; ++n) bfr[n] = ldy[m * DS + n * 16 + li];
+            // straight-line: slots beyond npairs alias the last pair (their accumulators are never stored)
+            float av[NP];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int pid = wave + 4 * j;
-                if (pid < npairs) {
-                    const int tap = pid / citn, cit = pid - tap * citn;
-                    const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
-                    const float a = lds[((prow + tyy) * PW + pcol + txx) * CS + cit * 16 + li];
+            for (int j = 0; j < NP; ++j) av[j] = abase[aoff[j]];
 #pragma unroll
-                    for (int n = 0; n < NCO; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[n], acc[j][n], 0, 0, 0);
-                }
-            }
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int n = 0; n < NCO; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bfr[n], acc[j][n], 0, 0, 0);
         }
+    }
+    if (p.ws) {
+        // partial sums go to this block's slab in accumulator order (coalesced 16-byte stores); the reduce kernel
+        // folds the slabs into dW.  Avoids ~1e7 contended float atomics on a KB-sized dW.
+        const size_t bl = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+        float4* slab = reinterpret_cast<float4*>(p.ws) + ((bl * 4 + wave) * NP * NCO) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int n = 0; n < NCO; ++n)
+                slab[(j * NCO + n) * 64] = make_float4(acc[j][n][0], acc[j][n][1], acc[j][n][2], acc[j][n][3]);
+        if (p.dbias && blockIdx.z == 0 && tid < NCO * 16) {
+            float* wsb = p.ws + (size_t)gridDim.x * gridDim.y * gridDim.z * 4 * NP * NCO * 256;
+            wsb[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 + tid] = bsum;
+        }
+        return;
     }
     const float osc = out_scale_of(p.kappa);
 #pragma unroll
@@ -269,6 +313,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         }
     }
     if (p.dbias && blockIdx.z == 0 && tid < NCO * 16 && co0 + tid < p.Cout) atomicAdd(p.dbias + co0 + tid, bsum * osc);
+}
+
+// Fold the per-block slabs of conv_wgrad_kernel into dW / dbias.  grid = (ceil(items/256), xchunks):
+// each thread sums one accumulator float4 over a chunk of the pixel-share (x) dimension, then adds it to dW.
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
+                                         const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int CITG,
+                                         int cit_total, int Cin, int Cout, int ntaps, int xchunk) {
+    const int items = gy * gz * 4 * NP * NCO * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x0 = blockIdx.y * xchunk, x1 = min(gx, x0 + xchunk);
+    const float osc = out_scale_of(kappa);
+    if (i < items) {
+        int r_ = i;
+        const int lane = r_ & 63; r_ >>= 6;
+        const int n = r_ % NCO; r_ /= NCO;
+        const int j = r_ % NP; r_ /= NP;
+        const int wave = r_ & 3; r_ >>= 2;
+        const int z = r_ % gz;
+        const int y = r_ / gz;
+        const int citn = min(CITG, cit_total - z * CITG);
+        const int pid = wave + 4 * j;
+        if (pid < ntaps * citn) {
+            const size_t per_x = (size_t)gy * gz * 4 * NP * NCO * 64;
+            const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * 4 + wave) * NP + j) * NCO + n) * 64 + lane;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int x = x0; x < x1; ++x) {
+                const float4 v = src[(size_t)x * per_x];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            const int tap = pid / citn, cit = pid - tap * citn;
+            const int co = (y * NCO + n) * 16 + (lane & 15);
+            const int ci = (z * CITG + cit) * 16 + (lane >> 4) * 4;
+            if (co < Cout) {
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ci + r < Cin) atomicAdd(dW + ((size_t)co * Cin + ci + r) * ntaps + tap, av[r] * osc);
+            }
+        }
+    }
+    // bias partials: [gx][gy][64]
+    if (dbias && i < gy * 64) {
+        const int y = i >> 6, t = i & 63;
+        const int co = y * NCO * 16 + t;
+        if (t < NCO * 16 && co < Cout) {
+            const float* wsb = ws + (size_t)gx * gy * gz * 4 * NP * NCO * 256;
+            float a = 0.f;
+            for (int x = x0; x < x1; ++x) a += wsb[((size_t)x * gy + y) * 64 + t];
+            atomicAdd(dbias + co, a * osc);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -366,16 +461,8 @@ __global__ void conv_rep_border_fix_kernel(BorderP p) {
             }
         }
         int nl = ci;
-        const TmgOSeg* os = &p.out[0];
-        if (nl >= os->n) {
-            nl -= os->n;
-            os = &p.out[1];
-            if (nl >= os->n) {
-                nl -= os->n;
-                os = &p.out[2];
-            }
-        }
-        float* dst = os->p + (((size_t)b * p.H + qy) * p.W + qx) * os->stride + os->off + nl;
+        TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
+        float* dst = optr + (((size_t)b * p.H + qy) * p.W + qx) * ostride + ooff + nl;
         *dst += acc * osc;
     }
 }
@@ -428,8 +515,8 @@ static int g_prof_on = 0;
 static const char* const g_prof_names[] = {
     "conv_mfma_kernel<4,1,4,1>", "conv_mfma_kernel<4,2,4,1>", "conv_mfma_kernel<4,3,4,1>", "conv_mfma_kernel<4,4,4,1>",
     "conv_mfma_kernel<4,3,2,2>", "conv_mfma_kernel<4,4,2,2>", "conv_mfma_kernel<4,3,1,4>", "conv_mfma_kernel<4,4,1,4>",
-    "conv_wgrad_kernel<8,1>", "conv_wgrad_kernel<8,2>", "conv_wgrad_kernel<8,4>", "conv_wgrad_kernel<16,1>", "conv_wgrad_kernel<16,2>"};
-#define TMG_NPROF 13
+    "conv_wgrad_kernel<*,1>", "conv_wgrad_kernel<*,2>", "conv_wgrad_kernel<*,4>"};
+#define TMG_NPROF 11
 
 struct ProfScope {
     ProfRec r; bool on; hipStream_t st;
@@ -582,22 +669,83 @@ template <int NP, int NCO>
 static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NP, NCO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NP, NCO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
         attr_set = true;
     }
-    const int kid = 8 + (NP == 8 ? (NCO == 1 ? 0 : (NCO == 2 ? 1 : 2)) : (NCO == 1 ? 3 : 4));
+    const int kid = 8 + (NCO == 1 ? 0 : (NCO == 2 ? 1 : 2));
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO>), grid, dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
 }
 
+struct WgradPlan {
+    int twl, TH, tiles_x, tiles_y, ntiles, CITG, NCO, NP, gx, gy, gz;
+    size_t lds_bytes, ws_floats;
+};
+
+static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin, int Cout, WgradPlan* pl) {
+    int twl = ilog2_ceil(Wout);
+    if (twl > 5) twl = 5;
+    if (twl < 1) twl = 1;
+    pl->twl = twl;
+    const int TW = 1 << twl;
+    pl->TH = 64 >> twl;
+    pl->tiles_x = (Wout + TW - 1) / TW;
+    pl->tiles_y = (Hout + pl->TH - 1) / pl->TH;
+    pl->ntiles = B * pl->tiles_x * pl->tiles_y;
+    const int cit = ((Cin + 15) & ~15) >> 4, ntaps = ksize * ksize;
+    const int cot = (Cout + 15) >> 4;
+    // Decomposition: a block owns (CITG input-channel tiles x all taps) x (NCO output-channel tiles) of dW and a
+    // strided share of the pixel tiles.  Prefer large register tiles (operand reuse); when the image is small,
+    // fall back to smaller ones so that output groups x pixel shares still fill the chip with >= 4 tiles per block.
+    static const int pref[][2] = {{4, 2}, {2, 4}, {3, 2}, {2, 2}, {1, 4}, {1, 2}, {1, 1}};
+    const int gmin = (2048 + pl->ntiles - 1) / pl->ntiles;
+    int CITG = 1, NCO = 1, bestg = -1;
+    for (auto& c : pref) {
+        int cg = c[0], nc = c[1];
+        if (ntaps == 1) cg *= 4;  // 1x1: one pair per channel tile
+        if (cg > cit) cg = cit;
+        if (nc > cot) continue;
+        const int g = ((cit + cg - 1) / cg) * ((cot + nc - 1) / nc);
+        if (g >= gmin) { CITG = cg; NCO = nc; bestg = g; break; }
+        if (g > bestg) { CITG = cg; NCO = nc; bestg = g; }
+    }
+    const int ngroups = (cit + CITG - 1) / CITG;
+    pl->CITG = (cit + ngroups - 1) / ngroups;
+    pl->NCO = NCO;
+    const int np = (ntaps * pl->CITG + 3) / 4;
+    pl->NP = np <= 3 ? 3 : (np <= 5 ? 5 : (np <= 7 ? 7 : 9));
+    if (np > 9) return -7;
+    pl->gy = (cot + NCO - 1) / NCO;
+    pl->gz = ngroups;
+    const int halo = ksize >> 1;
+    const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
+    pl->lds_bytes = ((size_t)PH * PW * (pl->CITG * 16 + 4) + 64 * (NCO * 16 + 4)) * 4;
+    if (pl->lds_bytes > 160 * 1024) return -6;
+    int gx = pl->ntiles;
+    const int target = 1024 / (pl->gy * ngroups) > 0 ? 1024 / (pl->gy * ngroups) : 1;
+    if (gx > target) gx = target;
+    pl->gx = gx;
+    pl->ws_floats = (size_t)gx * pl->gy * pl->gz * 4 * pl->NP * NCO * 256 + (size_t)gx * pl->gy * 64;
+    return 0;
+}
+
+// Number of floats of scratch the slab path of tmg_conv_wgrad wants for these dims (same layout as tmg_conv_wgrad's dims).
+extern "C" int64_t tmg_conv_wgrad_ws_floats(const int64_t* dims) {
+    WgradPlan pl;
+    if (plan_wgrad((int)dims[0], (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7], (int)dims[8], &pl) != 0) return 0;
+    return (int64_t)pl.ws_floats;
+}
+
 // dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep]; dy_desc: [stride, off]
-// dW (and dbias) must be zero-initialised by the caller (or hold a value to accumulate onto).
+// dW (and dbias) are ACCUMULATED onto (caller zero-fills).  ws: optional scratch of >= tmg_conv_wgrad_ws_floats(dims)
+// floats; when given, per-block partial sums go through it and a small reduce kernel (few, low-contention atomics),
+// otherwise every block adds its partial sums to dW with float atomics.
 extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
                               const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias,
-                              const void* kappa, const int64_t* dims, hipStream_t st) {
+                              const void* kappa, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st) {
     WgradP p;
     p.nseg = (int)nseg;
     p.vec4 = 1;
@@ -611,44 +759,30 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     p.dy = TmgSeg{(const float*)dy, (int)dy_desc[0], (int)dy_desc[1], p.Cout};
     p.dy_vec4 = (((p.dy.stride | p.dy.off) & 3) == 0) && ((((uintptr_t)dy) & 15) == 0);
     p.dW = (float*)dW; p.dbias = (float*)dbias; p.kappa = (const float*)kappa;
-    int twl = ilog2_ceil(p.Wout);
-    if (twl > 5) twl = 5;
-    if (twl < 1) twl = 1;
-    p.TW_log2 = twl;
-    const int TW = 1 << twl;
-    p.TH = 64 >> twl;
-    p.tiles_x = (p.Wout + TW - 1) / TW;
-    p.tiles_y = (p.Hout + p.TH - 1) / p.TH;
-    p.ntiles = p.B * p.tiles_x * p.tiles_y;
-    const int cit = p.Cin_pad >> 4, ntaps = p.ksize * p.ksize;
-    // pairs per wave NP = ceil(ntaps*CITG/4) must be <= 16 (3x3: CITG <= 7) ; 1x1: CITG <= 64 -> cap at 16 tiles for LDS
-    int citg_max = (16 * 4) / ntaps;
-    if (citg_max > 16) citg_max = 16;
-    const int ngroups = (cit + citg_max - 1) / citg_max;
-    p.CITG = (cit + ngroups - 1) / ngroups;
-    const int np = (ntaps * p.CITG + 3) / 4;
-    const int cot = (p.Cout + 15) >> 4;
-    int NCO;
-    if (np <= 8) NCO = cot >= 4 ? 4 : (cot >= 2 ? 2 : 1);
-    else NCO = cot >= 2 ? 2 : 1;
-    const int gy = (cot + NCO - 1) / NCO;
-    const int halo = p.ksize >> 1;
-    const int PW = p.stride * (TW - 1) + 1 + 2 * halo, PH = p.stride * (p.TH - 1) + 1 + 2 * halo;
-    const size_t lds_bytes = ((size_t)PH * PW * (p.CITG * 16 + 4) + 64 * (NCO * 16 + 4)) * 4;
-    if (lds_bytes > 160 * 1024) return -6;
-    int gx = p.ntiles;
-    const int target = 2048 / (gy * ngroups) > 0 ? 2048 / (gy * ngroups) : 1;
-    if (gx > target) gx = target;
-    dim3 grid(gx, gy, ngroups);
+    WgradPlan pl;
+    const int rc = plan_wgrad(p.B, p.Hout, p.Wout, p.ksize, p.stride, p.Cin, p.Cout, &pl);
+    if (rc != 0) return rc;
+    p.TW_log2 = pl.twl; p.TH = pl.TH; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.CITG = pl.CITG;
+    p.ws = (ws && (size_t)ws_floats >= pl.ws_floats && (((uintptr_t)ws) & 15) == 0) ? (float*)ws : nullptr;
+    dim3 grid(pl.gx, pl.gy, pl.gz);
+    int lrc = -7;
 #define TMG_WG_CASE(NP_, NCO_) \
-    if (np <= NP_ && NCO == NCO_) return launch_wgrad<NP_, NCO_>(p, grid, lds_bytes, st);
-    TMG_WG_CASE(8, 1)
-    TMG_WG_CASE(8, 2)
-    TMG_WG_CASE(8, 4)
-    TMG_WG_CASE(16, 1)
-    TMG_WG_CASE(16, 2)
+    if (pl.NP == NP_ && pl.NCO == NCO_) lrc = launch_wgrad<NP_, NCO_>(p, grid, pl.lds_bytes, st);
+    TMG_WG_CASE(3, 1) TMG_WG_CASE(3, 2) TMG_WG_CASE(3, 4)
+    TMG_WG_CASE(5, 1) TMG_WG_CASE(5, 2) TMG_WG_CASE(5, 4)
+    TMG_WG_CASE(7, 1) TMG_WG_CASE(7, 2) TMG_WG_CASE(7, 4)
+    TMG_WG_CASE(9, 1) TMG_WG_CASE(9, 2)
 #undef TMG_WG_CASE
-    return -7;
+    if (lrc != 0) return lrc;
+    if (p.ws) {
+        const int items = pl.gy * pl.gz * 4 * pl.NP * pl.NCO * 64;
+        int xchunk = 32;
+        const int xc = (pl.gx + xchunk - 1) / xchunk;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
+                           p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.Cin, p.Cout, p.ksize * p.ksize, xchunk);
+        TMG_CHECK_LAUNCH();
+    }
+    return 0;
 }
 
 // Replicate-padding fold for the 3x3 input gradient (see conv_rep_border_fix_kernel).

@@ -530,16 +530,8 @@ __global__ __launch_bounds__(256) void c1_bwd_kernel(C1BP p) {
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) v += lw[tap * kch + c] * dnb[tap];
                     int nl = ci;
-                    const TmgOSeg* os = &p.g[0];
-                    if (nl >= os->n) {
-                        nl -= os->n;
-                        os = &p.g[1];
-                        if (nl >= os->n) {
-                            nl -= os->n;
-                            os = &p.g[2];
-                        }
-                    }
-                    float* d = os->p + opix * os->stride + os->off + nl;
+                    TMG_PICK_OSEG(p.g, nl, gptr, gstride, goff)
+                    float* d = gptr + opix * gstride + goff + nl;
                     *d += v;
                 }
             }

@@ -25,7 +25,7 @@ c_i64 = ctypes.c_int64
 c_vp = ctypes.c_void_p
 
 EXPORTS = [
-    "tmg_conv_pack", "tmg_conv_fwd", "tmg_conv_wgrad", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
+    "tmg_conv_pack", "tmg_conv_fwd", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_prof_enable", "tmg_prof_collect",
@@ -56,6 +56,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(_lib, name).restype = ctypes.c_int
+        _lib.tmg_conv_wgrad_ws_floats.restype = ctypes.c_int64
     return _lib
 
 
@@ -166,14 +167,29 @@ def conv_fwd(inputs, wpk, Cout, ksize, stride, outs, bias=None, kappa=None, in_s
                             c_i64(n_out), dims, _stream()), "tmg_conv_fwd")
 
 
-def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, in_shift=None, relu_in=False, pad_rep=False):
+_WS = {}
+
+
+def workspace(nfloats, device):
+    """Grow-only scratch buffer per (device, stream): kernels on one stream run in order, so sharing it is safe."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
+        _WS[key] = buf
+    return buf
+
+
+def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, in_shift=None, relu_in=False, pad_rep=False,
+               use_ws=True):
     B, Hin, Win, _ = inputs[0].shape
     _, Hout, Wout, Cout = dy.shape
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
     dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep)
+    ws = workspace(lib().tmg_conv_wgrad_ws_floats(dims), dy.device) if use_ws else None
     _chk(lib().tmg_conv_wgrad(ip, idesc, c_i64(n_in), _ptr(in_scale), _ptr(in_shift), _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
-                              _ptr(kappa), dims, _stream()), "tmg_conv_wgrad")
+                              _ptr(kappa), _ptr(ws), c_i64(ws.numel() if ws is not None else 0), dims, _stream()), "tmg_conv_wgrad")
 
 
 def conv_rep_border_fix(dy, w, outs, kappa=None):

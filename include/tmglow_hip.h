@@ -50,11 +50,14 @@ int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nse
                  const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
 
 /* dW[Cout][Cin][k][k] += scale * sum_pixels act(in)(p*s+tap) (x) dy(p) ; dbias += scale * sum dy.
- * (float atomics: caller zero-fills.)  Replaces the autograd weight-gradient of the convs above.
+ * (accumulating: caller zero-fills; per-block partial sums go through the scratch `ws` and a reduce kernel.)  Replaces the autograd weight-gradient of the convs above.
  * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate}; dy_desc = {stride, off} */
 int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
                    const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, const void* kappa,
-                   const int64_t* dims, tmg_stream_t st);
+                   void* ws, int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
+/* Scratch (in floats) the slab path of tmg_conv_wgrad wants for `dims`; with ws == NULL the kernel falls back to
+ * direct float atomics on dW. */
+int64_t tmg_conv_wgrad_ws_floats(const int64_t* dims);
 
 /* Adds the contribution of the replicate-padded ring to the border pixels of a 3x3 input gradient
  * (adjoint of F.pad(mode='replicate'), flowUtils.py:246).  dims = {B,H,W,Cdy,Cx}; w in torch layout. */

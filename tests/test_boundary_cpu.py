@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     path = tmg_hip.build()
     lib = ctypes.CDLL(path)
     hdr = open(os.path.join(C.ROOT, "include", "tmglow_hip.h")).read()
-    declared = sorted(set(re.findall(r"\bint\s+(tmg_\w+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(?:int|int64_t)\s+(tmg_\w+)\s*\(", hdr)))
     assert declared, "no declarations parsed"
     assert sorted(tmg_hip.EXPORTS) == declared
     for name in declared:

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the contraction kernels at the metric configuration's layer shapes (GPU only).
+Prints achieved algorithmic TFLOP/s for forward / input-gradient / weight-gradient of each shape."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import tmg_hip as H  # noqa: E402
+
+SHAPES = {
+    # name: (B, H, W, seg channels, Cout, ksize, relu_in, pad_rep)
+    "gate_L1": (64, 128, 128, [8, 32, 64], 256, 3, False, False),
+    "gate_L2": (64, 64, 64, [16, 32, 64], 256, 3, False, False),
+    "outc_L1": (64, 128, 128, [8, 32, 64], 40, 3, False, False),
+    "zero_L1": (64, 128, 128, [8, 32, 4], 16, 3, True, True),
+    "zero_L2": (64, 64, 64, [16, 32, 4], 32, 3, True, True),
+    "zero_L3": (64, 32, 32, [32, 32, 4], 64, 3, True, True),
+    "zero_L4": (64, 16, 16, [64, 32, 4], 128, 3, True, True),
+    "mix_L1": (64, 128, 128, [16], 16, 1, False, False),
+    "mix_L4": (64, 16, 16, [128], 128, 1, False, False),
+}
+
+
+def timeit(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    names = sys.argv[1:] or list(SHAPES)
+    dev = "cuda"
+    for name in names:
+        B, Hh, Ww, segs, Cout, k, relu_in, pad_rep = SHAPES[name]
+        xs = [torch.randn(B, Hh, Ww, c, device=dev) for c in segs]
+        cin = sum(segs)
+        w = 0.1 * torch.randn(Cout, cin, k, k, device=dev)
+        out = torch.empty(B, Hh, Ww, Cout, device=dev)
+        dy = torch.randn(B, Hh, Ww, Cout, device=dev)
+        dxs = [torch.empty_like(t) for t in xs]
+        dW = torch.zeros_like(w)
+        wpk, wpk_t = H.conv_pack(w, 0), H.conv_pack(w, 1)
+        fl = 2.0 * B * Hh * Ww * Cout * cin * k * k
+        t_f = timeit(lambda: H.conv_fwd(xs, wpk, Cout, k, 1, [out], relu_in=relu_in, pad_rep=pad_rep))
+        t_d = timeit(lambda: H.conv_fwd([dy], wpk_t, cin, k, 1, dxs))
+        t_w = timeit(lambda: H.conv_wgrad(xs, dy, dW, None, k, 1, relu_in=relu_in, pad_rep=pad_rep))
+        print("%-8s fwd %8.3f ms %6.1f TF | dgrad %8.3f ms %6.1f TF | wgrad %8.3f ms %6.1f TF" % (
+            name, t_f, fl / t_f / 1e9, t_d, fl / t_d / 1e9, t_w, fl / t_w / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    main()
