@@ -32,12 +32,14 @@ class AffineCouplingLayer(nn.Module):
         self.coupling_nn.add_module('zero_conv', Conv2dZeros(in_channels + 2, out_channels))
 
     def run(self, xn, condn, reverse):
-        ch = xn.shape[3] // 2
-        t = self.coupling_nn.dense_block.run([xn[..., :ch], condn])
-        if len(t) > 3:
+        db, zc = self.coupling_nn.dense_block, self.coupling_nn.zero_conv
+        if zc.logscale_factor != 1:  # never the case in TMGlow; keep the un-fused composition for it
+            ch = xn.shape[3] // 2
+            t = db.run([xn[..., :ch], condn])
             t = t[:2] + [torch.cat(t[2:], 3)]
-        hh = self.coupling_nn.zero_conv.run(t, relu_in=True)
-        return ops.AffineFn.apply(hh, xn, reverse)
+            return ops.AffineFn.apply(zc.run(t, relu_in=True), xn, reverse)
+        return ops.CouplingTailFn.apply(xn, condn, db.denselayer1.conv1.weight, db.denselayer2.conv1.weight, zc.conv.weight,
+                                        zc.conv.bias, zc.scale, reverse, 0)
 
     def forward(self, x, cond):
         y, ld = self.run(H.nhwc(x), H.nhwc(cond), False)
@@ -64,9 +66,9 @@ class LSTMAffineCouplingLayer(nn.Module):
     def run(self, xn, condn, state, reverse):
         ch = xn.shape[3] // 2
         out, h_next, c_next = self.resid_lstm.run([xn[..., :ch], condn], state)
-        t = self.dense_nn.dense_block.run([out])
-        hh = self.out_conv.zero_conv.run(t, relu_in=True)
-        y, ld = ops.AffineFn.apply(hh, xn, reverse)
+        db, zc = self.dense_nn.dense_block, self.out_conv.zero_conv
+        y, ld = ops.CouplingTailFn.apply(xn, out, db.denselayer1.conv1.weight, db.denselayer2.conv1.weight, zc.conv.weight,
+                                         zc.conv.bias, zc.scale, reverse, 1)
         return y, ld, (h_next, c_next)
 
     def _call(self, x, cond, rec_states, reverse):

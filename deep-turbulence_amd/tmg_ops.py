@@ -302,3 +302,86 @@ class UpsampleFn(torch.autograd.Function):
         dx = torch.empty(ctx.in_shape, device=dy.device, dtype=torch.float32)
         H.upsample_bwd(dy.contiguous(), dx)
         return dx, None
+
+
+class CouplingTailFn(torch.autograd.Function):
+    """Coupling network + affine apply as ONE autograd node with a hand-written backward:
+        t0 = cat(nn inputs);  d1 = c1(relu(t0));  d2 = c1(relu(t0|d1));  hh = ZeroConv(relu(t0|d1|d2))
+        y = [x1 | affine(x2; hh)],  logdet[b]
+    (reference flowAffine.py:73-83 / :98-109 and :189-198 / :227-236).
+    The two growth-1 layers run on the vector ALUs (tmg_c1_*), the zero-conv on the matrix cores; the
+    concatenations are never built: the kernels read x1 / cond / D as segments, D being a 4-channel buffer
+    (2 used) so every segment stays 16-byte aligned.  Saved for backward: x, cond/out, D, r -- not hh.
+
+    mode 0: nn inputs = (x[..., :C/2], cond)      -- AffineCouplingLayer
+    mode 1: nn inputs = (feat,)                   -- LSTMAffineCouplingLayer (feat = ResidLSTMBlock output)
+    """
+
+    @staticmethod
+    def forward(ctx, x, aux, w1, w2, wz, bz, kappa, reverse, mode):
+        x = x if x.stride(3) == 1 else x.contiguous()
+        aux = aux if aux.stride(3) == 1 else aux.contiguous()
+        B, Hh, Ww, C = x.shape
+        ch = C // 2
+        dev = x.device
+        nn_in = [x[..., :ch], aux] if mode == 0 else [aux]
+        cin = sum(t.shape[3] for t in nn_in)
+        D = torch.zeros((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
+        w1f = w1.reshape(cin, 9)
+        w2p = torch.zeros((cin + 4, 9), device=dev, dtype=torch.float32)
+        w2p[:cin + 1] = w2.reshape(cin + 1, 9)
+        wzp = torch.zeros((C, cin + 4, 3, 3), device=dev, dtype=torch.float32)
+        wzp[:, :cin + 2] = wz
+        H.c1_fwd(nn_in, w1f, D[..., 0:1], relu_in=True)
+        H.c1_fwd(nn_in + [D], w2p, D[..., 1:2], relu_in=True)
+        hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+        H.conv_fwd(nn_in + [D], H.conv_pack(wzp, 0), C, 3, 1, [hh], bias=bz, kappa=kappa, relu_in=True, pad_rep=True)
+        y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+        H.masked_add(y[..., :ch], src=x[..., :ch])
+        r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+        logdet = torch.zeros(B, device=dev, dtype=torch.float32)
+        H.affine_apply(hh, x[..., ch:], y[..., ch:], r, logdet, reverse)
+        ctx.reverse, ctx.mode, ctx.cin = reverse, mode, cin
+        ctx.save_for_backward(x, aux, D, r, y, w1f, w2p, wzp, bz, kappa)
+        return y, logdet
+
+    @staticmethod
+    def backward(ctx, dy, dld):
+        x, aux, D, r, y, w1f, w2p, wzp, bz, kappa = ctx.saved_tensors
+        reverse, mode, cin = ctx.reverse, ctx.mode, ctx.cin
+        dy = dy.contiguous()
+        B, Hh, Ww, C = dy.shape
+        ch = C // 2
+        dev = dy.device
+        nn_in = [x[..., :ch], aux] if mode == 0 else [aux]
+        # 1. affine
+        dx = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+        dhh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+        g = dld.contiguous() if dld is not None else None
+        H.affine_bwd(dy[..., ch:], (x if reverse else y)[..., ch:], r, g, dx[..., ch:], dhh, reverse)
+        # 2. zero-conv: weight / bias / scale gradients, raw input gradient
+        dwzp = torch.zeros_like(wzp)
+        dbz = torch.zeros_like(bz)
+        H.conv_wgrad(nn_in + [D], dhh, dwzp, dbz, 3, 1, kappa=kappa, relu_in=True, pad_rep=True)
+        dk = (wzp * dwzp).sum() + (bz * dbz).sum()
+        dk = (dk * ((kappa >= -4.0) & (kappa <= LOG4)).to(dk.dtype)).reshape(kappa.shape)
+        G = [torch.empty(t.shape, device=dev, dtype=torch.float32) for t in nn_in]
+        GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
+        H.conv_fwd([dhh], H.conv_pack(wzp, 1), cin + 4, 3, 1, G + [GD], kappa=kappa)
+        H.conv_rep_border_fix(dhh, wzp, G + [GD], kappa=kappa)
+        # 3. growth-1 layers, last first; each adds its raw input gradient into G / GD
+        dw2p = torch.zeros_like(w2p)
+        H.c1_bwd(nn_in + [D], w2p, dw2p, GD[..., 1:2], D[..., 1:2], G + [GD], relu_in=True)
+        dw1 = torch.zeros_like(w1f)
+        H.c1_bwd(nn_in, w1f, dw1, GD[..., 0:1], D[..., 0:1], G, relu_in=True)
+        # 4. ReLU masks and the concat adjoint
+        if mode == 0:
+            H.masked_add(dx[..., :ch], src=G[0], ref=x[..., :ch], add=dy[..., :ch])
+            H.masked_add(G[1], src=G[1], ref=aux)
+            daux = G[1]
+        else:
+            H.masked_add(dx[..., :ch], src=dy[..., :ch])
+            H.masked_add(G[0], src=G[0], ref=aux)
+            daux = G[0]
+        return (dx, daux, dw1.reshape(1, cin, 3, 3), dw2p[:cin + 1].reshape(1, cin + 1, 3, 3), dwzp[:, :cin + 2].contiguous(), dbz, dk,
+                None, None)
