@@ -570,6 +570,216 @@ __global__ __launch_bounds__(256) void c1_bwd_kernel(C1BP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused backward of the two growth-1 dense layers (one pass over the coupling-network input):
+//   dd2m = GD[1] * [d2 > 0]
+//   dd1m = [d1 > 0] * (GD[0] + sum_tap W2[cin_nn][tap] * dd2m(p - tap + 1))
+//   grad(t0)[c] = [t0[c] > 0] * (G0[c] + sum_tap W2[c][tap] dd2m(p-tap+1) + W1[c][tap] dd1m(p-tap+1)) (+ add0)
+//   dW1[c][tap] += sum_p relu(t0)(p+tap-1)[c] dd1m(p);   dW2[c][tap] += sum_p relu(t1)(p+tap-1)[c] dd2m(p)
+// G0 = raw zero-conv input gradient (MFMA kernel output), GD its 4-channel part for D = (d1, d2, 0, 0).
+// Input segments = nn inputs followed by D (so Cin counts D's 4 channels; W1/W2/dW1/dW2 are [Cin][9], zero-padded).
+// ---------------------------------------------------------------------------------------------
+struct D2BP {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg, vec4;
+    int B, Hin, Win;
+    int Cin;
+    const float* in_scale;
+    const float* in_shift;
+    int relu_in, pad_rep;
+    const float* w1;
+    const float* w2;
+    float* dW1;
+    float* dW2;
+    const float* GD; int gd_stride;
+    const float* Dp; int d_stride;
+    int cin_nn;
+    TmgSeg g0[2];
+    TmgOSeg out[2];
+    const float* add0; int add0_stride;
+    int TW_log2, tiles_x, tiles_y, ntiles, KCH;
+};
+
+__global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = 256 >> TWl;
+    const int PW = TW + 2, PH = TH + 2, QW = TW + 4, QH = TH + 4;
+    const int row = tid >> TWl, col = tid & (TW - 1);
+    const int Cpad = (p.Cin + 3) & ~3;
+    const int nchunks = (Cpad + p.KCH - 1) / p.KCH;
+    float* A2 = lds;                              // [QH*QW] dd2m, halo 2
+    float* A1 = A2 + ((QH * QW + 3) & ~3);        // [PH*PW] dd1m, halo 1
+    float* lw1 = A1 + ((PH * PW + 3) & ~3);       // [9][KCH]
+    float* lw2 = lw1 + 9 * p.KCH;                 // [9][KCH]
+    float* lin = lw2 + 9 * p.KCH;                 // [PH*PW][CS]
+    float wa1[2][8], wa2[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { wa1[k][c] = 0.f; wa2[k][c] = 0.f; }
+    // W2 row of the d1 input channel (9 scalars)
+    float w2d[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w2d[t] = p.w2[(size_t)p.cin_nn * 9 + t];
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        const int b = t / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        for (int i = tid; i < QH * QW; i += 256) {
+            const int py = i / QW, px = i - py * QW;
+            const int y = oy0 - 2 + py, x = ox0 - 2 + px;
+            float v = 0.f;
+            if (y >= 0 && y < p.Hin && x >= 0 && x < p.Win) {
+                const size_t pix = ((size_t)b * p.Hin + y) * p.Win + x;
+                v = p.GD[pix * p.gd_stride + 1];
+                if (!(p.Dp[pix * p.d_stride + 1] > 0.f)) v = 0.f;
+            }
+            A2[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < PH * PW; i += 256) {
+            const int py = i / PW, px = i - py * PW;
+            const int y = oy0 - 1 + py, x = ox0 - 1 + px;
+            float v = 0.f;
+            if (y >= 0 && y < p.Hin && x >= 0 && x < p.Win) {
+                const size_t pix = ((size_t)b * p.Hin + y) * p.Win + x;
+                if (p.Dp[pix * p.d_stride] > 0.f) {
+                    v = p.GD[pix * p.gd_stride];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int ky = tap / 3, kx = tap - ky * 3;
+                        // A2 origin is tile-2: pixel (py-1, px-1) of the tile frame sits at (py+1, px+1); minus (ky-1, kx-1)
+                        v += w2d[tap] * A2[(py + 2 - ky) * QW + px + 2 - kx];
+                    }
+                }
+            }
+            A1[i] = v;
+        }
+        __syncthreads();
+        float n1[9], n2[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            n1[tap] = A1[(row + 2 - ky) * PW + col + 2 - kx];
+            n2[tap] = A2[(row + 3 - ky) * QW + col + 3 - kx];
+        }
+        const int oy = oy0 + row, ox = ox0 + col;
+        const bool inside = oy < p.Hin && ox < p.Win;
+        const size_t opix = ((size_t)b * p.Hin + oy) * p.Win + ox;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            if (ch >= nchunks) break;
+            const int c0 = ch * p.KCH;
+            const int kch = min(p.KCH, Cpad - c0);
+            const int CS = kch + 4;
+            __syncthreads();
+            stage_patch(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
+            for (int i = tid; i < 9 * kch; i += 256) {
+                const int tap = i / kch, c = i - tap * kch;
+                const bool ok = c0 + c < p.Cin;
+                lw1[i] = ok ? p.w1[(size_t)(c0 + c) * 9 + tap] : 0.f;
+                lw2[i] = ok ? p.w2[(size_t)(c0 + c) * 9 + tap] : 0.f;
+            }
+            __syncthreads();
+            if (inside) {
+                const float* cen = lin + ((row + 1) * PW + col + 1) * CS;
+                for (int c = 0; c < kch; c += 4) {
+                    const int ci = c0 + c;
+                    if (ci >= p.cin_nn) break;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const float4 a = *reinterpret_cast<const float4*>(lw1 + tap * kch + c);
+                        const float4 bq = *reinterpret_cast<const float4*>(lw2 + tap * kch + c);
+                        v.x += a.x * n1[tap] + bq.x * n2[tap];
+                        v.y += a.y * n1[tap] + bq.y * n2[tap];
+                        v.z += a.z * n1[tap] + bq.z * n2[tap];
+                        v.w += a.w * n1[tap] + bq.w * n2[tap];
+                    }
+                    const float4 m = *reinterpret_cast<const float4*>(cen + c);
+                    if (p.vec4) {
+                        int nl = ci;
+                        const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
+                        if (sgi) nl -= p.g0[0].n;
+                        const float* gp = (sgi ? p.g0[1].p : p.g0[0].p) + opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl;
+                        float* op = (sgi ? p.out[1].p : p.out[0].p) + opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl;
+                        const float4 g = *reinterpret_cast<const float4*>(gp);
+                        float4 o;
+                        o.x = m.x > 0.f ? g.x + v.x : 0.f;
+                        o.y = m.y > 0.f ? g.y + v.y : 0.f;
+                        o.z = m.z > 0.f ? g.z + v.z : 0.f;
+                        o.w = m.w > 0.f ? g.w + v.w : 0.f;
+                        if (p.add0 && !sgi) {
+                            const float4 ad = *reinterpret_cast<const float4*>(p.add0 + opix * p.add0_stride + nl);
+                            o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                        }
+                        *reinterpret_cast<float4*>(op) = o;
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+                        const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            int nl = ci + e;
+                            if (nl >= p.cin_nn) break;
+                            const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
+                            if (sgi) nl -= p.g0[0].n;
+                            const float g = (sgi ? p.g0[1].p : p.g0[0].p)[opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl];
+                            float o = mm[e] > 0.f ? g + vv[e] : 0.f;
+                            if (p.add0 && !sgi) o += p.add0[opix * p.add0_stride + nl];
+                            (sgi ? p.out[1].p : p.out[0].p)[opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl] = o;
+                        }
+                    }
+                }
+            }
+            // weight gradients of both layers from the same staged activations
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int o = tid + 256 * k;
+                if (o < kch * 9) {
+                    const int tap = o / kch, c = o - tap * kch;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int r = 0; r < TH; ++r) {
+                        const float* ip = lin + ((r + ky) * PW + kx) * CS + c;
+                        const float* d1p = A1 + (r + 1) * PW + 1;
+                        const float* d2p = A2 + (r + 2) * QW + 2;
+                        for (int cc = 0; cc < TW; ++cc) {
+                            const float a = ip[cc * CS];
+                            s1 += a * d1p[cc];
+                            s2 += a * d2p[cc];
+                        }
+                    }
+                    wa1[k][ch] += s1;
+                    wa2[k][ch] += s2;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        if (ch >= nchunks) break;
+        const int c0 = ch * p.KCH;
+        const int kch = min(p.KCH, Cpad - c0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int o = tid + 256 * k;
+            if (o < kch * 9) {
+                const int tap = o / kch, c = o - tap * kch;
+                if (c0 + c < p.Cin) {
+                    atomicAdd(p.dW1 + (size_t)(c0 + c) * 9 + tap, wa1[k][ch]);
+                    atomicAdd(p.dW2 + (size_t)(c0 + c) * 9 + tap, wa2[k][ch]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 // dims: [B, pix_per_img, Ch, reverse]; each *_d = [stride, off]
@@ -800,6 +1010,52 @@ extern "C" int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, in
     }
     int gx = p.ntiles < 1024 ? p.ntiles : 1024;
     hipLaunchKernelGGL(c1_bwd_kernel, dim3(gx), dim3(256), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// Fused backward of both growth-1 layers (see dense2_bwd_kernel).
+// in segments: nn inputs followed by D (4 channels); dims = {B,H,W,Cin_total (incl. D's 4),cin_nn}
+// g0/out: up to two segments each (same channel split as the nn inputs); add0 optional (null) added to out segment 0.
+extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2,
+                              void* dW1, void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride,
+                              const void* const* g0_ptrs, const int64_t* g0_desc, void* const* out_ptrs, const int64_t* out_desc,
+                              int64_t ng, const void* add0, int64_t add0_stride, const int64_t* dims, hipStream_t st) {
+    D2BP p;
+    p.nseg = (int)nseg;
+    p.vec4 = 1;
+    fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.cin_nn = (int)dims[4];
+    p.relu_in = 1; p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
+    if (p.Cin & 3) p.vec4 = 0;
+    p.w1 = (const float*)w1; p.w2 = (const float*)w2; p.dW1 = (float*)dW1; p.dW2 = (float*)dW2;
+    p.GD = (const float*)GD; p.gd_stride = (int)gd_stride; p.Dp = (const float*)Dp; p.d_stride = (int)d_stride;
+    for (int i = 0; i < 2; ++i) { p.g0[i] = TmgSeg{nullptr, 0, 0, 0}; p.out[i] = TmgOSeg{nullptr, 0, 0, 0}; }
+    for (int i = 0; i < (int)ng; ++i) {
+        p.g0[i] = TmgSeg{(const float*)g0_ptrs[i], (int)g0_desc[3 * i], (int)g0_desc[3 * i + 1], (int)g0_desc[3 * i + 2]};
+        p.out[i] = TmgOSeg{(float*)out_ptrs[i], (int)out_desc[3 * i], (int)out_desc[3 * i + 1], (int)out_desc[3 * i + 2]};
+        if ((p.g0[i].stride | p.g0[i].off | p.g0[i].n | p.out[i].stride | p.out[i].off) & 3) p.vec4 = 0;
+        if ((((uintptr_t)g0_ptrs[i]) | ((uintptr_t)out_ptrs[i])) & 15) p.vec4 = 0;
+    }
+    p.add0 = (const float*)add0; p.add0_stride = (int)add0_stride;
+    if (add0 && ((add0_stride & 3) || (((uintptr_t)add0) & 15))) p.vec4 = 0;
+    c1_tile(p.Win, p.Hin, &p.TW_log2);
+    const int TW = 1 << p.TW_log2, TH = 256 >> p.TW_log2;
+    p.tiles_x = (p.Win + TW - 1) / TW;
+    p.tiles_y = (p.Hin + TH - 1) / TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const int Cpad = (p.Cin + 3) & ~3;
+    p.KCH = Cpad < 32 ? Cpad : 32;
+    if ((Cpad + p.KCH - 1) / p.KCH > 8) return -2;
+    const int PP = (TH + 2) * (TW + 2), QQ = (TH + 4) * (TW + 4);
+    const size_t lds_bytes = ((size_t)((QQ + 3) & ~3) + ((PP + 3) & ~3) + 18 * p.KCH + (size_t)PP * (p.KCH + 4)) * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const int gx = p.ntiles < 768 ? p.ntiles : 768;
+    hipLaunchKernelGGL(dense2_bwd_kernel, dim3(gx), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_fwd", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_prof_enable", "tmg_prof_collect",
+    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_prof_enable", "tmg_prof_collect",
 ]
 
 
@@ -316,3 +316,16 @@ def c1_bwd(inputs, w, dW, dd, dref, gsegs, relu_in=True):
     rd = _d2(dref) if dref is not None else _i64(0, 0)
     _chk(lib().tmg_c1_bwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(dW), _ptr(dd), _d2(dd), _ptr(dref), rd, gp, gdesc, c_i64(ng),
                           _i64(B, H, W, Cin, relu_in), _stream()), "tmg_c1_bwd")
+
+
+def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None):
+    """Fused backward of the two growth-1 layers; `inputs` = nn inputs + [D]; g0 / outs: lists (<= 2) of NHWC tensors."""
+    B, H, W, _ = inputs[0].shape
+    ip, idesc, n_in = _segs(inputs)
+    gp, gdesc, ng = _segs(g0)
+    op, odesc, _ = _segs(outs)
+    Cin = sum(t.shape[3] for t in inputs)
+    a_stride = seg(add0)[1] if add0 is not None else 0
+    _chk(lib().tmg_dense2_bwd(ip, idesc, c_i64(n_in), _ptr(w1p), _ptr(w2p), _ptr(dW1p), _ptr(dW2p), _ptr(GD), c_i64(seg(GD)[1]), _ptr(D),
+                              c_i64(seg(D)[1]), gp, gdesc, op, odesc, c_i64(ng), _ptr(add0), c_i64(a_stride), _i64(B, H, W, Cin, cin_nn),
+                              _stream()), "tmg_dense2_bwd")

@@ -327,7 +327,8 @@ class CouplingTailFn(torch.autograd.Function):
         nn_in = [x[..., :ch], aux] if mode == 0 else [aux]
         cin = sum(t.shape[3] for t in nn_in)
         D = torch.zeros((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-        w1f = w1.reshape(cin, 9)
+        w1f = torch.zeros((cin + 4, 9), device=dev, dtype=torch.float32)
+        w1f[:cin] = w1.reshape(cin, 9)
         w2p = torch.zeros((cin + 4, 9), device=dev, dtype=torch.float32)
         w2p[:cin + 1] = w2.reshape(cin + 1, 9)
         wzp = torch.zeros((C, cin + 4, 3, 3), device=dev, dtype=torch.float32)
@@ -369,19 +370,15 @@ class CouplingTailFn(torch.autograd.Function):
         GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
         H.conv_fwd([dhh], H.conv_pack(wzp, 1), cin + 4, 3, 1, G + [GD], kappa=kappa)
         H.conv_rep_border_fix(dhh, wzp, G + [GD], kappa=kappa)
-        # 3. growth-1 layers, last first; each adds its raw input gradient into G / GD
-        dw2p = torch.zeros_like(w2p)
-        H.c1_bwd(nn_in + [D], w2p, dw2p, GD[..., 1:2], D[..., 1:2], G + [GD], relu_in=True)
+        # 3. both growth-1 layers, ReLU masks and the concat adjoint in one pass over the network input
         dw1 = torch.zeros_like(w1f)
-        H.c1_bwd(nn_in, w1f, dw1, GD[..., 0:1], D[..., 0:1], G, relu_in=True)
-        # 4. ReLU masks and the concat adjoint
+        dw2p = torch.zeros_like(w2p)
         if mode == 0:
-            H.masked_add(dx[..., :ch], src=G[0], ref=x[..., :ch], add=dy[..., :ch])
-            H.masked_add(G[1], src=G[1], ref=aux)
+            H.dense2_bwd(nn_in + [D], w1f, w2p, dw1, dw2p, GD, D, G, [dx[..., :ch], G[1]], cin, add0=dy[..., :ch])
             daux = G[1]
         else:
+            H.dense2_bwd(nn_in + [D], w1f, w2p, dw1, dw2p, GD, D, G, [G[0]], cin)
             H.masked_add(dx[..., :ch], src=dy[..., :ch])
-            H.masked_add(G[0], src=G[0], ref=aux)
             daux = G[0]
-        return (dx, daux, dw1.reshape(1, cin, 3, 3), dw2p[:cin + 1].reshape(1, cin + 1, 3, 3), dwzp[:, :cin + 2].contiguous(), dbz, dk,
+        return (dx, daux, dw1[:cin].reshape(1, cin, 3, 3), dw2p[:cin + 1].reshape(1, cin + 1, 3, 3), dwzp[:, :cin + 2].contiguous(), dbz, dk,
                 None, None)

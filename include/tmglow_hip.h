@@ -130,6 +130,14 @@ int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg,
                const int64_t* dd_d, const void* dref, const int64_t* dref_d, void* const* g_ptrs, const int64_t* g_desc,
                int64_t ng, const int64_t* dims, tmg_stream_t st);
 
+/* Fused backward of both growth-1 layers of a coupling network (denseBlock.py:135-152 x2) incl. the ReLU masks
+ * and the concat adjoint: one pass over the network input.  in segments = nn inputs followed by the 4-channel D
+ * buffer; dims = {B,H,W,Cin_total(incl. D),cin_nn}. */
+int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2, void* dW1,
+                   void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride, const void* const* g0_ptrs,
+                   const int64_t* g0_desc, void* const* out_ptrs, const int64_t* out_desc, int64_t ng, const void* add0,
+                   int64_t add0_stride, const int64_t* dims, tmg_stream_t st);
+
 #ifdef __cplusplus
 }
 #endif
