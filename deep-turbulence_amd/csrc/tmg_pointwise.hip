@@ -25,12 +25,34 @@ static inline int grid_for(size_t n, int cap = 4096) {
 // hh: [npix][C] interleaved (shift_j, r_j).  x2 -> y2 over C/2 channels.  logdet[b] += sum 2*softsign(r).
 __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ hh, int hs, int ho, const float* x2, int xs,
                                                            int xo, float* y2, int ys, int yo, float* __restrict__ rsave,
-                                                           float* __restrict__ logdet, int pix_per_img, int Ch, int reverse) {
+                                                           float* __restrict__ logdet, int pix_per_img, int Ch, int reverse, int vec) {
     __shared__ float red[4];
     const int b = blockIdx.y;
     const size_t base = (size_t)b * pix_per_img;
     const size_t total = (size_t)pix_per_img * Ch;
     float ld = 0.f;
+    if (vec) {
+        // 4 channel pairs per thread: two float4 of hh, one float4 of x2 / y2 / r
+        const int c4n = Ch >> 2;
+        const size_t tot4 = (size_t)pix_per_img * c4n;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < tot4; i += (size_t)gridDim.x * 256) {
+            const size_t pix = base + i / c4n;
+            const int j = (int)(i % c4n) * 4;
+            const float4 ha = *reinterpret_cast<const float4*>(hh + pix * hs + ho + 2 * j);
+            const float4 hb = *reinterpret_cast<const float4*>(hh + pix * hs + ho + 2 * j + 4);
+            const float4 xv = *reinterpret_cast<const float4*>(x2 + pix * xs + xo + j);
+            const float sh[4] = {ha.x, ha.z, hb.x, hb.z}, rr[4] = {ha.y, ha.w, hb.y, hb.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+            float oo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sg = 2.f * rr[e] / (1.f + fabsf(rr[e]));
+                oo[e] = reverse ? xx[e] * expf(-sg) - sh[e] : (xx[e] + sh[e]) * expf(sg);
+                ld += sg;
+            }
+            *reinterpret_cast<float4*>(y2 + pix * ys + yo + j) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+            if (rsave) *reinterpret_cast<float4*>(rsave + pix * Ch + j) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        }
+    } else
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t pix = base + i / Ch;
         const int j = i % Ch;
@@ -600,27 +622,35 @@ struct D2BP {
 };
 
 __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
+    // grid = (pixel-tile shares, channel chunks): a block owns ONE chunk of <= KCH input channels (KCH*9 <= 256, one
+    // weight-gradient output per thread) and walks its share of the 256-pixel tiles.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int TWl = p.TW_log2, TW = 1 << TWl, TH = 256 >> TWl;
     const int PW = TW + 2, PH = TH + 2, QW = TW + 4, QH = TH + 4;
     const int row = tid >> TWl, col = tid & (TW - 1);
     const int Cpad = (p.Cin + 3) & ~3;
-    const int nchunks = (Cpad + p.KCH - 1) / p.KCH;
+    const int c0 = blockIdx.y * p.KCH;
+    const int kch = min(p.KCH, Cpad - c0);
+    const int CS = kch + 8;
     float* A2 = lds;                              // [QH*QW] dd2m, halo 2
     float* A1 = A2 + ((QH * QW + 3) & ~3);        // [PH*PW] dd1m, halo 1
     float* lw1 = A1 + ((PH * PW + 3) & ~3);       // [9][KCH]
     float* lw2 = lw1 + 9 * p.KCH;                 // [9][KCH]
     float* lin = lw2 + 9 * p.KCH;                 // [PH*PW][CS]
-    float wa1[2][8], wa2[2][8];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { wa1[k][c] = 0.f; wa2[k][c] = 0.f; }
-    // W2 row of the d1 input channel (9 scalars)
+    float wa1 = 0.f, wa2 = 0.f;
     float w2d[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) w2d[t] = p.w2[(size_t)p.cin_nn * 9 + t];
+    for (int i = tid; i < 9 * kch; i += 256) {
+        const int tap = i / kch, c = i - tap * kch;
+        const bool ok = c0 + c < p.Cin;
+        lw1[i] = ok ? p.w1[(size_t)(c0 + c) * 9 + tap] : 0.f;
+        lw2[i] = ok ? p.w2[(size_t)(c0 + c) * 9 + tap] : 0.f;
+    }
+    const int wo_tap = tid / kch, wo_c = tid - wo_tap * kch;   // this thread's weight-gradient output
+    const bool wo_ok = tid < kch * 9;
+    const int wo_ky = wo_tap / 3, wo_kx = wo_tap - wo_ky * 3;
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         int t = tile;
@@ -630,14 +660,16 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
         const int b = t / p.tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
         __syncthreads();
+        stage_patch(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
         for (int i = tid; i < QH * QW; i += 256) {
             const int py = i / QW, px = i - py * QW;
             const int y = oy0 - 2 + py, x = ox0 - 2 + px;
             float v = 0.f;
             if (y >= 0 && y < p.Hin && x >= 0 && x < p.Win) {
                 const size_t pix = ((size_t)b * p.Hin + y) * p.Win + x;
-                v = p.GD[pix * p.gd_stride + 1];
-                if (!(p.Dp[pix * p.d_stride + 1] > 0.f)) v = 0.f;
+                const float2 gd = *reinterpret_cast<const float2*>(p.GD + pix * p.gd_stride);
+                const float2 dv = *reinterpret_cast<const float2*>(p.Dp + pix * p.d_stride);
+                v = dv.y > 0.f ? gd.y : 0.f;
             }
             A2[i] = v;
         }
@@ -653,7 +685,6 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) {
                         const int ky = tap / 3, kx = tap - ky * 3;
-                        // A2 origin is tile-2: pixel (py-1, px-1) of the tile frame sits at (py+1, px+1); minus (ky-1, kx-1)
                         v += w2d[tap] * A2[(py + 2 - ky) * QW + px + 2 - kx];
                     }
                 }
@@ -661,71 +692,55 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
             A1[i] = v;
         }
         __syncthreads();
-        float n1[9], n2[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            n1[tap] = A1[(row + 2 - ky) * PW + col + 2 - kx];
-            n2[tap] = A2[(row + 3 - ky) * QW + col + 3 - kx];
-        }
         const int oy = oy0 + row, ox = ox0 + col;
-        const bool inside = oy < p.Hin && ox < p.Win;
-        const size_t opix = ((size_t)b * p.Hin + oy) * p.Win + ox;
+        if (oy < p.Hin && ox < p.Win && c0 < p.cin_nn) {
+            float n1[9], n2[9];
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            if (ch >= nchunks) break;
-            const int c0 = ch * p.KCH;
-            const int kch = min(p.KCH, Cpad - c0);
-            const int CS = kch + 4;
-            __syncthreads();
-            stage_patch(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
-            for (int i = tid; i < 9 * kch; i += 256) {
-                const int tap = i / kch, c = i - tap * kch;
-                const bool ok = c0 + c < p.Cin;
-                lw1[i] = ok ? p.w1[(size_t)(c0 + c) * 9 + tap] : 0.f;
-                lw2[i] = ok ? p.w2[(size_t)(c0 + c) * 9 + tap] : 0.f;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                n1[tap] = A1[(row + 2 - ky) * PW + col + 2 - kx];
+                n2[tap] = A2[(row + 3 - ky) * QW + col + 3 - kx];
             }
-            __syncthreads();
-            if (inside) {
-                const float* cen = lin + ((row + 1) * PW + col + 1) * CS;
-                for (int c = 0; c < kch; c += 4) {
-                    const int ci = c0 + c;
-                    if (ci >= p.cin_nn) break;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const size_t opix = ((size_t)b * p.Hin + oy) * p.Win + ox;
+            const float* cen = lin + ((row + 1) * PW + col + 1) * CS;
+            for (int c = 0; c < kch; c += 4) {
+                const int ci = c0 + c;
+                if (ci >= p.cin_nn) break;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const float4 a = *reinterpret_cast<const float4*>(lw1 + tap * kch + c);
-                        const float4 bq = *reinterpret_cast<const float4*>(lw2 + tap * kch + c);
-                        v.x += a.x * n1[tap] + bq.x * n2[tap];
-                        v.y += a.y * n1[tap] + bq.y * n2[tap];
-                        v.z += a.z * n1[tap] + bq.z * n2[tap];
-                        v.w += a.w * n1[tap] + bq.w * n2[tap];
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float4 a = *reinterpret_cast<const float4*>(lw1 + tap * kch + c);
+                    const float4 bq = *reinterpret_cast<const float4*>(lw2 + tap * kch + c);
+                    v.x += a.x * n1[tap] + bq.x * n2[tap];
+                    v.y += a.y * n1[tap] + bq.y * n2[tap];
+                    v.z += a.z * n1[tap] + bq.z * n2[tap];
+                    v.w += a.w * n1[tap] + bq.w * n2[tap];
+                }
+                const float4 m = *reinterpret_cast<const float4*>(cen + c);
+                if (p.vec4) {
+                    int nl = ci;
+                    const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
+                    if (sgi) nl -= p.g0[0].n;
+                    const float* gp = (sgi ? p.g0[1].p : p.g0[0].p) + opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl;
+                    float* op = (sgi ? p.out[1].p : p.out[0].p) + opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl;
+                    const float4 g = *reinterpret_cast<const float4*>(gp);
+                    float4 o;
+                    o.x = m.x > 0.f ? g.x + v.x : 0.f;
+                    o.y = m.y > 0.f ? g.y + v.y : 0.f;
+                    o.z = m.z > 0.f ? g.z + v.z : 0.f;
+                    o.w = m.w > 0.f ? g.w + v.w : 0.f;
+                    if (p.add0 && !sgi) {
+                        const float4 ad = *reinterpret_cast<const float4*>(p.add0 + opix * p.add0_stride + nl);
+                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
                     }
-                    const float4 m = *reinterpret_cast<const float4*>(cen + c);
-                    if (p.vec4) {
-                        int nl = ci;
-                        const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
-                        if (sgi) nl -= p.g0[0].n;
-                        const float* gp = (sgi ? p.g0[1].p : p.g0[0].p) + opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl;
-                        float* op = (sgi ? p.out[1].p : p.out[0].p) + opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl;
-                        const float4 g = *reinterpret_cast<const float4*>(gp);
-                        float4 o;
-                        o.x = m.x > 0.f ? g.x + v.x : 0.f;
-                        o.y = m.y > 0.f ? g.y + v.y : 0.f;
-                        o.z = m.z > 0.f ? g.z + v.z : 0.f;
-                        o.w = m.w > 0.f ? g.w + v.w : 0.f;
-                        if (p.add0 && !sgi) {
-                            const float4 ad = *reinterpret_cast<const float4*>(p.add0 + opix * p.add0_stride + nl);
-                            o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-                        }
-                        *reinterpret_cast<float4*>(op) = o;
-                    } else {
-                        const float vv[4] = {v.x, v.y, v.z, v.w};
-                        const float mm[4] = {m.x, m.y, m.z, m.w};
+                    *reinterpret_cast<float4*>(op) = o;
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    const float mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            int nl = ci + e;
-                            if (nl >= p.cin_nn) break;
+                    for (int e = 0; e < 4; ++e) {
+                        int nl = ci + e;
+                        if (nl < p.cin_nn) {
                             const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
                             if (sgi) nl -= p.g0[0].n;
                             const float g = (sgi ? p.g0[1].p : p.g0[0].p)[opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl];
@@ -736,46 +751,28 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
                     }
                 }
             }
-            // weight gradients of both layers from the same staged activations
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int o = tid + 256 * k;
-                if (o < kch * 9) {
-                    const int tap = o / kch, c = o - tap * kch;
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    float s1 = 0.f, s2 = 0.f;
-                    for (int r = 0; r < TH; ++r) {
-                        const float* ip = lin + ((r + ky) * PW + kx) * CS + c;
-                        const float* d1p = A1 + (r + 1) * PW + 1;
-                        const float* d2p = A2 + (r + 2) * QW + 2;
-                        for (int cc = 0; cc < TW; ++cc) {
-                            const float a = ip[cc * CS];
-                            s1 += a * d1p[cc];
-                            s2 += a * d2p[cc];
-                        }
-                    }
-                    wa1[k][ch] += s1;
-                    wa2[k][ch] += s2;
+        }
+        // weight gradients of both layers from the same staged activations: one (channel, tap) output per thread
+        if (wo_ok) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < TH; ++r) {
+                const float* ip = lin + ((r + wo_ky) * PW + wo_kx) * CS + wo_c;
+                const float* d1p = A1 + (r + 1) * PW + 1;
+                const float* d2p = A2 + (r + 2) * QW + 2;
+#pragma unroll 4
+                for (int cc = 0; cc < TW; ++cc) {
+                    const float a = ip[cc * CS];
+                    s1 += a * d1p[cc];
+                    s2 += a * d2p[cc];
                 }
             }
+            wa1 += s1;
+            wa2 += s2;
         }
     }
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-        if (ch >= nchunks) break;
-        const int c0 = ch * p.KCH;
-        const int kch = min(p.KCH, Cpad - c0);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int o = tid + 256 * k;
-            if (o < kch * 9) {
-                const int tap = o / kch, c = o - tap * kch;
-                if (c0 + c < p.Cin) {
-                    atomicAdd(p.dW1 + (size_t)(c0 + c) * 9 + tap, wa1[k][ch]);
-                    atomicAdd(p.dW2 + (size_t)(c0 + c) * 9 + tap, wa2[k][ch]);
-                }
-            }
-        }
+    if (wo_ok && c0 + wo_c < p.Cin) {
+        atomicAdd(p.dW1 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa1);
+        atomicAdd(p.dW2 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa2);
     }
 }
 
@@ -786,13 +783,15 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
 extern "C" int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2,
                                 const int64_t* y_d, void* rsave, void* logdet, const int64_t* dims, hipStream_t st) {
     const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
-    const size_t per = (size_t)ppi * Ch;
-    int gx = (int)((per + 255) / 256);
-    if (gx > 256) gx = 256;
+    const int vec = ((Ch & 3) == 0) && (((hh_d[0] | hh_d[1] | x_d[0] | x_d[1] | y_d[0] | y_d[1]) & 3) == 0) &&
+                    (((((uintptr_t)hh) | ((uintptr_t)x2) | ((uintptr_t)y2) | ((uintptr_t)rsave)) & 15) == 0);
+    const size_t per = (size_t)ppi * (vec ? Ch / 4 : Ch);
+    int gx = (int)((per + 1023) / 1024);  // >= 4 items per thread
+    if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(affine_apply_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)hh, (int)hh_d[0], (int)hh_d[1],
                        (const float*)x2, (int)x_d[0], (int)x_d[1], (float*)y2, (int)y_d[0], (int)y_d[1], (float*)rsave, (float*)logdet,
-                       ppi, Ch, (int)dims[3]);
+                       ppi, Ch, (int)dims[3], vec);
     TMG_CHECK_LAUNCH();
     return 0;
 }
@@ -1045,17 +1044,19 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     p.tiles_y = (p.Hin + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     const int Cpad = (p.Cin + 3) & ~3;
-    p.KCH = Cpad < 32 ? Cpad : 32;
-    if ((Cpad + p.KCH - 1) / p.KCH > 8) return -2;
+    p.KCH = Cpad < 28 ? Cpad : 28;  // KCH*9 <= 256: one weight-gradient output per thread
+    const int nchunks = (Cpad + p.KCH - 1) / p.KCH;
     const int PP = (TH + 2) * (TW + 2), QQ = (TH + 4) * (TW + 4);
-    const size_t lds_bytes = ((size_t)((QQ + 3) & ~3) + ((PP + 3) & ~3) + 18 * p.KCH + (size_t)PP * (p.KCH + 4)) * 4;
+    const size_t lds_bytes = ((size_t)((QQ + 3) & ~3) + ((PP + 3) & ~3) + 18 * p.KCH + (size_t)PP * (p.KCH + 8)) * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    const int gx = p.ntiles < 768 ? p.ntiles : 768;
-    hipLaunchKernelGGL(dense2_bwd_kernel, dim3(gx), dim3(256), lds_bytes, st, p);
+    int gx = 1024 / nchunks;
+    if (gx > p.ntiles) gx = p.ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(dense2_bwd_kernel, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
 }

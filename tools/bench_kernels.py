@@ -58,5 +58,41 @@ def main():
             name, t_f, fl / t_f / 1e9, t_d, fl / t_d / 1e9, t_w, fl / t_w / 1e9), flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "tail" not in sys.argv:
     main()
+
+
+def bench_tail():
+    """Coupling tail (dense2 + zero-conv + affine) forward / backward per level of the metric config."""
+    import tmg_ops as ops
+    dev = "cuda"
+    for lvl, (hw, C) in enumerate([(128, 16), (64, 32), (32, 64), (16, 128)], 1):
+        B, Cc = 64, 32
+        ch = C // 2
+        cin = ch + Cc
+        x = torch.randn(B, hw, hw, C, device=dev, requires_grad=True)
+        cond = torch.randn(B, hw, hw, Cc, device=dev, requires_grad=True)
+        w1 = (0.1 * torch.randn(1, cin, 3, 3, device=dev)).requires_grad_(True)
+        w2 = (0.1 * torch.randn(1, cin + 1, 3, 3, device=dev)).requires_grad_(True)
+        wz = (0.02 * torch.randn(C, cin + 2, 3, 3, device=dev)).requires_grad_(True)
+        bz = torch.zeros(C, device=dev, requires_grad=True)
+        kap = torch.zeros(1, 1, 1, 1, device=dev, requires_grad=True)
+        gy = torch.randn(B, hw, hw, C, device=dev)
+        gl = torch.randn(B, device=dev)
+        H.prof_enable(False)
+
+        def fwd():
+            return ops.CouplingTailFn.apply(x, cond, w1, w2, wz, bz, kap, True, 0)
+
+        t_f = timeit(fwd)
+        y, ld = fwd()
+
+        def bwd():
+            torch.autograd.grad([y, ld], [x, cond, w1, w2, wz, bz, kap], [gy, gl], retain_graph=True)
+
+        t_b = timeit(bwd)
+        print("tail L%d: fwd %7.3f ms  bwd %7.3f ms" % (lvl, t_f, t_b), flush=True)
+
+
+if __name__ == "__main__" and "tail" in sys.argv:
+    bench_tail()
