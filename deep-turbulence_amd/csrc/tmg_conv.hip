@@ -401,8 +401,8 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 struct BorderP {
     const float* dy;  // [B,H,W] x Cdy, stride/off
     int dy_stride, dy_off, Cdy;
-    const float* w;  // torch layout W[Cdy][Cx][3][3]
-    int Cx;
+    const float* wpk;  // input-gradient packed weights [tap'][Cdy_pad/16][Cx_pad][16] (tmg_conv_pack mode 1)
+    int Cx, Npad, KB, dy_vec;
     const float* kappa;
     int B, H, W;
     TmgOSeg out[TMG_MAX_OUT_SEG];
@@ -452,9 +452,22 @@ __global__ void conv_rep_border_fix_kernel(BorderP p) {
                         const int px = rx - (kx - 1);
                         if (px < 0 || px >= p.W) continue;
                         const float* d = p.dy + (((size_t)b * p.H + py) * p.W + px) * p.dy_stride + p.dy_off;
-                        const float* wp = p.w + (size_t)ci * 9 + ky * 3 + kx;
+                        // packed operand: 16 consecutive dy-channels of one ci are contiguous, consecutive ci adjacent
+                        const float* wq = p.wpk + (((size_t)(8 - (ky * 3 + kx)) * p.KB) * p.Npad + ci) * 16;
                         float sacc = 0.f;
-                        for (int co = 0; co < p.Cdy; ++co) sacc += d[co] * wp[(size_t)co * p.Cx * 9];
+                        if (p.dy_vec) {
+                            for (int kb = 0; kb < p.KB; ++kb) {
+                                const float4* w4 = reinterpret_cast<const float4*>(wq + (size_t)kb * p.Npad * 16);
+                                const float4* d4 = reinterpret_cast<const float4*>(d + kb * 16);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float4 a = w4[e], v = d4[e];
+                                    sacc += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+                                }
+                            }
+                        } else {
+                            for (int co = 0; co < p.Cdy; ++co) sacc += d[co] * wq[(size_t)(co >> 4) * p.Npad * 16 + (co & 15)];
+                        }
                         acc += sacc;
                     }
                 }
@@ -629,10 +642,18 @@ extern "C" int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
     else if (ntt <= 12) { WM = 1; WN = 4; NTW = 3; }
     else { WM = 1; WN = 4; NTW = 4; }
     const int gy = (ntt + WN * NTW - 1) / (WN * NTW);
-    const int MBLK = 64 * WM;
+    // m-tiles per wave: 4 when the image is large; fewer when that would leave CUs idle (small levels)
+    int MT = 4;
+    while (MT > 1) {
+        const long npix = (long)p.B * p.Hout * p.Wout;
+        if ((npix / (16 * MT * WM)) * gy >= 512) break;
+        MT >>= 1;
+    }
+    const int MBLK = 16 * MT * WM;
     int twl = ilog2_ceil(p.Wout);
     if (twl > 5) twl = 5;
     if (twl < 2) twl = 2;
+    while ((1 << twl) > MBLK) --twl;
     // keep the tile no taller than needed when the image is small
     while (twl < 5 && (MBLK >> twl) > p.Hout && (1 << twl) < p.Wout) ++twl;
     p.TW_log2 = twl;
@@ -651,16 +672,20 @@ extern "C" int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
     const size_t lds_bytes = (size_t)PH * PW * (kch + 8) * 4;
     if (lds_bytes > 160 * 1024) return -6;
 
-#define TMG_CONV_CASE(MT_, NTW_, WM_, WN_) \
-    if (NTW == NTW_ && WM == WM_ && WN == WN_) return launch_conv<MT_, NTW_, WM_, WN_>(p, gy, lds_bytes, st);
-    TMG_CONV_CASE(4, 1, 4, 1)
-    TMG_CONV_CASE(4, 2, 4, 1)
-    TMG_CONV_CASE(4, 3, 4, 1)
-    TMG_CONV_CASE(4, 4, 4, 1)
-    TMG_CONV_CASE(4, 3, 2, 2)
-    TMG_CONV_CASE(4, 4, 2, 2)
-    TMG_CONV_CASE(4, 3, 1, 4)
-    TMG_CONV_CASE(4, 4, 1, 4)
+#define TMG_CONV_CASE(NTW_, WM_, WN_)                                                                  \
+    if (NTW == NTW_ && WM == WM_ && WN == WN_) {                                                       \
+        if (MT == 4) return launch_conv<4, NTW_, WM_, WN_>(p, gy, lds_bytes, st);                      \
+        if (MT == 2) return launch_conv<2, NTW_, WM_, WN_>(p, gy, lds_bytes, st);                      \
+        return launch_conv<1, NTW_, WM_, WN_>(p, gy, lds_bytes, st);                                   \
+    }
+    TMG_CONV_CASE(1, 4, 1)
+    TMG_CONV_CASE(2, 4, 1)
+    TMG_CONV_CASE(3, 4, 1)
+    TMG_CONV_CASE(4, 4, 1)
+    TMG_CONV_CASE(3, 2, 2)
+    TMG_CONV_CASE(4, 2, 2)
+    TMG_CONV_CASE(3, 1, 4)
+    TMG_CONV_CASE(4, 1, 4)
 #undef TMG_CONV_CASE
     return -7;
 }
@@ -724,9 +749,10 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
     pl->lds_bytes = ((size_t)PH * PW * (pl->CITG * 16 + 4) + 64 * (NCO * 16 + 4)) * 4;
     if (pl->lds_bytes > 160 * 1024) return -6;
-    int gx = pl->ntiles;
-    const int target = 1024 / (pl->gy * ngroups) > 0 ? 1024 / (pl->gy * ngroups) : 1;
-    if (gx > target) gx = target;
+    // pixel shares: enough blocks to fill the chip (~512) but >= 4 tiles per block so slab traffic stays small
+    int gx = 512 / (pl->gy * ngroups);
+    if (gx > pl->ntiles / 4) gx = pl->ntiles / 4;
+    if (gx < 1) gx = 1;
     pl->gx = gx;
     pl->ws_floats = (size_t)gx * pl->gy * pl->gz * 4 * pl->NP * NCO * 256 + (size_t)gx * pl->gy * 64;
     return 0;
@@ -786,14 +812,17 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
 }
 
 // Replicate-padding fold for the 3x3 input gradient (see conv_rep_border_fix_kernel).
-// dims: [B,H,W,Cdy,Cx]; dy_desc: [stride, off]
+// dims: [B,H,W,Cdy,Cx]; dy_desc: [stride, off]; w: the mode-1 packed weights of the SAME conv (tmg_conv_pack)
 extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, const void* w, const void* kappa,
                                        void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims,
                                        hipStream_t st) {
     BorderP p;
     p.dy = (const float*)dy; p.dy_stride = (int)dy_desc[0]; p.dy_off = (int)dy_desc[1];
     p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.Cdy = (int)dims[3]; p.Cx = (int)dims[4];
-    p.w = (const float*)w; p.kappa = (const float*)kappa;
+    p.wpk = (const float*)w; p.kappa = (const float*)kappa;
+    p.Npad = (p.Cx + 15) & ~15;
+    p.KB = (p.Cdy + 15) >> 4;
+    p.dy_vec = ((p.Cdy & 15) == 0) && (((p.dy_stride | p.dy_off) & 3) == 0) && ((((uintptr_t)dy) & 15) == 0);
     for (int i = 0; i < TMG_MAX_OUT_SEG; ++i) p.out[i] = TmgOSeg{nullptr, 0, 0, 0};
     for (int i = 0; i < (int)nout; ++i)
         p.out[i] = TmgOSeg{(float*)out_ptrs[i], (int)out_desc[3 * i], (int)out_desc[3 * i + 1], (int)out_desc[3 * i + 2]};

@@ -73,7 +73,7 @@ class ConvFn(torch.autograd.Function):
                 cin = sum(t.shape[3] for t in inputs)
                 H.conv_fwd([dy], wpk_t, cin, ksize, 1, dins, kappa=kappa)
                 if pad_rep and ksize == 3:
-                    H.conv_rep_border_fix(dy, weight, dins, kappa=kappa)
+                    H.conv_rep_border_fix(dy, wpk_t, dins, kappa=kappa)
             else:
                 assert ctx.n_in == 1 and not ctx.has_kappa and not pad_rep
                 H.conv_dgrad_direct(dy, weight, dins[0], ksize, stride)
@@ -368,8 +368,9 @@ class CouplingTailFn(torch.autograd.Function):
         dk = (dk * ((kappa >= -4.0) & (kappa <= LOG4)).to(dk.dtype)).reshape(kappa.shape)
         G = [torch.empty(t.shape, device=dev, dtype=torch.float32) for t in nn_in]
         GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-        H.conv_fwd([dhh], H.conv_pack(wzp, 1), cin + 4, 3, 1, G + [GD], kappa=kappa)
-        H.conv_rep_border_fix(dhh, wzp, G + [GD], kappa=kappa)
+        wzp_t = H.conv_pack(wzp, 1)
+        H.conv_fwd([dhh], wzp_t, cin + 4, 3, 1, G + [GD], kappa=kappa)
+        H.conv_rep_border_fix(dhh, wzp_t, G + [GD], kappa=kappa)
         # 3. both growth-1 layers, ReLU masks and the concat adjoint in one pass over the network input
         dw1 = torch.zeros_like(w1f)
         dw2p = torch.zeros_like(w2p)

@@ -60,7 +60,7 @@ int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t n
 int64_t tmg_conv_wgrad_ws_floats(const int64_t* dims);
 
 /* Adds the contribution of the replicate-padded ring to the border pixels of a 3x3 input gradient
- * (adjoint of F.pad(mode='replicate'), flowUtils.py:246).  dims = {B,H,W,Cdy,Cx}; w in torch layout. */
+ * (adjoint of F.pad(mode='replicate'), flowUtils.py:246).  dims = {B,H,W,Cdy,Cx}; w = the conv's mode-1 packed weights. */
 int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, const void* w, const void* kappa, void* const* out_ptrs,
                             const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
 

@@ -66,7 +66,10 @@ def bench_tail():
     """Coupling tail (dense2 + zero-conv + affine) forward / backward per level of the metric config."""
     import tmg_ops as ops
     dev = "cuda"
+    only = [int(a[1:]) for a in sys.argv if a.startswith("L") and a[1:].isdigit()]
     for lvl, (hw, C) in enumerate([(128, 16), (64, 32), (32, 64), (16, 128)], 1):
+        if only and lvl not in only:
+            continue
         B, Cc = 64, 32
         ch = C // 2
         cin = ch + Cc
