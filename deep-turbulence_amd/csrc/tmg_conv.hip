@@ -188,6 +188,7 @@ struct WgradP {
     int dy_vec4;
     float* dW;     // [Cout][Cin][ksize*ksize], accumulated with atomics (caller zeroes)
     float* dbias;  // [Cout] or null, accumulated with atomics
+    int cin_dst;   // dW holds channels [0, cin_dst) per output channel (<= Cin; the rest is dropped)
     float* ws;     // optional partial-sum slabs (see conv_wgrad_reduce_kernel); null -> direct atomics
     const float* kappa;
     int TW_log2, TH;  // pixel tile (TH*TW == 64)
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = (cit0 + cit) * 16 + q * 4 + r;
-                if (ci < p.Cin) atomicAdd(p.dW + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[j][n][r] * osc);
+                if (ci < p.cin_dst) atomicAdd(p.dW + ((size_t)co * p.cin_dst + ci) * ntaps + tap, acc[j][n][r] * osc);
             }
         }
     }
@@ -349,7 +350,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
                 const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (ci + r < Cin) atomicAdd(dW + ((size_t)co * Cin + ci + r) * ntaps + tap, av[r] * osc);
+                    if (ci + r < Cin) atomicAdd(dW + ((size_t)co * Cin + ci + r) * ntaps + tap, av[r] * osc);  // Cin == cin_dst here
             }
         }
     }
@@ -594,9 +595,13 @@ static void fill_segs(TmgSeg* dst, const void* const* ptrs, const int64_t* desc,
     }
 }
 
-extern "C" int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t ksize, int64_t mode, hipStream_t st) {
+// cin_eff >= Cin: the operand is built for cin_eff input channels, the extra ones zero (lets a conv read a wider,
+// 16-byte aligned segment list than the weight tensor has channels for).
+extern "C" int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize, int64_t mode,
+                             hipStream_t st) {
     const int ntaps = (int)(ksize * ksize);
-    const int K = mode == 0 ? (int)Cin : (int)Cout, N = mode == 0 ? (int)Cout : (int)Cin;
+    if (cin_eff < Cin) cin_eff = Cin;
+    const int K = mode == 0 ? (int)cin_eff : (int)Cout, N = mode == 0 ? (int)Cout : (int)cin_eff;
     const int Kpad = (K + 15) & ~15, Npad = (N + 15) & ~15;
     const size_t total = (size_t)ntaps * Kpad * Npad;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -765,8 +770,8 @@ extern "C" int64_t tmg_conv_wgrad_ws_floats(const int64_t* dims) {
     return (int64_t)pl.ws_floats;
 }
 
-// dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep]; dy_desc: [stride, off]
-// dW (and dbias) are ACCUMULATED onto (caller zero-fills).  ws: optional scratch of >= tmg_conv_wgrad_ws_floats(dims)
+// dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep,cin_dst]; dy_desc: [stride, off]
+// dW is [Cout][cin_dst][k*k] (cin_dst = 0 -> Cin).  dW (and dbias) are ACCUMULATED onto (caller zero-fills).  ws: optional scratch of >= tmg_conv_wgrad_ws_floats(dims)
 // floats; when given, per-block partial sums go through it and a small reduce kernel (few, low-contention atomics),
 // otherwise every block adds its partial sums to dW with float atomics.
 extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
@@ -779,6 +784,7 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Hout = (int)dims[3]; p.Wout = (int)dims[4];
     p.ksize = (int)dims[5]; p.stride = (int)dims[6]; p.Cin = (int)dims[7]; p.Cout = (int)dims[8];
     p.relu_in = (int)dims[9]; p.pad_rep = (int)dims[10];
+    p.cin_dst = (dims[11] > 0 && dims[11] < p.Cin) ? (int)dims[11] : p.Cin;
     if (p.ksize != 1 && p.ksize != 3) return -2;
     p.Cin_pad = (p.Cin + 15) & ~15;
     p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
@@ -805,7 +811,7 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
         int xchunk = 32;
         const int xc = (pl.gx + xchunk - 1) / xchunk;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
-                           p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.Cin, p.Cout, p.ksize * p.ksize, xchunk);
+                           p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.cin_dst, p.Cout, p.ksize * p.ksize, xchunk);
         TMG_CHECK_LAUNCH();
     }
     return 0;

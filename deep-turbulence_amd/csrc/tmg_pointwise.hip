@@ -418,7 +418,8 @@ struct C1P {
     const float* in_scale;
     const float* in_shift;
     int relu_in, pad_rep;
-    const float* w;  // [Cin][9]
+    const float* w;  // [w_rows][9]; input channels >= w_rows have zero weight
+    int w_rows;
     float* out; int out_stride, out_off;
     int TW_log2, tiles_x, tiles_y, KCH;
 };
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1P p) {
         stage_patch(p, lds, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
         for (int i = tid; i < 9 * kch; i += 256) {
             const int tap = i / kch, c = i - tap * kch;
-            lw[i] = (c0 + c < p.Cin) ? p.w[(size_t)(c0 + c) * 9 + tap] : 0.f;
+            lw[i] = (c0 + c < p.w_rows) ? p.w[(size_t)(c0 + c) * 9 + tap] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -614,7 +615,7 @@ struct D2BP {
     float* dW2;
     const float* GD; int gd_stride;
     const float* Dp; int d_stride;
-    int cin_nn;
+    int cin_nn, rows1, rows2;  // w1/dW1 have rows1 rows, w2/dW2 rows2 rows ([rows][9]); missing rows are zero
     TmgSeg g0[2];
     TmgOSeg out[2];
     const float* add0; int add0_stride;
@@ -644,9 +645,8 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
     for (int t = 0; t < 9; ++t) w2d[t] = p.w2[(size_t)p.cin_nn * 9 + t];
     for (int i = tid; i < 9 * kch; i += 256) {
         const int tap = i / kch, c = i - tap * kch;
-        const bool ok = c0 + c < p.Cin;
-        lw1[i] = ok ? p.w1[(size_t)(c0 + c) * 9 + tap] : 0.f;
-        lw2[i] = ok ? p.w2[(size_t)(c0 + c) * 9 + tap] : 0.f;
+        lw1[i] = (c0 + c < p.rows1) ? p.w1[(size_t)(c0 + c) * 9 + tap] : 0.f;
+        lw2[i] = (c0 + c < p.rows2) ? p.w2[(size_t)(c0 + c) * 9 + tap] : 0.f;
     }
     const int wo_tap = tid / kch, wo_c = tid - wo_tap * kch;   // this thread's weight-gradient output
     const bool wo_ok = tid < kch * 9;
@@ -770,9 +770,25 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
             wa2 += s2;
         }
     }
-    if (wo_ok && c0 + wo_c < p.Cin) {
-        atomicAdd(p.dW1 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa1);
-        atomicAdd(p.dW2 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa2);
+    if (wo_ok) {
+        if (c0 + wo_c < p.rows1) atomicAdd(p.dW1 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa1);
+        if (c0 + wo_c < p.rows2) atomicAdd(p.dW2 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa2);
+    }
+}
+
+// d(kappa) of a Conv2dZeros from its parameter gradients: h = e^k (W*x + b) is degree-1 homogeneous in (W, b), so
+// sum dh*h = <W, dW> + <b, db>; zero when kappa sits outside the clamp range (flowUtils.py:247).
+__global__ __launch_bounds__(256) void dkappa_kernel(const float* __restrict__ w, const float* __restrict__ dw, int nw,
+                                                     const float* __restrict__ b, const float* __restrict__ db, int nb,
+                                                     const float* __restrict__ kappa, float* __restrict__ dk) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nw; i += 256) a += w[i] * dw[i];
+    for (int i = threadIdx.x; i < nb; i += 256) a += b[i] * db[i];
+    const float tot = block_sum_256(a, red);
+    if (threadIdx.x == 0) {
+        const float k = *kappa;
+        *dk = (k >= -4.0f && k <= 1.3862943611198906f) ? tot : 0.f;
     }
 }
 
@@ -947,7 +963,7 @@ static int c1_tile(int W, int H, int* twl) {
     return 0;
 }
 
-// dims: [B,H,W,Cin,relu_in]; out_d = [stride, off]
+// dims: [B,H,W,Cin,relu_in,w_rows]; out_d = [stride, off]; w is [w_rows][9] (w_rows = 0 -> Cin)
 extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out,
                           const int64_t* out_d, const int64_t* dims, hipStream_t st) {
     C1P p;
@@ -955,6 +971,7 @@ extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, in
     p.vec4 = 1;
     fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.relu_in = (int)dims[4];
+    p.w_rows = (dims[5] > 0 && dims[5] < p.Cin) ? (int)dims[5] : p.Cin;
     if (p.Cin & 3) p.vec4 = 0;
     p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
     p.w = (const float*)w; p.out = (float*)out; p.out_stride = (int)out_d[0]; p.out_off = (int)out_d[1];
@@ -1014,7 +1031,7 @@ extern "C" int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, in
 }
 
 // Fused backward of both growth-1 layers (see dense2_bwd_kernel).
-// in segments: nn inputs followed by D (4 channels); dims = {B,H,W,Cin_total (incl. D's 4),cin_nn}
+// in segments: nn inputs followed by D (4 channels); dims = {B,H,W,Cin_total (incl. D's 4),cin_nn,rows1,rows2}
 // g0/out: up to two segments each (same channel split as the nn inputs); add0 optional (null) added to out segment 0.
 extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2,
                               void* dW1, void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride,
@@ -1025,6 +1042,7 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     p.vec4 = 1;
     fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.cin_nn = (int)dims[4];
+    p.rows1 = (int)dims[5]; p.rows2 = (int)dims[6];
     p.relu_in = 1; p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
     if (p.Cin & 3) p.vec4 = 0;
     p.w1 = (const float*)w1; p.w2 = (const float*)w2; p.dW1 = (float*)dW1; p.dW2 = (float*)dW2;
@@ -1057,6 +1075,14 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     if (gx > p.ntiles) gx = p.ntiles;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(dense2_bwd_kernel, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void* b, const void* db, int64_t nb, const void* kappa,
+                          void* dk, hipStream_t st) {
+    hipLaunchKernelGGL(dkappa_kernel, dim3(1), dim3(256), 0, st, (const float*)w, (const float*)dw, (int)nw, (const float*)b,
+                       (const float*)db, (int)nb, (const float*)kappa, (float*)dk);
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -48,8 +48,8 @@ class _BlockBase(nn.Module):
             ld = ld + norm.weight.abs().log().sum() * hw
         return ld
 
-    def _mix(self, xn, reverse):
-        W, b = self._mix_params(reverse)
+    def _mix(self, xn, reverse, mix=None):
+        W, b = self._mix_params(reverse) if mix is None else mix
         c = W.shape[0]
         return ops.conv([xn], W.reshape(c, c, 1, 1), b, ksize=1)
 
@@ -61,14 +61,17 @@ class AffineCouplingBlock(_BlockBase):
         self.conv = _make_conv(in_features, train_sampling, LUdecompose)
         self.coupling = AffineCouplingLayer(in_features, cond_features)
 
-    def run(self, xn, condn, reverse):
+    def run(self, xn, condn, reverse, mix=None):
+        """mix: optional pre-folded (W, b) of this block's ActNorm + 1x1 conv (LSTMFLowBlock builds them for all its
+        layers in one batched pass and also accounts for their log-dets); None -> fold here and add the log-det."""
         if not isinstance(self.conv, InvertibleConv1x1LU):
             return _run_unfused(self, xn, condn, None, reverse)[:2]
+        extra = self._mix_logdet(xn) if mix is None else 0.
         if reverse:
             t, ld = self.coupling.run(xn, condn, True)
-            return self._mix(t, True), ld + self._mix_logdet(xn)
-        y, ld = self.coupling.run(self._mix(xn, False), condn, False)
-        return y, ld + self._mix_logdet(xn)
+            return self._mix(t, True, mix), ld + extra
+        y, ld = self.coupling.run(self._mix(xn, False, mix), condn, False)
+        return y, ld + extra
 
     def forward(self, x, cond):
         y, ld = self.run(H.nhwc(x), H.nhwc(cond), False)
@@ -99,14 +102,15 @@ class LSTMCouplingBlock(_BlockBase):
         self.conv = _make_conv(in_features, train_sampling, LUdecompose)
         self.coupling = LSTMAffineCouplingLayer(in_features, cond_features, rec_features)
 
-    def run(self, xn, condn, state, reverse):
+    def run(self, xn, condn, state, reverse, mix=None):
         if not isinstance(self.conv, InvertibleConv1x1LU):
             return _run_unfused(self, xn, condn, state, reverse)
+        extra = self._mix_logdet(xn) if mix is None else 0.
         if reverse:
             t, ld, st = self.coupling.run(xn, condn, state, True)
-            return self._mix(t, True), ld + self._mix_logdet(xn), st
-        y, ld, st = self.coupling.run(self._mix(xn, False), condn, state, False)
-        return y, ld + self._mix_logdet(xn), st
+            return self._mix(t, True, mix), ld + extra, st
+        y, ld, st = self.coupling.run(self._mix(xn, False, mix), condn, state, False)
+        return y, ld + extra, st
 
     def _call(self, x, cond, rec_states, reverse):
         st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
@@ -177,6 +181,43 @@ class LSTMFLowBlock(nn.Module):
         if do_split:
             self.split = Split(in_features)
 
+    def _level_mix(self, reverse, hw):
+        """Fold ActNorm + PLU 1x1 conv of ALL K layers of this level in one batched pass of O(K C^3) torch ops
+        (parameter-side bookkeeping, reference glowConv.py:151-174 + actNorm.py:66-83) instead of K separate ones.
+        Returns ([K,C,C] matrices, [K,C] biases, scalar log-det of all K mixes) or None if a layer is not LU."""
+        layers = list(self.revlayers._modules.values())
+        convs = [l.conv for l in layers]
+        if not all(isinstance(c, InvertibleConv1x1LU) and c.train_sampling == convs[0].train_sampling for c in convs):
+            return None
+        st = lambda name: torch.stack([getattr(c, name) for c in convs])  # noqa: E731
+        eye = convs[0].eye
+        logs = st('log_s')
+        lower = st('l') * st('l_mask') + eye
+        upper = st('u') * st('u_mask') + torch.diag_embed(logs.exp() * st('sign_s')) + 0.01 * eye
+        P = st('p')
+        ts = convs[0].train_sampling
+        use_weight = reverse if ts else not reverse
+        if use_weight:
+            W = P @ (lower @ upper)
+            with torch.no_grad():
+                for c in convs:
+                    c.log_s_old.copy_(c.log_s)
+        else:
+            from nn.modules.glowConv import _TriInv
+            W = _TriInv.apply(upper, True) @ (_TriInv.apply(lower, False) @ P.transpose(1, 2))
+        ones = torch.ones_like(logs[0])
+        a = torch.stack([l.norm.weight.view(-1) if hasattr(l, 'norm') else ones for l in layers])
+        b = torch.stack([l.norm.bias.view(-1) if hasattr(l, 'norm') else torch.zeros_like(ones) for l in layers])
+        if reverse:      # (W y - b) / a
+            Wm = W / a.unsqueeze(2)
+            bm = -b / a
+        else:            # W (a x + b)
+            Wm = W * a.unsqueeze(1)
+            bm = (W @ b.unsqueeze(2)).squeeze(2)
+        ld = logs.sum() * hw
+        ld = (-ld if ts else ld) + a.abs().log().sum() * hw
+        return Wm, bm, ld
+
     def _squeeze_nhwc(self, xn, to_small):
         if isinstance(self.squeeze, CheckerSqueeze):
             return ops.CheckerFn.apply(xn, to_small)
@@ -187,14 +228,16 @@ class LSTMFLowBlock(nn.Module):
         xn, condn = self._squeeze_nhwc(H.nhwc(x), True), H.nhwc(cond)
         st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
         layers = list(self.revlayers._modules.values())
-        logdet = 0.
+        lm = self._level_mix(False, xn.shape[1] * xn.shape[2])
+        logdet = 0. if lm is None else lm[2]
         out_states = []
         for i, layer in enumerate(layers):
+            mix = None if lm is None else (lm[0][i], lm[1][i])
             if i == self.n_layers - 1:
-                xn, dld, so = layer.run(xn, condn, st, False)
+                xn, dld, so = layer.run(xn, condn, st, False, mix)
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
             else:
-                xn, dld = layer.run(xn, condn, False)
+                xn, dld = layer.run(xn, condn, False, mix)
             logdet = logdet + dld
         if self.do_split:
             z1, lp, eps = self.split(H.nchw(xn), return_eps=return_eps)
@@ -210,11 +253,15 @@ class LSTMFLowBlock(nn.Module):
         yn, condn = H.nhwc(y), H.nhwc(cond)
         st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
         layers = list(self.revlayers._modules.values())
+        lm = self._level_mix(True, yn.shape[1] * yn.shape[2])
+        if lm is not None:
+            logdet = logdet + lm[2]
         for i in range(len(layers) - 1, -1, -1):
+            mix = None if lm is None else (lm[0][i], lm[1][i])
             if i == self.n_layers - 1:
-                yn, dld, so = layers[i].run(yn, condn, st, True)
+                yn, dld, so = layers[i].run(yn, condn, st, True, mix)
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
             else:
-                yn, dld = layers[i].run(yn, condn, True)
+                yn, dld = layers[i].run(yn, condn, True, mix)
             logdet = logdet + dld
         return H.nchw(self._squeeze_nhwc(yn, False)), logdet, out_states

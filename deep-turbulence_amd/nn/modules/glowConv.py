@@ -15,15 +15,15 @@ class _TriInv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, upper):
-        eye = torch.eye(a.shape[0], device=a.device, dtype=a.dtype)
-        x = torch.linalg.solve_triangular(a.detach(), eye, upper=upper)
+        eye = torch.eye(a.shape[-1], device=a.device, dtype=a.dtype)
+        x = torch.linalg.solve_triangular(a.detach(), eye.expand_as(a), upper=upper)
         ctx.save_for_backward(x)
         return x
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        xt = x.t()
+        xt = x.transpose(-1, -2)
         return -(xt @ g @ xt), None
 
 

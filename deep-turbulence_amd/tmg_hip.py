@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_fwd", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_prof_enable", "tmg_prof_collect",
+    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
 ]
 
 
@@ -141,15 +141,17 @@ def _i64(*v):
 # ------------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------------
-def conv_pack(w, mode):
-    """w: torch layout [Cout, Cin, k, k] -> packed MFMA operand (see tmg_conv_pack)."""
+def conv_pack(w, mode, cin_eff=0):
+    """w: torch layout [Cout, Cin, k, k] -> packed MFMA operand (see tmg_conv_pack); cin_eff > Cin zero-extends the
+    input-channel dimension."""
     check_act(w)
     w = w.contiguous()
     Cout, Cin, k, _ = w.shape
-    K, N = (Cin, Cout) if mode == 0 else (Cout, Cin)
+    ce = max(int(cin_eff), Cin)
+    K, N = (ce, Cout) if mode == 0 else (Cout, ce)
     Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
     wpk = torch.empty(k * k * Kp * Np, device=w.device, dtype=torch.float32)
-    _chk(lib().tmg_conv_pack(_ptr(w), _ptr(wpk), c_i64(Cout), c_i64(Cin), c_i64(k), c_i64(mode), _stream()), "tmg_conv_pack")
+    _chk(lib().tmg_conv_pack(_ptr(w), _ptr(wpk), c_i64(Cout), c_i64(Cin), c_i64(ce), c_i64(k), c_i64(mode), _stream()), "tmg_conv_pack")
     return wpk
 
 
@@ -181,12 +183,12 @@ def workspace(nfloats, device):
 
 
 def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, in_shift=None, relu_in=False, pad_rep=False,
-               use_ws=True):
+               use_ws=True, cin_dst=0):
     B, Hin, Win, _ = inputs[0].shape
     _, Hout, Wout, Cout = dy.shape
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
-    dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep)
+    dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep, cin_dst)
     ws = workspace(lib().tmg_conv_wgrad_ws_floats(dims), dy.device) if use_ws else None
     _chk(lib().tmg_conv_wgrad(ip, idesc, c_i64(n_in), _ptr(in_scale), _ptr(in_shift), _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
                               _ptr(kappa), _ptr(ws), c_i64(ws.numel() if ws is not None else 0), dims, _stream()), "tmg_conv_wgrad")
@@ -301,11 +303,12 @@ def masked_add(dst, src=None, ref=None, add=None, accumulate=False):
          "tmg_masked_add")
 
 
-def c1_fwd(inputs, w, out, relu_in=True):
+def c1_fwd(inputs, w, out, relu_in=True, w_rows=0):
     B, H, W, _ = inputs[0].shape
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
-    _chk(lib().tmg_c1_fwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(out), _d2(out), _i64(B, H, W, Cin, relu_in), _stream()), "tmg_c1_fwd")
+    _chk(lib().tmg_c1_fwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(out), _d2(out), _i64(B, H, W, Cin, relu_in, w_rows), _stream()),
+         "tmg_c1_fwd")
 
 
 def c1_bwd(inputs, w, dW, dd, dref, gsegs, relu_in=True):
@@ -318,7 +321,12 @@ def c1_bwd(inputs, w, dW, dd, dref, gsegs, relu_in=True):
                           _i64(B, H, W, Cin, relu_in), _stream()), "tmg_c1_bwd")
 
 
-def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None):
+def dkappa(w, dw, b, db, kappa, dk):
+    _chk(lib().tmg_dkappa(_ptr(w), _ptr(dw), c_i64(w.numel()), _ptr(b), _ptr(db), c_i64(b.numel()), _ptr(kappa), _ptr(dk), _stream()),
+         "tmg_dkappa")
+
+
+def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None, rows1=0, rows2=0):
     """Fused backward of the two growth-1 layers; `inputs` = nn inputs + [D]; g0 / outs: lists (<= 2) of NHWC tensors."""
     B, H, W, _ = inputs[0].shape
     ip, idesc, n_in = _segs(inputs)
@@ -327,5 +335,5 @@ def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None)
     Cin = sum(t.shape[3] for t in inputs)
     a_stride = seg(add0)[1] if add0 is not None else 0
     _chk(lib().tmg_dense2_bwd(ip, idesc, c_i64(n_in), _ptr(w1p), _ptr(w2p), _ptr(dW1p), _ptr(dW2p), _ptr(GD), c_i64(seg(GD)[1]), _ptr(D),
-                              c_i64(seg(D)[1]), gp, gdesc, op, odesc, c_i64(ng), _ptr(add0), c_i64(a_stride), _i64(B, H, W, Cin, cin_nn),
-                              _stream()), "tmg_dense2_bwd")
+                              c_i64(seg(D)[1]), gp, gdesc, op, odesc, c_i64(ng), _ptr(add0), c_i64(a_stride),
+                              _i64(B, H, W, Cin, cin_nn, rows1 or Cin, rows2 or Cin), _stream()), "tmg_dense2_bwd")

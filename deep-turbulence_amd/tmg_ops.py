@@ -309,9 +309,10 @@ class CouplingTailFn(torch.autograd.Function):
         t0 = cat(nn inputs);  d1 = c1(relu(t0));  d2 = c1(relu(t0|d1));  hh = ZeroConv(relu(t0|d1|d2))
         y = [x1 | affine(x2; hh)],  logdet[b]
     (reference flowAffine.py:73-83 / :98-109 and :189-198 / :227-236).
-    The two growth-1 layers run on the vector ALUs (tmg_c1_*), the zero-conv on the matrix cores; the
-    concatenations are never built: the kernels read x1 / cond / D as segments, D being a 4-channel buffer
-    (2 used) so every segment stays 16-byte aligned.  Saved for backward: x, cond/out, D, r -- not hh.
+    The two growth-1 layers run on the vector ALUs (tmg_c1_fwd / tmg_dense2_bwd), the zero-conv on the matrix
+    cores; the concatenations are never built: the kernels read x1 / cond / D as segments, D being a 4-channel
+    buffer (2 used) so every segment stays 16-byte aligned; weights are consumed in their native layout.
+    Saved for backward: x, cond/feat, D, r, y -- not hh.
 
     mode 0: nn inputs = (x[..., :C/2], cond)      -- AffineCouplingLayer
     mode 1: nn inputs = (feat,)                   -- LSTMAffineCouplingLayer (feat = ResidLSTMBlock output)
@@ -326,29 +327,24 @@ class CouplingTailFn(torch.autograd.Function):
         dev = x.device
         nn_in = [x[..., :ch], aux] if mode == 0 else [aux]
         cin = sum(t.shape[3] for t in nn_in)
+        w1, w2, wz = w1.contiguous(), w2.contiguous(), wz.contiguous()
         D = torch.zeros((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-        w1f = torch.zeros((cin + 4, 9), device=dev, dtype=torch.float32)
-        w1f[:cin] = w1.reshape(cin, 9)
-        w2p = torch.zeros((cin + 4, 9), device=dev, dtype=torch.float32)
-        w2p[:cin + 1] = w2.reshape(cin + 1, 9)
-        wzp = torch.zeros((C, cin + 4, 3, 3), device=dev, dtype=torch.float32)
-        wzp[:, :cin + 2] = wz
-        H.c1_fwd(nn_in, w1f, D[..., 0:1], relu_in=True)
-        H.c1_fwd(nn_in + [D], w2p, D[..., 1:2], relu_in=True)
+        H.c1_fwd(nn_in, w1, D[..., 0:1], relu_in=True)
+        H.c1_fwd(nn_in + [D], w2, D[..., 1:2], relu_in=True, w_rows=cin + 1)
         hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
-        H.conv_fwd(nn_in + [D], H.conv_pack(wzp, 0), C, 3, 1, [hh], bias=bz, kappa=kappa, relu_in=True, pad_rep=True)
+        H.conv_fwd(nn_in + [D], H.conv_pack(wz, 0, cin + 4), C, 3, 1, [hh], bias=bz, kappa=kappa, relu_in=True, pad_rep=True)
         y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
         H.masked_add(y[..., :ch], src=x[..., :ch])
         r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
         logdet = torch.zeros(B, device=dev, dtype=torch.float32)
         H.affine_apply(hh, x[..., ch:], y[..., ch:], r, logdet, reverse)
         ctx.reverse, ctx.mode, ctx.cin = reverse, mode, cin
-        ctx.save_for_backward(x, aux, D, r, y, w1f, w2p, wzp, bz, kappa)
+        ctx.save_for_backward(x, aux, D, r, y, w1, w2, wz, bz, kappa)
         return y, logdet
 
     @staticmethod
     def backward(ctx, dy, dld):
-        x, aux, D, r, y, w1f, w2p, wzp, bz, kappa = ctx.saved_tensors
+        x, aux, D, r, y, w1, w2, wz, bz, kappa = ctx.saved_tensors
         reverse, mode, cin = ctx.reverse, ctx.mode, ctx.cin
         dy = dy.contiguous()
         B, Hh, Ww, C = dy.shape
@@ -360,26 +356,28 @@ class CouplingTailFn(torch.autograd.Function):
         dhh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
         g = dld.contiguous() if dld is not None else None
         H.affine_bwd(dy[..., ch:], (x if reverse else y)[..., ch:], r, g, dx[..., ch:], dhh, reverse)
+        # one zero-filled buffer for every parameter gradient of this node
+        n1, n2, nz = cin * 9, (cin + 1) * 9, C * (cin + 2) * 9
+        flat = torch.zeros(n1 + n2 + nz + C + 1, device=dev, dtype=torch.float32)
+        dw1 = flat[:n1].view(1, cin, 3, 3)
+        dw2 = flat[n1:n1 + n2].view(1, cin + 1, 3, 3)
+        dwz = flat[n1 + n2:n1 + n2 + nz].view(C, cin + 2, 3, 3)
+        dbz = flat[n1 + n2 + nz:n1 + n2 + nz + C]
+        dk = flat[n1 + n2 + nz + C:].view(kappa.shape)
         # 2. zero-conv: weight / bias / scale gradients, raw input gradient
-        dwzp = torch.zeros_like(wzp)
-        dbz = torch.zeros_like(bz)
-        H.conv_wgrad(nn_in + [D], dhh, dwzp, dbz, 3, 1, kappa=kappa, relu_in=True, pad_rep=True)
-        dk = (wzp * dwzp).sum() + (bz * dbz).sum()
-        dk = (dk * ((kappa >= -4.0) & (kappa <= LOG4)).to(dk.dtype)).reshape(kappa.shape)
+        H.conv_wgrad(nn_in + [D], dhh, dwz, dbz, 3, 1, kappa=kappa, relu_in=True, pad_rep=True, cin_dst=cin + 2)
+        H.dkappa(wz, dwz, bz, dbz, kappa, dk)
         G = [torch.empty(t.shape, device=dev, dtype=torch.float32) for t in nn_in]
         GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-        wzp_t = H.conv_pack(wzp, 1)
-        H.conv_fwd([dhh], wzp_t, cin + 4, 3, 1, G + [GD], kappa=kappa)
-        H.conv_rep_border_fix(dhh, wzp_t, G + [GD], kappa=kappa)
+        wz_t = H.conv_pack(wz, 1, cin + 4)
+        H.conv_fwd([dhh], wz_t, cin + 4, 3, 1, G + [GD], kappa=kappa)
+        H.conv_rep_border_fix(dhh, wz_t, G + [GD], kappa=kappa)
         # 3. both growth-1 layers, ReLU masks and the concat adjoint in one pass over the network input
-        dw1 = torch.zeros_like(w1f)
-        dw2p = torch.zeros_like(w2p)
         if mode == 0:
-            H.dense2_bwd(nn_in + [D], w1f, w2p, dw1, dw2p, GD, D, G, [dx[..., :ch], G[1]], cin, add0=dy[..., :ch])
+            H.dense2_bwd(nn_in + [D], w1, w2, dw1, dw2, GD, D, G, [dx[..., :ch], G[1]], cin, add0=dy[..., :ch], rows1=cin, rows2=cin + 1)
             daux = G[1]
         else:
-            H.dense2_bwd(nn_in + [D], w1f, w2p, dw1, dw2p, GD, D, G, [G[0]], cin)
+            H.dense2_bwd(nn_in + [D], w1, w2, dw1, dw2, GD, D, G, [G[0]], cin, rows1=cin, rows2=cin + 1)
             H.masked_add(dx[..., :ch], src=dy[..., :ch])
             daux = G[0]
-        return (dx, daux, dw1[:cin].reshape(1, cin, 3, 3), dw2p[:cin + 1].reshape(1, cin + 1, 3, 3), dwzp[:, :cin + 2].contiguous(), dbz, dk,
-                None, None)
+        return dx, daux, dw1, dw2, dwz, dbz, dk, None, None

@@ -36,8 +36,9 @@ typedef struct ihipStream_t* tmg_stream_t; /* == hipStream_t */
 /* Re-layout torch weights W[Cout][Cin][k][k] into the MFMA operand order
  * wpk[k*k][Kpad/16][Npad][16].  mode 0: forward operand (K=Cin, N=Cout).  mode 1: input-gradient
  * operand (K=Cout, N=Cin, taps flipped).  wpk must hold k*k*Kpad*Npad floats (Kpad, Npad = K, N
- * rounded up to 16). */
-int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t ksize, int64_t mode, tmg_stream_t st);
+ * rounded up to 16).  cin_eff >= Cin builds the operand for cin_eff input channels (extra ones zero). */
+int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize, int64_t mode,
+                  tmg_stream_t st);
 
 /* out = [relu]( (conv_k(pad(act(in)); wpk) + bias) * exp(clamp(kappa,-4,ln4)) ), ksize 1 or 3,
  * stride 1 or 2, zero or replicate padding, act = optional per-channel affine then optional ReLU.
@@ -51,7 +52,8 @@ int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nse
 
 /* dW[Cout][Cin][k][k] += scale * sum_pixels act(in)(p*s+tap) (x) dy(p) ; dbias += scale * sum dy.
  * (accumulating: caller zero-fills; per-block partial sums go through the scratch `ws` and a reduce kernel.)  Replaces the autograd weight-gradient of the convs above.
- * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate}; dy_desc = {stride, off} */
+ * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate,cin_dst}; dy_desc = {stride, off};
+ * dW is [Cout][cin_dst][k*k] (cin_dst = 0: Cin) */
 int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
                    const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, const void* kappa,
                    void* ws, int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
@@ -123,7 +125,7 @@ int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const i
 
 /* Growth-1 dense layer of the coupling network, C_out = 1 (denseBlock.py:135-138), forward and
  * backward (input gradient accumulated into g segments, weight gradient accumulated atomically).
- * dims = {B,H,W,Cin,relu_in} */
+ * dims = {B,H,W,Cin,relu_in[,w_rows]} */
 int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out, const int64_t* out_d,
                const int64_t* dims, tmg_stream_t st);
 int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* dW, const void* dd,
@@ -132,11 +134,16 @@ int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg,
 
 /* Fused backward of both growth-1 layers of a coupling network (denseBlock.py:135-152 x2) incl. the ReLU masks
  * and the concat adjoint: one pass over the network input.  in segments = nn inputs followed by the 4-channel D
- * buffer; dims = {B,H,W,Cin_total(incl. D),cin_nn}. */
+ * buffer; dims = {B,H,W,Cin_total(incl. D),cin_nn,rows1,rows2}. */
 int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2, void* dW1,
                    void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride, const void* const* g0_ptrs,
                    const int64_t* g0_desc, void* const* out_ptrs, const int64_t* out_desc, int64_t ng, const void* add0,
                    int64_t add0_stride, const int64_t* dims, tmg_stream_t st);
+
+/* d(kappa) of a Conv2dZeros from its parameter gradients: <W,dW> + <b,db>, zero outside the clamp range
+ * (flowUtils.py:247). */
+int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void* b, const void* db, int64_t nb, const void* kappa, void* dk,
+               tmg_stream_t st);
 
 #ifdef __cplusplus
 }
