@@ -115,21 +115,38 @@ __device__ __forceinline__ float4 load_in4(const P& p, int b, int iy, int ix, in
 }
 
 // Stage channels [c0, c0+kch) of the (PH x PW) input patch whose top-left input pixel is (iy0, ix0).
-template <typename P>
+// U loads are issued back to back before any is written to LDS: a thread that waits for each load before issuing
+// the next one is bound by U x the memory latency (measured: 5x slower staging at U = 1).
+template <int U = 8, typename P>
 __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int iy0, int ix0, int PH, int PW, int c0,
                                             int kch, int CS) {
     const int k4 = kch >> 2;
     const int items = PH * PW * k4;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int pix = it / k4;
-        const int c4 = it - pix * k4;
-        const int py = pix / PW;
-        const int px = pix - py * PW;
-        const float4 v = load_in4(p, b, iy0 + py, ix0 + px, c0 + 4 * c4);
-        *reinterpret_cast<float4*>(lds + pix * CS + 4 * c4) = v;
+    const int nt = blockDim.x;
+    // floor(n / d) == umulhi(n, ceil(2^32 / d)) for n * d < 2^32 (d >= 2): two multiplies instead of two divisions per item
+    const unsigned mk = k4 > 1 ? 0xFFFFFFFFu / (unsigned)k4 + 1u : 0u;
+    const unsigned mp = 0xFFFFFFFFu / (unsigned)PW + 1u;
+    for (int base = threadIdx.x; base < items; base += nt * U) {
+        float4 v[U];
+        int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = base + u * nt;
+            dst[u] = -1;
+            if (it < items) {
+                const int pix = k4 > 1 ? (int)__umulhi((unsigned)it, mk) : it;
+                const int c4 = it - pix * k4;
+                const int py = (int)__umulhi((unsigned)pix, mp);
+                const int px = pix - py * PW;
+                v[u] = load_in4(p, b, iy0 + py, ix0 + px, c0 + 4 * c4);
+                dst[u] = pix * CS + 4 * c4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<float4*>(lds + dst[u]) = v[u];
     }
 }
-
 
 // Select the output segment holding concatenated channel `nl` BY VALUE (taking a pointer into the
 // kernel-argument struct would push the whole struct into scratch memory).

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
             for (int m = 0; m < MPIX; ++m) sacc += ldy[m * DS + tid];
             bsum += sacc;
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int ks = 0; ks < MPIX / 4; ++ks) {
             const int m = ks * 4 + q;
             const float* abase = lds + (((m >> TWl) * s) * PW + (m & (TW - 1)) * s) * CS + li;
@@ -730,7 +730,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     // Decomposition: a block owns (CITG input-channel tiles x all taps) x (NCO output-channel tiles) of dW and a
     // strided share of the pixel tiles.  Prefer large register tiles (operand reuse); when the image is small,
     // fall back to smaller ones so that output groups x pixel shares still fill the chip with >= 4 tiles per block.
-    static const int pref[][2] = {{4, 2}, {2, 4}, {3, 2}, {2, 2}, {1, 4}, {1, 2}, {1, 1}};
+    static const int pref[][2] = {{4, 2}, {2, 4}, {3, 2}, {2, 2}, {4, 1}, {3, 1}, {1, 4}, {1, 2}, {2, 1}, {1, 1}};
     const int gmin = (2048 + pl->ntiles - 1) / pl->ntiles;
     int CITG = 1, NCO = 1, bestg = -1;
     for (auto& c : pref) {

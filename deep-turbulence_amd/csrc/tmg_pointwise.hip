@@ -10,6 +10,7 @@
 // Every tensor argument is (pointer, pixel stride in floats, channel offset) so channel slices of
 // wider NHWC buffers are addressed in place.
 #include "tmg_common.h"
+#include <stdlib.h>
 
 #define LN5 1.6094379124341003f
 #define LOG2PI 1.8378770664093453f
@@ -783,12 +784,13 @@ __global__ __launch_bounds__(256) void dkappa_kernel(const float* __restrict__ w
                                                      const float* __restrict__ kappa, float* __restrict__ dk) {
     __shared__ float red[4];
     float a = 0.f;
-    for (int i = threadIdx.x; i < nw; i += 256) a += w[i] * dw[i];
-    for (int i = threadIdx.x; i < nb; i += 256) a += b[i] * db[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nw; i += gridDim.x * 256) a += w[i] * dw[i];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nb; i += 256) a += b[i] * db[i];
     const float tot = block_sum_256(a, red);
     if (threadIdx.x == 0) {
         const float k = *kappa;
-        *dk = (k >= -4.0f && k <= 1.3862943611198906f) ? tot : 0.f;
+        if (k >= -4.0f && k <= 1.3862943611198906f) atomicAdd(dk, tot);   // dk is zero-filled by the caller
     }
 }
 
@@ -957,7 +959,7 @@ static int c1_tile(int W, int H, int* twl) {
     int l = 0;
     while ((1 << l) < W) ++l;
     if (l > 5) l = 5;
-    if (l < 2) l = 2;
+    if (l < 3) l = 3;   // >= 8 wide keeps the halo-2 frame of a 256-pixel tile under 512 positions
     *twl = l;
     (void)H;
     return 0;
@@ -1081,7 +1083,10 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
 
 extern "C" int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void* b, const void* db, int64_t nb, const void* kappa,
                           void* dk, hipStream_t st) {
-    hipLaunchKernelGGL(dkappa_kernel, dim3(1), dim3(256), 0, st, (const float*)w, (const float*)dw, (int)nw, (const float*)b,
+    int blocks = (int)((nw + 2047) / 2048);
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dkappa_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (const float*)dw, (int)nw, (const float*)b,
                        (const float*)db, (int)nb, (const float*)kappa, (float*)dk);
     TMG_CHECK_LAUNCH();
     return 0;

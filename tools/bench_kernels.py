@@ -58,7 +58,7 @@ def main():
             name, t_f, fl / t_f / 1e9, t_d, fl / t_d / 1e9, t_w, fl / t_w / 1e9), flush=True)
 
 
-if __name__ == "__main__" and "tail" not in sys.argv:
+if __name__ == "__main__" and "tail" not in sys.argv and "d2" not in sys.argv:
     main()
 
 
@@ -99,3 +99,33 @@ def bench_tail():
 
 if __name__ == "__main__" and "tail" in sys.argv:
     bench_tail()
+
+
+def bench_d2():
+    """dense2 backward alone at level-1 shape; TMG_D2_DBG=1 skips the input-gradient part, =2 the weight-gradient part."""
+    dev = "cuda"
+    for lvl, (hw, C) in enumerate([(128, 16), (64, 32), (32, 64), (16, 128)], 1):
+        B, Cc = 64, 32
+        ch, cin = C // 2, C // 2 + 32
+        x = torch.randn(B, hw, hw, C, device=dev)
+        cond = torch.randn(B, hw, hw, Cc, device=dev)
+        D = torch.randn(B, hw, hw, 4, device=dev)
+        GD = torch.randn(B, hw, hw, 4, device=dev)
+        G = [torch.randn(B, hw, hw, ch, device=dev), torch.randn(B, hw, hw, Cc, device=dev)]
+        dx = torch.empty(B, hw, hw, C, device=dev)
+        dy = torch.randn(B, hw, hw, C, device=dev)
+        w1, w2 = torch.randn(cin, 9, device=dev), torch.randn(cin + 1, 9, device=dev)
+        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        nn_in = [x[..., :ch], cond]
+        for dbg in ("0", "1", "2", "3"):
+            os.environ["TMG_D2_DBG"] = dbg
+            t = timeit(lambda: H.dense2_bwd(nn_in + [D], w1, w2, dw1, dw2, GD, D, G, [dx[..., :ch], G[1]], cin, add0=dy[..., :ch], rows1=cin, rows2=cin + 1))
+            print("dense2_bwd L%d dbg=%s: %7.3f ms" % (lvl, dbg, t), flush=True)
+        os.environ["TMG_D2_DBG"] = "0"
+        D0 = torch.zeros(B, hw, hw, 4, device=dev)
+        t = timeit(lambda: H.c1_fwd(nn_in, w1, D0[..., 0:1], relu_in=True))
+        print("c1_fwd L%d: %7.3f ms" % (lvl, t), flush=True)
+
+
+if __name__ == "__main__" and "d2" in sys.argv:
+    bench_d2()
