@@ -121,15 +121,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
                     if (nt < ntiles_total) bnext[j] = *reinterpret_cast<const float4*>(wn + (size_t)nt * 256);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+            // k-step outermost: consecutive MFMAs hit different accumulators (a 16x16x4 f32 MFMA issues every 32 cycles
+            // but a dependent one must wait 40), so no issue slot is lost to the accumulate chain
+#define TMG_MFMA_STEP(E)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)          \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].E, bf[j].E, acc[i][j], 0, 0, 0);
+            TMG_MFMA_STEP(x)
+            TMG_MFMA_STEP(y)
+            TMG_MFMA_STEP(z)
+            TMG_MFMA_STEP(w)
+#undef TMG_MFMA_STEP
         }
     }
 
@@ -191,7 +192,8 @@ struct WgradP {
     int cin_dst;   // dW holds channels [0, cin_dst) per output channel (<= Cin; the rest is dropped)
     float* ws;     // optional partial-sum slabs (see conv_wgrad_reduce_kernel); null -> direct atomics
     const float* kappa;
-    int TW_log2, TH;  // pixel tile (TH*TW == 64)
+    int TW_log2, TH;  // pixel tile (TH*TW == MPIX)
+    int MPIX;
     int tiles_x, tiles_y, ntiles;
     int CITG;  // input-channel tiles (of 16) handled per block group (grid.z walks the groups)
 };
@@ -199,8 +201,9 @@ struct WgradP {
 template <int NP, int NCO>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int MPIX = 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int MPIX = p.MPIX;  // pixels per staged tile (64 or 128)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar branches
     const int li = lane & 15, q = lane >> 4;
     const int TWl = p.TW_log2, TW = 1 << TWl, TH = MPIX >> TWl;
     const int s = p.stride, halo = p.ksize >> 1, ntaps = p.ksize * p.ksize;
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     float* ldy = lds + PH * PW * CS;
 
     const int npairs = ntaps * citn;
+    const int npw = (npairs - wave + 3) >> 2;  // pairs owned by this wave: wave, wave+4, ...
     f32x4 acc[NP][NCO];
 #pragma unroll
     for (int j = 0; j < NP; ++j)
@@ -263,21 +267,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
             for (int m = 0; m < MPIX; ++m) sacc += ldy[m * DS + tid];
             bsum += sacc;
         }
-#pragma unroll 4
-        for (int ks = 0; ks < MPIX / 4; ++ks) {
-            const int m = ks * 4 + q;
+        // software-pipelined pixel loop: the LDS reads of k-step ks+1 are issued before the MFMAs of k-step ks
+        const int nks = MPIX / 4;
+        float av[NP], bfr[NCO], avn[NP], bfn[NCO];
+        {
+            const int m = q;
             const float* abase = lds + (((m >> TWl) * s) * PW + (m & (TW - 1)) * s) * CS + li;
-            float bfr[NCO];
 #pragma unroll
             for (int n = 0; n < NCO; ++n) bfr[n] = ldy[m * DS + n * 16 + li];
-            // straight-line: slots beyond npairs alias the last pair (their accumulators are never stored)
-            float av[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) av[j] = abase[aoff[j]];
+        }
+        for (int ks = 0; ks < nks; ++ks) {
+            const int m = min(ks + 1, nks - 1) * 4 + q;  // last iteration re-reads its own k-step (harmless)
+            const float* abase = lds + (((m >> TWl) * s) * PW + (m & (TW - 1)) * s) * CS + li;
 #pragma unroll
-            for (int j = 0; j < NP; ++j)
+            for (int n = 0; n < NCO; ++n) bfn[n] = ldy[m * DS + n * 16 + li];
 #pragma unroll
-                for (int n = 0; n < NCO; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bfr[n], acc[j][n], 0, 0, 0);
+            for (int j = 0; j < NP; ++j) avn[j] = abase[aoff[j]];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                if (j < npw) {  // scalar (wave-uniform) test: slots past this wave's last pair issue no MFMA
+#pragma unroll
+                    for (int n = 0; n < NCO; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bfr[n], acc[j][n], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NCO; ++n) bfr[n] = bfn[n];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) av[j] = avn[j];
         }
     }
     if (p.ws) {
@@ -711,7 +729,7 @@ static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_
 }
 
 struct WgradPlan {
-    int twl, TH, tiles_x, tiles_y, ntiles, CITG, NCO, NP, gx, gy, gz;
+    int twl, TH, MPIX, tiles_x, tiles_y, ntiles, CITG, NCO, NP, gx, gy, gz;
     size_t lds_bytes, ws_floats;
 };
 
@@ -721,7 +739,9 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     if (twl < 1) twl = 1;
     pl->twl = twl;
     const int TW = 1 << twl;
-    pl->TH = 64 >> twl;
+    // 128-pixel tiles on large images (fewer barriers and less halo per staged byte), 64 otherwise
+    pl->MPIX = (stride == 1 && (long)B * Hout * Wout >= 262144 && TW >= 16) ? 128 : 64;
+    pl->TH = pl->MPIX >> twl;
     pl->tiles_x = (Wout + TW - 1) / TW;
     pl->tiles_y = (Hout + pl->TH - 1) / pl->TH;
     pl->ntiles = B * pl->tiles_x * pl->tiles_y;
@@ -752,7 +772,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     pl->gz = ngroups;
     const int halo = ksize >> 1;
     const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
-    pl->lds_bytes = ((size_t)PH * PW * (pl->CITG * 16 + 4) + 64 * (NCO * 16 + 4)) * 4;
+    pl->lds_bytes = ((size_t)PH * PW * (pl->CITG * 16 + 4) + (size_t)pl->MPIX * (NCO * 16 + 4)) * 4;
     if (pl->lds_bytes > 160 * 1024) return -6;
     // pixel shares: enough blocks to fill the chip (~512) but >= 4 tiles per block so slab traffic stays small
     int gx = 512 / (pl->gy * ngroups);
@@ -794,7 +814,7 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     WgradPlan pl;
     const int rc = plan_wgrad(p.B, p.Hout, p.Wout, p.ksize, p.stride, p.Cin, p.Cout, &pl);
     if (rc != 0) return rc;
-    p.TW_log2 = pl.twl; p.TH = pl.TH; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.CITG = pl.CITG;
+    p.TW_log2 = pl.twl; p.TH = pl.TH; p.MPIX = pl.MPIX; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.CITG = pl.CITG;
     p.ws = (ws && (size_t)ws_floats >= pl.ws_floats && (((uintptr_t)ws) & 15) == 0) ? (float*)ws : nullptr;
     dim3 grid(pl.gx, pl.gy, pl.gz);
     int lrc = -7;
