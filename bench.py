@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP-event timing")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step in one hipGraph and replay it (N=1 only)")
     args = ap.parse_args()
 
     import tmg_dist
@@ -121,7 +122,8 @@ def main():
     model = build_model(cfg, dev)
     tmg_dist.broadcast_parameters(model)
     bucket = tmg_dist.GradBucket(model.parameters()) if world > 1 else None
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    use_graph = args.graph and world == 1
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True, capturable=use_graph)
     Hin, Win = cfg["_in_hw"]
     up = cfg["_up"]
     g = torch.Generator().manual_seed(12345 + rank)
@@ -143,6 +145,30 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graph = None
+    if use_graph:
+        # standard whole-step capture: warm up on a side stream, then record forward + backward + Adam into one hipGraph;
+        # every replay draws fresh latents (graph-safe Philox offsets) and updates the weights in place
+        ws_ = torch.cuda.Stream()
+        ws_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws_):
+            for _ in range(max(args.warmup, 2)):
+                step()
+        torch.cuda.current_stream().wait_stream(ws_)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y_, ld_, _ = model.sample(x, states)
+            gloss = C.loss_reverse(y_, ld_)
+            gloss.backward()
+            opt.step()
+        eager_step = step
+
+        def step():  # noqa: F811
+            graph.replay()
+            return gloss
+        args.no_events = True  # per-launch events cannot be recorded inside a replayed graph
     for _ in range(args.warmup):
         step()
     barrier()
@@ -183,7 +209,7 @@ def main():
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "tmglow %s: sample()+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
                args.config, Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
-               "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss)},
+               "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss), "launch": "hipGraph replay" if graph is not None else "eager"},
            "roofline": roof}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)

@@ -148,6 +148,57 @@ __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int i
     }
 }
 
+// Split staging for software pipelining (async-STAGE split): stage_issue() puts up to U loads per thread in flight into
+// registers, stage_commit() writes them to LDS after the compute they overlap; items beyond U per thread are staged
+// directly at commit time.
+template <int U>
+struct StageRegs {
+    float4 v[U];
+    int dst[U];
+};
+
+template <int U, typename P>
+__device__ __forceinline__ void stage_issue(const P& p, StageRegs<U>& R, int b, int iy0, int ix0, int PH, int PW, int c0, int kch,
+                                            int CS) {
+    const int k4 = kch >> 2;
+    const int items = PH * PW * k4;
+    const int nt = blockDim.x;
+    const unsigned mk = k4 > 1 ? 0xFFFFFFFFu / (unsigned)k4 + 1u : 0u;
+    const unsigned mp = 0xFFFFFFFFu / (unsigned)PW + 1u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int it = threadIdx.x + u * nt;
+        R.dst[u] = -1;
+        if (it < items) {
+            const int pix = k4 > 1 ? (int)__umulhi((unsigned)it, mk) : it;
+            const int c4 = it - pix * k4;
+            const int py = (int)__umulhi((unsigned)pix, mp);
+            const int px = pix - py * PW;
+            R.v[u] = load_in4(p, b, iy0 + py, ix0 + px, c0 + 4 * c4);
+            R.dst[u] = pix * CS + 4 * c4;
+        }
+    }
+}
+
+template <int U, typename P>
+__device__ __forceinline__ void stage_commit(const P& p, StageRegs<U>& R, float* lds, int b, int iy0, int ix0, int PH, int PW,
+                                             int c0, int kch, int CS) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (R.dst[u] >= 0) *reinterpret_cast<float4*>(lds + R.dst[u]) = R.v[u];
+    const int k4 = kch >> 2;
+    const int items = PH * PW * k4;
+    const unsigned mk = k4 > 1 ? 0xFFFFFFFFu / (unsigned)k4 + 1u : 0u;
+    const unsigned mp = 0xFFFFFFFFu / (unsigned)PW + 1u;
+    for (int it = threadIdx.x + U * blockDim.x; it < items; it += blockDim.x) {
+        const int pix = k4 > 1 ? (int)__umulhi((unsigned)it, mk) : it;
+        const int c4 = it - pix * k4;
+        const int py = (int)__umulhi((unsigned)pix, mp);
+        const int px = pix - py * PW;
+        *reinterpret_cast<float4*>(lds + pix * CS + 4 * c4) = load_in4(p, b, iy0 + py, ix0 + px, c0 + 4 * c4);
+    }
+}
+
 // Select the output segment holding concatenated channel `nl` BY VALUE (taking a pointer into the
 // kernel-argument struct would push the whole struct into scratch memory).
 #define TMG_PICK_OSEG(ARR, NL_, PTR_, STRIDE_, OFF_)                                                      \

@@ -15,6 +15,7 @@
 // weights with 16-byte global loads (4 k-steps per load).  fp32 MFMA issues one 16x16x4 tile per 32
 // cycles per SIMD, so the kernel is matrix-pipe bound by construction and LDS traffic is negligible.
 #include "tmg_common.h"
+#include <stdlib.h>
 
 struct ConvP {
     TmgSeg in[TMG_MAX_IN_SEG];
@@ -75,12 +76,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     }
     const int ntiles_total = p.Cout_pad >> 4;
 
+    // chunk pipeline (async-STAGE split): the next channel chunk's global loads are issued into registers before this
+    // chunk's MFMA loop and written to LDS after it, so HBM/L2 latency hides under the matrix work
+    StageRegs<6> R;
+    {
+        const int k0 = min(p.KCH, p.Cin_pad);
+        stage_issue(p, R, b, iy0, ix0, PH, PW, 0, k0, k0 + 8);
+    }
     for (int c0 = 0; c0 < p.Cin_pad; c0 += p.KCH) {
         const int kch = min(p.KCH, p.Cin_pad - c0);
         const int CS = kch + 8;
         __syncthreads();
-        stage_patch(p, lds, b, iy0, ix0, PH, PW, c0, kch, CS);
+        stage_commit(p, R, lds, b, iy0, ix0, PH, PW, c0, kch, CS);
         __syncthreads();
+        if (c0 + p.KCH < p.Cin_pad) {
+            const int kn = min(p.KCH, p.Cin_pad - c0 - p.KCH);
+            stage_issue(p, R, b, iy0, ix0, PH, PW, c0 + p.KCH, kn, kn + 8);
+        }
         const int kbn = kch >> 4;
         // flattened (tap, kb) loop with the next iteration's B fragments (L2-resident packed weights) prefetched
         // into registers while the current iteration's MFMAs issue
@@ -687,7 +699,10 @@ extern "C" int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
     p.tiles_y = (p.Hout + p.TH - 1) / p.TH;
     const int halo = p.ksize >> 1;
     const int PW = p.stride * (TW - 1) + 1 + 2 * halo, PH = p.stride * (p.TH - 1) + 1 + 2 * halo;
-    int kch = (int)(65536 / (4 * (size_t)PH * PW)) - 8;
+    // LDS per block: ~40 KB keeps 3-4 blocks per CU for the narrow-N kernels (their staging overlaps other blocks' MFMA
+    // work); the wide-N kernels are register-limited to 2 blocks per CU and take the whole input patch in one chunk
+    const int lds_budget = (WM == 1) ? 65536 : 40000;
+    int kch = (int)(lds_budget / (4 * (size_t)PH * PW)) - 8;
     kch &= ~15;
     if (kch < 16) kch = 16;
     if (kch > p.Cin_pad) kch = p.Cin_pad;

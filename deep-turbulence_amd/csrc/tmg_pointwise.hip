@@ -982,7 +982,7 @@ extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, in
     p.tiles_x = (p.Win + TW - 1) / TW;
     p.tiles_y = (p.Hin + TH - 1) / TH;
     const int Cpad = (p.Cin + 3) & ~3;
-    p.KCH = Cpad < 32 ? Cpad : 32;
+    { const char* e = getenv("TMG_C1_KCH"); const int k = e ? atoi(e) : 32; p.KCH = Cpad < k ? Cpad : k; }
     const size_t lds_bytes = ((size_t)(TH + 2) * (TW + 2) * (p.KCH + 4) + 9 * p.KCH) * 4;
     static bool attr = false;
     if (!attr) {

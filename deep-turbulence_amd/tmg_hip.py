@@ -169,6 +169,54 @@ def conv_fwd(inputs, wpk, Cout, ksize, stride, outs, bias=None, kappa=None, in_s
                             c_i64(n_out), dims, _stream()), "tmg_conv_fwd")
 
 
+_SIDE = {}
+
+
+class side_stream:
+    """Context manager: run the enclosed launches on a per-device side HIP stream, ordered after everything already
+    enqueued on the current stream, and make the current stream wait for them on exit of `join()`.
+
+        with H.side_stream(dev, keep=(tensors read on the side stream)) as ss:
+            ... launches ...          # run concurrently with what the main stream enqueues afterwards
+        ... main-stream work ...
+        ss.join()                     # main stream waits for the side work (no host sync)
+
+    Used to overlap weight-gradient kernels (off the critical path of back-propagation) with the input-gradient chain.
+    Measured on MI355X at config M: the step is GPU-bound and the overlapped kernels only contend (568 vs 584 samples/s),
+    so it is opt-in (TMG_SIDE=1) and the default runs everything on the current stream.
+    """
+
+    def __init__(self, device, keep=()):
+        self.main = torch.cuda.current_stream(device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in _SIDE:
+            _SIDE[key] = torch.cuda.Stream(device=device)
+        self.side = _SIDE[key]
+        self.keep = keep
+        self.ctx = None
+
+    def __enter__(self):
+        self.inline = torch.cuda.is_current_stream_capturing() or not os.environ.get('TMG_SIDE')  # capture, or not opted in: single stream
+        if self.inline:
+            return self
+        self.side.wait_stream(self.main)
+        for t in self.keep:
+            if t is not None:
+                t.record_stream(self.side)   # the caching allocator must not recycle these while the side stream reads them
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if not self.inline:
+            self.ctx.__exit__(*a)
+        return False
+
+    def join(self):
+        if not self.inline:
+            self.main.wait_stream(self.side)
+
+
 _WS = {}
 
 

@@ -55,16 +55,18 @@ class ConvFn(torch.autograd.Function):
         else:
             dy = dout
         dW = db = dk = None
+        ss = None
         if ctx.needs_input_grad[0] or ctx.has_kappa:
             dW = torch.zeros_like(weight)
             db = torch.zeros_like(bias) if ctx.has_bias else None
-            H.conv_wgrad(list(inputs), dy, dW, db, ksize, stride, kappa=kappa, relu_in=relu_in, pad_rep=pad_rep)
             if ctx.has_kappa:
-                dk = (weight * dW).sum()
-                if ctx.has_bias:
-                    dk = dk + (bias * db).sum()
-                inside = ((kappa >= -4.0) & (kappa <= LOG4)).to(dk.dtype)
-                dk = (dk * inside).reshape(kappa.shape)
+                dk = torch.zeros_like(kappa)
+            # weight gradients run on the side stream, concurrently with the input-gradient kernels below
+            ss = H.side_stream(dy.device, keep=(dy, dW, db, dk, weight, bias, kappa) + tuple(inputs))
+            with ss:
+                H.conv_wgrad(list(inputs), dy, dW, db, ksize, stride, kappa=kappa, relu_in=relu_in, pad_rep=pad_rep)
+                if ctx.has_kappa:
+                    H.dkappa(weight, dW, bias if ctx.has_bias else weight[:0], db if ctx.has_bias else dW[:0], kappa, dk)
         dins = [None] * ctx.n_in
         if any(ctx.needs_input_grad[4:]):
             dins = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in inputs]
@@ -80,6 +82,8 @@ class ConvFn(torch.autograd.Function):
             if relu_in:
                 for d, t in zip(dins, inputs):
                     H.masked_add(d, src=d, ref=t)
+        if ss is not None:
+            ss.join()
         return (dW, db, dk, None) + tuple(dins)
 
 
@@ -364,9 +368,11 @@ class CouplingTailFn(torch.autograd.Function):
         dwz = flat[n1 + n2:n1 + n2 + nz].view(C, cin + 2, 3, 3)
         dbz = flat[n1 + n2 + nz:n1 + n2 + nz + C]
         dk = flat[n1 + n2 + nz + C:].view(kappa.shape)
-        # 2. zero-conv: weight / bias / scale gradients, raw input gradient
-        H.conv_wgrad(nn_in + [D], dhh, dwz, dbz, 3, 1, kappa=kappa, relu_in=True, pad_rep=True, cin_dst=cin + 2)
-        H.dkappa(wz, dwz, bz, dbz, kappa, dk)
+        # 2. zero-conv weight / bias / scale gradients on the side stream: they are off the critical path and overlap
+        #    with the input-gradient chain below
+        with H.side_stream(dev, keep=(dhh, x, aux, D, flat, wz, bz, kappa)) as ss:
+            H.conv_wgrad(nn_in + [D], dhh, dwz, dbz, 3, 1, kappa=kappa, relu_in=True, pad_rep=True, cin_dst=cin + 2)
+            H.dkappa(wz, dwz, bz, dbz, kappa, dk)
         G = [torch.empty(t.shape, device=dev, dtype=torch.float32) for t in nn_in]
         GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
         wz_t = H.conv_pack(wz, 1, cin + 4)
@@ -380,4 +386,5 @@ class CouplingTailFn(torch.autograd.Function):
             H.dense2_bwd(nn_in + [D], w1, w2, dw1, dw2, GD, D, G, [G[0]], cin, rows1=cin, rows2=cin + 1)
             H.masked_add(dx[..., :ch], src=dy[..., :ch])
             daux = G[0]
+        ss.join()
         return dx, daux, dw1, dw2, dwz, dbz, dk, None, None
