@@ -421,6 +421,7 @@ struct C1P {
     int relu_in, pad_rep;
     const float* w;  // [w_rows][9]; input channels >= w_rows have zero weight
     int w_rows;
+    int fill4;  // write (value, 0, 0, 0) as one float4: initialises the 4-channel growth buffer D without a separate fill
     float* out; int out_stride, out_off;
     int TW_log2, tiles_x, tiles_y, KCH;
 };
@@ -463,7 +464,11 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1P p) {
         }
     }
     const int oy = oy0 + row, ox = ox0 + col;
-    if (oy < p.Hin && ox < p.Win) p.out[(((size_t)b * p.Hin + oy) * p.Win + ox) * p.out_stride + p.out_off] = acc;
+    if (oy < p.Hin && ox < p.Win) {
+        float* o = p.out + (((size_t)b * p.Hin + oy) * p.Win + ox) * p.out_stride + p.out_off;
+        if (p.fill4) *reinterpret_cast<float4*>(o) = make_float4(acc, 0.f, 0.f, 0.f);
+        else *o = acc;
+    }
 }
 
 // Backward of the C_out = 1 layer.  ddm(p) = dd(p) * [dref(p) > 0]  (dref null -> no mask)
@@ -965,7 +970,8 @@ static int c1_tile(int W, int H, int* twl) {
     return 0;
 }
 
-// dims: [B,H,W,Cin,relu_in,w_rows]; out_d = [stride, off]; w is [w_rows][9] (w_rows = 0 -> Cin)
+// dims: [B,H,W,Cin,relu_in,w_rows,fill4]; out_d = [stride, off]; w is [w_rows][9] (w_rows = 0 -> Cin);
+// fill4 = 1: out points at channel 0 of a 16-byte aligned 4-channel pixel and (value,0,0,0) is stored
 extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out,
                           const int64_t* out_d, const int64_t* dims, hipStream_t st) {
     C1P p;
@@ -974,6 +980,7 @@ extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, in
     fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.relu_in = (int)dims[4];
     p.w_rows = (dims[5] > 0 && dims[5] < p.Cin) ? (int)dims[5] : p.Cin;
+    p.fill4 = (int)dims[6];
     if (p.Cin & 3) p.vec4 = 0;
     p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
     p.w = (const float*)w; p.out = (float*)out; p.out_stride = (int)out_d[0]; p.out_off = (int)out_d[1];

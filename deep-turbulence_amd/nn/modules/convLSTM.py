@@ -32,8 +32,10 @@ class ConvLSTMCell(nn.Module):
             c_cur = None
         else:
             h_cur, c_cur = state
-        gates = ops.conv(list(inputs) + [h_cur], self.conv.weight, self.conv.bias)
-        return ops.LSTMPointwiseFn.apply(gates, c_cur)
+        if self.conv.bias is None or tuple(self.kernel_size) != (3, 3):
+            gates = ops.conv(list(inputs) + [h_cur], self.conv.weight, self.conv.bias)
+            return ops.LSTMPointwiseFn.apply(gates, c_cur)
+        return ops.ConvLSTMCellFn.apply(self.conv.weight, self.conv.bias, h_cur, c_cur, *inputs)
 
     def forward(self, input_tensor, cur_state):
         st = None if cur_state is None else (H.nhwc(cur_state[0]), H.nhwc(cur_state[1]))

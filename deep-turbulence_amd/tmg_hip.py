@@ -351,11 +351,11 @@ def masked_add(dst, src=None, ref=None, add=None, accumulate=False):
          "tmg_masked_add")
 
 
-def c1_fwd(inputs, w, out, relu_in=True, w_rows=0):
+def c1_fwd(inputs, w, out, relu_in=True, w_rows=0, fill4=False):
     B, H, W, _ = inputs[0].shape
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
-    _chk(lib().tmg_c1_fwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(out), _d2(out), _i64(B, H, W, Cin, relu_in, w_rows), _stream()),
+    _chk(lib().tmg_c1_fwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(out), _d2(out), _i64(B, H, W, Cin, relu_in, w_rows, fill4), _stream()),
          "tmg_c1_fwd")
 
 

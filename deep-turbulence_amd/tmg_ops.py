@@ -208,6 +208,53 @@ class LSTMPointwiseFn(torch.autograd.Function):
         return dg, (dc_prev if ctx.has_c else None)
 
 
+class ConvLSTMCellFn(torch.autograd.Function):
+    """ConvLSTM cell as one node: gates = conv3x3(cat(inputs, h)) + b; i,f,o,g activations; c' = f c + i g; h' = o tanh(c')
+    (reference convLSTM.py:72-85).  The 4R-wide gate tensor is activated in place and, in backward, overwritten in place
+    by the pre-activation gradients, so the largest activation of the model exists once (no clones).  Consequently the
+    node supports a single backward pass (no retain_graph double backward)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, h_cur, c_cur, *inputs):
+        inputs = tuple(t if t.stride(3) == 1 else t.contiguous() for t in inputs)
+        h_cur = h_cur if h_cur.stride(3) == 1 else h_cur.contiguous()
+        if c_cur is not None and c_cur.stride(3) != 1:
+            c_cur = c_cur.contiguous()
+        B, Hh, Ww, _ = inputs[0].shape
+        R4 = weight.shape[0]
+        R = R4 // 4
+        dev = weight.device
+        gates = torch.empty((B, Hh, Ww, R4), device=dev, dtype=torch.float32)
+        H.conv_fwd(list(inputs) + [h_cur], H.conv_pack(weight, 0), R4, 3, 1, [gates], bias=bias)
+        c_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
+        h_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
+        H.lstm_pointwise_fwd(gates, c_cur, c_next, h_next)
+        ctx.n_in = len(inputs)
+        ctx.has_c = c_cur is not None
+        ctx.consumed = False
+        ctx.save_for_backward(weight, bias, h_cur, c_cur, gates, c_next, *inputs)
+        return h_next, c_next
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        if ctx.consumed:
+            raise RuntimeError("ConvLSTMCellFn: the gate buffer was consumed by a previous backward pass")
+        ctx.consumed = True
+        weight, bias, h_cur, c_cur, acts, c_next = ctx.saved_tensors[:6]
+        inputs = ctx.saved_tensors[6:]
+        dc_prev = torch.empty_like(c_next)
+        H.lstm_pointwise_bwd(acts, c_cur, c_next, dh.contiguous() if dh is not None else None,
+                             dc.contiguous() if dc is not None else None, dc_prev)
+        dg = acts  # now the pre-activation gate gradients
+        segs = list(inputs) + [h_cur]
+        dW = torch.zeros_like(weight)
+        db = torch.zeros_like(bias)
+        H.conv_wgrad(segs, dg, dW, db, 3, 1)
+        dins = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in segs]
+        H.conv_fwd([dg], H.conv_pack(weight, 1), sum(t.shape[3] for t in segs), 3, 1, dins)
+        return (dW, db, dins[-1], dc_prev if ctx.has_c else None) + tuple(dins[:-1])
+
+
 class GaussLogpFn(torch.autograd.Function):
     """log N(z2; mean, exp(lsd)) summed per sample, and eps = (z2-mean)/exp(lsd)  (flowUtils.py:176-192, :311)."""
 
@@ -332,8 +379,8 @@ class CouplingTailFn(torch.autograd.Function):
         nn_in = [x[..., :ch], aux] if mode == 0 else [aux]
         cin = sum(t.shape[3] for t in nn_in)
         w1, w2, wz = w1.contiguous(), w2.contiguous(), wz.contiguous()
-        D = torch.zeros((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-        H.c1_fwd(nn_in, w1, D[..., 0:1], relu_in=True)
+        D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
+        H.c1_fwd(nn_in, w1, D[..., 0:1], relu_in=True, fill4=True)   # writes (d1, 0, 0, 0)
         H.c1_fwd(nn_in + [D], w2, D[..., 1:2], relu_in=True, w_rows=cin + 1)
         hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
         H.conv_fwd(nn_in + [D], H.conv_pack(wz, 0, cin + 4), C, 3, 1, [hh], bias=bz, kappa=kappa, relu_in=True, pad_rep=True)

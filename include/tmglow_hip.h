@@ -125,7 +125,7 @@ int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const i
 
 /* Growth-1 dense layer of the coupling network, C_out = 1 (denseBlock.py:135-138), forward and
  * backward (input gradient accumulated into g segments, weight gradient accumulated atomically).
- * dims = {B,H,W,Cin,relu_in[,w_rows]} */
+ * dims = {B,H,W,Cin,relu_in,w_rows,fill4} */
 int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out, const int64_t* out_d,
                const int64_t* dims, tmg_stream_t st);
 int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* dW, const void* dd,
