@@ -97,6 +97,26 @@ def cpu_baseline(name, hard_timeout_s=240):
         return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "failed: %s" % type(e).__name__}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_traffic_per_launch.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, launch-weighted over the template instances the event id groups)."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic_per_launch.json")
+    if not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    base, _, tail = kernel.partition("<")
+    want = tail.rstrip(">").split(",")
+    tot = n = 0
+    for k, v in tab.items():
+        if not isinstance(v, dict) or not k.startswith(base + "<"):
+            continue
+        have = [a.strip() for a in k[len(base) + 1:].rstrip(">").split(",")]
+        if len(have) == len(want) and all(w == "*" or w == h for w, h in zip(want, have)):
+            tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
+            n += v["launches"]
+    return round(tot / n) if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +219,7 @@ def main():
                 "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2), "time_share_of_step": round(ms * 1e-3 / dt, 4),
                 "all_contraction_kernels": {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
                                             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+        roof["traffic"] = pmc_traffic(name) if args.config == "M" and B == 64 else None
         if args.config in GFLOP_PER_SAMPLE:
             e2e = value / world * GFLOP_PER_SAMPLE[args.config] / 1e3
             roof["end_to_end_tflops_per_gpu"] = round(e2e, 2)
