@@ -32,6 +32,7 @@ struct ConvP {
     int relu_in, pad_rep, relu_out, accumulate;
     TmgOSeg out[TMG_MAX_OUT_SEG];
     int nout;
+    TmgSeg add;  // optional tensor added to the accumulator before bias / scale (p == null: none); n == Cout
     int TW_log2, TH;
     int KCH;  // channels staged per LDS chunk (multiple of 16)
     int tiles_x, tiles_y;
@@ -172,9 +173,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
                 const int m = (wm * MT + i) * 16 + q * 4 + r;
                 const int oy = oy0 + (m >> TWl), ox = ox0 + (m & (TW - 1));
                 if (oy < p.Hout && ox < p.Wout) {
-                    float v = (acc[i][j][r] + bv) * osc;
+                    const size_t opx = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                    float v = acc[i][j][r] + bv;
+                    if (p.add.p) v += p.add.p[opx * p.add.stride + p.add.off + n];
+                    v *= osc;
                     if (p.relu_out) v = fmaxf(v, 0.f);
-                    float* dst = obase + (((size_t)b * p.Hout + oy) * p.Wout + ox) * ostride;
+                    float* dst = obase + opx * ostride;
                     if (p.accumulate) v += *dst;
                     *dst = v;
                 }
@@ -201,7 +205,10 @@ struct WgradP {
     int dy_vec4;
     float* dW;     // [Cout][Cin][ksize*ksize], accumulated with atomics (caller zeroes)
     float* dbias;  // [Cout] or null, accumulated with atomics
-    int cin_dst;   // dW holds channels [0, cin_dst) per output channel (<= Cin; the rest is dropped)
+    // destination layout of dW: row length cin_dst per output channel; source channel ci < cin_valid lands at
+    // ci + (ci < ci_split ? ci_off0 : ci_off1); channels >= cin_valid are dropped.  Lets one launch write a channel
+    // sub-range of a wider native weight-gradient tensor (or skip padding channels).
+    int cin_dst, cin_valid, ci_split, ci_off0, ci_off1;
     float* ws;     // optional partial-sum slabs (see conv_wgrad_reduce_kernel); null -> direct atomics
     const float* kappa;
     int TW_log2, TH;  // pixel tile (TH*TW == MPIX)
@@ -339,7 +346,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = (cit0 + cit) * 16 + q * 4 + r;
-                if (ci < p.cin_dst) atomicAdd(p.dW + ((size_t)co * p.cin_dst + ci) * ntaps + tap, acc[j][n][r] * osc);
+                if (ci < p.cin_valid)
+                    atomicAdd(p.dW + ((size_t)co * p.cin_dst + ci + (ci < p.ci_split ? p.ci_off0 : p.ci_off1)) * ntaps + tap, acc[j][n][r] * osc);
             }
         }
     }
@@ -350,7 +358,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 // each thread sums one accumulator float4 over a chunk of the pixel-share (x) dimension, then adds it to dW.
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
                                          const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int CITG,
-                                         int cit_total, int Cin, int Cout, int ntaps, int xchunk) {
+                                         int cit_total, int Cin, int Cout, int ntaps, int xchunk, int cin_valid, int ci_split,
+                                         int ci_off0, int ci_off1) {
     const int items = gy * gz * 4 * NP * NCO * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int x0 = blockIdx.y * xchunk, x1 = min(gx, x0 + xchunk);
@@ -380,7 +389,8 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
                 const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (ci + r < Cin) atomicAdd(dW + ((size_t)co * Cin + ci + r) * ntaps + tap, av[r] * osc);  // Cin == cin_dst here
+                    if (ci + r < cin_valid)   // Cin == destination row length here
+                        atomicAdd(dW + ((size_t)co * Cin + ci + r + (ci + r < ci_split ? ci_off0 : ci_off1)) * ntaps + tap, av[r] * osc);
             }
         }
     }
@@ -403,7 +413,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
 //         wpk[tap][co/16][ci][co%16] = W[co][ci][ntaps-1-tap]
 // ---------------------------------------------------------------------------------------------
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin, int ntaps,
-                                 int Kpad, int Npad, int mode) {
+                                 int Kpad, int Npad, int mode, int cvalid, int csplit, int cgap) {
     const size_t total = (size_t)ntaps * Kpad * Npad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c16 = i & 15;
@@ -414,10 +424,11 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
         const int tap = r / (Kpad >> 4);
         const int k = kb * 16 + c16;
         float v = 0.f;
+        // operand input channel c maps to source channel c (+ cgap when c >= csplit); channels >= cvalid are zero
         if (mode == 0) {
-            if (k < Cin && n < Cout) v = w[((size_t)n * Cin + k) * ntaps + tap];
+            if (k < cvalid && n < Cout) v = w[((size_t)n * Cin + k + (k < csplit ? 0 : cgap)) * ntaps + tap];
         } else {
-            if (k < Cout && n < Cin) v = w[((size_t)k * Cin + n) * ntaps + (ntaps - 1 - tap)];
+            if (k < Cout && n < cvalid) v = w[((size_t)k * Cin + n + (n < csplit ? 0 : cgap)) * ntaps + (ntaps - 1 - tap)];
         }
         wpk[i] = v;
     }
@@ -625,26 +636,53 @@ static void fill_segs(TmgSeg* dst, const void* const* ptrs, const int64_t* desc,
     }
 }
 
+extern "C" int tmg_conv_pack_map(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize, int64_t mode,
+                                 const int64_t* map, hipStream_t st);
+
 // cin_eff >= Cin: the operand is built for cin_eff input channels, the extra ones zero (lets a conv read a wider,
 // 16-byte aligned segment list than the weight tensor has channels for).
 extern "C" int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize, int64_t mode,
                              hipStream_t st) {
+    const int64_t map[3] = {Cin, 0x7fffffff, 0};
+    return tmg_conv_pack_map(w, wpk, Cout, Cin, cin_eff < Cin ? Cin : cin_eff, ksize, mode, map, st);
+}
+
+// As tmg_conv_pack with an input-channel map = {cvalid, csplit, cgap}: operand channel c < cvalid reads source channel
+// c (+ cgap if c >= csplit); operand channels >= cvalid (up to cin_eff) are zero.  cin_eff may be smaller than Cin.
+extern "C" int tmg_conv_pack_map(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize, int64_t mode,
+                                 const int64_t* map, hipStream_t st) {
     const int ntaps = (int)(ksize * ksize);
-    if (cin_eff < Cin) cin_eff = Cin;
     const int K = mode == 0 ? (int)cin_eff : (int)Cout, N = mode == 0 ? (int)Cout : (int)cin_eff;
     const int Kpad = (K + 15) & ~15, Npad = (N + 15) & ~15;
     const size_t total = (size_t)ntaps * Kpad * Npad;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (float*)wpk, (int)Cout, (int)Cin, ntaps, Kpad, Npad, (int)mode);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (float*)wpk, (int)Cout, (int)Cin, ntaps, Kpad, Npad,
+                       (int)mode, (int)map[0], (int)map[1], (int)map[2]);
     TMG_CHECK_LAUNCH();
     return 0;
 }
+
+extern "C" int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* wpk, const void* bias,
+                                const void* kappa, const void* in_scale, const void* in_shift, const void* add,
+                                const int64_t* add_desc, void* const* out_ptrs, const int64_t* out_desc, int64_t nout,
+                                const int64_t* dims, hipStream_t st);
 
 // dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep,relu_out,accumulate]
 extern "C" int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* wpk, const void* bias,
                             const void* kappa, const void* in_scale, const void* in_shift, void* const* out_ptrs,
                             const int64_t* out_desc, int64_t nout, const int64_t* dims, hipStream_t st) {
+    return tmg_conv_fwd_add(in_ptrs, in_desc, nseg, wpk, bias, kappa, in_scale, in_shift, nullptr, nullptr, out_ptrs, out_desc, nout,
+                            dims, st);
+}
+
+// As tmg_conv_fwd with an extra tensor `add` ({stride, off}, Cout channels) summed into the accumulator before the bias
+// and the exp(kappa) scale:  out = [relu]((conv + add + bias) * scale).
+extern "C" int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* wpk, const void* bias,
+                                const void* kappa, const void* in_scale, const void* in_shift, const void* add,
+                                const int64_t* add_desc, void* const* out_ptrs, const int64_t* out_desc, int64_t nout,
+                                const int64_t* dims, hipStream_t st) {
     ConvP p;
+    p.add = TmgSeg{(const float*)add, add ? (int)add_desc[0] : 0, add ? (int)add_desc[1] : 0, 0};
     p.nseg = (int)nseg;
     p.vec4 = 1;
     fill_segs(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
@@ -805,7 +843,7 @@ extern "C" int64_t tmg_conv_wgrad_ws_floats(const int64_t* dims) {
     return (int64_t)pl.ws_floats;
 }
 
-// dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep,cin_dst]; dy_desc: [stride, off]
+// dims: [B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_rep,cin_dst,cin_valid,ci_split,ci_off0,ci_off1]; dy_desc: [stride, off]
 // dW is [Cout][cin_dst][k*k] (cin_dst = 0 -> Cin).  dW (and dbias) are ACCUMULATED onto (caller zero-fills).  ws: optional scratch of >= tmg_conv_wgrad_ws_floats(dims)
 // floats; when given, per-block partial sums go through it and a small reduce kernel (few, low-contention atomics),
 // otherwise every block adds its partial sums to dW with float atomics.
@@ -819,7 +857,11 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Hout = (int)dims[3]; p.Wout = (int)dims[4];
     p.ksize = (int)dims[5]; p.stride = (int)dims[6]; p.Cin = (int)dims[7]; p.Cout = (int)dims[8];
     p.relu_in = (int)dims[9]; p.pad_rep = (int)dims[10];
-    p.cin_dst = (dims[11] > 0 && dims[11] < p.Cin) ? (int)dims[11] : p.Cin;
+    // dims[11..15] = {cin_dst, cin_valid, ci_split, ci_off0, ci_off1}; all zero -> dense [Cout][Cin][k*k]
+    p.cin_dst = dims[11] > 0 ? (int)dims[11] : p.Cin;
+    p.cin_valid = dims[12] > 0 ? (int)dims[12] : (p.cin_dst < p.Cin ? p.cin_dst : p.Cin);
+    p.ci_split = dims[13] > 0 ? (int)dims[13] : 0x7fffffff;
+    p.ci_off0 = (int)dims[14]; p.ci_off1 = (int)dims[15];
     if (p.ksize != 1 && p.ksize != 3) return -2;
     p.Cin_pad = (p.Cin + 15) & ~15;
     p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
@@ -846,7 +888,8 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
         int xchunk = 32;
         const int xc = (pl.gx + xchunk - 1) / xchunk;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
-                           p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.cin_dst, p.Cout, p.ksize * p.ksize, xchunk);
+                           p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.cin_dst, p.Cout, p.ksize * p.ksize, xchunk,
+                           p.cin_valid, p.ci_split, p.ci_off0, p.ci_off1);
         TMG_CHECK_LAUNCH();
     }
     return 0;

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
 // gin: grad w.r.t. op input half; dhh: [npix][C] interleaved (da, dr).  g: per-sample grad on logdet.
 __global__ void affine_bwd_kernel(const float* gout, int gs, int go, const float* __restrict__ yref, int rs_, int ro,
                                   const float* __restrict__ rsave, const float* __restrict__ g, float* gin, int is, int io,
-                                  float* __restrict__ dhh, int ds, int dof, int pix_per_img, int Ch, size_t npix, int reverse) {
+                                  float* __restrict__ dhh, int ds, int dof, int pix_per_img, int Ch, size_t npix, int reverse,
+                                  const float* __restrict__ kappa) {
+    const float hsc = out_scale_of(kappa);   // kappa given: dhh is written pre-multiplied by exp(clamp(kappa))
     const size_t total = npix * Ch;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i / Ch;
@@ -101,7 +103,7 @@ __global__ void affine_bwd_kernel(const float* gout, int gs, int go, const float
             dsg = 2.f * go_ * yv + 2.f * gb;
         }
         gin[pix * is + io + j] = gi;
-        *reinterpret_cast<float2*>(dhh + pix * ds + dof + 2 * j) = make_float2(da, dsg / (den * den));
+        *reinterpret_cast<float2*>(dhh + pix * ds + dof + 2 * j) = make_float2(da * hsc, hsc * dsg / (den * den));
     }
 }
 
@@ -419,8 +421,9 @@ struct C1P {
     const float* in_scale;
     const float* in_shift;
     int relu_in, pad_rep;
-    const float* w;  // [w_rows][9]; input channels >= w_rows have zero weight
-    int w_rows;
+    const float* w;  // [rows][9]; input channel c < w_rows reads row c (+ w_gap if c >= w_split); others have zero weight
+    int w_rows, w_split, w_gap;
+    const float* add; int add_stride, add_off;  // optional per-pixel value added to the result (null: none)
     int fill4;  // write (value, 0, 0, 0) as one float4: initialises the 4-channel growth buffer D without a separate fill
     float* out; int out_stride, out_off;
     int TW_log2, tiles_x, tiles_y, KCH;
@@ -448,7 +451,8 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1P p) {
         stage_patch(p, lds, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
         for (int i = tid; i < 9 * kch; i += 256) {
             const int tap = i / kch, c = i - tap * kch;
-            lw[i] = (c0 + c < p.w_rows) ? p.w[(size_t)(c0 + c) * 9 + tap] : 0.f;
+            const int cs = c0 + c;
+            lw[i] = (cs < p.w_rows) ? p.w[(size_t)(cs + (cs < p.w_split ? 0 : p.w_gap)) * 9 + tap] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -465,7 +469,9 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1P p) {
     }
     const int oy = oy0 + row, ox = ox0 + col;
     if (oy < p.Hin && ox < p.Win) {
-        float* o = p.out + (((size_t)b * p.Hin + oy) * p.Win + ox) * p.out_stride + p.out_off;
+        const size_t opx = ((size_t)b * p.Hin + oy) * p.Win + ox;
+        if (p.add) acc += p.add[opx * p.add_stride + p.add_off];
+        float* o = p.out + opx * p.out_stride + p.out_off;
         if (p.fill4) *reinterpret_cast<float4*>(o) = make_float4(acc, 0.f, 0.f, 0.f);
         else *o = acc;
     }
@@ -621,10 +627,12 @@ struct D2BP {
     float* dW2;
     const float* GD; int gd_stride;
     const float* Dp; int d_stride;
-    int cin_nn, rows1, rows2;  // w1/dW1 have rows1 rows, w2/dW2 rows2 rows ([rows][9]); missing rows are zero
+    int cin_nn, rows1, rows2;  // input channel c uses w1 row c if c < rows1 and w2 row c (+ gap2 if c >= split2) if c < rows2
+    int split2, gap2;
     TmgSeg g0[2];
     TmgOSeg out[2];
     const float* add0; int add0_stride;
+    float* dd1_out; float* dd2_out; int dd_stride;  // optional: masked gradients w.r.t. d1 / d2 per pixel (null: not written)
     int TW_log2, tiles_x, tiles_y, ntiles, KCH;
 };
 
@@ -648,11 +656,11 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
     float wa1 = 0.f, wa2 = 0.f;
     float w2d[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) w2d[t] = p.w2[(size_t)p.cin_nn * 9 + t];
+    for (int t = 0; t < 9; ++t) w2d[t] = p.w2[(size_t)(p.cin_nn + (p.cin_nn < p.split2 ? 0 : p.gap2)) * 9 + t];
     for (int i = tid; i < 9 * kch; i += 256) {
         const int tap = i / kch, c = i - tap * kch;
         lw1[i] = (c0 + c < p.rows1) ? p.w1[(size_t)(c0 + c) * 9 + tap] : 0.f;
-        lw2[i] = (c0 + c < p.rows2) ? p.w2[(size_t)(c0 + c) * 9 + tap] : 0.f;
+        lw2[i] = (c0 + c < p.rows2) ? p.w2[(size_t)(c0 + c + (c0 + c < p.split2 ? 0 : p.gap2)) * 9 + tap] : 0.f;
     }
     const int wo_tap = tid / kch, wo_c = tid - wo_tap * kch;   // this thread's weight-gradient output
     const bool wo_ok = tid < kch * 9;
@@ -699,6 +707,11 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
         }
         __syncthreads();
         const int oy = oy0 + row, ox = ox0 + col;
+        if (p.dd1_out && blockIdx.y == 0 && oy < p.Hin && ox < p.Win) {
+            const size_t px_ = ((size_t)b * p.Hin + oy) * p.Win + ox;
+            p.dd1_out[px_ * p.dd_stride] = A1[(row + 1) * PW + col + 1];
+            p.dd2_out[px_ * p.dd_stride] = A2[(row + 2) * QW + col + 2];
+        }
         if (oy < p.Hin && ox < p.Win && c0 < p.cin_nn) {
             float n1[9], n2[9];
 #pragma unroll
@@ -778,7 +791,7 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
     }
     if (wo_ok) {
         if (c0 + wo_c < p.rows1) atomicAdd(p.dW1 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa1);
-        if (c0 + wo_c < p.rows2) atomicAdd(p.dW2 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa2);
+        if (c0 + wo_c < p.rows2) atomicAdd(p.dW2 + (size_t)(c0 + wo_c + (c0 + wo_c < p.split2 ? 0 : p.gap2)) * 9 + wo_tap, wa2);
     }
 }
 
@@ -798,6 +811,13 @@ __global__ __launch_bounds__(256) void dkappa_kernel(const float* __restrict__ w
         if (k >= -4.0f && k <= 1.3862943611198906f) atomicAdd(dk, tot);   // dk is zero-filled by the caller
     }
 }
+
+extern "C" int tmg_affine_bwd_scaled(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
+                                     const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d,
+                                     const void* kappa, const int64_t* dims, hipStream_t st);
+
+extern "C" int tmg_c1_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, const void* add,
+                              const int64_t* add_d, void* out, const int64_t* out_d, const int64_t* dims, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
@@ -822,11 +842,18 @@ extern "C" int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void*
 extern "C" int tmg_affine_bwd(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
                               const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d, const int64_t* dims,
                               hipStream_t st) {
+    return tmg_affine_bwd_scaled(gout, go_d, yref, yr_d, rsave, g, gin, gi_d, dhh, dh_d, nullptr, dims, st);
+}
+
+// As tmg_affine_bwd; dhh is multiplied by exp(clamp(*kappa)) (the Conv2dZeros output scale) when kappa is given.
+extern "C" int tmg_affine_bwd_scaled(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
+                                     const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d,
+                                     const void* kappa, const int64_t* dims, hipStream_t st) {
     const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
     const size_t npix = (size_t)B * ppi;
     hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid_for(npix * Ch)), dim3(256), 0, st, (const float*)gout, (int)go_d[0], (int)go_d[1],
                        (const float*)yref, (int)yr_d[0], (int)yr_d[1], (const float*)rsave, (const float*)g, (float*)gin, (int)gi_d[0],
-                       (int)gi_d[1], (float*)dhh, (int)dh_d[0], (int)dh_d[1], ppi, Ch, npix, (int)dims[3]);
+                       (int)gi_d[1], (float*)dhh, (int)dh_d[0], (int)dh_d[1], ppi, Ch, npix, (int)dims[3], (const float*)kappa);
     TMG_CHECK_LAUNCH();
     return 0;
 }
@@ -970,10 +997,16 @@ static int c1_tile(int W, int H, int* twl) {
     return 0;
 }
 
-// dims: [B,H,W,Cin,relu_in,w_rows,fill4]; out_d = [stride, off]; w is [w_rows][9] (w_rows = 0 -> Cin);
+// dims: [B,H,W,Cin,relu_in,w_rows,fill4,w_split,w_gap]; out_d = [stride, off]; w is [w_rows][9] (w_rows = 0 -> Cin);
 // fill4 = 1: out points at channel 0 of a 16-byte aligned 4-channel pixel and (value,0,0,0) is stored
 extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out,
                           const int64_t* out_d, const int64_t* dims, hipStream_t st) {
+    return tmg_c1_fwd_add(in_ptrs, in_desc, nseg, w, nullptr, nullptr, out, out_d, dims, st);
+}
+
+// As tmg_c1_fwd plus a per-pixel scalar `add` ({stride, off}) summed onto the result.
+extern "C" int tmg_c1_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, const void* add,
+                              const int64_t* add_d, void* out, const int64_t* out_d, const int64_t* dims, hipStream_t st) {
     C1P p;
     p.nseg = (int)nseg;
     p.vec4 = 1;
@@ -981,6 +1014,8 @@ extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, in
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.relu_in = (int)dims[4];
     p.w_rows = (dims[5] > 0 && dims[5] < p.Cin) ? (int)dims[5] : p.Cin;
     p.fill4 = (int)dims[6];
+    p.w_split = dims[7] > 0 ? (int)dims[7] : 0x7fffffff; p.w_gap = (int)dims[8];
+    p.add = (const float*)add; p.add_stride = add ? (int)add_d[0] : 0; p.add_off = add ? (int)add_d[1] : 0;
     if (p.Cin & 3) p.vec4 = 0;
     p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
     p.w = (const float*)w; p.out = (float*)out; p.out_stride = (int)out_d[0]; p.out_off = (int)out_d[1];
@@ -1040,7 +1075,7 @@ extern "C" int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, in
 }
 
 // Fused backward of both growth-1 layers (see dense2_bwd_kernel).
-// in segments: nn inputs followed by D (4 channels); dims = {B,H,W,Cin_total (incl. D's 4),cin_nn,rows1,rows2}
+// in segments: nn inputs followed by D (4 channels); dims = {B,H,W,Cin_total (incl. D's 4),cin_nn,rows1,rows2,dd1_out ptr,dd2_out ptr,dd stride,split2,gap2}
 // g0/out: up to two segments each (same channel split as the nn inputs); add0 optional (null) added to out segment 0.
 extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2,
                               void* dW1, void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride,
@@ -1064,6 +1099,8 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
         if ((((uintptr_t)g0_ptrs[i]) | ((uintptr_t)out_ptrs[i])) & 15) p.vec4 = 0;
     }
     p.add0 = (const float*)add0; p.add0_stride = (int)add0_stride;
+    p.dd1_out = (float*)dims[7]; p.dd2_out = (float*)dims[8]; p.dd_stride = (int)dims[9];
+    p.split2 = dims[10] > 0 ? (int)dims[10] : 0x7fffffff; p.gap2 = (int)dims[11];
     if (add0 && ((add0_stride & 3) || (((uintptr_t)add0) & 15))) p.vec4 = 0;
     c1_tile(p.Win, p.Hin, &p.TW_log2);
     const int TW = 1 << p.TW_log2, TH = 256 >> p.TW_log2;

@@ -1,6 +1,8 @@
 """Flow blocks on the HIP path.  API mirror of the reference's nn/modules/flowLSTMBlock.py
 (AffineCouplingBlock :24-86, UnNormedAffineCouplingBlock :88-146, LSTMCouplingBlock :148-218,
 LSTMFLowBlock :220-361)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -218,6 +220,22 @@ class LSTMFLowBlock(nn.Module):
         ld = (-ld if ts else ld) + a.abs().log().sum() * hw
         return Wm, bm, ld
 
+    def _fusable(self, lm, xn):
+        """The level-fused node needs LU blocks throughout (lm), >= 1 non-LSTM layer and 16-byte aligned halves."""
+        if lm is None or self.n_layers < 2 or os.environ.get("TMG_NO_LEVEL_FUSION"):
+            return False
+        layers = list(self.revlayers._modules.values())[:-1]
+        return (xn.shape[3] // 2) % 4 == 0 and all(l.coupling.coupling_nn.zero_conv.logscale_factor == 1 for l in layers)
+
+    @staticmethod
+    def _tail_weights(layers):
+        out = []
+        for l in layers:
+            nn_ = l.coupling.coupling_nn
+            out += [nn_.dense_block.denselayer1.conv1.weight, nn_.dense_block.denselayer2.conv1.weight, nn_.zero_conv.conv.weight,
+                    nn_.zero_conv.conv.bias, nn_.zero_conv.scale]
+        return out
+
     def _squeeze_nhwc(self, xn, to_small):
         if isinstance(self.squeeze, CheckerSqueeze):
             return ops.CheckerFn.apply(xn, to_small)
@@ -231,7 +249,13 @@ class LSTMFLowBlock(nn.Module):
         lm = self._level_mix(False, xn.shape[1] * xn.shape[2])
         logdet = 0. if lm is None else lm[2]
         out_states = []
+        fused = self._fusable(lm, xn)
+        if fused:
+            xn, dld = ops.LevelCouplingFn.apply(xn, condn, lm[0][:-1], lm[1][:-1], False, *self._tail_weights(layers[:-1]))
+            logdet = logdet + dld
         for i, layer in enumerate(layers):
+            if fused and i < self.n_layers - 1:
+                continue
             mix = None if lm is None else (lm[0][i], lm[1][i])
             if i == self.n_layers - 1:
                 xn, dld, so = layer.run(xn, condn, st, False, mix)
@@ -256,11 +280,16 @@ class LSTMFLowBlock(nn.Module):
         lm = self._level_mix(True, yn.shape[1] * yn.shape[2])
         if lm is not None:
             logdet = logdet + lm[2]
+        fused = self._fusable(lm, yn)
         for i in range(len(layers) - 1, -1, -1):
             mix = None if lm is None else (lm[0][i], lm[1][i])
             if i == self.n_layers - 1:
                 yn, dld, so = layers[i].run(yn, condn, st, True, mix)
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
+            elif fused:
+                yn, dld = ops.LevelCouplingFn.apply(yn, condn, lm[0][:-1], lm[1][:-1], True, *self._tail_weights(layers[:-1]))
+                logdet = logdet + dld
+                break
             else:
                 yn, dld = layers[i].run(yn, condn, True, mix)
             logdet = logdet + dld

@@ -25,7 +25,7 @@ c_i64 = ctypes.c_int64
 c_vp = ctypes.c_void_p
 
 EXPORTS = [
-    "tmg_conv_pack", "tmg_conv_fwd", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
+    "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
@@ -141,12 +141,20 @@ def _i64(*v):
 # ------------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------------
-def conv_pack(w, mode, cin_eff=0):
+def conv_pack(w, mode, cin_eff=0, cmap=None):
     """w: torch layout [Cout, Cin, k, k] -> packed MFMA operand (see tmg_conv_pack); cin_eff > Cin zero-extends the
-    input-channel dimension."""
+    input-channel dimension.  cmap = (cvalid, csplit, cgap) selects / re-maps source channels (tmg_conv_pack_map)."""
     check_act(w)
     w = w.contiguous()
     Cout, Cin, k, _ = w.shape
+    if cmap is not None:
+        ce = int(cin_eff)
+        K, N = (ce, Cout) if mode == 0 else (Cout, ce)
+        Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
+        wpk = torch.empty(k * k * Kp * Np, device=w.device, dtype=torch.float32)
+        _chk(lib().tmg_conv_pack_map(_ptr(w), _ptr(wpk), c_i64(Cout), c_i64(Cin), c_i64(ce), c_i64(k), c_i64(mode), _i64(*cmap), _stream()),
+             "tmg_conv_pack_map")
+        return wpk
     ce = max(int(cin_eff), Cin)
     K, N = (ce, Cout) if mode == 0 else (Cout, ce)
     Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
@@ -156,8 +164,9 @@ def conv_pack(w, mode, cin_eff=0):
 
 
 def conv_fwd(inputs, wpk, Cout, ksize, stride, outs, bias=None, kappa=None, in_scale=None, in_shift=None, relu_in=False,
-             pad_rep=False, relu_out=False, accumulate=False):
-    """inputs / outs: lists of NHWC tensors (or channel-slice views) forming the channel concatenation."""
+             pad_rep=False, relu_out=False, accumulate=False, add=None):
+    """inputs / outs: lists of NHWC tensors (or channel-slice views) forming the channel concatenation.
+    add: optional NHWC tensor / channel-slice view with Cout channels summed in before bias and scale."""
     B, Hin, Win, _ = inputs[0].shape
     Hout, Wout = outs[0].shape[1], outs[0].shape[2]
     ip, idesc, n_in = _segs(inputs)
@@ -165,6 +174,10 @@ def conv_fwd(inputs, wpk, Cout, ksize, stride, outs, bias=None, kappa=None, in_s
     Cin = sum(t.shape[3] for t in inputs)
     assert sum(t.shape[3] for t in outs) == Cout
     dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep, relu_out, accumulate)
+    if add is not None:
+        _chk(lib().tmg_conv_fwd_add(ip, idesc, c_i64(n_in), _ptr(wpk), _ptr(bias), _ptr(kappa), _ptr(in_scale), _ptr(in_shift), _ptr(add),
+                                    _d2(add), op, odesc, c_i64(n_out), dims, _stream()), "tmg_conv_fwd_add")
+        return
     _chk(lib().tmg_conv_fwd(ip, idesc, c_i64(n_in), _ptr(wpk), _ptr(bias), _ptr(kappa), _ptr(in_scale), _ptr(in_shift), op, odesc,
                             c_i64(n_out), dims, _stream()), "tmg_conv_fwd")
 
@@ -231,12 +244,12 @@ def workspace(nfloats, device):
 
 
 def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, in_shift=None, relu_in=False, pad_rep=False,
-               use_ws=True, cin_dst=0):
+               use_ws=True, cin_dst=0, cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0):
     B, Hin, Win, _ = inputs[0].shape
     _, Hout, Wout, Cout = dy.shape
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
-    dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep, cin_dst)
+    dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
     ws = workspace(lib().tmg_conv_wgrad_ws_floats(dims), dy.device) if use_ws else None
     _chk(lib().tmg_conv_wgrad(ip, idesc, c_i64(n_in), _ptr(in_scale), _ptr(in_shift), _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
                               _ptr(kappa), _ptr(ws), c_i64(ws.numel() if ws is not None else 0), dims, _stream()), "tmg_conv_wgrad")
@@ -267,10 +280,11 @@ def affine_apply(hh, x2, y2, rsave, logdet, reverse):
                                 _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_apply")
 
 
-def affine_bwd(gout, yref, rsave, g, gin, dhh, reverse):
+def affine_bwd(gout, yref, rsave, g, gin, dhh, reverse, kappa=None):
+    """kappa given: dhh is written pre-multiplied by exp(clamp(kappa))."""
     B, H, W, Ch = gout.shape
-    _chk(lib().tmg_affine_bwd(_ptr(gout), _d2(gout), _ptr(yref), _d2(yref), _ptr(rsave), _ptr(g), _ptr(gin), _d2(gin), _ptr(dhh),
-                              _d2(dhh), _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_bwd")
+    _chk(lib().tmg_affine_bwd_scaled(_ptr(gout), _d2(gout), _ptr(yref), _d2(yref), _ptr(rsave), _ptr(g), _ptr(gin), _d2(gin), _ptr(dhh),
+                                     _d2(dhh), _ptr(kappa), _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_bwd_scaled")
 
 
 def lstm_pointwise_fwd(gates, c_prev, c_next, h_next):
@@ -351,12 +365,13 @@ def masked_add(dst, src=None, ref=None, add=None, accumulate=False):
          "tmg_masked_add")
 
 
-def c1_fwd(inputs, w, out, relu_in=True, w_rows=0, fill4=False):
+def c1_fwd(inputs, w, out, relu_in=True, w_rows=0, fill4=False, add=None, w_split=0, w_gap=0):
     B, H, W, _ = inputs[0].shape
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
-    _chk(lib().tmg_c1_fwd(ip, idesc, c_i64(n_in), _ptr(w), _ptr(out), _d2(out), _i64(B, H, W, Cin, relu_in, w_rows, fill4), _stream()),
-         "tmg_c1_fwd")
+    ad = _d2(add) if add is not None else _i64(0, 0)
+    _chk(lib().tmg_c1_fwd_add(ip, idesc, c_i64(n_in), _ptr(w), _ptr(add), ad, _ptr(out), _d2(out),
+                              _i64(B, H, W, Cin, relu_in, w_rows, fill4, w_split, w_gap), _stream()), "tmg_c1_fwd_add")
 
 
 def c1_bwd(inputs, w, dW, dd, dref, gsegs, relu_in=True):
@@ -374,7 +389,7 @@ def dkappa(w, dw, b, db, kappa, dk):
          "tmg_dkappa")
 
 
-def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None, rows1=0, rows2=0):
+def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None, rows1=0, rows2=0, dd1=None, dd2=None, split2=0, gap2=0):
     """Fused backward of the two growth-1 layers; `inputs` = nn inputs + [D]; g0 / outs: lists (<= 2) of NHWC tensors."""
     B, H, W, _ = inputs[0].shape
     ip, idesc, n_in = _segs(inputs)
@@ -384,4 +399,7 @@ def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None,
     a_stride = seg(add0)[1] if add0 is not None else 0
     _chk(lib().tmg_dense2_bwd(ip, idesc, c_i64(n_in), _ptr(w1p), _ptr(w2p), _ptr(dW1p), _ptr(dW2p), _ptr(GD), c_i64(seg(GD)[1]), _ptr(D),
                               c_i64(seg(D)[1]), gp, gdesc, op, odesc, c_i64(ng), _ptr(add0), c_i64(a_stride),
-                              _i64(B, H, W, Cin, cin_nn, rows1 or Cin, rows2 or Cin), _stream()), "tmg_dense2_bwd")
+                              _i64(B, H, W, Cin, cin_nn, rows1 or Cin, rows2 or Cin, dd1.data_ptr() if dd1 is not None else 0,
+                                   dd2.data_ptr() if dd2 is not None else 0, seg(dd1)[1] if dd1 is not None else 0, split2, gap2),
+                              _stream()),
+         "tmg_dense2_bwd")

@@ -40,6 +40,12 @@ typedef struct ihipStream_t* tmg_stream_t; /* == hipStream_t */
 int tmg_conv_pack(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize, int64_t mode,
                   tmg_stream_t st);
 
+/* tmg_conv_pack with an input-channel map {cvalid, csplit, cgap}: operand channel c < cvalid reads source channel
+ * c (+ cgap when c >= csplit), channels in [cvalid, cin_eff) are zero.  Lets a conv over the segments (x1 | D) use the
+ * matching rows of a weight stored for cat(x1, cond, d1, d2) without re-laying it out on the host. */
+int tmg_conv_pack_map(const void* w, void* wpk, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize, int64_t mode,
+                      const int64_t* map, tmg_stream_t st);
+
 /* out = [relu]( (conv_k(pad(act(in)); wpk) + bias) * exp(clamp(kappa,-4,ln4)) ), ksize 1 or 3,
  * stride 1 or 2, zero or replicate padding, act = optional per-channel affine then optional ReLU.
  * Replaces F.conv2d at flowUtils.py:246-247 (Conv2dZeros), convLSTM.py:74 and :152, glowConv.py:194
@@ -50,10 +56,18 @@ int tmg_conv_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nse
                  const void* kappa, const void* in_scale, const void* in_shift, void* const* out_ptrs,
                  const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
 
+/* tmg_conv_fwd with an extra tensor `add` ({stride, off}, Cout channels) summed before bias and scale:
+ * out = [relu]((conv + add + bias) * exp(clamp(kappa))).  Used to inject the conditioning map's pre-computed
+ * contribution to a coupling network (flowAffine.py:74: cat(x1, cond) is linear in the conv). */
+int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* wpk, const void* bias,
+                     const void* kappa, const void* in_scale, const void* in_shift, const void* add, const int64_t* add_desc,
+                     void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
+
 /* dW[Cout][Cin][k][k] += scale * sum_pixels act(in)(p*s+tap) (x) dy(p) ; dbias += scale * sum dy.
  * (accumulating: caller zero-fills; per-block partial sums go through the scratch `ws` and a reduce kernel.)  Replaces the autograd weight-gradient of the convs above.
- * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate,cin_dst}; dy_desc = {stride, off};
- * dW is [Cout][cin_dst][k*k] (cin_dst = 0: Cin) */
+ * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate,cin_dst,cin_valid,ci_split,ci_off0,ci_off1};
+ * dy_desc = {stride, off}; dW rows have cin_dst entries, source channel ci < cin_valid lands at
+ * ci + (ci < ci_split ? ci_off0 : ci_off1) (all zero: dense [Cout][Cin][k*k]) */
 int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
                    const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, const void* kappa,
                    void* ws, int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
@@ -87,6 +101,11 @@ int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void* x2, const 
 int tmg_affine_bwd(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
                    const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d, const int64_t* dims,
                    tmg_stream_t st);
+
+/* tmg_affine_bwd with dhh pre-multiplied by exp(clamp(*kappa)) (the Conv2dZeros output scale, flowUtils.py:247). */
+int tmg_affine_bwd_scaled(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
+                          const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d, const void* kappa,
+                          const int64_t* dims, tmg_stream_t st);
 
 /* ConvLSTM gates (convLSTM.py:76-83): gates [npix][4R] in order i,f,o,g are activated in place.
  * dims = {npix, R} */
@@ -125,16 +144,20 @@ int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const i
 
 /* Growth-1 dense layer of the coupling network, C_out = 1 (denseBlock.py:135-138), forward and
  * backward (input gradient accumulated into g segments, weight gradient accumulated atomically).
- * dims = {B,H,W,Cin,relu_in,w_rows,fill4} */
+ * dims = {B,H,W,Cin,relu_in,w_rows,fill4,w_split,w_gap} */
 int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out, const int64_t* out_d,
                const int64_t* dims, tmg_stream_t st);
+/* tmg_c1_fwd plus a per-pixel scalar `add` ({stride, off}) summed onto the result. */
+int tmg_c1_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, const void* add,
+                   const int64_t* add_d, void* out, const int64_t* out_d, const int64_t* dims, tmg_stream_t st);
 int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* dW, const void* dd,
                const int64_t* dd_d, const void* dref, const int64_t* dref_d, void* const* g_ptrs, const int64_t* g_desc,
                int64_t ng, const int64_t* dims, tmg_stream_t st);
 
 /* Fused backward of both growth-1 layers of a coupling network (denseBlock.py:135-152 x2) incl. the ReLU masks
  * and the concat adjoint: one pass over the network input.  in segments = nn inputs followed by the 4-channel D
- * buffer; dims = {B,H,W,Cin_total(incl. D),cin_nn,rows1,rows2}. */
+ * buffer; dims = {B,H,W,Cin_total(incl. D),cin_nn,rows1,rows2,dd1_out,dd2_out,dd_stride,split2,gap2} (dd*_out: optional device
+ * pointers, passed as integers, receiving the masked gradients w.r.t. d1 / d2). */
 int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2, void* dW1,
                    void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride, const void* const* g0_ptrs,
                    const int64_t* g0_desc, void* const* out_ptrs, const int64_t* out_desc, int64_t ng, const void* add0,
