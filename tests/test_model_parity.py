@@ -186,3 +186,69 @@ def test_cpu_tensors_are_rejected_loudly():
     from nn.modules.flowUtils import Conv2dZeros
     with pytest.raises(RuntimeError):
         Conv2dZeros(4, 4)(torch.randn(1, 4, 4, 4))
+
+
+def test_full_size_round_trip_and_logdet_bookkeeping():
+    """Metric configuration (256x256x4 output, L=4, K=16, default widths) at batch 2: size-independent properties.
+    (i) forward -> reconstruct is the identity (the reference's own self-test, tmGlow.py:511-530);
+    (ii) forward log-prob minus the top prior equals the log-det reported by the generative direction on the same
+         latents (every per-layer term has the same sign in both directions)."""
+    from nn.tmGlow import TMGlow
+    from nn.modules.flowUtils import GaussianDiag
+    cfg = C.CFG_M
+    C.seed_all(12345)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, 0.004, 0.02, 0.004)
+    m.to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    x = torch.randn(B, 4, 128, 128, generator=g).to(DEV)
+    y = torch.randn(B, 4, 256, 256, generator=g).to(DEV)
+    h_in = m.initLSTMStates(torch.arange(B), [256, 256])
+    with torch.no_grad():
+        z, logp, h_out, eps = m.forward(x, y, h_in, return_eps=True)
+        yr, logdet, h_out2 = m.reconstruct(x, h_in, eps)
+        z_out, _ = m.encoder.forward(x)
+        cmean, clsd = z_out.chunk(2, 1)
+        top = GaussianDiag(cmean, clsd).log_prob(z)
+    assert z.shape == (B, 64, 16, 16) and yr.shape == y.shape
+    assert float((yr - y).abs().max()) < 5e-4
+    C.assert_logdet(logp - top, logdet, "forward logp - top prior vs reverse logdet", rtol=2e-5, atol=0.5)
+    for (h1, c1), (h2, c2) in zip(h_out, h_out2):
+        C.assert_field(h1, h2, "h states both directions", atol=5e-4)
+
+
+def test_level_fused_node_matches_per_layer_path():
+    """The level-fused coupling node (cond contributions batched over layers) against the per-layer path, both on HIP."""
+    import os
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+    C.seed_all(77)
+    blk = LSTMFLowBlock(4, 32, 16, 5, LUdecompose=True, train_sampling=True, do_split=True, squeeze_type=0)
+    C.perturb_(blk, 5, 0.05, 0.1, 0.05)
+    blk.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 4, 24, 40, generator=g).to(DEV)
+    cond = torch.randn(3, 32, 12, 20, generator=g).to(DEV)
+    res = {}
+    for tag, env in (("fused", None), ("plain", "1")):
+        if env:
+            os.environ["TMG_NO_LEVEL_FUSION"] = env
+        else:
+            os.environ.pop("TMG_NO_LEVEL_FUSION", None)
+        blk.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        ci = cond.clone().requires_grad_(True)
+        z, ld, st, eps = blk.forward(xi, ci, None, return_eps=True)
+        xr, ldr, _ = blk.reverse(z, ci, None, eps=eps.detach())
+        ((z ** 2).sum() + ld.sum() * 0.01 + (xr ** 2).sum() * 0.5 + ldr.sum() * 0.02).backward()
+        res[tag] = (z.detach(), ld.detach(), xr.detach(), {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None},
+                    xi.grad.clone(), ci.grad.clone())
+    os.environ.pop("TMG_NO_LEVEL_FUSION", None)
+    a, b = res["fused"], res["plain"]
+    C.assert_field(a[0], b[0], "z")
+    C.assert_logdet(a[1], b[1])
+    C.assert_field(a[2], b[2], "x_rec")
+    ga, gb = dict(a[3]), dict(b[3])
+    ga.update({"@dx": a[4], "@dcond": a[5]})
+    gb.update({"@dx": b[4], "@dcond": b[5]})
+    C.assert_grads(ga, gb, "fused vs per-layer grads", global_tol=1e-4, tensor_tol=2e-3)
