@@ -250,8 +250,15 @@ class ConvLSTMCellFn(torch.autograd.Function):
         dW = torch.zeros_like(weight)
         db = torch.zeros_like(bias)
         H.conv_wgrad(segs, dg, dW, db, 3, 1)
-        dins = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in segs]
-        H.conv_fwd([dg], H.conv_pack(weight, 1), sum(t.shape[3] for t in segs), 3, 1, dins)
+        # input gradients only for the channel prefix that needs them: the recurrent state of the first time-step of a
+        # window (and any constant input) carries no gradient, which removes R of the Cin+R gradient channels
+        need = [ctx.needs_input_grad[4 + i] for i in range(ctx.n_in)] + [ctx.needs_input_grad[2]]
+        last = max([i for i, n in enumerate(need) if n], default=-1)
+        dins = [None] * len(segs)
+        if last >= 0:
+            nch = sum(t.shape[3] for t in segs[:last + 1])
+            dins[:last + 1] = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in segs[:last + 1]]
+            H.conv_fwd([dg], H.conv_pack(weight, 1, nch, (nch, 1 << 30, 0)), nch, 3, 1, dins[:last + 1])
         return (dW, db, dins[-1], dc_prev if ctx.has_c else None) + tuple(dins[:-1])
 
 
