@@ -135,6 +135,8 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU product path"
     tmg_hip.lib()
+    if os.environ.get("TMG_SINGLE_DEVICE"):   # functional test of the N>1 path on a one-GPU box: every rank on cuda:0
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = CONFIGS[args.config]
@@ -230,7 +232,7 @@ def main():
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "tmglow %s: sample()+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
                args.config, Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
-               "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss), "launch": "hipGraph replay" if graph is not None else "eager"},
+               "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
            "roofline": roof}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)
