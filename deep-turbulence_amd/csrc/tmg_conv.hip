@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
             stage_issue(p, R, b, iy0, ix0, PH, PW, c0 + p.KCH, kn, kn + 8);
         }
         const int kbn = kch >> 4;
+        const int CS4 = CS >> 2;
+        const float4* lds4 = reinterpret_cast<const float4*>(lds);
         // flattened (tap, kb) loop with the next iteration's B fragments (L2-resident packed weights) prefetched
         // into registers while the current iteration's MFMAs issue
         const size_t tap_stride = (size_t)KB * p.Cout_pad * 16, kb_stride = (size_t)p.Cout_pad * 16;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
             float4 af[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                af[i] = *reinterpret_cast<const float4*>(lds + ((mrow[i] + tyy) * PW + mcol[i] + txx) * CS + kb * 16 + 4 * q);
+                af[i] = lds4[((mrow[i] + tyy) * PW + mcol[i] + txx) * CS4 + kb * 4 + q];  // float4 index: provably 16-byte aligned -> ds_read_b128
             // advance (tap, kb) and prefetch
             ++kb;
             if (kb == kbn) {

@@ -252,3 +252,31 @@ def test_level_fused_node_matches_per_layer_path():
     ga.update({"@dx": a[4], "@dcond": a[5]})
     gb.update({"@dx": b[4], "@dcond": b[5]})
     C.assert_grads(ga, gb, "fused vs per-layer grads", global_tol=1e-4, tensor_tol=2e-3)
+
+
+def test_training_window_capture_matches_reference():
+    """A16 on the HIP path: three optimizer steps of the trainer's inner loop (3-step BPTT windows with LSTM-state
+    gradients flowing across time-steps, clip, Adam(amsgrad), state re-anchoring) against the capture recorded from
+    the reference; latents injected through reconstruct()."""
+    import tmg_dist
+    d = C.load_npz("tiny_train.npz")
+    cfg = C.CFG_TINY
+    L = len(cfg["glow_blocks"])
+    m = _model(cfg, {k: torch.from_numpy(v) for k, v in C.sub(d, "sd.").items()})
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    a_key = m.initLSTMStates(torch.from_numpy(d["seeds"]), [16, 16])
+    a0 = [(h.clone(), c.clone()) for h, c in a_key]
+    xs = torch.from_numpy(d["xs"]).to(DEV)
+    for a in range(xs.shape[0]):
+        tol = 1.0 + 4.0 * a
+        eps = [[torch.from_numpy(d["eps.%d.%d.%d" % (a, t, i)]).to(DEV) for i in range(L + 1)] for t in range(xs.shape[1])]
+        loss, gn, a0, outs = tmg_dist.train_window(m, opt, [xs[a, t] for t in range(xs.shape[1])], a0, a_key, C.loss_reverse,
+                                                   max_grad_norm=float(d["max_grad_norm"]),
+                                                   sample=lambda mod, x, st, t: mod.reconstruct(x, st, eps[t]))
+        for t, (y, logp) in enumerate(outs):
+            C.assert_field(y, d["step%d.t%d.y" % (a, t)], "y", atol=C.FIELD_ATOL * tol, rtol=C.FIELD_RTOL * tol)
+            C.assert_logdet(logp, d["step%d.t%d.logp" % (a, t)], rtol=C.LOGDET_RTOL * 10 * tol)
+        assert abs(float(loss) - float(d["step%d.loss" % a])) < 2e-4 * tol
+        assert abs(float(gn) - float(d["step%d.gradnorm" % a])) < 2e-3 * float(d["step%d.gradnorm" % a]) * tol
+        log_s = dict(m.named_parameters())[str(d["log_s_key"])]
+        C.assert_field(log_s, d["step%d.log_s" % a], "log_s", atol=2e-5 * tol)
