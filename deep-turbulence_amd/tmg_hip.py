@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtmglow_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip"]
+SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip"]
 _lib = None
 
 c_i64 = ctypes.c_int64
@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
+    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
 ]
 
 
@@ -403,3 +403,31 @@ def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None,
                                    dd2.data_ptr() if dd2 is not None else 0, seg(dd1)[1] if dd1 is not None else 0, split2, gap2),
                               _stream()),
          "tmg_dense2_bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# physics-constrained loss (row F1)
+# ------------------------------------------------------------------------------------------------
+def _flts(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def phys_fwd(y, target, sums, sd, mu, dx, dy, rho=1.0, pstar=None, ustar=None):
+    """y / target: contiguous [N,3,H,W]; sums: zero-filled [3] (sum pstar^2, sum ustar^2, sum (y-target)^2)."""
+    check_act(y)
+    N, _, Hh, Ww = y.shape
+    _chk(lib().tmg_phys_fwd(_ptr(y), _ptr(target), _ptr(sums), _ptr(pstar), _ptr(ustar), _i64(N, Hh, Ww),
+                            _flts(list(sd) + list(mu) + [dx, dy, rho]), _stream()), "tmg_phys_fwd")
+
+
+def phys_rms(y, trms, mean_out, coef_out, sum_out):
+    """y: contiguous [B,T,3,H,W]; trms: [B,3,H,W]; sum_out: zero-filled [1]."""
+    B, T = y.shape[0], y.shape[1]
+    chw = y.shape[2] * y.shape[3] * y.shape[4]
+    _chk(lib().tmg_phys_rms(_ptr(y), _ptr(trms), _ptr(mean_out), _ptr(coef_out), _ptr(sum_out), _i64(B, T, chw), _stream()), "tmg_phys_rms")
+
+
+def phys_bwd(y, target, mean, coef, dyo, T, sd, mu, dx, dy, rho, cp, cd, cl, cr):
+    N, _, Hh, Ww = y.shape
+    _chk(lib().tmg_phys_bwd(_ptr(y), _ptr(target), _ptr(mean), _ptr(coef), _ptr(dyo), _i64(N, T, Hh, Ww),
+                            _flts(list(sd) + list(mu) + [dx, dy, rho, cp, cd, cl, cr]), _stream()), "tmg_phys_bwd")

@@ -168,6 +168,22 @@ int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t n
 int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void* b, const void* db, int64_t nb, const void* kappa, void* dk,
                tmg_stream_t st);
 
+/* ---- physics-constrained reverse-KL loss (tmg_physics.hip) ------------------------------ */
+
+/* Residual sums of TMGLowLoss (trainFlowParallel.py:121-177 / physicsConstrained.py:42-94): y, target = [N,3,H,W]
+ * planar (u_x,u_y,p); sums[3] += {sum pstar^2 over the interior, sum ustar^2 over interior rows, sum (y-target)^2};
+ * optional residual fields pstar [N,1,H,W], ustar [N,1,H,W+2].  dims = {N,H,W}; fl = {sd[3], mu[3], dx, dy, rho}. */
+int tmg_phys_fwd(const void* y, const void* target, void* sums, void* pstar_out, void* ustar_out, const int64_t* dims,
+                 const float* fl, tmg_stream_t st);
+/* Per-pixel RMS over the T steps of y = [B,T,3,H,W] against target_rms [B,3,H,W] (trainFlowParallel.py:143-144);
+ * writes mean / coefficient maps for the backward pass; sum_out += sum (rms - target_rms)^2.  dims = {B,T,3*H*W}. */
+int tmg_phys_rms(const void* y, const void* trms, void* mean_out, void* coef_out, void* sum_out, const int64_t* dims,
+                 tmg_stream_t st);
+/* d loss / d y for all four data terms.  dims = {N,T,H,W}; fl = {sd[3], mu[3], dx, dy, rho, cp, cd, cl, cr} with
+ * c* = upstream * beta * 2 / (element count of the term). */
+int tmg_phys_bwd(const void* y, const void* target, const void* mean, const void* coef, void* dy, const int64_t* dims,
+                 const float* fl, tmg_stream_t st);
+
 #ifdef __cplusplus
 }
 #endif

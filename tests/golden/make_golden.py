@@ -285,8 +285,42 @@ def init_checksum_case(ref, cfg, fname):
     print(fname, len(cs), "tensors")
 
 
+def loss_case(fname):
+    """F1: the physics-constrained reverse-KL loss of the trainer (TMGLowLoss) with its input gradients."""
+    from types import SimpleNamespace
+    import nn.trainFlowParallel as tfp
+    out = {}
+    for tag, (B, T, Hh, Ww, amp, dx) in {"small": (2, 3, 10, 12, 1.0, 2.0 / 64), "clamped": (2, 4, 9, 8, 3.0, 5.0 / 64)}.items():
+        g = torch.Generator().manual_seed(11)
+        std = torch.tensor([1.3, 0.7, 2.1])
+        mu = torch.tensor([0.2, -0.1, 0.4])
+        model = SimpleNamespace(module=SimpleNamespace(out_std=std, out_mu=mu))
+        args = SimpleNamespace(beta=200.0, dx=dx, dy=dx * 1.25)
+        crit = tfp.TMGLowLoss(args, model)
+        y = (amp * 0.05 * torch.randn(B, T, 3, Hh, Ww, generator=g)).requires_grad_(True)
+        logp = (100 * torch.randn(B, T, generator=g)).requires_grad_(True)
+        tgt = amp * 0.05 * torch.randn(B, T, 3, Hh, Ww, generator=g)
+        tmean = tgt.mean(1)
+        trms = torch.sqrt(torch.mean((tgt - tmean.unsqueeze(1)) ** 2, dim=1))
+        loss = crit(y, logp, tgt, tmean, trms)
+        loss.backward()
+        out.update({tag + ".y": y.detach().numpy().copy(), tag + ".logp": logp.detach().numpy().copy(), tag + ".target": tgt.numpy(),
+                    tag + ".tmean": tmean.numpy(), tag + ".trms": trms.numpy(), tag + ".std": std.numpy(), tag + ".mu": mu.numpy(),
+                    tag + ".cfg": np.array([args.beta, args.dx, args.dy]), tag + ".loss": np.array(loss.item()),
+                    tag + ".dy": y.grad.numpy().copy(), tag + ".dlogp": logp.grad.numpy().copy()})
+        with torch.no_grad():
+            hat = std.view(1, 3, 1, 1) * y.detach().reshape(-1, 3, Hh, Ww) + mu.view(1, 3, 1, 1)
+            out[tag + ".pstar"] = crit.phys.calcPressurePoisson(hat[:, :2], hat[:, 2:]).numpy()
+            out[tag + ".ustar"] = crit.phys.calcDivergence(hat[:, :2]).numpy()
+        print("loss case", tag, loss.item(), "clamped frac", float((out[tag + ".pstar"].__abs__() >= 1).mean()))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
 if __name__ == "__main__":
     ref = import_reference()
+    if "loss" in sys.argv:
+        loss_case("phys_loss.npz")
+        sys.exit(0)
     torch.set_num_threads(8)
     model_case(ref, CFG_TINY, 2, "tiny_model.npz")
     model_case(ref, CFG_TINY3, 3, "tiny3_model.npz", scales=(0.03, 0.05, 0.03))

@@ -276,3 +276,28 @@ def test_c1_forward_and_backward(shape):
     _close(dW.cpu().reshape(1, cin, 3, 3), wr.grad, tol=5e-5, what="c1 dW")
     got = torch.cat([_back(t) for t in gs], 1)
     _close(got, act.grad, tol=5e-5, what="c1 raw input grad")
+
+
+@pytest.mark.parametrize("tag", ["small", "clamped"])
+def test_physics_loss_matches_reference_fixture(tag):
+    """Row F1: fused physics-constrained loss kernels against the fixture recorded from the reference's TMGLowLoss."""
+    from types import SimpleNamespace
+    from nn.trainFlowParallel import TMGLowLoss
+    from pc.physicsConstrained import PhysConstrainedLES
+    d = C.load_npz("phys_loss.npz")
+    t = lambda k: torch.from_numpy(d[tag + "." + k])  # noqa: E731
+    beta, dx, dy = (float(v) for v in d[tag + ".cfg"])
+    model = SimpleNamespace(out_std=t("std"), out_mu=t("mu"))
+    crit = TMGLowLoss(SimpleNamespace(beta=beta, dx=dx, dy=dy), model).to(DEV)
+    y = t("y").to(DEV).requires_grad_(True)
+    logp = t("logp").to(DEV).requires_grad_(True)
+    loss = crit(y, logp, t("target").to(DEV), t("tmean").to(DEV), t("trms").to(DEV))
+    ref = float(d[tag + ".loss"])
+    assert abs(loss.item() - ref) <= 2e-5 * abs(ref), (loss.item(), ref)
+    loss.backward()
+    C.assert_grads({"y": y.grad, "logp": logp.grad}, {"y": d[tag + ".dy"], "logp": d[tag + ".dlogp"]}, "loss grads",
+                   global_tol=2e-5, tensor_tol=2e-4)
+    hat = (t("std").view(1, 3, 1, 1) * t("y").reshape(-1, 3, y.shape[-2], y.shape[-1]) + t("mu").view(1, 3, 1, 1)).to(DEV)
+    phys = PhysConstrainedLES(dx, dy)
+    _close(phys.calcPressurePoisson(hat[:, :2], hat[:, 2:]), t("pstar"), what="pstar")
+    _close(phys.calcDivergence(hat[:, :2]), t("ustar"), what="ustar")
