@@ -119,7 +119,7 @@ __device__ __forceinline__ float4 load_in4(const P& p, int b, int iy, int ix, in
 // the next one is bound by U x the memory latency (measured: 5x slower staging at U = 1).
 template <int U = 8, typename P>
 __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int iy0, int ix0, int PH, int PW, int c0,
-                                            int kch, int CS) {
+                                            int kch, int CS, int swz = 0) {
     const int k4 = kch >> 2;
     const int items = PH * PW * k4;
     const int nt = blockDim.x;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int i
                 const int py = (int)__umulhi((unsigned)pix, mp);
                 const int px = pix - py * PW;
                 v[u] = load_in4(p, b, iy0 + py, ix0 + px, c0 + 4 * c4);
-                dst[u] = pix * CS + 4 * c4;
+                dst[u] = pix * CS + ((4 * c4) ^ ((px & 1) ? swz : 0));  // swz: XOR swizzle of odd patch columns (0 = linear)
             }
         }
 #pragma unroll

@@ -217,11 +217,28 @@ struct WgradP {
     int MPIX;
     int tiles_x, tiles_y, ntiles;
     int CITG;  // input-channel tiles (of 16) handled per block group (grid.z walks the groups)
+    int dbg;     // timing experiments (TMG_WG_DBG): 1 = no MFMA loop, 2 = no staging
+    int ksplit;  // 1: waves split the pixels of a tile instead of the (tap, channel tile) pairs (see the kernel)
 };
 
+// A block owns (CITG input-channel tiles x all taps) x (NCO output-channel tiles) of dW and a strided share of the
+// pixel tiles.  Work split inside the block (p.ksplit, wave-uniform):
+//   0: the (tap, channel tile) pairs are dealt round-robin to the 4 waves, every wave walks all pixels of a tile;
+//   1: (<= 9 pairs) every wave owns ALL pairs and walks a quarter of the tile's pixels - keeps narrow layers at
+//      9*NCO MFMAs per k-step per wave instead of 2-3, perfectly balanced; partial sums meet in the reduce kernel.
+// LDS layout (channel-tile major): patch [citn][PH*PW][16], dy [NCO][MPIX][16].  A pixel is 16 words apart in every
+// configuration, so a fragment read (16 channels x 4 consecutive pixels) covers 64 consecutive words: conflict-free,
+// and the four k-steps of a 16-pixel unit are reached with immediates from one address register per pair.
+// Staging is software-pipelined through registers: the global loads of the next tile are in flight during the MFMA
+// loop of the current one and only the LDS stores sit between two barriers.
 template <int NP, int NCO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef const __attribute__((address_space(3))) float* lds_cptr;
+    // patch float4 per thread prefetched in registers (the rest is staged at commit time); sized so that accumulators +
+    // fragments + prefetch stay within the 256 registers two waves per SIMD allow
+    constexpr int UP = (NP * NCO >= 28) ? 1 : (NP * NCO >= 20) ? 4 : (NP * NCO >= 12) ? 8 : 13;
+    constexpr int UD = 2 * NCO;              // dy float4 per thread (covers MPIX * NCO * 4 / 256 for MPIX <= 128)
     const int MPIX = p.MPIX;  // pixels per staged tile (64 or 128)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar branches
@@ -229,94 +246,221 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     const int TWl = p.TW_log2, TW = 1 << TWl, TH = MPIX >> TWl;
     const int s = p.stride, halo = p.ksize >> 1, ntaps = p.ksize * p.ksize;
     const int PW = s * (TW - 1) + 1 + 2 * halo, PH = s * (TH - 1) + 1 + 2 * halo;
+    const int PHPW = PH * PW, plane = PHPW * 16;
     const int cit0 = blockIdx.z * p.CITG;
     const int citn = min(p.CITG, (p.Cin_pad >> 4) - cit0);
-    const int kch = citn * 16, CS = kch + 4;
+    const int k4 = citn * 4;
     const int co0 = blockIdx.y * NCO * 16;
-    constexpr int DS = NCO * 16 + 4;
-    float* ldy = lds + PH * PW * CS;
+    const int ldy_w = citn * plane;  // word offset of the dy tile
+    const int ksplit = p.ksplit;
 
     const int npairs = ntaps * citn;
-    const int npw = (npairs - wave + 3) >> 2;  // pairs owned by this wave: wave, wave+4, ...
     f32x4 acc[NP][NCO];
 #pragma unroll
     for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int n = 0; n < NCO; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    // LDS offset of each (tap, input-channel tile) pair owned by this wave, hoisted out of the pixel loop
-    int aoff[NP];
+    // LDS word offset of each owned pair (+ this lane's channel), hoisted out of the pixel loop
+    int aoffw[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int pid = min(wave + 4 * j, npairs - 1);
+        const int pid = min(ksplit ? j : wave + 4 * j, npairs - 1);
         const int tap = pid / citn, cit = pid - tap * citn;
         const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
-        aoff[j] = (tyy * PW + txx) * CS + cit * 16;
+        aoffw[j] = cit * plane + (tyy * PW + txx) * 16 + li;
     }
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        int t = tile;
-        const int tx = t % p.tiles_x;
-        t /= p.tiles_x;
-        const int ty = t % p.tiles_y;
-        const int b = t / p.tiles_y;
-        const int oy0 = ty * TH, ox0 = tx * TW;
-        __syncthreads();
-        stage_patch(p, lds, b, s * oy0 - halo, s * ox0 - halo, PH, PW, cit0 * 16, kch, CS);
-        // dy tile: MPIX pixels x NCO*16 channels (zero outside the image / beyond Cout)
-        for (int it = tid; it < MPIX * NCO * 4; it += 256) {
-            const int m = it / (NCO * 4), c4 = it - m * (NCO * 4);
-            const int oy = oy0 + (m >> TWl), ox = ox0 + (m & (TW - 1));
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < p.Hout && ox < p.Wout) {
-                const float* src = p.dy.p + (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.dy.stride + p.dy.off;
-                const int c = co0 + 4 * c4;
-                if (p.dy_vec4 && c + 3 < p.Cout) {
-                    v = *reinterpret_cast<const float4*>(src + c);
-                } else {
-                    float* f = reinterpret_cast<float*>(&v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c + e < p.Cout) f[e] = src[c + e];
-                }
-            }
-            *reinterpret_cast<float4*>(ldy + m * DS + 4 * c4) = v;
+    // ---- register-staged tile loads -----------------------------------------------------------------------------
+    const int pitems = PHPW * k4, ditems = MPIX * NCO * 4;
+    // floor(n / d) == umulhi(n, ceil(2^32 / d)) for n * d < 2^32 (d >= 2)
+    const unsigned mk = 0xFFFFFFFFu / (unsigned)k4 + 1u;
+    const unsigned mp = 0xFFFFFFFFu / (unsigned)PW + 1u;
+    float4 pv[UP], dv[UD];
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);  // dbias partial of this thread's 4 output channels
+#define TMG_WG_ORIGIN(TILE)                  \
+    int b_, oy0_, ox0_;                      \
+    {                                        \
+        int t_ = (TILE);                     \
+        const int tx_ = t_ % p.tiles_x;      \
+        t_ /= p.tiles_x;                     \
+        const int ty_ = t_ % p.tiles_y;      \
+        b_ = t_ / p.tiles_y;                 \
+        oy0_ = ty_ * TH;                     \
+        ox0_ = tx_ * TW;                     \
+    }
+#define TMG_WG_PATCH_ITEM(IT)                                                                 \
+    const int pix_ = (int)__umulhi((unsigned)(IT), mk), c4_ = (IT) - pix_ * k4;               \
+    const int py_ = (int)__umulhi((unsigned)pix_, mp), px_ = pix_ - py_ * PW;                 \
+    float* dst_ = lds + ((c4_ >> 2) * PHPW + pix_) * 16 + (c4_ & 3) * 4;
+    // global loads of one tile into registers (no LDS access)
+#define TMG_WG_ISSUE(TILE, TID)                                                                                        \
+    {                                                                                                             \
+        TMG_WG_ORIGIN(TILE)                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                          \
+            const int it = (TID) + u * 256;                                                                         \
+            if (it < pitems) {                                                                                    \
+                TMG_WG_PATCH_ITEM(it)                                                                             \
+                (void)dst_;                                                                                       \
+                pv[u] = load_in4(p, b_, s * oy0_ - halo + py_, s * ox0_ - halo + px_, cit0 * 16 + 4 * c4_);       \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                          \
+            const int it = (TID) + u * 256;                                                                         \
+            if (it < ditems) {                                                                                    \
+                const int m = it / (NCO * 4), c4 = it - m * (NCO * 4);                                            \
+                const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));                                     \
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+                if (oy < p.Hout && ox < p.Wout) {                                                                 \
+                    const float* src = p.dy.p + (((size_t)b_ * p.Hout + oy) * p.Wout + ox) * p.dy.stride + p.dy.off; \
+                    const int c = co0 + 4 * c4;                                                                   \
+                    if (p.dy_vec4 && c + 3 < p.Cout) {                                                            \
+                        v = *reinterpret_cast<const float4*>(src + c);                                            \
+                    } else {                                                                                      \
+                        if (c < p.Cout) v.x = src[c];                                                             \
+                        if (c + 1 < p.Cout) v.y = src[c + 1];                                                     \
+                        if (c + 2 < p.Cout) v.z = src[c + 2];                                                     \
+                        if (c + 3 < p.Cout) v.w = src[c + 3];                                                     \
+                    }                                                                                             \
+                }                                                                                                 \
+                dv[u] = v;                                                                                        \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+    // registers -> LDS (+ the part of a large patch that does not fit the register window, staged synchronously)
+#define TMG_WG_COMMIT(TILE, TID)                                                                                       \
+    {                                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                          \
+            const int it = (TID) + u * 256;                                                                         \
+            if (it < pitems) {                                                                                    \
+                TMG_WG_PATCH_ITEM(it)                                                                             \
+                (void)py_; (void)px_;                                                                             \
+                *reinterpret_cast<float4*>(dst_) = pv[u];                                                         \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (pitems > UP * 256) {                                                                                  \
+            TMG_WG_ORIGIN(TILE)                                                                                   \
+            for (int it = (TID) + UP * 256; it < pitems; it += 256) {                                               \
+                TMG_WG_PATCH_ITEM(it)                                                                             \
+                *reinterpret_cast<float4*>(dst_) =                                                                \
+                    load_in4(p, b_, s * oy0_ - halo + py_, s * ox0_ - halo + px_, cit0 * 16 + 4 * c4_);           \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                          \
+            const int it = (TID) + u * 256;                                                                         \
+            if (it < ditems) {                                                                                    \
+                const int m = it / (NCO * 4), c4 = it - m * (NCO * 4);                                            \
+                *reinterpret_cast<float4*>(lds + ldy_w + ((c4 >> 2) * MPIX + m) * 16 + (c4 & 3) * 4) = dv[u];     \
+                /* 256 % (NCO*4) == 0: c4 is the same for all of a thread's items -> per-thread bias partial */   \
+                bacc.x += dv[u].x; bacc.y += dv[u].y; bacc.z += dv[u].z; bacc.w += dv[u].w;                       \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+    // Slots past a wave's last pair are not guarded: they redo the wave's last pair (aoffw is clamped) and their sums
+    // are dropped by the epilogue / reduce kernel.  A block is as slow as its busiest wave anyway, and branch-free
+    // k-steps keep the read/MFMA schedule intact.
+#define TMG_WG_MFMA(AV, BF)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NP; ++j) {                                                    \
+        _Pragma("unroll") for (int n = 0; n < NCO; ++n)                                                 \
+            acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[j], BF[n], acc[j][n], 0, 0, 0);         \
+    }
+#define TMG_SB __builtin_amdgcn_sched_barrier(0);
+
+    const bool fast = (s == 1) && (TWl >= 4);  // a 16-pixel unit lies inside one tile row
+    // Rotated tile loop: round r commits + computes tile r and, before the MFMAs, issues the loads of tile r+1 (one
+    // ISSUE site keeps the unrolled staging code from being emitted twice); the first round only issues.
+    for (int tile = (int)blockIdx.x - (int)gridDim.x; tile < p.ntiles; tile += gridDim.x) {
+        // The item -> (pixel, channel) index math of the staging macros is tile-invariant; left alone the compiler hoists
+        // all of it out of this loop and spills.  Laundering the thread id makes it recompute (~200 VALU per tile).
+        int tid_c = tid, tid_i = tid;
+        asm volatile("" : "+v"(tid_c));
+        asm volatile("" : "+v"(tid_i));
+        if (tile >= 0 && p.dbg != 2) {
+            __syncthreads();  // every wave is done reading the previous tile
+            TMG_WG_COMMIT(tile, tid_c)
+            __syncthreads();
         }
-        __syncthreads();
-        if (p.dbias && blockIdx.z == 0 && tid < NCO * 16) {
-            float sacc = 0.f;
-            for (int m = 0; m < MPIX; ++m) sacc += ldy[m * DS + tid];
-            bsum += sacc;
-        }
-        // software-pipelined pixel loop: the LDS reads of k-step ks+1 are issued before the MFMAs of k-step ks
-        const int nks = MPIX / 4;
+        if (tile + (int)gridDim.x < p.ntiles && p.dbg != 2) TMG_WG_ISSUE(tile + (int)gridDim.x, tid_i)  // in flight during the MFMA loop below
+        if (tile < 0 || p.dbg == 1) continue;
         float av[NP], bfr[NCO], avn[NP], bfn[NCO];
-        {
-            const int m = q;
-            const float* abase = lds + (((m >> TWl) * s) * PW + (m & (TW - 1)) * s) * CS + li;
+        if (fast) {
+            // 16-pixel units; fragment registers ping-pong between k-steps, LDS byte addresses are bumped in place once
+            // per unit, and the scheduling barriers keep "issue the next k-step's reads, then this k-step's MFMAs"
+            const int nun = MPIX >> 4;
+            const int upw = ksplit ? nun >> 2 : nun;
+            const int u0 = ksplit ? wave * upw : 0;
+            const int p00 = u0 * 16;
+            unsigned aa[NP], ba[NCO];
 #pragma unroll
-            for (int n = 0; n < NCO; ++n) bfr[n] = ldy[m * DS + n * 16 + li];
+            for (int j = 0; j < NP; ++j) aa[j] = 4u * (aoffw[j] + q * 16 + ((p00 >> TWl) * PW + (p00 & (TW - 1))) * 16);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) av[j] = abase[aoff[j]];
-        }
-        for (int ks = 0; ks < nks; ++ks) {
-            const int m = min(ks + 1, nks - 1) * 4 + q;  // last iteration re-reads its own k-step (harmless)
-            const float* abase = lds + (((m >> TWl) * s) * PW + (m & (TW - 1)) * s) * CS + li;
-#pragma unroll
-            for (int n = 0; n < NCO; ++n) bfn[n] = ldy[m * DS + n * 16 + li];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) avn[j] = abase[aoff[j]];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                if (j < npw) {  // scalar (wave-uniform) test: slots past this wave's last pair issue no MFMA
-#pragma unroll
-                    for (int n = 0; n < NCO; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bfr[n], acc[j][n], 0, 0, 0);
-                }
+            for (int n = 0; n < NCO; ++n) ba[n] = 4u * (ldy_w + (n * MPIX + p00 + q) * 16 + li);
+#define TMG_WG_LD(AV, BF, K)                                                                                     \
+            {                                                                                                    \
+                _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = *(lds_cptr)(uintptr_t)(ba[n] + (K) * 256); \
+                _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = *(lds_cptr)(uintptr_t)(aa[j] + (K) * 256);  \
             }
+            TMG_WG_LD(av, bfr, 0) TMG_SB
+            for (int u = u0; u < u0 + upw; ++u) {
+                TMG_WG_LD(avn, bfn, 1) TMG_SB
+                TMG_WG_MFMA(av, bfr) TMG_SB
+                TMG_WG_LD(av, bfr, 2) TMG_SB
+                TMG_WG_MFMA(avn, bfn) TMG_SB
+                TMG_WG_LD(avn, bfn, 3) TMG_SB
+                TMG_WG_MFMA(av, bfr) TMG_SB
+                {
+                    const int un = min(u + 1, u0 + upw - 1);  // the last unit re-reads its own first k-step (harmless)
+                    const int pa = u * 16, pb = un * 16;
+                    const int d = (((pb >> TWl) * PW + (pb & (TW - 1))) - ((pa >> TWl) * PW + (pa & (TW - 1)))) * 64;
+                    const int db = (pb - pa) * 64;
 #pragma unroll
-            for (int n = 0; n < NCO; ++n) bfr[n] = bfn[n];
+                    for (int j = 0; j < NP; ++j) aa[j] += d;
 #pragma unroll
-            for (int j = 0; j < NP; ++j) av[j] = avn[j];
+                    for (int n = 0; n < NCO; ++n) ba[n] += db;
+                }
+                TMG_WG_LD(av, bfr, 0) TMG_SB
+                TMG_WG_MFMA(avn, bfn) TMG_SB
+            }
+#undef TMG_WG_LD
+        } else {
+            // generic walk (narrow tiles, stride 2): per-k-step addresses, reads one k-step ahead
+            const int nks = MPIX >> 2;
+            const int kpw = ksplit ? nks >> 2 : nks;
+            const int k0 = ksplit ? wave * kpw : 0;
+#define TMG_WG_LD(AV, BF, KS)                                                                           \
+            {                                                                                           \
+                const int m_ = (KS) * 4 + q;                                                            \
+                const float* ab_ = lds + (((m_ >> TWl) * s) * PW + (m_ & (TW - 1)) * s) * 16;           \
+                _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = lds[ldy_w + (n * MPIX + m_) * 16 + li]; \
+                _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = ab_[aoffw[j]];                   \
+            }
+            TMG_WG_LD(av, bfr, k0)
+            for (int ks = k0; ks < k0 + kpw; ks += 2) {
+                TMG_WG_LD(avn, bfn, ks + 1)
+                TMG_WG_MFMA(av, bfr)
+                TMG_WG_LD(av, bfr, min(ks + 2, k0 + kpw - 1))
+                TMG_WG_MFMA(avn, bfn)
+            }
+#undef TMG_WG_LD
+        }
+    }
+#undef TMG_WG_MFMA
+#undef TMG_SB
+#undef TMG_WG_ISSUE
+#undef TMG_WG_COMMIT
+#undef TMG_WG_PATCH_ITEM
+#undef TMG_WG_ORIGIN
+
+    // dbias: fold the per-thread partials (thread t owns channels 4*(t % (NCO*4)) ..+3) through LDS
+    float bsum = 0.f;
+    const bool do_bias = p.dbias && blockIdx.z == 0;
+    if (do_bias) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(lds + tid * 4) = bacc;
+        __syncthreads();
+        if (tid < NCO * 16) {
+            const int c4 = tid >> 2, e = tid & 3;
+            for (int t = c4; t < 256; t += NCO * 4) bsum += lds[t * 4 + e];
         }
     }
     if (p.ws) {
@@ -329,7 +473,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int n = 0; n < NCO; ++n)
                 slab[(j * NCO + n) * 64] = make_float4(acc[j][n][0], acc[j][n][1], acc[j][n][2], acc[j][n][3]);
-        if (p.dbias && blockIdx.z == 0 && tid < NCO * 16) {
+        if (do_bias && tid < NCO * 16) {
             float* wsb = p.ws + (size_t)gridDim.x * gridDim.y * gridDim.z * 4 * NP * NCO * 256;
             wsb[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 + tid] = bsum;
         }
@@ -338,7 +482,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     const float osc = out_scale_of(p.kappa);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int pid = wave + 4 * j;
+        const int pid = ksplit ? j : wave + 4 * j;
         if (pid >= npairs) continue;
         const int tap = pid / citn, cit = pid - tap * citn;
 #pragma unroll
@@ -353,7 +497,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
             }
         }
     }
-    if (p.dbias && blockIdx.z == 0 && tid < NCO * 16 && co0 + tid < p.Cout) atomicAdd(p.dbias + co0 + tid, bsum * osc);
+    if (do_bias && tid < NCO * 16 && co0 + tid < p.Cout) atomicAdd(p.dbias + co0 + tid, bsum * osc);
 }
 
 // Fold the per-block slabs of conv_wgrad_kernel into dW / dbias.  grid = (ceil(items/256), xchunks):
@@ -361,7 +505,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
                                          const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int CITG,
                                          int cit_total, int Cin, int Cout, int ntaps, int xchunk, int cin_valid, int ci_split,
-                                         int ci_off0, int ci_off1) {
+                                         int ci_off0, int ci_off1, int ksplit) {
     const int items = gy * gz * 4 * NP * NCO * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int x0 = blockIdx.y * xchunk, x1 = min(gx, x0 + xchunk);
@@ -375,7 +519,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
         const int z = r_ % gz;
         const int y = r_ / gz;
         const int citn = min(CITG, cit_total - z * CITG);
-        const int pid = wave + 4 * j;
+        const int pid = ksplit ? j : wave + 4 * j;  // ksplit: the four waves hold partial sums of the same pair
         if (pid < ntaps * citn) {
             const size_t per_x = (size_t)gy * gz * 4 * NP * NCO * 64;
             const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * 4 + wave) * NP + j) * NCO + n) * 64 + lane;
@@ -784,7 +928,7 @@ static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_
 }
 
 struct WgradPlan {
-    int twl, TH, MPIX, tiles_x, tiles_y, ntiles, CITG, NCO, NP, gx, gy, gz;
+    int twl, TH, MPIX, tiles_x, tiles_y, ntiles, CITG, NCO, NP, ksplit, gx, gy, gz;
     size_t lds_bytes, ws_floats;
 };
 
@@ -820,14 +964,17 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     const int ngroups = (cit + CITG - 1) / CITG;
     pl->CITG = (cit + ngroups - 1) / ngroups;
     pl->NCO = NCO;
-    const int np = (ntaps * pl->CITG + 3) / 4;
+    // <= 9 pairs: every wave owns all of them and a quarter of each tile's pixels; otherwise pairs are dealt to the waves
+    pl->ksplit = ntaps * pl->CITG <= (NCO == 4 ? 5 : 9);  // (NP, NCO) = (7|9, 4) would not fit the register file
+    const int np = pl->ksplit ? ntaps * pl->CITG : (ntaps * pl->CITG + 3) / 4;
     pl->NP = np <= 3 ? 3 : (np <= 5 ? 5 : (np <= 7 ? 7 : 9));
     if (np > 9) return -7;
     pl->gy = (cot + NCO - 1) / NCO;
     pl->gz = ngroups;
     const int halo = ksize >> 1;
     const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
-    pl->lds_bytes = ((size_t)PH * PW * (pl->CITG * 16 + 4) + (size_t)pl->MPIX * (NCO * 16 + 4)) * 4;
+    pl->lds_bytes = ((size_t)PH * PW * pl->CITG * 16 + (size_t)pl->MPIX * NCO * 16) * 4;
+    if (pl->lds_bytes < 4096) pl->lds_bytes = 4096;  // the dbias fold reuses the first 4 KB
     if (pl->lds_bytes > 160 * 1024) return -6;
     // pixel shares: enough blocks to fill the chip (~512) but >= 4 tiles per block so slab traffic stays small
     int gx = 512 / (pl->gy * ngroups);
@@ -876,12 +1023,15 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     p.TW_log2 = pl.twl; p.TH = pl.TH; p.MPIX = pl.MPIX; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.CITG = pl.CITG;
     p.ws = (ws && (size_t)ws_floats >= pl.ws_floats && (((uintptr_t)ws) & 15) == 0) ? (float*)ws : nullptr;
     dim3 grid(pl.gx, pl.gy, pl.gz);
+    p.ksplit = pl.ksplit;
+    static const int wg_dbg = getenv("TMG_WG_DBG") ? atoi(getenv("TMG_WG_DBG")) : 0;
+    p.dbg = wg_dbg;
     int lrc = -7;
 #define TMG_WG_CASE(NP_, NCO_) \
     if (pl.NP == NP_ && pl.NCO == NCO_) lrc = launch_wgrad<NP_, NCO_>(p, grid, pl.lds_bytes, st);
     TMG_WG_CASE(3, 1) TMG_WG_CASE(3, 2) TMG_WG_CASE(3, 4)
     TMG_WG_CASE(5, 1) TMG_WG_CASE(5, 2) TMG_WG_CASE(5, 4)
-    TMG_WG_CASE(7, 1) TMG_WG_CASE(7, 2) TMG_WG_CASE(7, 4)
+    TMG_WG_CASE(7, 1) TMG_WG_CASE(7, 2)
     TMG_WG_CASE(9, 1) TMG_WG_CASE(9, 2)
 #undef TMG_WG_CASE
     if (lrc != 0) return lrc;
@@ -891,7 +1041,7 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
         const int xc = (pl.gx + xchunk - 1) / xchunk;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
                            p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.cin_dst, p.Cout, p.ksize * p.ksize, xchunk,
-                           p.cin_valid, p.ci_split, p.ci_off0, p.ci_off1);
+                           p.cin_valid, p.ci_split, p.ci_off0, p.ci_off1, pl.ksplit);
         TMG_CHECK_LAUNCH();
     }
     return 0;
