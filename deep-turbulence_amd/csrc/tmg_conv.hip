@@ -218,30 +218,35 @@ struct WgradP {
     int tiles_x, tiles_y, ntiles;
     int CITG;  // input-channel tiles (of 16) handled per block group (grid.z walks the groups)
     int dbg;     // timing experiments (TMG_WG_DBG): 1 = no MFMA loop, 2 = no staging
+    const float* zero_page;  // >= 16 bytes of zeros in global memory: out-of-image / padding-channel lanes load from it
+    int fstage;  // 1: every segment / dy is float4-addressable and offsets fit 24-bit multiplies -> lean staging path
     int ksplit;  // 1: waves split the pixels of a tile instead of the (tap, channel tile) pairs (see the kernel)
 };
 
-// A block owns (CITG input-channel tiles x all taps) x (NCO output-channel tiles) of dW and a strided share of the
-// pixel tiles.  Work split inside the block (p.ksplit, wave-uniform):
-//   0: the (tap, channel tile) pairs are dealt round-robin to the 4 waves, every wave walks all pixels of a tile;
-//   1: (<= 9 pairs) every wave owns ALL pairs and walks a quarter of the tile's pixels - keeps narrow layers at
-//      9*NCO MFMAs per k-step per wave instead of 2-3, perfectly balanced; partial sums meet in the reduce kernel.
+// A block (512 threads = 8 waves, two per SIMD) owns (CITG input-channel tiles x all taps) x (NCO output-channel
+// tiles) of dW and a strided share of the pixel tiles.  Work split inside the block (p.ksplit, wave-uniform):
+//   0: the (tap, channel tile) pairs are dealt round-robin to 4 waves, and the two wave quartets each walk one half of
+//      a tile's pixels;
+//   1: (<= 9 pairs) every wave owns ALL pairs and walks an eighth of the tile's pixels - keeps narrow layers at
+//      9*NCO MFMAs per k-step per wave instead of 2-3, perfectly balanced.
+// Partial sums of the waves meet in the reduce kernel (or in the atomics of the direct path).
 // LDS layout (channel-tile major): patch [citn][PH*PW][16], dy [NCO][MPIX][16].  A pixel is 16 words apart in every
 // configuration, so a fragment read (16 channels x 4 consecutive pixels) covers 64 consecutive words: conflict-free,
 // and the four k-steps of a 16-pixel unit are reached with immediates from one address register per pair.
-// Staging is software-pipelined through registers: the global loads of the next tile are in flight during the MFMA
-// loop of the current one and only the LDS stores sit between two barriers.
-template <int NP, int NCO>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
+// Pipeline: LDS is double-buffered and tiles are prefetched two rounds ahead - round k stores the registers holding
+// tile k+1 into the idle buffer, issues the global loads of tile k+2 into those registers, runs the MFMA loop of tile
+// k from the other buffer, and ends with the only barrier of the round.  No load latency is exposed.
+template <int NP, int NCO, bool LEAN>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef const __attribute__((address_space(3))) float* lds_cptr;
-    // patch float4 per thread prefetched in registers (the rest is staged at commit time); sized so that accumulators +
-    // fragments + prefetch stay within the 256 registers two waves per SIMD allow
-    constexpr int UP = (NP * NCO >= 28) ? 1 : (NP * NCO >= 20) ? 4 : (NP * NCO >= 12) ? 8 : 13;
-    constexpr int UD = 2 * NCO;              // dy float4 per thread (covers MPIX * NCO * 4 / 256 for MPIX <= 128)
+    constexpr int NT = 512;
+    constexpr int UP = 7;    // patch float4 per thread (plan_wgrad keeps PH*PW*k4p <= UP*NT; 3x3 on a 4x32 tile needs 6.4)
+    constexpr int UD = NCO;  // dy float4 per thread (MPIX * NCO * 4 / NT for MPIX = 128)
     const int MPIX = p.MPIX;  // pixels per staged tile (64 or 128)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar branches
+    const int w4 = wave & 3;
     const int li = lane & 15, q = lane >> 4;
     const int TWl = p.TW_log2, TW = 1 << TWl, TH = MPIX >> TWl;
     const int s = p.stride, halo = p.ksize >> 1, ntaps = p.ksize * p.ksize;
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     const int citn = min(p.CITG, (p.Cin_pad >> 4) - cit0);
     const int k4 = citn * 4;
     const int co0 = blockIdx.y * NCO * 16;
-    const int ldy_w = citn * plane;  // word offset of the dy tile
+    const int ldy_w = citn * plane;           // word offset of the dy tile inside a buffer
+    const int bufw = p.CITG * plane + MPIX * NCO * 16;  // words per buffer
     const int ksplit = p.ksplit;
 
     const int npairs = ntaps * citn;
@@ -260,11 +266,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int n = 0; n < NCO; ++n) acc[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // LDS word offset of each owned pair (+ this lane's channel), hoisted out of the pixel loop
+    // LDS word offset of each owned pair (+ this lane's channel), hoisted out of the pixel loop.  Slots past the last
+    // pair repeat it (their sums are dropped later): branch-free k-steps keep the read/MFMA schedule intact, and a
+    // block is as slow as its busiest wave anyway.
     int aoffw[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int pid = min(ksplit ? j : wave + 4 * j, npairs - 1);
+        const int pid = min(ksplit ? j : w4 + 4 * j, npairs - 1);
         const int tap = pid / citn, cit = pid - tap * citn;
         const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
         aoffw[j] = cit * plane + (tyy * PW + txx) * 16 + li;
@@ -290,22 +298,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     }
 #define TMG_WG_PATCH_ITEM(IT)                                                                 \
     const int pix_ = (int)__umulhi((unsigned)(IT), mk), c4_ = (IT) - pix_ * k4;               \
-    const int py_ = (int)__umulhi((unsigned)pix_, mp), px_ = pix_ - py_ * PW;                 \
-    float* dst_ = lds + ((c4_ >> 2) * PHPW + pix_) * 16 + (c4_ & 3) * 4;
+    const int py_ = (int)__umulhi((unsigned)pix_, mp), px_ = pix_ - py_ * PW;
     // global loads of one tile into registers (no LDS access)
-#define TMG_WG_ISSUE(TILE, TID)                                                                                        \
+#define TMG_WG_ISSUE(TILE, TID)                                                                                   \
     {                                                                                                             \
         TMG_WG_ORIGIN(TILE)                                                                                       \
         _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                          \
-            const int it = (TID) + u * 256;                                                                         \
+            const int it = (TID) + u * NT;                                                                        \
             if (it < pitems) {                                                                                    \
                 TMG_WG_PATCH_ITEM(it)                                                                             \
-                (void)dst_;                                                                                       \
                 pv[u] = load_in4(p, b_, s * oy0_ - halo + py_, s * ox0_ - halo + px_, cit0 * 16 + 4 * c4_);       \
             }                                                                                                     \
         }                                                                                                         \
         _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                          \
-            const int it = (TID) + u * 256;                                                                         \
+            const int it = (TID) + u * NT;                                                                        \
             if (it < ditems) {                                                                                    \
                 const int m = it / (NCO * 4), c4 = it - m * (NCO * 4);                                            \
                 const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));                                     \
@@ -326,39 +332,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
             }                                                                                                     \
         }                                                                                                         \
     }
-    // registers -> LDS (+ the part of a large patch that does not fit the register window, staged synchronously)
-#define TMG_WG_COMMIT(TILE, TID)                                                                                       \
+    // registers -> LDS buffer starting at word BW
+#define TMG_WG_COMMIT(BW, TID)                                                                                    \
     {                                                                                                             \
         _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                          \
-            const int it = (TID) + u * 256;                                                                         \
+            const int it = (TID) + u * NT;                                                                        \
             if (it < pitems) {                                                                                    \
                 TMG_WG_PATCH_ITEM(it)                                                                             \
                 (void)py_; (void)px_;                                                                             \
-                *reinterpret_cast<float4*>(dst_) = pv[u];                                                         \
-            }                                                                                                     \
-        }                                                                                                         \
-        if (pitems > UP * 256) {                                                                                  \
-            TMG_WG_ORIGIN(TILE)                                                                                   \
-            for (int it = (TID) + UP * 256; it < pitems; it += 256) {                                               \
-                TMG_WG_PATCH_ITEM(it)                                                                             \
-                *reinterpret_cast<float4*>(dst_) =                                                                \
-                    load_in4(p, b_, s * oy0_ - halo + py_, s * ox0_ - halo + px_, cit0 * 16 + 4 * c4_);           \
+                *reinterpret_cast<float4*>(lds + (BW) + ((c4_ >> 2) * PHPW + pix_) * 16 + (c4_ & 3) * 4) = pv[u]; \
             }                                                                                                     \
         }                                                                                                         \
         _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                          \
-            const int it = (TID) + u * 256;                                                                         \
+            const int it = (TID) + u * NT;                                                                        \
             if (it < ditems) {                                                                                    \
                 const int m = it / (NCO * 4), c4 = it - m * (NCO * 4);                                            \
-                *reinterpret_cast<float4*>(lds + ldy_w + ((c4 >> 2) * MPIX + m) * 16 + (c4 & 3) * 4) = dv[u];     \
-                /* 256 % (NCO*4) == 0: c4 is the same for all of a thread's items -> per-thread bias partial */   \
+                *reinterpret_cast<float4*>(lds + (BW) + ldy_w + ((c4 >> 2) * MPIX + m) * 16 + (c4 & 3) * 4) = dv[u]; \
+                /* NT % (NCO*4) == 0: c4 is the same for all of a thread's items -> per-thread bias partial */    \
                 bacc.x += dv[u].x; bacc.y += dv[u].y; bacc.z += dv[u].z; bacc.w += dv[u].w;                       \
             }                                                                                                     \
         }                                                                                                         \
     }
 
-    // Slots past a wave's last pair are not guarded: they redo the wave's last pair (aoffw is clamped) and their sums
-    // are dropped by the epilogue / reduce kernel.  A block is as slow as its busiest wave anyway, and branch-free
-    // k-steps keep the read/MFMA schedule intact.
 #define TMG_WG_MFMA(AV, BF)                                                                             \
     _Pragma("unroll") for (int j = 0; j < NP; ++j) {                                                    \
         _Pragma("unroll") for (int n = 0; n < NCO; ++n)                                                 \
@@ -366,88 +361,193 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     }
 #define TMG_SB __builtin_amdgcn_sched_barrier(0);
 
-    const bool fast = (s == 1) && (TWl >= 4);  // a 16-pixel unit lies inside one tile row
-    // Rotated tile loop: round r commits + computes tile r and, before the MFMAs, issues the loads of tile r+1 (one
-    // ISSUE site keeps the unrolled staging code from being emitted twice); the first round only issues.
-    for (int tile = (int)blockIdx.x - (int)gridDim.x; tile < p.ntiles; tile += gridDim.x) {
+    // ---- lean staging (p.fstage): VALU cycles add to MFMA cycles on a SIMD, so the per-item address math is kept to
+    // ~a dozen full-rate instructions.  A thread owns one channel quad (its segment is resolved once) and every
+    // (NT / k4p)-th patch pixel; the patch coordinates of its items are tile-invariant and live in registers.
+    const int k4l = citn <= 1 ? 2 : (citn <= 2 ? 3 : 4), k4p = 1 << k4l;  // float4 slots per pixel, padded to 2^n
+    const int pc4 = tid & (k4p - 1), ppix0 = tid >> k4l, pstep = NT >> k4l;
+    const float* tptr = p.zero_page;  // this thread's segment base (+ channel); padding channels read zeros
+    int tss = 0;
+    {
+        int cl = cit0 * 16 + 4 * pc4;
+        if (cl < p.Cin) {
+            const float* sp = p.in[0].p;
+            int ss = p.in[0].stride, so = p.in[0].off;
+            if (cl >= p.in[0].n) {
+                cl -= p.in[0].n;
+                sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+                if (cl >= p.in[1].n) {
+                    cl -= p.in[1].n;
+                    sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+                }
+            }
+            tptr = sp + so + cl;
+            tss = ss;
+        }
+    }
+    const bool pcv = pc4 < k4;  // slots past the group's channel tiles do not exist in LDS
+    unsigned pyx[UP];           // (py << 16) | px of item u
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+        const int pix = min(ppix0 + u * pstep, PHPW - 1);
+        const int py = (int)__umulhi((unsigned)pix, mp), px = pix - py * PW;
+        pyx[u] = ((unsigned)py << 16) | (unsigned)px;
+    }
+    const unsigned pdst0 = 4u * ((pc4 >> 2) * plane + ppix0 * 16 + (pc4 & 3) * 4);  // LDS byte offset of item 0
+    // dy: thread owns channel quad dc4 of every (NT / (NCO*4))-th pixel
+    constexpr int DL = (NCO == 1) ? 2 : (NCO == 2 ? 3 : 4);
+    const int dc4 = tid & (NCO * 4 - 1), dm0 = tid >> DL;
+    constexpr int dstep = NT >> DL;
+    const bool dcv = co0 + 4 * dc4 < p.Cout;
+    const float* dptr = dcv ? p.dy.p + p.dy.off + co0 + 4 * dc4 : p.zero_page;
+    const int dss = dcv ? p.dy.stride : 0;
+    const unsigned ddst0 = 4u * (ldy_w + ((dc4 >> 2) * MPIX + dm0) * 16 + (dc4 & 3) * 4);
+    unsigned oobm = 0;  // per-item out-of-image bits (only maintained when an input affine must not touch padding)
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LEAN && p.in_scale) {
+        const int c = cit0 * 16 + 4 * pc4;
+        float* fs = reinterpret_cast<float*>(&isc);
+        float* fh = reinterpret_cast<float*>(&ish);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < p.Cin) { fs[e] = p.in_scale[c + e]; fh[e] = p.in_shift[c + e]; }
+    }
+#define TMG_WG_ISSUE_F(TILE)                                                                                       \
+    {                                                                                                             \
+        TMG_WG_ORIGIN(TILE)                                                                                       \
+        const int iy0_ = s * oy0_ - halo, ix0_ = s * ox0_ - halo;                                                 \
+        const int tbv_ = b_ * p.Hin * p.Win * tss;          /* element offset of image b in this thread's segment */ \
+        if (p.in_scale) oobm = 0;                                                                                 \
+        /* branch-free: a load inside a divergent block makes the compiler drain vmcnt before the next one, which   \
+           serialises the whole batch; lanes without an item read the zero page instead */                         \
+        _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                          \
+            const int iy = iy0_ + (int)(pyx[u] >> 16), ix = ix0_ + (int)(pyx[u] & 0xffffu);                       \
+            const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);                         \
+            const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);                                              \
+            const int elem = (int)__umul24(__umul24(iyc, p.Win) + ixc, tss) + tbv_;                               \
+            const float* a_ = (oob || !pcv || ppix0 + u * pstep >= PHPW) ? p.zero_page : tptr + elem;             \
+            pv[u] = *reinterpret_cast<const float4*>(a_);                                                         \
+            if (p.in_scale) oobm |= (oob ? 1u : 0u) << u;                                                         \
+        }                                                                                                         \
+        const int tbd_ = b_ * p.Hout * p.Wout * dss;                                                              \
+        _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                          \
+            const int m = dm0 + u * dstep;                                                                        \
+            const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));                                         \
+            const bool inb = oy < p.Hout && ox < p.Wout && m < MPIX;                                              \
+            const int elem = (int)__umul24(__umul24(oy, p.Wout) + ox, dss) + tbd_;                                \
+            const float* a_ = inb ? dptr + elem : p.zero_page;                                                    \
+            dv[u] = *reinterpret_cast<const float4*>(a_);                                                         \
+        }                                                                                                         \
+    }
+#define TMG_WG_COMMIT_F(BW)                                                                                       \
+    {                                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < UP; ++u) {                                                          \
+            if (pcv && ppix0 + u * pstep < PHPW) {                                                                \
+                float4 v = pv[u];                                                                                 \
+                if (p.in_scale && !((oobm >> u) & 1u)) {                                                          \
+                    v.x = v.x * isc.x + ish.x; v.y = v.y * isc.y + ish.y;                                         \
+                    v.z = v.z * isc.z + ish.z; v.w = v.w * isc.w + ish.w;                                         \
+                }                                                                                                 \
+                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + 4u * (BW) + pdst0 + u * pstep * 64) = v; \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                          \
+            if (dm0 + u * dstep < MPIX) {                                                                         \
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + 4u * (BW) + ddst0 + u * dstep * 64) = dv[u]; \
+                bacc.x += dv[u].x; bacc.y += dv[u].y; bacc.z += dv[u].z; bacc.w += dv[u].w;                       \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+    // pixels of a tile walked by this wave: [px0, px0 + npx)
+    const int npx = ksplit ? MPIX >> 3 : MPIX >> 1;
+    const int px0 = (ksplit ? wave : (wave >> 2)) * npx;
+    const bool fast = (s == 1) && (TWl >= 4) && !(npx & 15);  // whole 16-pixel units, each inside one tile row
+    const int G = gridDim.x;
+    // Rotated tile loop (one ISSUE / COMMIT site): round k works on tile = blockIdx.x + k*G; rounds -2 and -1 only fill
+    // the pipeline.
+    int k = -2;
+    for (int tile = (int)blockIdx.x - 2 * G; tile < p.ntiles; tile += G, ++k) {
         // The item -> (pixel, channel) index math of the staging macros is tile-invariant; left alone the compiler hoists
         // all of it out of this loop and spills.  Laundering the thread id makes it recompute (~200 VALU per tile).
         int tid_c = tid, tid_i = tid;
         asm volatile("" : "+v"(tid_c));
         asm volatile("" : "+v"(tid_i));
-        if (tile >= 0 && p.dbg != 2) {
-            __syncthreads();  // every wave is done reading the previous tile
-            TMG_WG_COMMIT(tile, tid_c)
-            __syncthreads();
+        if constexpr (LEAN) {
+            if (k >= -1 && tile + G < p.ntiles && p.dbg != 2) TMG_WG_COMMIT_F(((k + 1) & 1) * bufw)  // tile k+1 (loaded a round ago)
+            if (tile + 2 * G < p.ntiles && p.dbg != 2) TMG_WG_ISSUE_F(p.dbg == 3 ? (int)blockIdx.x : tile + 2 * G)                   // tile k+2, in flight for a whole round
+        } else {
+            if (k >= -1 && tile + G < p.ntiles) TMG_WG_COMMIT(((k + 1) & 1) * bufw, tid_c)
+            if (tile + 2 * G < p.ntiles) TMG_WG_ISSUE(tile + 2 * G, tid_i)
         }
-        if (tile + (int)gridDim.x < p.ntiles && p.dbg != 2) TMG_WG_ISSUE(tile + (int)gridDim.x, tid_i)  // in flight during the MFMA loop below
-        if (tile < 0 || p.dbg == 1) continue;
-        float av[NP], bfr[NCO], avn[NP], bfn[NCO];
-        if (fast) {
-            // 16-pixel units; fragment registers ping-pong between k-steps, LDS byte addresses are bumped in place once
-            // per unit, and the scheduling barriers keep "issue the next k-step's reads, then this k-step's MFMAs"
-            const int nun = MPIX >> 4;
-            const int upw = ksplit ? nun >> 2 : nun;
-            const int u0 = ksplit ? wave * upw : 0;
-            const int p00 = u0 * 16;
-            unsigned aa[NP], ba[NCO];
+        if (k >= 0 && p.dbg != 1) {
+            const int cbw = (k & 1) * bufw;
+            float av[NP], bfr[NCO], avn[NP], bfn[NCO];
+            if (fast) {
+                // 16-pixel units; fragment registers ping-pong between k-steps, LDS byte addresses are bumped in place
+                // once per unit, and the scheduling barriers keep "issue the next k-step's reads, then this k-step's MFMAs"
+                const int u0 = px0 >> 4, u1 = (px0 + npx) >> 4;
+                unsigned aa[NP], ba[NCO];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) aa[j] = 4u * (aoffw[j] + q * 16 + ((p00 >> TWl) * PW + (p00 & (TW - 1))) * 16);
+                for (int j = 0; j < NP; ++j) aa[j] = 4u * (cbw + aoffw[j] + q * 16 + ((px0 >> TWl) * PW + (px0 & (TW - 1))) * 16);
 #pragma unroll
-            for (int n = 0; n < NCO; ++n) ba[n] = 4u * (ldy_w + (n * MPIX + p00 + q) * 16 + li);
+                for (int n = 0; n < NCO; ++n) ba[n] = 4u * (cbw + ldy_w + (n * MPIX + px0 + q) * 16 + li);
 #define TMG_WG_LD(AV, BF, K)                                                                                     \
-            {                                                                                                    \
-                _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = *(lds_cptr)(uintptr_t)(ba[n] + (K) * 256); \
-                _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = *(lds_cptr)(uintptr_t)(aa[j] + (K) * 256);  \
-            }
-            TMG_WG_LD(av, bfr, 0) TMG_SB
-            for (int u = u0; u < u0 + upw; ++u) {
-                TMG_WG_LD(avn, bfn, 1) TMG_SB
-                TMG_WG_MFMA(av, bfr) TMG_SB
-                TMG_WG_LD(av, bfr, 2) TMG_SB
-                TMG_WG_MFMA(avn, bfn) TMG_SB
-                TMG_WG_LD(avn, bfn, 3) TMG_SB
-                TMG_WG_MFMA(av, bfr) TMG_SB
-                {
-                    const int un = min(u + 1, u0 + upw - 1);  // the last unit re-reads its own first k-step (harmless)
-                    const int pa = u * 16, pb = un * 16;
-                    const int d = (((pb >> TWl) * PW + (pb & (TW - 1))) - ((pa >> TWl) * PW + (pa & (TW - 1)))) * 64;
-                    const int db = (pb - pa) * 64;
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) aa[j] += d;
-#pragma unroll
-                    for (int n = 0; n < NCO; ++n) ba[n] += db;
+                {                                                                                                \
+                    _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = *(lds_cptr)(uintptr_t)(ba[n] + (K) * 256); \
+                    _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = *(lds_cptr)(uintptr_t)(aa[j] + (K) * 256);  \
                 }
                 TMG_WG_LD(av, bfr, 0) TMG_SB
-                TMG_WG_MFMA(avn, bfn) TMG_SB
-            }
+                for (int u = u0; u < u1; ++u) {
+                    TMG_WG_LD(avn, bfn, 1) TMG_SB
+                    TMG_WG_MFMA(av, bfr) TMG_SB
+                    TMG_WG_LD(av, bfr, 2) TMG_SB
+                    TMG_WG_MFMA(avn, bfn) TMG_SB
+                    TMG_WG_LD(avn, bfn, 3) TMG_SB
+                    TMG_WG_MFMA(av, bfr) TMG_SB
+                    {
+                        const int un = min(u + 1, u1 - 1);  // the last unit re-reads its own first k-step (harmless)
+                        const int pa = u * 16, pb = un * 16;
+                        const int d = (((pb >> TWl) * PW + (pb & (TW - 1))) - ((pa >> TWl) * PW + (pa & (TW - 1)))) * 64;
+                        const int db = (pb - pa) * 64;
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) aa[j] += d;
+#pragma unroll
+                        for (int n = 0; n < NCO; ++n) ba[n] += db;
+                    }
+                    TMG_WG_LD(av, bfr, 0) TMG_SB
+                    TMG_WG_MFMA(avn, bfn) TMG_SB
+                }
 #undef TMG_WG_LD
-        } else {
-            // generic walk (narrow tiles, stride 2): per-k-step addresses, reads one k-step ahead
-            const int nks = MPIX >> 2;
-            const int kpw = ksplit ? nks >> 2 : nks;
-            const int k0 = ksplit ? wave * kpw : 0;
-#define TMG_WG_LD(AV, BF, KS)                                                                           \
-            {                                                                                           \
-                const int m_ = (KS) * 4 + q;                                                            \
-                const float* ab_ = lds + (((m_ >> TWl) * s) * PW + (m_ & (TW - 1)) * s) * 16;           \
-                _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = lds[ldy_w + (n * MPIX + m_) * 16 + li]; \
-                _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = ab_[aoffw[j]];                   \
-            }
-            TMG_WG_LD(av, bfr, k0)
-            for (int ks = k0; ks < k0 + kpw; ks += 2) {
-                TMG_WG_LD(avn, bfn, ks + 1)
-                TMG_WG_MFMA(av, bfr)
-                TMG_WG_LD(av, bfr, min(ks + 2, k0 + kpw - 1))
-                TMG_WG_MFMA(avn, bfn)
-            }
+            } else {
+                // generic walk (narrow tiles, stride 2): per-k-step addresses, reads one k-step ahead
+                const int k0 = px0 >> 2, k1 = (px0 + npx) >> 2;  // npx is a multiple of 8: an even number of k-steps
+#define TMG_WG_LD(AV, BF, KS)                                                                                  \
+                {                                                                                              \
+                    const int m_ = (KS) * 4 + q;                                                               \
+                    const float* ab_ = lds + cbw + (((m_ >> TWl) * s) * PW + (m_ & (TW - 1)) * s) * 16;        \
+                    _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = lds[cbw + ldy_w + (n * MPIX + m_) * 16 + li]; \
+                    _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = ab_[aoffw[j]];                      \
+                }
+                TMG_WG_LD(av, bfr, k0)
+                for (int ks = k0; ks < k1; ks += 2) {
+                    TMG_WG_LD(avn, bfn, ks + 1)
+                    TMG_WG_MFMA(av, bfr)
+                    TMG_WG_LD(av, bfr, min(ks + 2, k1 - 1))
+                    TMG_WG_MFMA(avn, bfn)
+                }
 #undef TMG_WG_LD
+            }
         }
+        __syncthreads();  // the buffer just read may be overwritten next round; the one just written is complete
     }
 #undef TMG_WG_MFMA
 #undef TMG_SB
 #undef TMG_WG_ISSUE
 #undef TMG_WG_COMMIT
+#undef TMG_WG_ISSUE_F
+#undef TMG_WG_COMMIT_F
 #undef TMG_WG_PATCH_ITEM
 #undef TMG_WG_ORIGIN
 
@@ -455,26 +555,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     float bsum = 0.f;
     const bool do_bias = p.dbias && blockIdx.z == 0;
     if (do_bias) {
-        __syncthreads();
         *reinterpret_cast<float4*>(lds + tid * 4) = bacc;
         __syncthreads();
         if (tid < NCO * 16) {
             const int c4 = tid >> 2, e = tid & 3;
-            for (int t = c4; t < 256; t += NCO * 4) bsum += lds[t * 4 + e];
+            for (int t = c4; t < NT; t += NCO * 4) bsum += lds[t * 4 + e];
         }
     }
     if (p.ws) {
         // partial sums go to this block's slab in accumulator order (coalesced 16-byte stores); the reduce kernel
         // folds the slabs into dW.  Avoids ~1e7 contended float atomics on a KB-sized dW.
         const size_t bl = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
-        float4* slab = reinterpret_cast<float4*>(p.ws) + ((bl * 4 + wave) * NP * NCO) * 64 + lane;
+        float4* slab = reinterpret_cast<float4*>(p.ws) + ((bl * 8 + wave) * NP * NCO) * 64 + lane;
 #pragma unroll
         for (int j = 0; j < NP; ++j)
 #pragma unroll
             for (int n = 0; n < NCO; ++n)
                 slab[(j * NCO + n) * 64] = make_float4(acc[j][n][0], acc[j][n][1], acc[j][n][2], acc[j][n][3]);
         if (do_bias && tid < NCO * 16) {
-            float* wsb = p.ws + (size_t)gridDim.x * gridDim.y * gridDim.z * 4 * NP * NCO * 256;
+            float* wsb = p.ws + (size_t)gridDim.x * gridDim.y * gridDim.z * 8 * NP * NCO * 256;
             wsb[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 + tid] = bsum;
         }
         return;
@@ -482,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     const float osc = out_scale_of(p.kappa);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int pid = ksplit ? j : wave + 4 * j;
+        const int pid = ksplit ? j : w4 + 4 * j;
         if (pid >= npairs) continue;
         const int tap = pid / citn, cit = pid - tap * citn;
 #pragma unroll
@@ -506,7 +605,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
                                          const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int CITG,
                                          int cit_total, int Cin, int Cout, int ntaps, int xchunk, int cin_valid, int ci_split,
                                          int ci_off0, int ci_off1, int ksplit) {
-    const int items = gy * gz * 4 * NP * NCO * 64;
+    const int items = gy * gz * 8 * NP * NCO * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int x0 = blockIdx.y * xchunk, x1 = min(gx, x0 + xchunk);
     const float osc = out_scale_of(kappa);
@@ -515,14 +614,14 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
         const int lane = r_ & 63; r_ >>= 6;
         const int n = r_ % NCO; r_ /= NCO;
         const int j = r_ % NP; r_ /= NP;
-        const int wave = r_ & 3; r_ >>= 2;
+        const int wave = r_ & 7; r_ >>= 3;
         const int z = r_ % gz;
         const int y = r_ / gz;
         const int citn = min(CITG, cit_total - z * CITG);
-        const int pid = ksplit ? j : wave + 4 * j;  // ksplit: the four waves hold partial sums of the same pair
+        const int pid = ksplit ? j : (wave & 3) + 4 * j;  // waves with the same pair hold partial sums over different pixels
         if (pid < ntaps * citn) {
-            const size_t per_x = (size_t)gy * gz * 4 * NP * NCO * 64;
-            const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * 4 + wave) * NP + j) * NCO + n) * 64 + lane;
+            const size_t per_x = (size_t)gy * gz * 8 * NP * NCO * 64;
+            const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * 8 + wave) * NP + j) * NCO + n) * 64 + lane;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int x = x0; x < x1; ++x) {
                 const float4 v = src[(size_t)x * per_x];
@@ -545,7 +644,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
         const int y = i >> 6, t = i & 63;
         const int co = y * NCO * 16 + t;
         if (t < NCO * 16 && co < Cout) {
-            const float* wsb = ws + (size_t)gx * gy * gz * 4 * NP * NCO * 256;
+            const float* wsb = ws + (size_t)gx * gy * gz * 8 * NP * NCO * 256;
             float a = 0.f;
             for (int x = x0; x < x1; ++x) a += wsb[((size_t)x * gy + y) * 64 + t];
             atomicAdd(dbias + co, a * osc);
@@ -912,17 +1011,19 @@ extern "C" int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_de
     return -7;
 }
 
-template <int NP, int NCO>
+__device__ float g_tmg_zero_page[64];  // zero-initialised module global
+
+template <int NP, int NCO, bool LEAN>
 static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NP, NCO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NP, NCO, LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_set = true;
     }
     const int kid = 8 + (NCO == 1 ? 0 : (NCO == 2 ? 1 : 2));
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
-    hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO>), grid, dim3(256), lds_bytes, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO, LEAN>), grid, dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
 }
@@ -949,39 +1050,46 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     // Decomposition: a block owns (CITG input-channel tiles x all taps) x (NCO output-channel tiles) of dW and a
     // strided share of the pixel tiles.  Prefer large register tiles (operand reuse); when the image is small,
     // fall back to smaller ones so that output groups x pixel shares still fill the chip with >= 4 tiles per block.
-    static const int pref[][2] = {{4, 2}, {2, 4}, {3, 2}, {2, 2}, {4, 1}, {3, 1}, {1, 4}, {1, 2}, {2, 1}, {1, 1}};
-    const int gmin = (2048 + pl->ntiles - 1) / pl->ntiles;
+    static const int pref[][2] = {{4, 2}, {3, 2}, {2, 2}, {4, 1}, {3, 1}, {1, 4}, {1, 2}, {2, 1}, {1, 1}};
+    const int gmin = (1024 + pl->ntiles - 1) / pl->ntiles;
+    const int halo = ksize >> 1;
+    const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
+    // kernel limits: the patch of one tile fits the register window (7 float4 x 512 threads) and two LDS buffers fit
+    auto fits = [&](int cg, int nc) {
+        const int k4p = cg <= 1 ? 4 : (cg <= 2 ? 8 : 16);  // float4 slots per pixel as the lean staging path pads them
+        return PH * PW * k4p <= 7 * 512 && 2 * ((size_t)PH * PW * cg * 16 + (size_t)pl->MPIX * nc * 16) * 4 <= 160 * 1024;
+    };
     int CITG = 1, NCO = 1, bestg = -1;
     for (auto& c : pref) {
         int cg = c[0], nc = c[1];
         if (ntaps == 1) cg *= 4;  // 1x1: one pair per channel tile
         if (cg > cit) cg = cit;
         if (nc > cot) continue;
+        while (cg > 1 && !fits(cg, nc)) --cg;
+        if (!fits(cg, nc)) continue;
         const int g = ((cit + cg - 1) / cg) * ((cot + nc - 1) / nc);
         if (g >= gmin) { CITG = cg; NCO = nc; bestg = g; break; }
         if (g > bestg) { CITG = cg; NCO = nc; bestg = g; }
     }
+    if (bestg < 0) return -6;
     const int ngroups = (cit + CITG - 1) / CITG;
     pl->CITG = (cit + ngroups - 1) / ngroups;
     pl->NCO = NCO;
-    // <= 9 pairs: every wave owns all of them and a quarter of each tile's pixels; otherwise pairs are dealt to the waves
+    // <= 9 pairs: every wave owns all of them and an eighth of each tile's pixels; otherwise the pairs are dealt to 4 waves
     pl->ksplit = ntaps * pl->CITG <= (NCO == 4 ? 5 : 9);  // (NP, NCO) = (7|9, 4) would not fit the register file
     const int np = pl->ksplit ? ntaps * pl->CITG : (ntaps * pl->CITG + 3) / 4;
     pl->NP = np <= 3 ? 3 : (np <= 5 ? 5 : (np <= 7 ? 7 : 9));
     if (np > 9) return -7;
     pl->gy = (cot + NCO - 1) / NCO;
     pl->gz = ngroups;
-    const int halo = ksize >> 1;
-    const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
-    pl->lds_bytes = ((size_t)PH * PW * pl->CITG * 16 + (size_t)pl->MPIX * NCO * 16) * 4;
-    if (pl->lds_bytes < 4096) pl->lds_bytes = 4096;  // the dbias fold reuses the first 4 KB
-    if (pl->lds_bytes > 160 * 1024) return -6;
-    // pixel shares: enough blocks to fill the chip (~512) but >= 4 tiles per block so slab traffic stays small
-    int gx = 512 / (pl->gy * ngroups);
+    pl->lds_bytes = 2 * ((size_t)PH * PW * pl->CITG * 16 + (size_t)pl->MPIX * NCO * 16) * 4;
+    if (pl->lds_bytes < 8192) pl->lds_bytes = 8192;  // the dbias fold reuses the first 8 KB
+    // pixel shares: one 512-thread block per CU, but >= 4 tiles per block (two rounds fill the pipeline)
+    int gx = 256 / (pl->gy * ngroups);
     if (gx > pl->ntiles / 4) gx = pl->ntiles / 4;
     if (gx < 1) gx = 1;
     pl->gx = gx;
-    pl->ws_floats = (size_t)gx * pl->gy * pl->gz * 4 * pl->NP * NCO * 256 + (size_t)gx * pl->gy * 64;
+    pl->ws_floats = (size_t)gx * pl->gy * pl->gz * 8 * pl->NP * NCO * 256 + (size_t)gx * pl->gy * 64;
     return 0;
 }
 
@@ -1024,11 +1132,26 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     p.ws = (ws && (size_t)ws_floats >= pl.ws_floats && (((uintptr_t)ws) & 15) == 0) ? (float*)ws : nullptr;
     dim3 grid(pl.gx, pl.gy, pl.gz);
     p.ksplit = pl.ksplit;
+    static const float* zero_page = nullptr;
+    if (!zero_page) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_tmg_zero_page)) != hipSuccess) return -8;
+        zero_page = (const float*)zp;
+    }
+    p.zero_page = zero_page;
+    // lean staging needs float4-addressable operands and element offsets that fit the 24-bit multiplies / 32-bit adds
+    p.fstage = p.vec4 && p.dy_vec4 && (p.Cout % 4 == 0) && (p.Cin % 4 == 0) && (long)p.Hin * p.Win < (1 << 24) && (long)p.Hout * p.Wout < (1 << 24);
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.in[i].stride >= (1 << 24) || (long)p.B * p.Hin * p.Win * p.in[i].stride >= (1L << 31)) p.fstage = 0;
+    if (p.dy.stride >= (1 << 24) || (long)p.B * p.Hout * p.Wout * p.dy.stride >= (1L << 31)) p.fstage = 0;
+    static const int no_fstage = getenv("TMG_WG_NOFSTAGE") ? 1 : 0;
+    if (no_fstage) p.fstage = 0;
     static const int wg_dbg = getenv("TMG_WG_DBG") ? atoi(getenv("TMG_WG_DBG")) : 0;
     p.dbg = wg_dbg;
     int lrc = -7;
-#define TMG_WG_CASE(NP_, NCO_) \
-    if (pl.NP == NP_ && pl.NCO == NCO_) lrc = launch_wgrad<NP_, NCO_>(p, grid, pl.lds_bytes, st);
+#define TMG_WG_CASE(NP_, NCO_)                                                                    \
+    if (pl.NP == NP_ && pl.NCO == NCO_)                                                           \
+        lrc = p.fstage ? launch_wgrad<NP_, NCO_, true>(p, grid, pl.lds_bytes, st) : launch_wgrad<NP_, NCO_, false>(p, grid, pl.lds_bytes, st);
     TMG_WG_CASE(3, 1) TMG_WG_CASE(3, 2) TMG_WG_CASE(3, 4)
     TMG_WG_CASE(5, 1) TMG_WG_CASE(5, 2) TMG_WG_CASE(5, 4)
     TMG_WG_CASE(7, 1) TMG_WG_CASE(7, 2)
@@ -1036,7 +1159,7 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
 #undef TMG_WG_CASE
     if (lrc != 0) return lrc;
     if (p.ws) {
-        const int items = pl.gy * pl.gz * 4 * pl.NP * pl.NCO * 64;
+        const int items = pl.gy * pl.gz * 8 * pl.NP * pl.NCO * 64;
         int xchunk = 32;
         const int xc = (pl.gx + xchunk - 1) / xchunk;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
