@@ -17,6 +17,11 @@
 #include "tmg_common.h"
 #include <stdlib.h>
 
+// Zero-filled global memory: lanes of a staging batch that have nothing to read (zero padding, channels past the end,
+// items past the end) load from here, so the batch needs no control flow.  A load inside a divergent block makes the
+// compiler drain vmcnt before the next load (the value meets a zero at the join), which serialises the whole batch.
+static __device__ float g_tmg_zero_page[64];
+
 struct ConvP {
     TmgSeg in[TMG_MAX_IN_SEG];
     int nseg;
@@ -36,6 +41,7 @@ struct ConvP {
     int TW_log2, TH;
     int KCH;  // channels staged per LDS chunk (multiple of 16)
     int tiles_x, tiles_y;
+    int ntiles, nchunks;  // conv_fwd_kernel only: tiles of the whole batch, channel chunks per tile
 };
 
 // MT m-tiles (16 px each) x NTW n-tiles (16 ch each) per wave; WM x WN waves per block (WM*WN == 4).
@@ -190,6 +196,247 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent, software-pipelined variant of the kernel above for stride-1 convolutions over float4-addressable
+// segment lists (every conv of the flow levels).  512 threads = WM x WN = 8 waves; a block walks a strided share of
+// the tiles and, per tile, the channel chunks; the unit of the pipeline is one (tile, chunk) stage:
+//   round k: registers holding stage k+1 -> idle LDS buffer; global loads of stage k+2 -> registers (in flight for a
+//   whole round); MFMA loop of stage k from the other buffer; one barrier.
+// Staging is the lean scheme of conv_wgrad_kernel: a thread owns one channel quad and every (512/k4p)-th patch pixel,
+// its patch coordinates are tile-invariant registers, a batch of loads has no control flow (lanes with nothing to read
+// use the zero page), so neither load latency nor per-item index math sits on the MFMA path (VALU cycles add to MFMA
+// cycles on a SIMD).  The first B fragments of the next stage are prefetched during the last iteration of this one.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NTW, int WM, int WN>
+__global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 512, UP = 7;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int li = lane & 15, q = lane >> 4;
+    constexpr int MBLK = 16 * MT * WM;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = MBLK >> TWl;
+    const int halo = p.ksize >> 1, ntaps = p.ksize * p.ksize;
+    const int PW = TW + 2 * halo, PH = TH + 2 * halo, PHPW = PH * PW;
+    const int KB = p.Cin_pad >> 4, KCH = p.KCH, CS = KCH + 8, CS4 = CS >> 2;
+    const int bufw = PHPW * CS;  // words per LDS buffer
+    const int nchunks = p.nchunks;
+    const int ntiles_total = p.Cout_pad >> 4;
+    const int ntile0 = (blockIdx.y * WN + wn) * NTW;  // first n-tile of this wave
+    const float* zero_page = g_tmg_zero_page;
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // per-lane operand bases: A as float4 index into a buffer, B as float offset into a (tap, kb) slice of wpk
+    int abase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wm * MT + i) * 16 + li;
+        abase[i] = ((m >> TWl) * PW + (m & (TW - 1))) * CS4 + q;
+    }
+    const int boff0 = li * 16 + 4 * q;  // + n-tile * 256 (scalar); tiles past the end repeat the last (dropped in the epilogue)
+#define TMG_FW_BOFF(J) (boff0 + min(ntile0 + (J), ntiles_total - 1) * 256)
+    const size_t tap_stride = (size_t)KB * p.Cout_pad * 16, kb_stride = (size_t)p.Cout_pad * 16;
+
+    // ---- lean staging state ---------------------------------------------------------------------------------------
+    const int k4l = KCH <= 16 ? 2 : (KCH <= 32 ? 3 : 4), k4p = 1 << k4l;  // float4 slots per pixel, padded to 2^n
+    const int pc4 = tid & (k4p - 1), ppix0 = tid >> k4l, pstep = NT >> k4l;
+    const unsigned mp = 0xFFFFFFFFu / (unsigned)PW + 1u;
+    unsigned pyx[UP];  // (py << 16) | px of item u
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+        const int pix = min(ppix0 + u * pstep, PHPW - 1);
+        const int py = (int)__umulhi((unsigned)pix, mp), px = pix - py * PW;
+        pyx[u] = ((unsigned)py << 16) | (unsigned)px;
+    }
+    const unsigned pdst0 = 4u * (ppix0 * CS + 4 * pc4);
+    float4 pv[UP];
+    unsigned oobm = 0;
+
+    const int G = gridDim.x;
+    const int nmine = (int)blockIdx.x < p.ntiles ? (p.ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int nst = nmine * nchunks;
+    // (tile, chunk) cursors of the stage being issued / committed / computed
+    int ti = blockIdx.x, ci = 0, tc = blockIdx.x, cc = 0, tm = blockIdx.x, cm = 0;
+
+#define TMG_FW_ORIGIN(TILE)                  \
+    int b_, oy0_, ox0_;                      \
+    {                                        \
+        int t_ = (TILE);                     \
+        const int tx_ = t_ % p.tiles_x;      \
+        t_ /= p.tiles_x;                     \
+        const int ty_ = t_ % p.tiles_y;      \
+        b_ = t_ / p.tiles_y;                 \
+        oy0_ = ty_ * TH;                     \
+        ox0_ = tx_ * TW;                     \
+    }
+    // first B fragments of stage 0 (every later stage gets them from the previous stage's last iteration)
+    float4 b0[NTW], b1[NTW];
+    if (nst > 0) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) b0[j] = *reinterpret_cast<const float4*>(p.wpk + TMG_FW_BOFF(j));
+    }
+
+    for (int k = -2; k < nst; ++k) {
+        // ---- commit stage k+1 (loaded during the previous round) into the idle buffer -------------------------------
+        if (k >= -1 && k + 1 < nst) {
+            const int c0 = cc * KCH, kch = min(KCH, p.Cin_pad - c0);
+            const bool pcv = 4 * pc4 < kch;
+            float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.in_scale) {
+                const int c = c0 + 4 * pc4;
+                float* fs = reinterpret_cast<float*>(&isc);
+                float* fh = reinterpret_cast<float*>(&ish);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < p.Cin) { fs[e] = p.in_scale[c + e]; fh[e] = p.in_shift[c + e]; }
+            }
+            char* bb = reinterpret_cast<char*>(lds) + 4u * (((k + 1) & 1) * bufw) + pdst0;
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                if (pcv && ppix0 + u * pstep < PHPW) {
+                    float4 v = pv[u];
+                    if (p.in_scale && !((oobm >> u) & 1u)) {
+                        v.x = v.x * isc.x + ish.x; v.y = v.y * isc.y + ish.y;
+                        v.z = v.z * isc.z + ish.z; v.w = v.w * isc.w + ish.w;
+                    }
+                    if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(bb + u * pstep * CS * 4) = v;
+                }
+            }
+            if (++cc == nchunks) { cc = 0; tc += G; }
+        }
+        // ---- issue the loads of stage k+2 ---------------------------------------------------------------------------
+        if (k + 2 < nst) {
+            TMG_FW_ORIGIN(ti)
+            const int c0 = ci * KCH, kch = min(KCH, p.Cin_pad - c0);
+            const float* tptr = zero_page;
+            int tss = 0;
+            {
+                int cl = c0 + 4 * pc4;
+                if (4 * pc4 < kch && cl < p.Cin) {
+                    const float* sp = p.in[0].p;
+                    int ss = p.in[0].stride, so = p.in[0].off;
+                    if (cl >= p.in[0].n) {
+                        cl -= p.in[0].n;
+                        sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+                        if (cl >= p.in[1].n) {
+                            cl -= p.in[1].n;
+                            sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+                        }
+                    }
+                    tptr = sp + so + cl;
+                    tss = ss;
+                }
+            }
+            const int iy0 = oy0_ - halo, ix0 = ox0_ - halo;
+            const int tbv = b_ * p.Hin * p.Win * tss;
+            oobm = 0;
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);
+                const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
+                const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);
+                const int elem = (int)__umul24(__umul24(iyc, p.Win) + ixc, tss) + tbv;
+                const float* a_ = (oob || ppix0 + u * pstep >= PHPW) ? zero_page : tptr + elem;
+                pv[u] = *reinterpret_cast<const float4*>(a_);
+                if (p.in_scale) oobm |= (oob ? 1u : 0u) << u;
+            }
+            if (++ci == nchunks) { ci = 0; ti += G; }
+        }
+        // ---- MFMA loop of stage k -----------------------------------------------------------------------------------
+        if (k >= 0) {
+            const int c0 = cm * KCH, kch = min(KCH, p.Cin_pad - c0);
+            const int kbn = kch >> 4, niter = ntaps * kbn;
+            const float4* lds4 = reinterpret_cast<const float4*>(lds + (k & 1) * bufw);
+            const float* wl = p.wpk + (size_t)(c0 >> 4) * kb_stride;
+            // where the B prefetch of the last iteration points: first fragments of the next stage (or anything valid)
+            const int c0n = (cm + 1 == nchunks) ? 0 : c0 + KCH;
+            const float* wl_next = p.wpk + (size_t)(c0n >> 4) * kb_stride;
+            int tap = 0, kb = 0, tyy = 0, txx = 0;
+#define TMG_FW_BODY(BC, BN)                                                                                          \
+            {                                                                                                        \
+                const int aoffs = (tyy * PW + txx) * CS4 + kb * 4;                                                   \
+                float4 af[MT];                                                                                       \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) af[i] = lds4[abase[i] + aoffs];                       \
+                ++kb;                                                                                                \
+                if (kb == kbn) {                                                                                     \
+                    kb = 0; ++tap; ++txx;                                                                            \
+                    if (txx == p.ksize) { txx = 0; ++tyy; }                                                          \
+                }                                                                                                    \
+                const float* wn_ = (tap == ntaps) ? wl_next : wl + tap * tap_stride + kb * kb_stride;                \
+                _Pragma("unroll") for (int j = 0; j < NTW; ++j) BN[j] = *reinterpret_cast<const float4*>(wn_ + TMG_FW_BOFF(j)); \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, BC[j].x, acc[i][j], 0, 0, 0);          \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, BC[j].y, acc[i][j], 0, 0, 0);          \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, BC[j].z, acc[i][j], 0, 0, 0);          \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, BC[j].w, acc[i][j], 0, 0, 0);          \
+            }
+            int it = 0;
+            for (; it + 1 < niter; it += 2) {
+                TMG_FW_BODY(b0, b1)
+                TMG_FW_BODY(b1, b0)
+            }
+            if (it < niter) {
+                TMG_FW_BODY(b0, b1)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) b0[j] = b1[j];
+            }
+#undef TMG_FW_BODY
+            if (cm + 1 == nchunks) {
+                // epilogue: C/D map of the 16x16 tile: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel)
+                TMG_FW_ORIGIN(tm)
+                const float osc = out_scale_of(p.kappa);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int n = (ntile0 + j) * 16 + li;
+                    if (n < p.Cout) {
+                        const float bv = p.bias ? p.bias[n] : 0.f;
+                        int nl = n;
+                        TMG_PICK_OSEG(p.out, nl, op_, ostride, ooff)
+                        float* obase = op_ + ooff + nl;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int m = (wm * MT + i) * 16 + q * 4 + r;
+                                const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));
+                                if (oy < p.Hout && ox < p.Wout) {
+                                    const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
+                                    float v = acc[i][j][r] + bv;
+                                    if (p.add.p) v += p.add.p[opx * p.add.stride + p.add.off + n];
+                                    v *= osc;
+                                    if (p.relu_out) v = fmaxf(v, 0.f);
+                                    float* dst = obase + opx * ostride;
+                                    if (p.accumulate) v += *dst;
+                                    *dst = v;
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cm = 0; tm += G;
+            } else {
+                ++cm;
+            }
+        }
+        __syncthreads();  // the buffer just read may be overwritten next round; the one just written is complete
+    }
+#undef TMG_FW_ORIGIN
+#undef TMG_FW_BOFF
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[co][ci][tap] (+)= scale * sum_p in(p*s + tap)[ci] * dy(p)[co]
 // GEMM view: M = input channels (per tap), N = output channels, K = pixels.
 // ---------------------------------------------------------------------------------------------
@@ -218,7 +465,6 @@ struct WgradP {
     int tiles_x, tiles_y, ntiles;
     int CITG;  // input-channel tiles (of 16) handled per block group (grid.z walks the groups)
     int dbg;     // timing experiments (TMG_WG_DBG): 1 = no MFMA loop, 2 = no staging
-    const float* zero_page;  // >= 16 bytes of zeros in global memory: out-of-image / padding-channel lanes load from it
     int fstage;  // 1: every segment / dy is float4-addressable and offsets fit 24-bit multiplies -> lean staging path
     int ksplit;  // 1: waves split the pixels of a tile instead of the (tap, channel tile) pairs (see the kernel)
 };
@@ -366,7 +612,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     // (NT / k4p)-th patch pixel; the patch coordinates of its items are tile-invariant and live in registers.
     const int k4l = citn <= 1 ? 2 : (citn <= 2 ? 3 : 4), k4p = 1 << k4l;  // float4 slots per pixel, padded to 2^n
     const int pc4 = tid & (k4p - 1), ppix0 = tid >> k4l, pstep = NT >> k4l;
-    const float* tptr = p.zero_page;  // this thread's segment base (+ channel); padding channels read zeros
+    const float* tptr = g_tmg_zero_page;  // this thread's segment base (+ channel); padding channels read zeros
     int tss = 0;
     {
         int cl = cit0 * 16 + 4 * pc4;
@@ -399,7 +645,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     const int dc4 = tid & (NCO * 4 - 1), dm0 = tid >> DL;
     constexpr int dstep = NT >> DL;
     const bool dcv = co0 + 4 * dc4 < p.Cout;
-    const float* dptr = dcv ? p.dy.p + p.dy.off + co0 + 4 * dc4 : p.zero_page;
+    const float* dptr = dcv ? p.dy.p + p.dy.off + co0 + 4 * dc4 : g_tmg_zero_page;
     const int dss = dcv ? p.dy.stride : 0;
     const unsigned ddst0 = 4u * (ldy_w + ((dc4 >> 2) * MPIX + dm0) * 16 + (dc4 & 3) * 4);
     unsigned oobm = 0;  // per-item out-of-image bits (only maintained when an input affine must not touch padding)
@@ -425,7 +671,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
             const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);                         \
             const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);                                              \
             const int elem = (int)__umul24(__umul24(iyc, p.Win) + ixc, tss) + tbv_;                               \
-            const float* a_ = (oob || !pcv || ppix0 + u * pstep >= PHPW) ? p.zero_page : tptr + elem;             \
+            const float* a_ = (oob || !pcv || ppix0 + u * pstep >= PHPW) ? g_tmg_zero_page : tptr + elem;             \
             pv[u] = *reinterpret_cast<const float4*>(a_);                                                         \
             if (p.in_scale) oobm |= (oob ? 1u : 0u) << u;                                                         \
         }                                                                                                         \
@@ -435,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
             const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));                                         \
             const bool inb = oy < p.Hout && ox < p.Wout && m < MPIX;                                              \
             const int elem = (int)__umul24(__umul24(oy, p.Wout) + ox, dss) + tbd_;                                \
-            const float* a_ = inb ? dptr + elem : p.zero_page;                                                    \
+            const float* a_ = inb ? dptr + elem : g_tmg_zero_page;                                                    \
             dv[u] = *reinterpret_cast<const float4*>(a_);                                                         \
         }                                                                                                         \
     }
@@ -815,8 +1061,10 @@ static int g_prof_on = 0;
 static const char* const g_prof_names[] = {
     "conv_mfma_kernel<4,1,4,1>", "conv_mfma_kernel<4,2,4,1>", "conv_mfma_kernel<4,3,4,1>", "conv_mfma_kernel<4,4,4,1>",
     "conv_mfma_kernel<4,3,2,2>", "conv_mfma_kernel<4,4,2,2>", "conv_mfma_kernel<4,3,1,4>", "conv_mfma_kernel<4,4,1,4>",
-    "conv_wgrad_kernel<*,1>", "conv_wgrad_kernel<*,2>", "conv_wgrad_kernel<*,4>"};
-#define TMG_NPROF 11
+    "conv_wgrad_kernel<*,1>", "conv_wgrad_kernel<*,2>", "conv_wgrad_kernel<*,4>",
+    "conv_fwd_kernel<*,1,8,1>", "conv_fwd_kernel<*,2,8,1>", "conv_fwd_kernel<*,3,8,1>", "conv_fwd_kernel<*,4,8,1>",
+    "conv_fwd_kernel<*,3,4,2>", "conv_fwd_kernel<*,4,4,2>", "conv_fwd_kernel<*,3,2,4>", "conv_fwd_kernel<*,4,2,4>"};
+#define TMG_NPROF 19
 
 struct ProfScope {
     ProfRec r; bool on; hipStream_t st;
@@ -867,6 +1115,80 @@ static int launch_conv(const ConvP& p, int gy, size_t lds_bytes, hipStream_t st)
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NTW, WM, WN>), grid, dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
+}
+
+template <int MT, int NTW, int WM, int WN>
+static int launch_fwd(const ConvP& p, int G, int gy, size_t lds_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<MT, NTW, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int kid = 11 + (WM == 8 ? NTW - 1 : (WM == 4 ? NTW + 1 : NTW + 3));
+    ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
+    hipLaunchKernelGGL((conv_fwd_kernel<MT, NTW, WM, WN>), dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// Tile / chunk plan and launch of conv_fwd_kernel; -100 when the shape is not eligible (caller falls back to conv_mfma_kernel).
+static int conv_fwd_lean(ConvP p, hipStream_t st) {
+    if (p.stride != 1 || !p.vec4 || (p.Cin & 3) || (long)p.Hin * p.Win >= (1 << 24)) return -100;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.in[i].stride >= (1 << 24) || (long)p.B * p.Hin * p.Win * p.in[i].stride >= (1L << 31)) return -100;
+    const int ntt = p.Cout_pad >> 4;
+    int WM, WN, NTW;
+    if (ntt <= 4) { WM = 8; WN = 1; NTW = ntt; }
+    else if (ntt <= 8) { WM = 4; WN = 2; NTW = ntt <= 6 ? 3 : 4; }
+    else { WM = 2; WN = 4; NTW = ntt <= 12 ? 3 : 4; }
+    const int gy = (ntt + WN * NTW - 1) / (WN * NTW);
+    const long npix = (long)p.B * p.Hout * p.Wout;
+    const int halo = p.ksize >> 1;
+    for (int MT = 4; MT >= 1; MT >>= 1) {
+        // m-tiles per wave: 4 when the image is large; fewer when that would leave CUs idle (small levels)
+        if (MT > 1 && (npix / (16 * MT * WM)) * gy < 256) continue;
+        const int MBLK = 16 * MT * WM;
+        int twl = ilog2_ceil(p.Wout);
+        if (twl > 5) twl = 5;
+        if (twl < 2) twl = 2;
+        while ((1 << twl) > MBLK) --twl;
+        while (twl < 5 && (MBLK >> twl) > p.Hout && (1 << twl) < p.Wout) ++twl;  // no taller than the image needs
+        const int TW = 1 << twl, TH = MBLK >> twl;
+        if (TH < 1) continue;
+        const int PHPW = (TW + 2 * halo) * (TH + 2 * halo);
+        // channel chunks: as few as possible, evenly sized, each fitting the register window (7 float4 x 512 threads,
+        // float4 slots per pixel padded to a power of two) and two LDS buffers
+        int nchunks = (p.Cin_pad + 63) / 64, kch = 0;
+        for (; nchunks <= p.Cin_pad / 16; ++nchunks) {
+            kch = (((p.Cin_pad / 16) + nchunks - 1) / nchunks) * 16;
+            const int k4p = kch <= 16 ? 4 : (kch <= 32 ? 8 : 16);
+            if (PHPW * k4p <= 7 * 512 && 2 * (size_t)PHPW * (kch + 8) * 4 <= 160 * 1024) break;
+            kch = 0;
+        }
+        if (!kch) continue;
+        p.TW_log2 = twl; p.TH = TH;
+        p.tiles_x = (p.Wout + TW - 1) / TW;
+        p.tiles_y = (p.Hout + TH - 1) / TH;
+        p.ntiles = p.B * p.tiles_x * p.tiles_y;
+        p.KCH = kch;
+        p.nchunks = (p.Cin_pad + kch - 1) / kch;
+        int G = 256 / gy;
+        if (G < 1) G = 1;
+        if (G > p.ntiles) G = p.ntiles;
+        const size_t lds_bytes = 2 * (size_t)PHPW * (kch + 8) * 4;
+#define TMG_FWD_CASE(NTW_, WM_, WN_)                                                                   \
+        if (NTW == NTW_ && WM == WM_ && WN == WN_) {                                                   \
+            if (MT == 4) return launch_fwd<4, NTW_, WM_, WN_>(p, G, gy, lds_bytes, st);                \
+            if (MT == 2) return launch_fwd<2, NTW_, WM_, WN_>(p, G, gy, lds_bytes, st);                \
+            return launch_fwd<1, NTW_, WM_, WN_>(p, G, gy, lds_bytes, st);                             \
+        }
+        TMG_FWD_CASE(1, 8, 1) TMG_FWD_CASE(2, 8, 1) TMG_FWD_CASE(3, 8, 1) TMG_FWD_CASE(4, 8, 1)
+        TMG_FWD_CASE(3, 4, 2) TMG_FWD_CASE(4, 4, 2) TMG_FWD_CASE(3, 2, 4) TMG_FWD_CASE(4, 2, 4)
+#undef TMG_FWD_CASE
+        return -100;
+    }
+    return -100;
 }
 
 static void fill_segs(TmgSeg* dst, const void* const* ptrs, const int64_t* desc, int n, int* vec4) {
@@ -951,6 +1273,12 @@ extern "C" int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_de
     }
     if (osum != p.Cout) return -4;
 
+    static const int fwd_old = getenv("TMG_FWD_OLD") ? 1 : 0;
+    if (!fwd_old) {
+        const int rc = conv_fwd_lean(p, st);
+        if (rc != -100) return rc;
+    }
+
     // tile configuration
     const int ntt = p.Cout_pad >> 4;
     int WM, WN, NTW;
@@ -1010,8 +1338,6 @@ extern "C" int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_de
 #undef TMG_CONV_CASE
     return -7;
 }
-
-__device__ float g_tmg_zero_page[64];  // zero-initialised module global
 
 template <int NP, int NCO, bool LEAN>
 static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
@@ -1132,13 +1458,6 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     p.ws = (ws && (size_t)ws_floats >= pl.ws_floats && (((uintptr_t)ws) & 15) == 0) ? (float*)ws : nullptr;
     dim3 grid(pl.gx, pl.gy, pl.gz);
     p.ksplit = pl.ksplit;
-    static const float* zero_page = nullptr;
-    if (!zero_page) {
-        void* zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_tmg_zero_page)) != hipSuccess) return -8;
-        zero_page = (const float*)zp;
-    }
-    p.zero_page = zero_page;
     // lean staging needs float4-addressable operands and element offsets that fit the 24-bit multiplies / 32-bit adds
     p.fstage = p.vec4 && p.dy_vec4 && (p.Cout % 4 == 0) && (p.Cin % 4 == 0) && (long)p.Hin * p.Win < (1 << 24) && (long)p.Hout * p.Wout < (1 << 24);
     for (int i = 0; i < p.nseg; ++i)
