@@ -357,6 +357,26 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
             const int c0n = (cm + 1 == nchunks) ? 0 : c0 + KCH;
             const float* wl_next = p.wpk + (size_t)(c0n >> 4) * kb_stride;
             int tap = 0, kb = 0, tyy = 0, txx = 0;
+            // Narrow register tiles: fetch the epilogue's `add` operand now, so that its latency hides under the MFMA loop
+            // instead of stalling every tile's epilogue (the per-layer coupling convs are only a few microseconds per tile)
+            constexpr bool PREADD = MT * NTW <= 8;
+            float addv[PREADD ? MT : 1][PREADD ? NTW : 1][4];
+            if (PREADD && p.add.p && cm + 1 == nchunks) {
+                TMG_FW_ORIGIN(tm)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int n = min((ntile0 + j) * 16 + li, p.Cout - 1);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = (wm * MT + i) * 16 + q * 4 + r;
+                            const int oy = min(oy0_ + (m >> TWl), p.Hout - 1), ox = min(ox0_ + (m & (TW - 1)), p.Wout - 1);
+                            const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
+                            addv[PREADD ? i : 0][PREADD ? j : 0][r] = p.add.p[opx * p.add.stride + p.add.off + n];
+                        }
+                }
+            }
 #define TMG_FW_BODY(BC, BN)                                                                                          \
             {                                                                                                        \
                 const int aoffs = (tyy * PW + txx) * CS4 + kb * 4;                                                   \
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                                 if (oy < p.Hout && ox < p.Wout) {
                                     const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
                                     float v = acc[i][j][r] + bv;
-                                    if (p.add.p) v += p.add.p[opx * p.add.stride + p.add.off + n];
+                                    if (p.add.p) v += PREADD ? addv[PREADD ? i : 0][PREADD ? j : 0][r] : p.add.p[opx * p.add.stride + p.add.off + n];
                                     v *= osc;
                                     if (p.relu_out) v = fmaxf(v, 0.f);
                                     float* dst = obase + opx * ostride;
