@@ -148,6 +148,86 @@ __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int i
     }
 }
 
+// Zero-filled global memory: lanes of a load batch that have nothing to read point here, so the batch has no control flow.
+static __device__ float tmg_zero_page[64];
+
+// Address of 4 consecutive (concatenated) input channels c..c+3 of pixel (b,iy,ix) under the padding rule, for
+// float4-addressable segment lists (p.vec4); the zero page when there is nothing to read.
+template <typename P>
+__device__ __forceinline__ const float* in4_addr(const P& p, int b, int iy, int ix, int c, bool& oob) {
+    const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
+    oob = !p.pad_rep && (iy != iyc || ix != ixc);
+    const size_t pix = ((size_t)b * p.Hin + iyc) * p.Win + ixc;
+    int cl = c;
+    const float* sp = p.in[0].p;
+    int ss = p.in[0].stride, so = p.in[0].off;
+    if (cl >= p.in[0].n) {
+        cl -= p.in[0].n;
+        sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+        if (cl >= p.in[1].n) {
+            cl -= p.in[1].n;
+            sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+        }
+    }
+    const float* a = sp + pix * ss + so + cl;
+    return (oob || c >= p.Cin) ? tmg_zero_page : a;
+}
+
+// stage_patch with the U loads of a batch issued back to back WITHOUT control flow between them (a load inside a
+// divergent block makes the compiler drain vmcnt before the next load, serialising the batch); the optional affine /
+// ReLU run after the whole batch has been issued.  Falls back to stage_patch for segment lists that are not
+// float4-addressable.
+template <int U = 4, typename P>
+__device__ __forceinline__ void stage_patch_bf(const P& p, float* lds, int b, int iy0, int ix0, int PH, int PW, int c0,
+                                               int kch, int CS) {
+    if (!p.vec4) {
+        stage_patch<U>(p, lds, b, iy0, ix0, PH, PW, c0, kch, CS);
+        return;
+    }
+    const int k4 = kch >> 2;
+    const int items = PH * PW * k4;
+    const int nt = blockDim.x;
+    const unsigned mk = k4 > 1 ? 0xFFFFFFFFu / (unsigned)k4 + 1u : 0u;
+    const unsigned mp = 0xFFFFFFFFu / (unsigned)PW + 1u;
+    for (int base = threadIdx.x; base < items; base += nt * U) {
+        float4 v[U];
+        const float* a[U];
+        int dst[U];
+        unsigned oobm = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = min(base + u * nt, items - 1);
+            const int pix = k4 > 1 ? (int)__umulhi((unsigned)it, mk) : it;
+            const int c4 = it - pix * k4;
+            const int py = (int)__umulhi((unsigned)pix, mp);
+            const int px = pix - py * PW;
+            bool oob;
+            a[u] = in4_addr(p, b, iy0 + py, ix0 + px, c0 + 4 * c4, oob);
+            oobm |= (oob ? 1u : 0u) << u;
+            dst[u] = (base + u * nt < items) ? pix * CS + 4 * c4 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(a[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p.in_scale && !((oobm >> u) & 1u)) {
+                const int it = min(base + u * nt, items - 1);
+                const int pix = k4 > 1 ? (int)__umulhi((unsigned)it, mk) : it;
+                const int c = c0 + 4 * (it - pix * k4);
+                float* f = reinterpret_cast<float*>(&v[u]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < p.Cin) f[e] = f[e] * p.in_scale[c + e] + p.in_shift[c + e];
+            }
+            if (p.relu_in) {
+                v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+                v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+            }
+            if (dst[u] >= 0) *reinterpret_cast<float4*>(lds + dst[u]) = v[u];
+        }
+    }
+}
+
 // Split staging for software pipelining (async-STAGE split): stage_issue() puts up to U loads per thread in flight into
 // registers, stage_commit() writes them to LDS after the compute they overlap; items beyond U per thread are staged
 // directly at commit time.

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1P p) {
         const int CS = kch + 4;
         float* lw = lds + PH * PW * CS;  // [9][kch]
         __syncthreads();
-        stage_patch(p, lds, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
+        stage_patch_bf(p, lds, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
         for (int i = tid; i < 9 * kch; i += 256) {
             const int tap = i / kch, c = i - tap * kch;
             const int cs = c0 + c;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void c1_bwd_kernel(C1BP p) {
             const int kch = min(p.KCH, Cpad - c0);
             const int CS = kch + 4;
             __syncthreads();
-            stage_patch(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
+            stage_patch_bf(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
             for (int i = tid; i < 9 * kch; i += 256) {
                 const int tap = i / kch, c = i - tap * kch;
                 lw[i] = (c0 + c < p.Cin) ? p.w[(size_t)(c0 + c) * 9 + tap] : 0.f;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
         const int b = t / p.tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
         __syncthreads();
-        stage_patch(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
+        stage_patch_bf(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
         for (int i = tid; i < QH * QW; i += 256) {
             const int py = i / QW, px = i - py * QW;
             const int y = oy0 - 2 + py, x = ox0 - 2 + px;
