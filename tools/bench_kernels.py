@@ -20,6 +20,11 @@ SHAPES = {
     "zero_L2": (64, 64, 64, [16, 32, 4], 32, 3, True, True),
     "zero_L3": (64, 32, 32, [32, 32, 4], 64, 3, True, True),
     "zero_L4": (64, 16, 16, [64, 32, 4], 128, 3, True, True),
+    # per-layer coupling zero-conv of the level-fused path: x1 half + the 4-channel growth buffer (cond enters as `add`)
+    "zl_L1": (64, 128, 128, [8, 4], 16, 3, True, True),
+    "zl_L2": (64, 64, 64, [16, 4], 32, 3, True, True),
+    "zl_L3": (64, 32, 32, [32, 4], 64, 3, True, True),
+    "zl_L4": (64, 16, 16, [64, 4], 128, 3, True, True),
     "mix_L1": (64, 128, 128, [16], 16, 1, False, False),
     "mix_L4": (64, 16, 16, [128], 128, 1, False, False),
 }
