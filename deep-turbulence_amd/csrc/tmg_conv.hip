@@ -817,10 +817,36 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
 #undef TMG_WG_PATCH_ITEM
 #undef TMG_WG_ORIGIN
 
+    // Waves holding the same pairs (all 8 with ksplit, the two quartets otherwise) fold their partial sums through LDS,
+    // upper half into lower half, until one copy per pair is left: 8x / 2x less slab traffic for the reduce kernel.
+    const int nws = ksplit ? 1 : 4;  // waves that still hold sums afterwards
+    for (int half = 4; half >= nws; half >>= 1) {
+        __syncthreads();
+        if (wave >= half && wave < 2 * half) {
+            float4* dst = reinterpret_cast<float4*>(lds) + ((wave - half) * NP * NCO) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int n = 0; n < NCO; ++n)
+                    dst[(j * NCO + n) * 64] = make_float4(acc[j][n][0], acc[j][n][1], acc[j][n][2], acc[j][n][3]);
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float4* src = reinterpret_cast<const float4*>(lds) + (wave * NP * NCO) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int n = 0; n < NCO; ++n) {
+                    const float4 v = src[(j * NCO + n) * 64];
+                    acc[j][n][0] += v.x; acc[j][n][1] += v.y; acc[j][n][2] += v.z; acc[j][n][3] += v.w;
+                }
+        }
+    }
     // dbias: fold the per-thread partials (thread t owns channels 4*(t % (NCO*4)) ..+3) through LDS
     float bsum = 0.f;
     const bool do_bias = p.dbias && blockIdx.z == 0;
     if (do_bias) {
+        __syncthreads();
         *reinterpret_cast<float4*>(lds + tid * 4) = bacc;
         __syncthreads();
         if (tid < NCO * 16) {
@@ -832,18 +858,21 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
         // partial sums go to this block's slab in accumulator order (coalesced 16-byte stores); the reduce kernel
         // folds the slabs into dW.  Avoids ~1e7 contended float atomics on a KB-sized dW.
         const size_t bl = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
-        float4* slab = reinterpret_cast<float4*>(p.ws) + ((bl * 8 + wave) * NP * NCO) * 64 + lane;
+        if (wave < nws) {
+            float4* slab = reinterpret_cast<float4*>(p.ws) + ((bl * nws + wave) * NP * NCO) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < NP; ++j)
+            for (int j = 0; j < NP; ++j)
 #pragma unroll
-            for (int n = 0; n < NCO; ++n)
-                slab[(j * NCO + n) * 64] = make_float4(acc[j][n][0], acc[j][n][1], acc[j][n][2], acc[j][n][3]);
+                for (int n = 0; n < NCO; ++n)
+                    slab[(j * NCO + n) * 64] = make_float4(acc[j][n][0], acc[j][n][1], acc[j][n][2], acc[j][n][3]);
+        }
         if (do_bias && tid < NCO * 16) {
-            float* wsb = p.ws + (size_t)gridDim.x * gridDim.y * gridDim.z * 8 * NP * NCO * 256;
+            float* wsb = p.ws + (size_t)gridDim.x * gridDim.y * gridDim.z * nws * NP * NCO * 256;
             wsb[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 + tid] = bsum;
         }
         return;
     }
+    if (wave >= nws) return;
     const float osc = out_scale_of(p.kappa);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -871,7 +900,8 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
                                          const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int CITG,
                                          int cit_total, int Cin, int Cout, int ntaps, int xchunk, int cin_valid, int ci_split,
                                          int ci_off0, int ci_off1, int ksplit) {
-    const int items = gy * gz * 8 * NP * NCO * 64;
+    const int nws = ksplit ? 1 : 4;  // wave copies per block that survive the in-block fold
+    const int items = gy * gz * nws * NP * NCO * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int x0 = blockIdx.y * xchunk, x1 = min(gx, x0 + xchunk);
     const float osc = out_scale_of(kappa);
@@ -880,14 +910,14 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
         const int lane = r_ & 63; r_ >>= 6;
         const int n = r_ % NCO; r_ /= NCO;
         const int j = r_ % NP; r_ /= NP;
-        const int wave = r_ & 7; r_ >>= 3;
+        const int wave = r_ % nws; r_ /= nws;
         const int z = r_ % gz;
         const int y = r_ / gz;
         const int citn = min(CITG, cit_total - z * CITG);
-        const int pid = ksplit ? j : (wave & 3) + 4 * j;  // waves with the same pair hold partial sums over different pixels
+        const int pid = ksplit ? j : wave + 4 * j;
         if (pid < ntaps * citn) {
-            const size_t per_x = (size_t)gy * gz * 8 * NP * NCO * 64;
-            const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * 8 + wave) * NP + j) * NCO + n) * 64 + lane;
+            const size_t per_x = (size_t)gy * gz * nws * NP * NCO * 64;
+            const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * nws + wave) * NP + j) * NCO + n) * 64 + lane;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int x = x0; x < x1; ++x) {
                 const float4 v = src[(size_t)x * per_x];
@@ -910,7 +940,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
         const int y = i >> 6, t = i & 63;
         const int co = y * NCO * 16 + t;
         if (t < NCO * 16 && co < Cout) {
-            const float* wsb = ws + (size_t)gx * gy * gz * 8 * NP * NCO * 256;
+            const float* wsb = ws + (size_t)gx * gy * gz * nws * NP * NCO * 256;
             float a = 0.f;
             for (int x = x0; x < x1; ++x) a += wsb[((size_t)x * gy + y) * 64 + t];
             atomicAdd(dbias + co, a * osc);
@@ -1430,12 +1460,13 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     pl->gz = ngroups;
     pl->lds_bytes = 2 * ((size_t)PH * PW * pl->CITG * 16 + (size_t)pl->MPIX * NCO * 16) * 4;
     if (pl->lds_bytes < 8192) pl->lds_bytes = 8192;  // the dbias fold reuses the first 8 KB
+    if (pl->lds_bytes < (size_t)4 * pl->NP * NCO * 1024) pl->lds_bytes = (size_t)4 * pl->NP * NCO * 1024;  // cross-wave fold of the partial sums
     // pixel shares: one 512-thread block per CU, but >= 4 tiles per block (two rounds fill the pipeline)
     int gx = 256 / (pl->gy * ngroups);
     if (gx > pl->ntiles / 4) gx = pl->ntiles / 4;
     if (gx < 1) gx = 1;
     pl->gx = gx;
-    pl->ws_floats = (size_t)gx * pl->gy * pl->gz * 8 * pl->NP * NCO * 256 + (size_t)gx * pl->gy * 64;
+    pl->ws_floats = (size_t)gx * pl->gy * pl->gz * (pl->ksplit ? 1 : 4) * pl->NP * NCO * 256 + (size_t)gx * pl->gy * 64;
     return 0;
 }
 
@@ -1498,7 +1529,7 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
 #undef TMG_WG_CASE
     if (lrc != 0) return lrc;
     if (p.ws) {
-        const int items = pl.gy * pl.gz * 8 * pl.NP * pl.NCO * 64;
+        const int items = pl.gy * pl.gz * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 64;
         int xchunk = 32;
         const int xc = (pl.gx + xchunk - 1) / xchunk;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
