@@ -149,3 +149,18 @@ def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_t
     assert glob <= global_tol, "%s: global rel-L2 %.3e > %.1e (worst tensor %s %.3e)" % (what, glob, global_tol, worst_k, worst)
     assert worst <= tensor_tol, "%s: tensor %s rel-max %.3e > %.1e" % (what, worst_k, worst, tensor_tol)
     return glob, worst
+
+
+# ---- synthetic simulation files for the data-loader tests (row F4) -------------------------------------------------
+LOADER_U0 = {0: 1.3, 1: 0.8}
+
+
+def write_synthetic_step_data(directory, seed=4321, T=6, hw=(6, 8), up=2):
+    """Two backward-step cases in the reference's on-disk format: `data` = [T, 4 (u_x,u_y,u_z,p), H, W] per file."""
+    import os
+    rs = np.random.RandomState(seed)
+    for case in LOADER_U0:
+        lo = rs.standard_normal((T, 4, hw[0], hw[1])).astype(np.float32) + 0.5 * case
+        hi = rs.standard_normal((T, 4, hw[0] * up, hw[1] * up)).astype(np.float32) * 1.5 - 0.25
+        np.savez(os.path.join(directory, "backwardStepCoarse%d-[U,p].npz" % case), data=lo)
+        np.savez(os.path.join(directory, "backwardStepFine%d-[U,p].npz" % case), data=hi)

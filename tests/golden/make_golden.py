@@ -316,8 +316,76 @@ def loss_case(fname):
     np.savez_compressed(os.path.join(HERE, fname), **out)
 
 
+def loader_case(fname):
+    """Row F4: the reference's BackwardStepLoader on synthetic files (tests/common.py writes them again at test time)."""
+    import tempfile
+    from common import write_synthetic_step_data, LOADER_U0
+    sys.path.insert(0, REF)
+    from utils.dataLoader import BackwardStepLoader
+
+    class _Quiet(object):
+        def log(self, *a, **k): pass
+        warning = error = info = log
+
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        write_synthetic_step_data(d)
+        seed_all(777)
+        ld = BackwardStepLoader(d, d, shuffle=False, log=_Quiet())
+        tr = ld.createTrainingLoader([0, 1], LOADER_U0, tSplit=2, inUpscale=2, batch_size=3, tar_noise_std=0)
+        xs, ys, ss = zip(*[b for b in tr])
+        out["train.x"], out["train.y"], out["train.seed"] = torch.cat(xs).numpy(), torch.cat(ys).numpy(), torch.cat(ss).numpy()
+        out["train.nbatch"] = np.array([len(tr)])
+        for k in ("input_mean", "input_std", "output_mean", "output_std"):
+            out["norm." + k] = getattr(ld, k).numpy().copy()
+        te = ld.createTestingLoader([1], LOADER_U0, inUpscale=2, batch_size=8)
+        xs, ys, us = zip(*[b for b in te])
+        out["test.x"], out["test.y"], out["test.u0"] = torch.cat(xs).numpy(), torch.cat(ys).numpy(), torch.cat(us).numpy()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print("wrote", fname, {k: v.shape for k, v in out.items()})
+
+
+def workspace_case(fname_zip):
+    """Row F3: a workspace written by the reference's saveWorkspace for the tiny model + Adam (one step taken)."""
+    import shutil
+    import tempfile
+    from types import SimpleNamespace
+    ref = import_reference()
+    from utils.utils import saveWorkspace, loadWorkspace
+    seed_all(12345)
+    model = ref.TMGlow(**build_kwargs(CFG_TINY))
+    perturb_(model, 7, 0.05, 0.1, 0.05)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    for p in model.parameters():
+        p.grad = 0.01 * torch.ones_like(p)
+    opt.step()
+    with tempfile.TemporaryDirectory() as d:
+        args = SimpleNamespace(ckpt_dir=d, device="cpu", beta=200.0, lr=1e-3, epochs=3, epoch_start=0, note="golden")
+        saveWorkspace(args, model, opt, file_id=7)
+        shutil.copy(os.path.join(d, "nsWorkspace7.zip"), os.path.join(HERE, fname_zip))
+        # the other direction: a workspace written by the new code loads with the reference's loader
+        sys.path.insert(0, os.path.join(HERE, "..", "..", "deep-turbulence_amd"))
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("amd_utils", os.path.join(HERE, "..", "..", "deep-turbulence_amd", "utils", "utils.py"))
+        mine = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mine)
+        args2 = SimpleNamespace(ckpt_dir=d, device="cpu", beta=1.0, lr=5e-4, epochs=9, epoch_start=2, note="mine")
+        mine.saveWorkspace(args2, model, opt, file_id=8)
+        a3, sd, osd = loadWorkspace(SimpleNamespace(epochs=1, epoch_start=0), d, file_id=8)
+        assert a3.note == "mine" and a3.epochs == 1 and all(torch.equal(sd[k], v) for k, v in model.state_dict().items())
+        assert len(osd["state"]) == len(opt.state_dict()["state"])
+    np.savez_compressed(os.path.join(HERE, fname_zip.replace(".zip", "_check.npz")), **{"sd." + k: np.array(v) for k, v in tensor_checksums(model.state_dict()).items()})
+    print("wrote", fname_zip)
+
+
 if __name__ == "__main__":
     ref = import_reference()
+    if "loader" in sys.argv:
+        loader_case("loader_case.npz")
+        sys.exit(0)
+    if "workspace" in sys.argv:
+        workspace_case("ref_workspace7.zip")
+        sys.exit(0)
     if "loss" in sys.argv:
         loss_case("phys_loss.npz")
         sys.exit(0)
