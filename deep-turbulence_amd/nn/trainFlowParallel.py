@@ -63,3 +63,67 @@ class TMGLowLoss(nn.Module):
         data = _PhysLossFn.apply(yPred, target, target_rms, sd, mu, float(self.beta), float(self.dx), float(self.dy))
         n_out_pixels = yPred.size(-3) * yPred.size(-2) * yPred.size(-1)
         return data + logp.mean() / math.log(2.) / n_out_pixels
+
+
+class TrainFlow(object):
+    """Epoch driver with the reference's interface (trainFlowParallel.py:178-311): `TrainFlow(args, model, train_loader,
+    test_loader, log)`, `trainParallel(model, optimizer, tback, epoch)` -> summed loss of the epoch.
+
+    What is different by design: one process per GPU instead of DataParallel threads - every
+    rank runs this loop on its shard of the batch, replicas are persistent (no per-window `replicate`), LSTM states stay
+    rank-local (no per-step gather) and the only exchange is one bucketed gradient all-reduce (RCCL, mean) per BPTT
+    window, which equals the reference's mean over per-GPU losses.  No `synchronize()` / `empty_cache()` per window."""
+
+    def __init__(self, args, model, train_loader, test_loader, log=None):
+        self.args = args
+        self.trainingLoader, self.testingLoader, self.log = train_loader, test_loader, log
+        core = getattr(model, "module", model)
+        self.loss = TMGLowLoss(args, model).to(next(core.parameters()).device)
+        self._bucket = None
+
+    def _grad_bucket(self, core):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        if self._bucket is None:
+            import tmg_dist
+            self._bucket = tmg_dist.GradBucket([p for p in core.parameters() if p.requires_grad])
+        return self._bucket
+
+    def trainParallel(self, model, optimizer, tback=1, epoch=0, **kwargs):
+        core = getattr(model, "module", model)
+        dev = next(core.parameters()).device
+        core.train()
+        total_loss = 0
+        optimizer.zero_grad()
+        for mbIdx, (input0, target0, lstm_seeds) in enumerate(self.trainingLoader):
+            input0, target0 = input0.to(dev), target0.to(dev)
+            aKey = core.initLSTMStates(lstm_seeds.cpu(), [target0.size(-2), target0.size(-1)])
+            a0 = [(h.clone(), c.clone()) for h, c in aKey]
+            tmax = target0.size(1)
+            tback = 10  # the reference overrides its own argument with this constant (trainFlowParallel.py:229)
+            tback = min(tback, tmax)
+            target0_mean = target0.mean(dim=1)
+            target0_rms = torch.sqrt(((target0 - target0_mean.unsqueeze(1)) ** 2).mean(dim=1))
+            for i in range(tmax // tback):
+                xin, ytarget = input0[:, i * tback:(i + 1) * tback], target0[:, i * tback:(i + 1) * tback]
+                ys, lps = [], []
+                for tstep in range(tback):
+                    y, logp, a0 = core.sample(xin[:, tstep], a0)
+                    ys.append(y)
+                    lps.append(logp)
+                loss = self.loss(torch.stack(ys, dim=1), torch.stack(lps, dim=1), ytarget, target0_mean, target0_rms)
+                loss.backward()
+                bucket = self._grad_bucket(core)
+                if bucket is not None:
+                    bucket.allreduce_mean()
+                torch.nn.utils.clip_grad_norm_([p for p in core.parameters() if p.grad is not None], self.args.max_grad_norm)
+                optimizer.step()
+                optimizer.zero_grad()
+                # pull the LSTM states half-way back to their seed states (reference :283-287)
+                a0 = [(0.5 * h.detach() + 0.5 * hk, 0.5 * c.detach() + 0.5 * ck) for (h, c), (hk, ck) in zip(a0, aKey)]
+                total_loss = total_loss + loss.detach()
+            if self.log is not None and (mbIdx + 1) % 5 == 0:
+                self.log.log('Train Epoch: {}; Mini-batch: {}/{} ({:.0f}%); \t Current Loss: {:.6f}'.format(
+                    epoch, mbIdx, len(self.trainingLoader), 100. * mbIdx / len(self.trainingLoader), float(total_loss)))
+        return total_loss

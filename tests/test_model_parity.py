@@ -280,3 +280,78 @@ def test_training_window_capture_matches_reference():
         assert abs(float(gn) - float(d["step%d.gradnorm" % a])) < 2e-3 * float(d["step%d.gradnorm" % a]) * tol
         log_s = dict(m.named_parameters())[str(d["log_s_key"])]
         C.assert_field(log_s, d["step%d.log_s" % a], "log_s", atol=2e-5 * tol)
+
+
+def test_trainer_epoch_matches_oracle_loop():
+    """Rows F1+F2 together: `TrainFlow.trainParallel` (BPTT window of model.sample steps -> physics-constrained loss ->
+    backward -> clip -> optimizer step -> state re-anchoring) on the HIP path against the same loop written with the CPU
+    oracles; latents injected through reconstruct() so that both sides see the same noise."""
+    from types import SimpleNamespace
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
+    import tmglow_oracle as O
+    import physics_oracle as PO
+    from nn.tmGlow import TMGlow
+    from nn.trainFlowParallel import TrainFlow
+    cfg = C.CFG_TINY3
+    L = len(cfg["glow_blocks"])
+    B, T, (h, w) = 2, 4, cfg["_in_hw"]
+    H, W = h * cfg["_up"], w * cfg["_up"]
+    C.seed_all(2468)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, 0.03, 0.05, 0.03)
+    m.out_std, m.out_mu = torch.tensor([1.3, 0.7, 2.1]), torch.tensor([0.2, -0.1, 0.4])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, T, cfg["in_features"], h, w, generator=g)
+    tgt = torch.randn(B, T, 3, H, W, generator=g)
+    seeds = torch.tensor([11, 505])
+    args = SimpleNamespace(beta=20.0, dx=0.05, dy=0.0625, max_grad_norm=0.25)
+
+    # shapes of the latents are the model's business: take them from one oracle forward instead of trusting the formula above
+    P = O.params_from_state_dict(sd)
+    with torch.no_grad():
+        st0 = O.init_lstm_states(cfg, seeds, [H, W])
+        _, _, _, e_ref = O.tmglow_forward(P, cfg, x[:, 0], tgt[:, 0], st0, return_eps=True, training=True)
+    eps = [[torch.randn(v.shape, generator=g) for v in e_ref] for _ in range(T)]
+
+    # ---- HIP path through the trainer
+    step = {"t": 0}
+
+    def sample_with_fixed_noise(x_t, states):
+        out = m.reconstruct(x_t, states, [e.to(DEV) for e in eps[step["t"]]])
+        step["t"] += 1
+        return out
+
+    m.sample = sample_with_fixed_noise
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    loader = [(x, tgt, seeds)]
+    total = TrainFlow(args, m, loader, None).trainParallel(m, opt, tback=10, epoch=0)
+
+    # ---- the same window with the oracles
+    states = O.init_lstm_states(cfg, seeds, [H, W])
+    ys, lps = [], []
+    for t in range(T):
+        y, lp, states = O.tmglow_reconstruct(P, cfg, x[:, t], states, eps[t], training=True)
+        ys.append(y)
+        lps.append(lp)
+    tmean = tgt.mean(1)
+    trms = torch.sqrt(((tgt - tmean.unsqueeze(1)) ** 2).mean(1))
+    loss = PO.tmglow_loss(torch.stack(ys, 1), torch.stack(lps, 1), tgt, tmean, trms, torch.tensor([1.3, 0.7, 2.1]),
+                          torch.tensor([0.2, -0.1, 0.4]), args.beta, args.dx, args.dy)
+    tr = O.trainable(P)
+    grads = torch.autograd.grad(loss, list(tr.values()), allow_unused=True)
+    live = [(k, p, gr) for (k, p), gr in zip(tr.items(), grads) if gr is not None]
+    gn = torch.sqrt(sum((gr.double() ** 2).sum() for _, _, gr in live)).float()
+    coef = torch.clamp(args.max_grad_norm / (gn + 1e-6), max=1.0)
+    assert abs(float(total) - float(loss)) <= 2e-5 * abs(float(loss)) + 2e-5, (float(total), float(loss))
+    new = dict(m.named_parameters())
+    worst = 0.0
+    for k, p, gr in live:
+        want = p.detach() - 0.05 * coef * gr
+        got = new[k].detach().cpu()
+        scale = float((0.05 * coef * gr).abs().max()) + 1e-12
+        worst = max(worst, float((got - want).abs().max()) / scale)
+    assert worst < 2e-2, worst  # updates agree to 2 % of the largest step taken in each tensor
