@@ -1111,10 +1111,13 @@ static int g_prof_on = 0;
 static const char* const g_prof_names[] = {
     "conv_mfma_kernel<4,1,4,1>", "conv_mfma_kernel<4,2,4,1>", "conv_mfma_kernel<4,3,4,1>", "conv_mfma_kernel<4,4,4,1>",
     "conv_mfma_kernel<4,3,2,2>", "conv_mfma_kernel<4,4,2,2>", "conv_mfma_kernel<4,3,1,4>", "conv_mfma_kernel<4,4,1,4>",
-    "conv_wgrad_kernel<*,1>", "conv_wgrad_kernel<*,2>", "conv_wgrad_kernel<*,4>",
+    "conv_wgrad_kernel<3,1,*>", "conv_wgrad_kernel<3,2,*>", "conv_wgrad_kernel<3,4,*>",
     "conv_fwd_kernel<*,1,8,1>", "conv_fwd_kernel<*,2,8,1>", "conv_fwd_kernel<*,3,8,1>", "conv_fwd_kernel<*,4,8,1>",
-    "conv_fwd_kernel<*,3,4,2>", "conv_fwd_kernel<*,4,4,2>", "conv_fwd_kernel<*,3,2,4>", "conv_fwd_kernel<*,4,2,4>"};
-#define TMG_NPROF 19
+    "conv_fwd_kernel<*,3,4,2>", "conv_fwd_kernel<*,4,4,2>", "conv_fwd_kernel<*,3,2,4>", "conv_fwd_kernel<*,4,2,4>",
+    "conv_wgrad_kernel<5,1,*>", "conv_wgrad_kernel<5,2,*>", "conv_wgrad_kernel<5,4,*>",
+    "conv_wgrad_kernel<7,1,*>", "conv_wgrad_kernel<7,2,*>", "conv_wgrad_kernel<7,4,*>",
+    "conv_wgrad_kernel<9,1,*>", "conv_wgrad_kernel<9,2,*>", "conv_wgrad_kernel<9,4,*>"};
+#define TMG_NPROF 28
 
 struct ProfScope {
     ProfRec r; bool on; hipStream_t st;
@@ -1397,7 +1400,8 @@ static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_
                                   160 * 1024);
         attr_set = true;
     }
-    const int kid = 8 + (NCO == 1 ? 0 : (NCO == 2 ? 1 : 2));
+    const int nco_i = NCO == 1 ? 0 : (NCO == 2 ? 1 : 2);
+    const int kid = NP == 3 ? 8 + nco_i : 19 + ((NP - 5) / 2) * 3 + nco_i;
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO, LEAN>), grid, dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
