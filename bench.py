@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP-event timing")
+    ap.add_argument("--direction", default="sample", choices=["sample", "forward"],
+                    help="sample: the generative direction the reference trains through (the metric); forward: density direction "
+                         "forward(x, y) with loss -mean(logp)/(noc*H*W), reported beside it (SURVEY 8-D)")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in one hipGraph and replay it (N=1 only)")
     args = ap.parse_args()
 
@@ -152,10 +155,16 @@ def main():
     x = torch.randn(B, cfg["in_features"], Hin, Win, generator=g).to(dev)
     states = model.initLSTMStates(torch.arange(B) + rank * B, [Hin * up, Win * up])
 
+    y_fwd = torch.randn(B, cfg["out_features"], Hin * up, Win * up, generator=g).to(dev) if args.direction == "forward" else None
+
     def step():
         opt.zero_grad(set_to_none=True)
-        y, ld, _ = model.sample(x, states)
-        loss = C.loss_reverse(y, ld)
+        if y_fwd is None:
+            y, ld, _ = model.sample(x, states)
+            loss = C.loss_reverse(y, ld)
+        else:
+            _, logp, _, _ = model.forward(x, y_fwd, states)
+            loss = C.loss_forward(logp, y_fwd)
         loss.backward()
         if bucket is not None:
             bucket.allreduce_mean()
@@ -230,8 +239,8 @@ def main():
            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "tmglow %s: sample()+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
-               args.config, Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
+           "config": {"workload": "tmglow %s: %s+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
+               args.config, "sample()" if args.direction == "sample" else "forward(x,y)", Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
                "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
            "roofline": roof}
     if not args.no_cpu_baseline:

@@ -136,10 +136,11 @@ class TMGlow(nn.Module):
         """x -> z.  Returns (z, log_prior + log_det [B], h_out, eps | None) (reference :378-414)."""
         cprior, c_out = self._prior(x)
         z, log_det, h_out, eps = self.glow.forward(y, c_out, h_in, return_eps=return_eps)
-        log_prior, eps0 = cprior.log_prob(z, return_eps=return_eps)
         if return_eps:
+            log_prior, eps0 = cprior.log_prob(z, return_eps=True)
             eps.append(eps0)  # deepest latent noise, from the clamped log-std (reference :407 + flowUtils.py:163)
         else:
+            log_prior = cprior.log_prob(z)
             eps = None
         return z, log_prior + log_det, h_out, eps
 

@@ -282,6 +282,21 @@ def test_training_window_capture_matches_reference():
         C.assert_field(log_s, d["step%d.log_s" % a], "log_s", atol=2e-5 * tol)
 
 
+def test_forward_default_arguments():
+    """forward(x, y) with the reference's defaults (no states, return_eps=False): same z / log-likelihood as with
+    return_eps=True, eps is None (reference tmGlow.py:378-414)."""
+    d = C.load_npz("tiny_model.npz")
+    cfg = C.CFG_TINY
+    m = _model(cfg, {k: torch.from_numpy(v) for k, v in C.sub(d, "sd.").items()})
+    x, y = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["y"]).to(DEV)
+    with torch.no_grad():
+        z0, lp0, h0, e0 = m.forward(x, y)
+        z1, lp1, h1, e1 = m.forward(x, y, None, return_eps=True)
+    assert e0 is None and len(e1) == len(cfg["glow_blocks"]) + 1
+    assert torch.equal(z0, z1) and torch.equal(lp0, lp1)
+    assert lp0.shape == (x.shape[0],) and len(h0) == len(cfg["glow_blocks"])
+
+
 def test_trainer_epoch_matches_oracle_loop():
     """Rows F1+F2 together: `TrainFlow.trainParallel` (BPTT window of model.sample steps -> physics-constrained loss ->
     backward -> clip -> optimizer step -> state re-anchoring) on the HIP path against the same loop written with the CPU
