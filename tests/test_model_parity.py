@@ -295,6 +295,13 @@ def test_forward_default_arguments():
     assert e0 is None and len(e1) == len(cfg["glow_blocks"]) + 1
     assert torch.equal(z0, z1) and torch.equal(lp0, lp1)
     assert lp0.shape == (x.shape[0],) and len(h0) == len(cfg["glow_blocks"])
+    # generative direction without states: zero LSTM states (reference convLSTM.py:87-104), fresh latents
+    with torch.no_grad():
+        ys, ld, hs = m.sample(x)
+        yr, ldr, _ = m.reconstruct(x, None, e1)
+    assert ys.shape == y.shape and ld.shape == (x.shape[0],) and len(hs) == len(cfg["glow_blocks"])
+    assert torch.isfinite(ys).all() and torch.isfinite(ld).all()
+    C.assert_field(yr, y.cpu().numpy(), "forward -> reconstruct round trip", atol=5e-4, rtol=1e-3)
 
 
 def test_trainer_epoch_matches_oracle_loop():
