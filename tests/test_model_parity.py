@@ -304,6 +304,42 @@ def test_forward_default_arguments():
     C.assert_field(yr, y.cpu().numpy(), "forward -> reconstruct round trip", atol=5e-4, rtol=1e-3)
 
 
+def test_eval_mode_uses_running_statistics():
+    """model.eval() (the reference's prediction path, utils/utils.py:162): the encoder's BatchNorm layers use their
+    running moments and leave them untouched; checked against the oracle with training=False."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
+    import tmglow_oracle as O
+    d = C.load_npz("tiny_model.npz")
+    cfg = C.CFG_TINY
+    L = len(cfg["glow_blocks"])
+    sd = {k: torch.from_numpy(v).clone() for k, v in C.sub(d, "sd.").items()}
+    g = torch.Generator().manual_seed(5)
+    for k in sd:  # non-trivial running statistics
+        if k.endswith("running_mean"):
+            sd[k] = 0.3 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    m = _model(cfg, sd).eval()
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"])
+    h_in = [(torch.from_numpy(d["h_in.%d.h" % i]), torch.from_numpy(d["h_in.%d.c" % i])) for i in range(L)]
+    P = O.params_from_state_dict(sd, requires_grad=False)
+    with torch.no_grad():
+        zo, lpo, ho, eo = O.tmglow_forward(P, cfg, x, y, h_in, return_eps=True, training=False)
+        z, lp, h, e = m.forward(x.to(DEV), y.to(DEV), [(a.to(DEV), b.to(DEV)) for a, b in h_in], return_eps=True)
+        yo, ldo, _ = O.tmglow_reconstruct(P, cfg, x, h_in, eo, training=False)
+        yr, ldr, _ = m.reconstruct(x.to(DEV), [(a.to(DEV), b.to(DEV)) for a, b in h_in], [t.to(DEV) for t in eo])
+    C.assert_field(z, zo.numpy(), "eval z")
+    C.assert_logdet(lp, lpo.numpy())
+    C.assert_field(yr, yo.numpy(), "eval reconstruct")
+    C.assert_logdet(ldr, ldo.numpy())
+    after = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+            assert torch.equal(after[k].cpu(), sd[k]), k
+
+
 def test_trainer_epoch_matches_oracle_loop():
     """Rows F1+F2 together: `TrainFlow.trainParallel` (BPTT window of model.sample steps -> physics-constrained loss ->
     backward -> clip -> optimizer step -> state re-anchoring) on the HIP path against the same loop written with the CPU
