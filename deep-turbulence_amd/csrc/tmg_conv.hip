@@ -508,7 +508,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     typedef const __attribute__((address_space(3))) float* lds_cptr;
     constexpr int NT = 512;
     constexpr int UP = 7;    // patch float4 per thread (plan_wgrad keeps PH*PW*k4p <= UP*NT; 3x3 on a 4x32 tile needs 6.4)
-    constexpr int UD = NCO;  // dy float4 per thread (MPIX * NCO * 4 / NT for MPIX = 128)
+    constexpr int UD = NCO == 1 ? 4 : NCO;  // dy float4 per thread: covers MPIX * NCO / 128 (tiles of up to 512 pixels when NCO == 1, else 128)
     const int MPIX = p.MPIX;  // pixels per staged tile (64 or 128)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar branches
@@ -1462,7 +1462,26 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     if (np > 9) return -7;
     pl->gy = (cot + NCO - 1) / NCO;
     pl->gz = ngroups;
-    pl->lds_bytes = 2 * ((size_t)PH * PW * pl->CITG * 16 + (size_t)pl->MPIX * NCO * 16) * 4;
+    int PHe = PH, PWe = PW;
+    if (pl->ksplit && NCO == 1 && stride == 1 && TW >= 16 && pl->MPIX == 128) {
+        // Narrow layers do little MFMA work per pixel: with 128-pixel tiles every wave walks ONE 16-pixel unit per tile and
+        // the read/MFMA pipeline never fills.  Larger tiles (as far as registers, LDS and the tile count allow) give each
+        // wave 2-4 units per tile and less halo per staged pixel.
+        const int k4p = pl->CITG <= 1 ? 4 : (pl->CITG <= 2 ? 8 : 16);
+        for (int mp = 512; mp > 128; mp >>= 1) {
+            const int th = mp >> twl, ph = th + 2 * halo;
+            const int tiles = B * ((Wout + TW - 1) / TW) * ((Hout + th - 1) / th);
+            if (ph * PW * k4p <= 7 * 512 && 2 * ((size_t)ph * PW * pl->CITG * 16 + (size_t)mp * NCO * 16) * 4 <= 160 * 1024 &&
+                tiles >= 4 * 256 / (pl->gy * pl->gz)) {
+                pl->MPIX = mp; pl->TH = th;
+                pl->tiles_y = (Hout + th - 1) / th;
+                pl->ntiles = tiles;
+                PHe = ph;
+                break;
+            }
+        }
+    }
+    pl->lds_bytes = 2 * ((size_t)PHe * PWe * pl->CITG * 16 + (size_t)pl->MPIX * NCO * 16) * 4;
     if (pl->lds_bytes < 8192) pl->lds_bytes = 8192;  // the dbias fold reuses the first 8 KB
     if (pl->lds_bytes < (size_t)4 * pl->NP * NCO * 1024) pl->lds_bytes = (size_t)4 * pl->NP * NCO * 1024;  // cross-wave fold of the partial sums
     // pixel shares: one 512-thread block per CU, but >= 4 tiles per block (two rounds fill the pipeline)
