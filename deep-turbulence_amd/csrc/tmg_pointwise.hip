@@ -674,45 +674,81 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
         const int b = t / p.tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
         __syncthreads();
-        stage_patch_bf(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
-        for (int i = tid; i < QH * QW; i += 256) {
-            const int py = i / QW, px = i - py * QW;
-            const int y = oy0 - 2 + py, x = ox0 - 2 + px;
-            float v = 0.f;
-            if (y >= 0 && y < p.Hin && x >= 0 && x < p.Win) {
-                const size_t pix = ((size_t)b * p.Hin + y) * p.Win + x;
-                const float2 gd = *reinterpret_cast<const float2*>(p.GD + pix * p.gd_stride);
-                const float2 dv = *reinterpret_cast<const float2*>(p.Dp + pix * p.d_stride);
-                v = dv.y > 0.f ? gd.y : 0.f;
+        // All global loads of the tile are issued up front and without control flow (out-of-image lanes read the zero
+        // page): the kernel is latency-bound (a handful of blocks per CU, ~6 dependent phases per tile before), so
+        // one exposed memory latency per tile instead of five is the whole game.
+        const int oy = oy0 + row, ox = ox0 + col;
+        const bool own = oy < p.Hin && ox < p.Win;
+        const size_t opix = ((size_t)b * p.Hin + min(oy, p.Hin - 1)) * p.Win + min(ox, p.Win - 1);
+        float a2g[2], a2d[2], a1g[2], a1d[2];
+        bool a2in[2], a1in[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            {
+                const int py = i / QW, px = i - py * QW;
+                const int y = oy0 - 2 + py, x = ox0 - 2 + px;
+                a2in[u] = i < QH * QW && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+                const size_t pix = ((size_t)b * p.Hin + min(max(y, 0), p.Hin - 1)) * p.Win + min(max(x, 0), p.Win - 1);
+                a2g[u] = *(a2in[u] ? p.GD + pix * p.gd_stride + 1 : tmg_zero_page);
+                a2d[u] = *(a2in[u] ? p.Dp + pix * p.d_stride + 1 : tmg_zero_page);
             }
-            A2[i] = v;
+            {
+                const int py = i / PW, px = i - py * PW;
+                const int y = oy0 - 1 + py, x = ox0 - 1 + px;
+                a1in[u] = i < PH * PW && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+                const size_t pix = ((size_t)b * p.Hin + min(max(y, 0), p.Hin - 1)) * p.Win + min(max(x, 0), p.Win - 1);
+                a1g[u] = *(a1in[u] ? p.GD + pix * p.gd_stride : tmg_zero_page);
+                a1d[u] = *(a1in[u] ? p.Dp + pix * p.d_stride : tmg_zero_page);
+            }
+        }
+        // gradient / add operands of this thread's own pixel for the first PQ channel quads of the chunk
+        constexpr int PQ = 4;
+        float4 gq[PQ], aq[PQ];
+        const bool pre_ok = p.vec4 && own && c0 < p.cin_nn;
+#pragma unroll
+        for (int j = 0; j < PQ; ++j) {
+            const int ci = c0 + 4 * j;
+            int nl = ci;
+            const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
+            if (sgi) nl -= p.g0[0].n;
+            const bool ok = pre_ok && 4 * j < kch && ci < p.cin_nn;
+            const float* gp = (sgi ? p.g0[1].p : p.g0[0].p) + opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl;
+            gq[j] = *reinterpret_cast<const float4*>(ok ? gp : tmg_zero_page);
+            const bool aok = ok && p.add0 && !sgi;
+            aq[j] = *reinterpret_cast<const float4*>(aok ? p.add0 + opix * p.add0_stride + nl : tmg_zero_page);
+        }
+        stage_patch_bf(p, lin, b, oy0 - 1, ox0 - 1, PH, PW, c0, kch, CS);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            if (i < QH * QW) A2[i] = (a2in[u] && a2d[u] > 0.f) ? a2g[u] : 0.f;
         }
         __syncthreads();
-        for (int i = tid; i < PH * PW; i += 256) {
-            const int py = i / PW, px = i - py * PW;
-            const int y = oy0 - 1 + py, x = ox0 - 1 + px;
-            float v = 0.f;
-            if (y >= 0 && y < p.Hin && x >= 0 && x < p.Win) {
-                const size_t pix = ((size_t)b * p.Hin + y) * p.Win + x;
-                if (p.Dp[pix * p.d_stride] > 0.f) {
-                    v = p.GD[pix * p.gd_stride];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            if (i < PH * PW) {
+                const int py = i / PW, px = i - py * PW;
+                float v = 0.f;
+                if (a1in[u] && a1d[u] > 0.f) {
+                    v = a1g[u];
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) {
                         const int ky = tap / 3, kx = tap - ky * 3;
                         v += w2d[tap] * A2[(py + 2 - ky) * QW + px + 2 - kx];
                     }
                 }
+                A1[i] = v;
             }
-            A1[i] = v;
         }
         __syncthreads();
-        const int oy = oy0 + row, ox = ox0 + col;
-        if (p.dd1_out && blockIdx.y == 0 && oy < p.Hin && ox < p.Win) {
+        if (p.dd1_out && blockIdx.y == 0 && own) {
             const size_t px_ = ((size_t)b * p.Hin + oy) * p.Win + ox;
             p.dd1_out[px_ * p.dd_stride] = A1[(row + 1) * PW + col + 1];
             p.dd2_out[px_ * p.dd_stride] = A2[(row + 2) * QW + col + 2];
         }
-        if (oy < p.Hin && ox < p.Win && c0 < p.cin_nn) {
+        if (own && c0 < p.cin_nn) {
             float n1[9], n2[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -720,56 +756,59 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
                 n1[tap] = A1[(row + 2 - ky) * PW + col + 2 - kx];
                 n2[tap] = A2[(row + 3 - ky) * QW + col + 3 - kx];
             }
-            const size_t opix = ((size_t)b * p.Hin + oy) * p.Win + ox;
             const float* cen = lin + ((row + 1) * PW + col + 1) * CS;
-            for (int c = 0; c < kch; c += 4) {
-                const int ci = c0 + c;
-                if (ci >= p.cin_nn) break;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float4 a = *reinterpret_cast<const float4*>(lw1 + tap * kch + c);
-                    const float4 bq = *reinterpret_cast<const float4*>(lw2 + tap * kch + c);
-                    v.x += a.x * n1[tap] + bq.x * n2[tap];
-                    v.y += a.y * n1[tap] + bq.y * n2[tap];
-                    v.z += a.z * n1[tap] + bq.z * n2[tap];
-                    v.w += a.w * n1[tap] + bq.w * n2[tap];
-                }
-                const float4 m = *reinterpret_cast<const float4*>(cen + c);
-                if (p.vec4) {
-                    int nl = ci;
-                    const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
-                    if (sgi) nl -= p.g0[0].n;
-                    const float* gp = (sgi ? p.g0[1].p : p.g0[0].p) + opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl;
-                    float* op = (sgi ? p.out[1].p : p.out[0].p) + opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl;
-                    const float4 g = *reinterpret_cast<const float4*>(gp);
-                    float4 o;
-                    o.x = m.x > 0.f ? g.x + v.x : 0.f;
-                    o.y = m.y > 0.f ? g.y + v.y : 0.f;
-                    o.z = m.z > 0.f ? g.z + v.z : 0.f;
-                    o.w = m.w > 0.f ? g.w + v.w : 0.f;
-                    if (p.add0 && !sgi) {
-                        const float4 ad = *reinterpret_cast<const float4*>(p.add0 + opix * p.add0_stride + nl);
-                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-                    }
-                    *reinterpret_cast<float4*>(op) = o;
-                } else {
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
-                    const float mm[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int nl = ci + e;
-                        if (nl < p.cin_nn) {
-                            const int sgi = (nl >= p.g0[0].n) ? 1 : 0;
-                            if (sgi) nl -= p.g0[0].n;
-                            const float g = (sgi ? p.g0[1].p : p.g0[0].p)[opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl];
-                            float o = mm[e] > 0.f ? g + vv[e] : 0.f;
-                            if (p.add0 && !sgi) o += p.add0[opix * p.add0_stride + nl];
-                            (sgi ? p.out[1].p : p.out[0].p)[opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl] = o;
-                        }
-                    }
-                }
+            // one channel quad: input gradient of both layers, ReLU mask, upstream gradient and optional add operand
+            // (G_/AD_: prefetched registers when PRE_, else loaded here)
+#define TMG_D2_QUAD(C_, G_, AD_, PRE_)                                                                                    \
+            {                                                                                                             \
+                const int c = (C_), ci = c0 + c;                                                                          \
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                               \
+                _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                                     \
+                    const float4 a = *reinterpret_cast<const float4*>(lw1 + tap * kch + c);                               \
+                    const float4 bq = *reinterpret_cast<const float4*>(lw2 + tap * kch + c);                              \
+                    v.x += a.x * n1[tap] + bq.x * n2[tap];                                                                \
+                    v.y += a.y * n1[tap] + bq.y * n2[tap];                                                                \
+                    v.z += a.z * n1[tap] + bq.z * n2[tap];                                                                \
+                    v.w += a.w * n1[tap] + bq.w * n2[tap];                                                                \
+                }                                                                                                         \
+                const float4 m = *reinterpret_cast<const float4*>(cen + c);                                               \
+                if (p.vec4) {                                                                                             \
+                    int nl = ci;                                                                                          \
+                    const int sgi = (nl >= p.g0[0].n) ? 1 : 0;                                                            \
+                    if (sgi) nl -= p.g0[0].n;                                                                             \
+                    float* op = (sgi ? p.out[1].p : p.out[0].p) + opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl; \
+                    float4 g = G_, ad = AD_;                                                                              \
+                    if (!(PRE_)) {                                                                                        \
+                        g = *reinterpret_cast<const float4*>((sgi ? p.g0[1].p : p.g0[0].p) + opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl); \
+                        ad = (p.add0 && !sgi) ? *reinterpret_cast<const float4*>(p.add0 + opix * p.add0_stride + nl) : make_float4(0.f, 0.f, 0.f, 0.f); \
+                    }                                                                                                     \
+                    float4 o;                                                                                             \
+                    o.x = (m.x > 0.f ? g.x + v.x : 0.f) + ad.x;                                                           \
+                    o.y = (m.y > 0.f ? g.y + v.y : 0.f) + ad.y;                                                           \
+                    o.z = (m.z > 0.f ? g.z + v.z : 0.f) + ad.z;                                                           \
+                    o.w = (m.w > 0.f ? g.w + v.w : 0.f) + ad.w;                                                           \
+                    *reinterpret_cast<float4*>(op) = o;                                                                   \
+                } else {                                                                                                  \
+                    const float vv[4] = {v.x, v.y, v.z, v.w};                                                             \
+                    const float mm[4] = {m.x, m.y, m.z, m.w};                                                             \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+                        int nl = ci + e;                                                                                  \
+                        if (nl < p.cin_nn) {                                                                              \
+                            const int sgi = (nl >= p.g0[0].n) ? 1 : 0;                                                    \
+                            if (sgi) nl -= p.g0[0].n;                                                                     \
+                            const float g = (sgi ? p.g0[1].p : p.g0[0].p)[opix * (sgi ? p.g0[1].stride : p.g0[0].stride) + (sgi ? p.g0[1].off : p.g0[0].off) + nl]; \
+                            float o = mm[e] > 0.f ? g + vv[e] : 0.f;                                                      \
+                            if (p.add0 && !sgi) o += p.add0[opix * p.add0_stride + nl];                                   \
+                            (sgi ? p.out[1].p : p.out[0].p)[opix * (sgi ? p.out[1].stride : p.out[0].stride) + (sgi ? p.out[1].off : p.out[0].off) + nl] = o; \
+                        }                                                                                                 \
+                    }                                                                                                     \
+                }                                                                                                         \
             }
+#pragma unroll
+            for (int j = 0; j < PQ; ++j)
+                if (4 * j < kch && c0 + 4 * j < p.cin_nn) TMG_D2_QUAD(4 * j, gq[j], aq[j], true)
+            for (int cq = 4 * PQ; cq < kch && c0 + cq < p.cin_nn; cq += 4) TMG_D2_QUAD(cq, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), false)
+#undef TMG_D2_QUAD
         }
         // weight gradients of both layers from the same staged activations: one (channel, tap) output per thread
         if (wo_ok) {
@@ -1117,7 +1156,8 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    int gx = 1024 / nchunks;
+    static const int d2_blocks = getenv("TMG_D2_BLOCKS") ? atoi(getenv("TMG_D2_BLOCKS")) : 1024;
+    int gx = d2_blocks / nchunks;
     if (gx > p.ntiles) gx = p.ntiles;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(dense2_bwd_kernel, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
