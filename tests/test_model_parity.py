@@ -93,6 +93,60 @@ def test_cfg1_seeded_model_matches_reference():
         assert abs(gn[str(k)] - v) <= 1e-2 * v + 1e-7, (k, gn[str(k)], v)
 
 
+@pytest.mark.parametrize("name,cfg,B,fatol,gtol", [("cfg2", C.CFG2, 2, C.FIELD_ATOL, (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX)),
+                                                  ("cfg3", C.CFG3, 1, 3e-3, (3e-3, 5e-2))])
+def test_baseline_configs_match_oracle(name, cfg, B, fatol, gtol):
+    """BASELINE configs[1] (64x64x3 -> 128x128x3, L=3) and configs[2] (non-square 64x128x4 -> 128x256x4, L=4) at the
+    default widths: forward, reconstruct and their gradients on the HIP path against the CPU oracle on the same seeded
+    weights (the oracle itself is pinned by the reference fixtures in tests/test_oracle_golden.py).  Field tolerance of
+    the 64-layer cfg3: the reference arithmetic's own fp32 noise there (oracle fp32 vs fp64, measured in the build
+    container) is 9.0e-4 on z (max|z| = 11.2), 1.9e-4 on the LSTM states, 6.4e-4 global / 1.2e-2 worst-tensor on the
+    gradients, so cfg3 is held to 3e-3 / 1.5e-3 / 3e-3 / 5e-2 (3-5x that floor); cfg2 (48 layers) holds the standard
+    tolerances of tests/common.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
+    import tmglow_oracle as O
+    from nn.tmGlow import TMGlow
+    C.seed_all(12345)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, 0.004, 0.02, 0.004)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(DEV).train()
+    h, w = cfg["_in_hw"]
+    H_, W_ = h * cfg["_up"], w * cfg["_up"]
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, cfg["in_features"], h, w, generator=g)
+    y = torch.randn(B, cfg["out_features"], H_, W_, generator=g)
+    seeds = torch.arange(B) + 3
+    P = O.params_from_state_dict(sd)
+    st_o = O.init_lstm_states(cfg, seeds, [H_, W_])
+    zo, lpo, ho, eo = O.tmglow_forward(P, cfg, x, y, st_o, return_eps=True, training=True)
+    C.loss_forward(lpo, y).backward()
+    go = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
+    st = m.initLSTMStates(seeds, [H_, W_])
+    z, lp, ho2, e = m.forward(x.to(DEV), y.to(DEV), st, return_eps=True)
+    C.assert_field(z, zo.detach().numpy(), name + " z", atol=fatol)
+    C.assert_logdet(lp, lpo.detach().numpy(), name + " logp")
+    for (a, b_), (ao, bo) in zip(ho2, ho):
+        C.assert_field(a, ao.detach().numpy(), name + " h", atol=max(C.STATE_ATOL * 10, 0.5 * fatol))
+    C.loss_forward(lp, y.to(DEV)).backward()
+    C.assert_grads(_grads(m), {k: v.numpy() for k, v in go.items()}, name + " forward grads", global_tol=gtol[0], tensor_tol=gtol[1])
+    # generative direction with the oracle's latents
+    m.zero_grad()
+    for v in O.trainable(P).values():
+        v.grad = None
+    eps = [t.detach() for t in eo]
+    yo, ldo, _ = O.tmglow_reconstruct(P, cfg, x, st_o, eps, training=True)
+    C.loss_reverse(yo, ldo).backward()
+    go = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
+    yr, ld, _ = m.reconstruct(x.to(DEV), st, [t.to(DEV) for t in eps])
+    C.assert_field(yr, yo.detach().numpy(), name + " y", atol=fatol)
+    C.assert_logdet(ld, ldo.detach().numpy(), name + " logdet")
+    C.loss_reverse(yr, ld).backward()
+    C.assert_grads(_grads(m), {k: v.numpy() for k, v in go.items()}, name + " reverse grads", global_tol=gtol[0], tensor_tol=gtol[1])
+
+
 def test_flow_level_module_matches_reference():
     from nn.modules.flowLSTMBlock import LSTMFLowBlock
     d = C.load_npz("modules.npz")
