@@ -919,9 +919,16 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
             const size_t per_x = (size_t)gy * gz * nws * NP * NCO * 64;
             const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * nws + wave) * NP + j) * NCO + n) * 64 + lane;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int x = x0; x < x1; ++x) {
-                const float4 v = src[(size_t)x * per_x];
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            // batches of 8 independent loads (slab index clamped, surplus weighted 0): a plain loop waits for every load
+            for (int xb = x0; xb < x1; xb += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(xb + u, x1 - 1) * per_x];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float wgt = (xb + u < x1) ? 1.f : 0.f;
+                    a.x += wgt * v[u].x; a.y += wgt * v[u].y; a.z += wgt * v[u].z; a.w += wgt * v[u].w;
+                }
             }
             const int tap = pid / citn, cit = pid - tap * citn;
             const int co = (y * NCO + n) * 16 + (lane & 15);
@@ -942,7 +949,13 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
         if (t < NCO * 16 && co < Cout) {
             const float* wsb = ws + (size_t)gx * gy * gz * nws * NP * NCO * 256;
             float a = 0.f;
-            for (int x = x0; x < x1; ++x) a += wsb[((size_t)x * gy + y) * 64 + t];
+            for (int xb = x0; xb < x1; xb += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = wsb[((size_t)min(xb + u, x1 - 1) * gy + y) * 64 + t];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (xb + u < x1) ? v[u] : 0.f;
+            }
             atomicAdd(dbias + co, a * osc);
         }
     }
