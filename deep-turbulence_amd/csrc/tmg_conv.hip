@@ -486,6 +486,12 @@ struct WgradP {
     int CITG;  // input-channel tiles (of 16) handled per block group (grid.z walks the groups)
     int dbg;     // timing experiments (TMG_WG_DBG): 1 = no MFMA loop, 2 = no staging
     int fstage;  // 1: every segment / dy is float4-addressable and offsets fit 24-bit multiplies -> lean staging path
+    // grouped launch (tmg_conv_wgrad_grouped): group g = blockIdx.y / bpg reads its own input segments from gtab[g],
+    // dy channels [g*dy_goff, +Cout) and writes dW + g*dw_gstride / dbias + g*db_gstride; null: one group
+    const long long* gtab;  // device: [ngroups][3][4] = {pointer, pixel stride, channel offset, channels}
+    int bpg, dy_goff;
+    long long dw_gstride;
+    int db_gstride;
     int ksplit;  // 1: waves split the pixels of a tile instead of the (tap, channel tile) pairs (see the kernel)
 };
 
@@ -521,7 +527,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     const int cit0 = blockIdx.z * p.CITG;
     const int citn = min(p.CITG, (p.Cin_pad >> 4) - cit0);
     const int k4 = citn * 4;
-    const int co0 = blockIdx.y * NCO * 16;
+    const int grp = p.gtab ? (int)blockIdx.y / p.bpg : 0;  // grouped launch: which (input segments, dy slice, dW slice)
+    const int co0 = ((int)blockIdx.y - grp * p.bpg) * NCO * 16;
     const int ldy_w = citn * plane;           // word offset of the dy tile inside a buffer
     const int bufw = p.CITG * plane + MPIX * NCO * 16;  // words per buffer
     const int ksplit = p.ksplit;
@@ -637,14 +644,24 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     {
         int cl = cit0 * 16 + 4 * pc4;
         if (cl < p.Cin) {
-            const float* sp = p.in[0].p;
-            int ss = p.in[0].stride, so = p.in[0].off;
-            if (cl >= p.in[0].n) {
-                cl -= p.in[0].n;
-                sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
-                if (cl >= p.in[1].n) {
-                    cl -= p.in[1].n;
-                    sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+            // segment descriptors: the launch's own, or this group's row of the device table (scalar loads)
+            const float* sp0 = p.in[0].p; int ss0 = p.in[0].stride, so0 = p.in[0].off, sn0 = p.in[0].n;
+            const float* sp1 = p.in[1].p; int ss1 = p.in[1].stride, so1 = p.in[1].off, sn1 = p.in[1].n;
+            const float* sp2 = p.in[2].p; int ss2 = p.in[2].stride, so2 = p.in[2].off;
+            if (p.gtab) {
+                const long long* gt = p.gtab + (size_t)grp * 12;
+                sp0 = reinterpret_cast<const float*>(gt[0]); ss0 = (int)gt[1]; so0 = (int)gt[2]; sn0 = (int)gt[3];
+                sp1 = reinterpret_cast<const float*>(gt[4]); ss1 = (int)gt[5]; so1 = (int)gt[6]; sn1 = (int)gt[7];
+                sp2 = reinterpret_cast<const float*>(gt[8]); ss2 = (int)gt[9]; so2 = (int)gt[10];
+            }
+            const float* sp = sp0;
+            int ss = ss0, so = so0;
+            if (cl >= sn0) {
+                cl -= sn0;
+                sp = sp1; ss = ss1; so = so1;
+                if (cl >= sn1) {
+                    cl -= sn1;
+                    sp = sp2; ss = ss2; so = so2;
                 }
             }
             tptr = sp + so + cl;
@@ -665,7 +682,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     const int dc4 = tid & (NCO * 4 - 1), dm0 = tid >> DL;
     constexpr int dstep = NT >> DL;
     const bool dcv = co0 + 4 * dc4 < p.Cout;
-    const float* dptr = dcv ? p.dy.p + p.dy.off + co0 + 4 * dc4 : g_tmg_zero_page;
+    const float* dptr = dcv ? p.dy.p + p.dy.off + grp * p.dy_goff + co0 + 4 * dc4 : g_tmg_zero_page;
     const int dss = dcv ? p.dy.stride : 0;
     const unsigned ddst0 = 4u * (ldy_w + ((dc4 >> 2) * MPIX + dm0) * 16 + (dc4 & 3) * 4);
     unsigned oobm = 0;  // per-item out-of-image bits (only maintained when an input affine must not touch padding)
@@ -899,7 +916,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
                                          const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int CITG,
                                          int cit_total, int Cin, int Cout, int ntaps, int xchunk, int cin_valid, int ci_split,
-                                         int ci_off0, int ci_off1, int ksplit) {
+                                         int ci_off0, int ci_off1, int ksplit, int bpg, long long dw_gstride, int db_gstride) {
+    // gy counts the blocks in y of the wgrad launch; with groups (bpg < gy) block y belongs to group y / bpg
     const int nws = ksplit ? 1 : 4;  // wave copies per block that survive the in-block fold
     const int items = gy * gz * nws * NP * NCO * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -931,8 +949,10 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
                 }
             }
             const int tap = pid / citn, cit = pid - tap * citn;
-            const int co = (y * NCO + n) * 16 + (lane & 15);
+            const int grp = y / bpg;
+            const int co = ((y - grp * bpg) * NCO + n) * 16 + (lane & 15);
             const int ci = (z * CITG + cit) * 16 + (lane >> 4) * 4;
+            dW += (size_t)grp * dw_gstride;
             if (co < Cout) {
                 const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -945,7 +965,9 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
     // bias partials: [gx][gy][64]
     if (dbias && i < gy * 64) {
         const int y = i >> 6, t = i & 63;
-        const int co = y * NCO * 16 + t;
+        const int grp = y / bpg;
+        const int co = (y - grp * bpg) * NCO * 16 + t;
+        dbias += (size_t)grp * db_gstride;
         if (t < NCO * 16 && co < Cout) {
             const float* wsb = ws + (size_t)gx * gy * gz * nws * NP * NCO * 256;
             float a = 0.f;
@@ -1517,9 +1539,11 @@ extern "C" int64_t tmg_conv_wgrad_ws_floats(const int64_t* dims) {
 // dW is [Cout][cin_dst][k*k] (cin_dst = 0 -> Cin).  dW (and dbias) are ACCUMULATED onto (caller zero-fills).  ws: optional scratch of >= tmg_conv_wgrad_ws_floats(dims)
 // floats; when given, per-block partial sums go through it and a small reduce kernel (few, low-contention atomics),
 // otherwise every block adds its partial sums to dW with float atomics.
-extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
-                              const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias,
-                              const void* kappa, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st) {
+// Shared body of tmg_conv_wgrad (ngroups == 1, gtab == null) and tmg_conv_wgrad_grouped.
+static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
+                      const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias,
+                      const void* kappa, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st,
+                      const long long* gtab, int ngroups, int dy_goff, long long dw_gstride, int db_gstride) {
     WgradP p;
     p.nseg = (int)nseg;
     p.vec4 = 1;
@@ -1542,9 +1566,22 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     const int rc = plan_wgrad(p.B, p.Hout, p.Wout, p.ksize, p.stride, p.Cin, p.Cout, &pl);
     if (rc != 0) return rc;
     p.TW_log2 = pl.twl; p.TH = pl.TH; p.MPIX = pl.MPIX; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.CITG = pl.CITG;
+    const int bpg = pl.gy;
+    if (ngroups > 1) {
+        // one launch for `ngroups` independent, identically shaped contractions: the groups share the pixel tiles' geometry,
+        // blockIdx.y walks (group, output-channel block); a group must fit one input-channel block
+        if (pl.gz != 1) return -100;
+        pl.gy = bpg * ngroups;
+        int gx = 256 / pl.gy;
+        if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
+        if (gx < 1) gx = 1;
+        pl.gx = gx;
+        pl.ws_floats = (size_t)gx * pl.gy * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * pl.gy * 64;
+    }
     p.ws = (ws && (size_t)ws_floats >= pl.ws_floats && (((uintptr_t)ws) & 15) == 0) ? (float*)ws : nullptr;
     dim3 grid(pl.gx, pl.gy, pl.gz);
     p.ksplit = pl.ksplit;
+    p.gtab = gtab; p.bpg = bpg; p.dy_goff = dy_goff; p.dw_gstride = dw_gstride; p.db_gstride = db_gstride;
     // lean staging needs float4-addressable operands and element offsets that fit the 24-bit multiplies / 32-bit adds
     p.fstage = p.vec4 && p.dy_vec4 && (p.Cout % 4 == 0) && (p.Cin % 4 == 0) && (long)p.Hin * p.Win < (1 << 24) && (long)p.Hout * p.Wout < (1 << 24);
     for (int i = 0; i < p.nseg; ++i)
@@ -1554,6 +1591,7 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
     if (no_fstage) p.fstage = 0;
     static const int wg_dbg = getenv("TMG_WG_DBG") ? atoi(getenv("TMG_WG_DBG")) : 0;
     p.dbg = wg_dbg;
+    if (ngroups > 1 && (!p.fstage || !p.ws)) return -100;  // grouped launches exist only on the lean, slab-reduced path
     int lrc = -7;
 #define TMG_WG_CASE(NP_, NCO_)                                                                    \
     if (pl.NP == NP_ && pl.NCO == NCO_)                                                           \
@@ -1570,10 +1608,40 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
         const int xc = (pl.gx + xchunk - 1) / xchunk;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
                            p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.cin_dst, p.Cout, p.ksize * p.ksize, xchunk,
-                           p.cin_valid, p.ci_split, p.ci_off0, p.ci_off1, pl.ksplit);
+                           p.cin_valid, p.ci_split, p.ci_off0, p.ci_off1, pl.ksplit, bpg, dw_gstride, db_gstride);
         TMG_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* in_scale,
+                              const void* in_shift, const void* dy, const int64_t* dy_desc, void* dW, void* dbias,
+                              const void* kappa, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st) {
+    return wgrad_impl(in_ptrs, in_desc, nseg, in_scale, in_shift, dy, dy_desc, dW, dbias, kappa, ws, ws_floats, dims, st, nullptr, 1, 0, 0, 0);
+}
+
+// `ngroups` identically shaped weight-gradient contractions in ONE launch (the per-layer coupling convolutions of a flow
+// level: 15 launches of a few microseconds of MFMA work each otherwise).  in_ptrs / in_desc describe group 0 (geometry,
+// alignment); gtab is a DEVICE table [ngroups][3][4] of int64 {pointer, pixel stride, channel offset, channels} with every
+// group's input segments.  Group g reads dy channels [g*gdims[0], +Cout), accumulates into dW + g*gdims[1] floats and
+// dbias + g*gdims[2] floats.  Returns -100 when the shape cannot be grouped (caller issues per-group launches).
+// ws must hold tmg_conv_wgrad_grouped_ws_floats(dims, ngroups) floats.
+extern "C" int tmg_conv_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* gtab,
+                                      int64_t ngroups, const int64_t* gdims, const void* dy, const int64_t* dy_desc, void* dW,
+                                      void* dbias, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st) {
+    if (ngroups < 1 || !gtab) return -3;
+    return wgrad_impl(in_ptrs, in_desc, nseg, nullptr, nullptr, dy, dy_desc, dW, dbias, nullptr, ws, ws_floats, dims, st,
+                      (const long long*)gtab, (int)ngroups, (int)gdims[0], (long long)gdims[1], (int)gdims[2]);
+}
+
+extern "C" int64_t tmg_conv_wgrad_grouped_ws_floats(const int64_t* dims, int64_t ngroups) {
+    WgradPlan pl;
+    if (plan_wgrad((int)dims[0], (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7], (int)dims[8], &pl) != 0) return 0;
+    const int gy = pl.gy * (int)ngroups;
+    int gx = 256 / gy;
+    if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
+    if (gx < 1) gx = 1;
+    return (int64_t)((size_t)gx * gy * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * gy * 64);
 }
 
 // Replicate-padding fold for the 3x3 input gradient (see conv_rep_border_fix_kernel).

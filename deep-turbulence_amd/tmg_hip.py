@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
+    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
 ]
 
 
@@ -57,6 +57,7 @@ def lib():
         for name in EXPORTS:
             getattr(_lib, name).restype = ctypes.c_int
         _lib.tmg_conv_wgrad_ws_floats.restype = ctypes.c_int64
+        _lib.tmg_conv_wgrad_grouped_ws_floats.restype = ctypes.c_int64
     return _lib
 
 
@@ -253,6 +254,38 @@ def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, 
     ws = workspace(lib().tmg_conv_wgrad_ws_floats(dims), dy.device) if use_ws else None
     _chk(lib().tmg_conv_wgrad(ip, idesc, c_i64(n_in), _ptr(in_scale), _ptr(in_shift), _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
                               _ptr(kappa), _ptr(ws), c_i64(ws.numel() if ws is not None else 0), dims, _stream()), "tmg_conv_wgrad")
+
+
+def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, stride, relu_in=False, pad_rep=False, cin_dst=0,
+                       cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0):
+    """One launch for len(group_inputs) identically shaped weight gradients.  group_inputs[g]: list of <= 3 NHWC segments;
+    dy: [B,H,W,>= G*Cg] with group g at channels [g*Cg, (g+1)*Cg); dW: [G, Cg, cin_dst, k, k] contiguous; dbias: [G, Cg] or
+    None.  Returns False when the library cannot group this shape (nothing was launched)."""
+    G = len(group_inputs)
+    first = group_inputs[0]
+    B, Hin, Win, _ = first[0].shape
+    _, Hout, Wout, _ = dy.shape
+    Cg = int(dy_group_channels)
+    ip, idesc, n_in = _segs(first)
+    Cin = sum(t.shape[3] for t in first)
+    rows = []
+    for segs in group_inputs:
+        assert len(segs) == n_in and all(a.shape == b.shape and a.stride() == b.stride() for a, b in zip(segs, first))
+        row = []
+        for t in segs:
+            row += list(seg(t))  # (pointer incl. the view's channel offset, pixel stride, 0, channels)
+        row += [0, 0, 0, 0] * (3 - n_in)
+        rows.append(row)
+    gtab = torch.tensor(rows, dtype=torch.int64).to(dy.device, non_blocking=True)
+    dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cg, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
+    ws = workspace(lib().tmg_conv_wgrad_grouped_ws_floats(dims, c_i64(G)), dy.device)
+    gd = _i64(Cg, dW[0].numel(), dbias[0].numel() if dbias is not None else 0)
+    rc = lib().tmg_conv_wgrad_grouped(ip, idesc, c_i64(n_in), _ptr(gtab), c_i64(G), gd, _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
+                                      _ptr(ws), c_i64(ws.numel()), dims, _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_conv_wgrad_grouped")
+    return True
 
 
 def conv_rep_border_fix(dy, w, outs, kappa=None):

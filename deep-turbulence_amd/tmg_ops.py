@@ -8,6 +8,8 @@ All activations are NHWC ([B,H,W,C] contiguous, or channel-slice views of such t
 """
 import math
 
+import os
+
 import torch
 
 import tmg_hip as H
@@ -553,6 +555,11 @@ class LevelCouplingFn(torch.autograd.Function):
         DH = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)     # exp(kappa_k) * dhh_k, all layers
         DD = torch.zeros((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)    # (dd1_k | dd2_k), all layers
         dcur = dy
+        # The NL zero-conv weight gradients (x1 | D part) are independent of each other once DH holds every layer's
+        # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
+        # dominated by launch / pipeline-fill).  Their inputs stay alive until then (NL * C floats per pixel).
+        grouped = NL > 1 and ch + 4 <= 64 and os.environ.get("TMG_NO_GROUPED_WGRAD") is None
+        wg_in = [None] * NL
         for k in (range(NL) if reverse else range(NL - 1, -1, -1)):
             xin, tin, D, r, y = saved[k]
             saved[k] = None
@@ -561,8 +568,11 @@ class LevelCouplingFn(torch.autograd.Function):
             dhh = DH[..., k * C:(k + 1) * C]
             H.affine_bwd(dto[..., ch:], (tin if reverse else y)[..., ch:], r, g, dtin[..., ch:], dhh, reverse, kappa=kps[k])
             x1 = tin[..., :ch]
-            H.conv_wgrad([x1, D], dhh, dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
-                         ci_split=ch, ci_off0=0, ci_off1=Cc)
+            if grouped:
+                wg_in[k] = [x1, D]  # weight gradient of this layer's zero conv: deferred, one grouped launch per level
+            else:
+                H.conv_wgrad([x1, D], dhh, dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
+                             ci_split=ch, ci_off0=0, ci_off1=Cc)
             G0 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
             GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
             wt = H.conv_pack(wzs[k], 1, ch + 4, (ch + 2, ch, Cc))
@@ -572,6 +582,13 @@ class LevelCouplingFn(torch.autograd.Function):
                          rows2=ch + 1, dd1=DD[..., k:k + 1], dd2=DD[..., NLp + k:NLp + k + 1], split2=ch, gap2=Cc)
             dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k])
             del xin, tin, D, r, y
+        if grouped:
+            if not H.conv_wgrad_grouped(wg_in, DH, C, dWz, dBz, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
+                                        ci_split=ch, ci_off0=0, ci_off1=Cc):
+                for k in range(NL):
+                    H.conv_wgrad(wg_in[k], DH[..., k * C:(k + 1) * C], dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2,
+                                 cin_valid=ch + 2, ci_split=ch, ci_off0=0, ci_off1=Cc)
+            wg_in = None
         # conditioning side of the whole level: one input-gradient pass, three weight-gradient passes
         Gc = torch.empty(cond.shape, device=dev, dtype=torch.float32)
         wzc_t = H.conv_pack(Wzc, 1)

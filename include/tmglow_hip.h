@@ -168,6 +168,16 @@ int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t n
 int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void* b, const void* db, int64_t nb, const void* kappa, void* dk,
                tmg_stream_t st);
 
+/* `ngroups` identically shaped weight-gradient contractions in one launch (the per-layer coupling convolutions of a flow
+ * level, flowAffine.py:49-55 under autograd: 15 small launches per level otherwise).  in_ptrs / in_desc / dims as
+ * tmg_conv_wgrad, describing group 0; gtab: DEVICE int64 table [ngroups][3][4] = {pointer, pixel stride, channel offset,
+ * channels} of every group's input segments; gdims = {dy channel offset between groups, dW floats between groups, dbias
+ * floats between groups}.  -100: this shape cannot be grouped, issue per-group tmg_conv_wgrad calls instead. */
+int tmg_conv_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* gtab, int64_t ngroups,
+                           const int64_t* gdims, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, void* ws,
+                           int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
+int64_t tmg_conv_wgrad_grouped_ws_floats(const int64_t* dims, int64_t ngroups);
+
 /* ---- physics-constrained reverse-KL loss (tmg_physics.hip) ------------------------------ */
 
 /* Residual sums of TMGLowLoss (trainFlowParallel.py:121-177 / physicsConstrained.py:42-94): y, target = [N,3,H,W]
