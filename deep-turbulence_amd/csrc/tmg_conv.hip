@@ -42,6 +42,7 @@ struct ConvP {
     int KCH;  // channels staged per LDS chunk (multiple of 16)
     int tiles_x, tiles_y;
     int ntiles, nchunks;  // conv_fwd_kernel only: tiles of the whole batch, channel chunks per tile
+    int ovec4;            // conv_fwd_kernel only: outputs / add operand are float4-addressable along channels
 };
 
 // MT m-tiles (16 px each) x NTW n-tiles (16 ch each) per wave; WM x WN waves per block (WM*WN == 4).
@@ -359,22 +360,25 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
             int tap = 0, kb = 0, tyy = 0, txx = 0;
             // Narrow register tiles: fetch the epilogue's `add` operand now, so that its latency hides under the MFMA loop
             // instead of stalling every tile's epilogue (the per-layer coupling convs are only a few microseconds per tile)
+            // The MFMA operands are swapped (weights as A, pixels as B): the 16x16 result tile is transposed, lane (li, q)
+            // holds channels 4q..4q+3 of pixel li, so the epilogue moves float4s along the channel axis (4x fewer store /
+            // add-load instructions and address computations than one float per lane and row).
+            // Narrow register tiles: fetch the epilogue's `add` operand now, so that its latency hides under the MFMA loop
+            // instead of stalling every tile's epilogue (the per-layer coupling convs are only a few microseconds per tile)
             constexpr bool PREADD = MT * NTW <= 8;
-            float addv[PREADD ? MT : 1][PREADD ? NTW : 1][4];
-            if (PREADD && p.add.p && cm + 1 == nchunks) {
+            float4 addv[PREADD ? MT : 1][PREADD ? NTW : 1];
+            if (PREADD && p.add.p && p.ovec4 && cm + 1 == nchunks) {
                 TMG_FW_ORIGIN(tm)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const int n = min((ntile0 + j) * 16 + li, p.Cout - 1);
+                for (int i = 0; i < MT; ++i) {
+                    const int m = (wm * MT + i) * 16 + li;
+                    const int oy = min(oy0_ + (m >> TWl), p.Hout - 1), ox = min(ox0_ + (m & (TW - 1)), p.Wout - 1);
+                    const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = (wm * MT + i) * 16 + q * 4 + r;
-                            const int oy = min(oy0_ + (m >> TWl), p.Hout - 1), ox = min(ox0_ + (m & (TW - 1)), p.Wout - 1);
-                            const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
-                            addv[PREADD ? i : 0][PREADD ? j : 0][r] = p.add.p[opx * p.add.stride + p.add.off + n];
-                        }
+                    for (int j = 0; j < NTW; ++j) {
+                        const int n0 = min((ntile0 + j) * 16 + 4 * q, p.Cout - 4);
+                        addv[PREADD ? i : 0][PREADD ? j : 0] = *reinterpret_cast<const float4*>(p.add.p + opx * p.add.stride + p.add.off + n0);
+                    }
                 }
             }
 #define TMG_FW_BODY(BC, BN)                                                                                          \
@@ -390,13 +394,13 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                 const float* wn_ = (tap == ntaps) ? wl_next : wl + tap * tap_stride + kb * kb_stride;                \
                 _Pragma("unroll") for (int j = 0; j < NTW; ++j) BN[j] = *reinterpret_cast<const float4*>(wn_ + TMG_FW_BOFF(j)); \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, BC[j].x, acc[i][j], 0, 0, 0);          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(BC[j].x, af[i].x, acc[i][j], 0, 0, 0);          \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, BC[j].y, acc[i][j], 0, 0, 0);          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(BC[j].y, af[i].y, acc[i][j], 0, 0, 0);          \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, BC[j].z, acc[i][j], 0, 0, 0);          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(BC[j].z, af[i].z, acc[i][j], 0, 0, 0);          \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, BC[j].w, acc[i][j], 0, 0, 0);          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(BC[j].w, af[i].w, acc[i][j], 0, 0, 0);          \
             }
             int it = 0;
             for (; it + 1 < niter; it += 2) {
@@ -410,32 +414,59 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
             }
 #undef TMG_FW_BODY
             if (cm + 1 == nchunks) {
-                // epilogue: C/D map of the 16x16 tile: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel)
+                // epilogue: transposed C/D map: col = lane & 15 (pixel of the m-tile), row = (lane >> 4) * 4 + r (channel)
                 TMG_FW_ORIGIN(tm)
                 const float osc = out_scale_of(p.kappa);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const int n = (ntile0 + j) * 16 + li;
-                    if (n < p.Cout) {
-                        const float bv = p.bias ? p.bias[n] : 0.f;
-                        int nl = n;
-                        TMG_PICK_OSEG(p.out, nl, op_, ostride, ooff)
-                        float* obase = op_ + ooff + nl;
+                for (int i = 0; i < MT; ++i) {
+                    const int m = (wm * MT + i) * 16 + li;
+                    const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));
+                    if (oy < p.Hout && ox < p.Wout) {
+                        const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
 #pragma unroll
-                        for (int i = 0; i < MT; ++i) {
+                        for (int j = 0; j < NTW; ++j) {
+                            const int n0 = (ntile0 + j) * 16 + 4 * q;
+                            if (n0 < p.Cout) {
+                                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                                if (p.bias) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int m = (wm * MT + i) * 16 + q * 4 + r;
-                                const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));
-                                if (oy < p.Hout && ox < p.Wout) {
-                                    const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
-                                    float v = acc[i][j][r] + bv;
-                                    if (p.add.p) v += PREADD ? addv[PREADD ? i : 0][PREADD ? j : 0][r] : p.add.p[opx * p.add.stride + p.add.off + n];
-                                    v *= osc;
-                                    if (p.relu_out) v = fmaxf(v, 0.f);
-                                    float* dst = obase + opx * ostride;
-                                    if (p.accumulate) v += *dst;
-                                    *dst = v;
+                                    for (int r = 0; r < 4; ++r) v[r] += (n0 + r < p.Cout) ? p.bias[n0 + r] : 0.f;
+                                }
+                                if (p.ovec4) {
+                                    int nl = n0;
+                                    TMG_PICK_OSEG(p.out, nl, op_, ostride, ooff)
+                                    float4* dst = reinterpret_cast<float4*>(op_ + opx * ostride + ooff + nl);
+                                    if (p.add.p) {
+                                        const float4 a4 = (PREADD) ? addv[PREADD ? i : 0][PREADD ? j : 0]
+                                                                   : *reinterpret_cast<const float4*>(p.add.p + opx * p.add.stride + p.add.off + n0);
+                                        v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+                                    }
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        v[r] *= osc;
+                                        if (p.relu_out) v[r] = fmaxf(v[r], 0.f);
+                                    }
+                                    if (p.accumulate) {
+                                        const float4 o4 = *dst;
+                                        v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
+                                    }
+                                    *dst = make_float4(v[0], v[1], v[2], v[3]);
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const int n = n0 + r;
+                                        if (n < p.Cout) {
+                                            int nl = n;
+                                            TMG_PICK_OSEG(p.out, nl, op_, ostride, ooff)
+                                            float x = v[r];
+                                            if (p.add.p) x += p.add.p[opx * p.add.stride + p.add.off + n];
+                                            x *= osc;
+                                            if (p.relu_out) x = fmaxf(x, 0.f);
+                                            float* dst = op_ + opx * ostride + ooff + nl;
+                                            if (p.accumulate) x += *dst;
+                                            *dst = x;
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -1225,6 +1256,11 @@ static int conv_fwd_lean(ConvP p, hipStream_t st) {
     if (p.stride != 1 || !p.vec4 || (p.Cin & 3) || (long)p.Hin * p.Win >= (1 << 24)) return -100;
     for (int i = 0; i < p.nseg; ++i)
         if (p.in[i].stride >= (1 << 24) || (long)p.B * p.Hin * p.Win * p.in[i].stride >= (1L << 31)) return -100;
+    // float4 epilogue: every output segment (and the add operand) addressable in channel quads
+    p.ovec4 = (p.Cout & 3) == 0;
+    for (int i = 0; i < p.nout; ++i)
+        if (((p.out[i].stride | p.out[i].off | p.out[i].n) & 3) || (((uintptr_t)p.out[i].p) & 15)) p.ovec4 = 0;
+    if (p.add.p && (((p.add.stride | p.add.off) & 3) || (((uintptr_t)p.add.p) & 15))) p.ovec4 = 0;
     const int ntt = p.Cout_pad >> 4;
     int WM, WN, NTW;
     if (ntt <= 4) { WM = 8; WN = 1; NTW = ntt; }
