@@ -1020,7 +1020,10 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
 //         wpk[tap][co/16][ci][co%16] = W[co][ci][ntaps-1-tap]
 // ---------------------------------------------------------------------------------------------
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin, int ntaps,
-                                 int Kpad, int Npad, int mode, int cvalid, int csplit, int cgap) {
+                                 int Kpad, int Npad, int mode, int cvalid, int csplit, int cgap, size_t w_bstride, size_t wpk_bstride) {
+    // blockIdx.y: weight tensor of a batch (the layers of a flow level packed in one launch)
+    w += blockIdx.y * w_bstride;
+    wpk += blockIdx.y * wpk_bstride;
     const size_t total = (size_t)ntaps * Kpad * Npad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c16 = i & 15;
@@ -1348,7 +1351,22 @@ extern "C" int tmg_conv_pack_map(const void* w, void* wpk, int64_t Cout, int64_t
     const size_t total = (size_t)ntaps * Kpad * Npad;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (float*)wpk, (int)Cout, (int)Cin, ntaps, Kpad, Npad,
-                       (int)mode, (int)map[0], (int)map[1], (int)map[2]);
+                       (int)mode, (int)map[0], (int)map[1], (int)map[2], (size_t)0, (size_t)0);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// `nbatch` equally shaped weight tensors (w + b * Cout*Cin*k*k) packed in one launch into wpk + b * taps*Kpad*Npad.
+// map = {cvalid, csplit, cgap} as tmg_conv_pack_map ({Cin, INT_MAX, 0}: identity).
+extern "C" int tmg_conv_pack_batched(const void* w, void* wpk, int64_t nbatch, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize,
+                                      int64_t mode, const int64_t* map, hipStream_t st) {
+    const int ntaps = (int)(ksize * ksize);
+    const int K = mode == 0 ? (int)cin_eff : (int)Cout, N = mode == 0 ? (int)Cout : (int)cin_eff;
+    const int Kpad = (K + 15) & ~15, Npad = (N + 15) & ~15;
+    const size_t total = (size_t)ntaps * Kpad * Npad;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, (unsigned)nbatch), dim3(256), 0, st, (const float*)w, (float*)wpk, (int)Cout, (int)Cin, ntaps,
+                       Kpad, Npad, (int)mode, (int)map[0], (int)map[1], (int)map[2], (size_t)(Cout * Cin * ntaps), total);
     TMG_CHECK_LAUNCH();
     return 0;
 }

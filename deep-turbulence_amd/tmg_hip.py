@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
+    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
 ]
 
 
@@ -161,6 +161,21 @@ def conv_pack(w, mode, cin_eff=0, cmap=None):
     Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
     wpk = torch.empty(k * k * Kp * Np, device=w.device, dtype=torch.float32)
     _chk(lib().tmg_conv_pack(_ptr(w), _ptr(wpk), c_i64(Cout), c_i64(Cin), c_i64(ce), c_i64(k), c_i64(mode), _stream()), "tmg_conv_pack")
+    return wpk
+
+
+def conv_pack_batched(w, mode, cin_eff=0, cmap=None):
+    """w: [N, Cout, Cin, k, k] -> [N, packed] (one launch); arguments as conv_pack."""
+    check_act(w)
+    w = w.contiguous()
+    N_, Cout, Cin, k, _ = w.shape
+    ce = int(cin_eff) if cmap is not None else max(int(cin_eff), Cin)
+    K, N = (ce, Cout) if mode == 0 else (Cout, ce)
+    Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
+    wpk = torch.empty((N_, k * k * Kp * Np), device=w.device, dtype=torch.float32)
+    m = cmap if cmap is not None else (Cin, 0x7fffffff, 0)
+    _chk(lib().tmg_conv_pack_batched(_ptr(w), _ptr(wpk), c_i64(N_), c_i64(Cout), c_i64(Cin), c_i64(ce), c_i64(k), c_i64(mode), _i64(*m),
+                                     _stream()), "tmg_conv_pack_batched")
     return wpk
 
 

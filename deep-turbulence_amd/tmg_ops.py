@@ -446,19 +446,19 @@ class CouplingTailFn(torch.autograd.Function):
         return dx, daux, dw1, dw2, dwz, dbz, dk, None, None
 
 
-def _mix_fwd(x, Wk, bk):
-    """y = Wk x + bk per pixel (ActNorm folded into the invertible 1x1 conv)."""
+def _mix_fwd(x, Wk, bk, packed=None):
+    """y = Wk x + bk per pixel (ActNorm folded into the invertible 1x1 conv).  packed: Wk already in operand order."""
     C = Wk.shape[0]
     y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-    H.conv_fwd([x], H.conv_pack(Wk.reshape(C, C, 1, 1), 0), C, 1, 1, [y], bias=bk)
+    H.conv_fwd([x], packed if packed is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 0), C, 1, 1, [y], bias=bk)
     return y
 
 
-def _mix_bwd(x, dy, Wk, dWk, dbk):
+def _mix_bwd(x, dy, Wk, dWk, dbk, packed_t=None):
     """Input gradient of _mix_fwd (returned) and weight / bias gradients (accumulated into dWk [C,C], dbk [C])."""
     C = Wk.shape[0]
     dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-    H.conv_fwd([dy], H.conv_pack(Wk.reshape(C, C, 1, 1), 1), C, 1, 1, [dx])
+    H.conv_fwd([dy], packed_t if packed_t is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 1), C, 1, 1, [dx])
     H.conv_wgrad([x], dy, dWk, dbk, 1, 1)
     return dx
 
@@ -505,23 +505,25 @@ class LevelCouplingFn(torch.autograd.Function):
         Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
         H.conv_fwd([cond], H.conv_pack(Wdc, 0), 2 * NLp, 3, 1, [Dc], relu_in=True)
         logdet = torch.zeros(B, device=dev, dtype=torch.float32)
+        # operand packing of every layer's weights in two launches per level instead of two per layer
+        PZ = H.conv_pack_batched(Wz, 0, ch + 4, (ch + 2, ch, Cc))
+        PM = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 0)
         saved = [None] * NL
         cur = x
         for k in (range(NL - 1, -1, -1) if reverse else range(NL)):
             xin = cur
-            tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k])
+            tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
             x1 = tin[..., :ch]
             D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
             H.c1_fwd([x1], w1s[k], D[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=Dc[..., k:k + 1])
             H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=Dc[..., NLp + k:NLp + k + 1])
             hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
-            H.conv_fwd([x1, D], H.conv_pack(wzs[k], 0, ch + 4, (ch + 2, ch, Cc)), C, 3, 1, [hh], bias=bzs[k], kappa=kps[k], relu_in=True,
-                       pad_rep=True, add=Hc[..., k * C:(k + 1) * C])
+            H.conv_fwd([x1, D], PZ[k], C, 3, 1, [hh], bias=bzs[k], kappa=kps[k], relu_in=True, pad_rep=True, add=Hc[..., k * C:(k + 1) * C])
             y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             H.masked_add(y[..., :ch], src=x1)
             r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
             H.affine_apply(hh, tin[..., ch:], y[..., ch:], r, logdet, reverse)
-            cur = _mix_fwd(y, Wm[k], bm[k]) if reverse else y
+            cur = _mix_fwd(y, Wm[k], bm[k], PM[k]) if reverse else y
             saved[k] = (xin, tin, D, r, y)
         del Hc, Dc
         ctx.saved = saved
@@ -559,11 +561,14 @@ class LevelCouplingFn(torch.autograd.Function):
         # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
         # dominated by launch / pipeline-fill).  Their inputs stay alive until then (NL * C floats per pixel).
         grouped = NL > 1 and ch + 4 <= 64 and os.environ.get("TMG_NO_GROUPED_WGRAD") is None
+        Wz = torch.stack(wzs)
+        PZt = H.conv_pack_batched(Wz, 1, ch + 4, (ch + 2, ch, Cc))          # input-gradient operands of all layers: one launch
+        PMt = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 1)
         wg_in = [None] * NL
         for k in (range(NL) if reverse else range(NL - 1, -1, -1)):
             xin, tin, D, r, y = saved[k]
             saved[k] = None
-            dto = _mix_bwd(y, dcur, Wm[k], dWm[k], dbm[k]) if reverse else dcur        # grad w.r.t. the tail output y
+            dto = _mix_bwd(y, dcur, Wm[k], dWm[k], dbm[k], PMt[k]) if reverse else dcur   # grad w.r.t. the tail output y
             dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)        # grad w.r.t. the tail input
             dhh = DH[..., k * C:(k + 1) * C]
             H.affine_bwd(dto[..., ch:], (tin if reverse else y)[..., ch:], r, g, dtin[..., ch:], dhh, reverse, kappa=kps[k])
@@ -575,12 +580,12 @@ class LevelCouplingFn(torch.autograd.Function):
                              ci_split=ch, ci_off0=0, ci_off1=Cc)
             G0 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
             GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-            wt = H.conv_pack(wzs[k], 1, ch + 4, (ch + 2, ch, Cc))
+            wt = PZt[k]
             H.conv_fwd([dhh], wt, ch + 4, 3, 1, [G0, GD])
             H.conv_rep_border_fix(dhh, wt, [G0, GD])
             H.dense2_bwd([x1, D], w1s[k], w2s[k], dW1[k], dW2[k], GD, D, [G0], [dtin[..., :ch]], ch, add0=dto[..., :ch], rows1=ch,
                          rows2=ch + 1, dd1=DD[..., k:k + 1], dd2=DD[..., NLp + k:NLp + k + 1], split2=ch, gap2=Cc)
-            dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k])
+            dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k])
             del xin, tin, D, r, y
         if grouped:
             if not H.conv_wgrad_grouped(wg_in, DH, C, dWz, dBz, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
@@ -600,7 +605,6 @@ class LevelCouplingFn(torch.autograd.Function):
         H.conv_wgrad([cond], DD[..., :NL], dW1, None, 3, 1, relu_in=True, cin_dst=cin, cin_valid=Cc, ci_off0=ch)
         H.conv_wgrad([cond], DD[..., NLp:NLp + NL], dW2, None, 3, 1, relu_in=True, cin_dst=cin + 1, cin_valid=Cc, ci_off0=ch)
         # d(kappa_k) = <wz_k, dwz_k> + <bz_k, dbz_k> inside the clamp range (homogeneity of the zero conv in (W, b))
-        Wz = torch.stack(wzs)
         Kp = torch.stack([kp.reshape(()) for kp in kps])
         dK = ((Wz * dWz).flatten(1).sum(1) + (torch.stack(bzs) * dBz).sum(1)) * ((Kp >= -4.0) & (Kp <= LOG4)).to(torch.float32)
         grads = []

@@ -168,6 +168,11 @@ int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t n
 int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void* b, const void* db, int64_t nb, const void* kappa, void* dk,
                tmg_stream_t st);
 
+/* `nbatch` equally shaped weight tensors (w + b*Cout*Cin*k*k floats) packed in one launch into wpk + b*taps*Kpad*Npad
+ * floats; map = {cvalid, csplit, cgap} as tmg_conv_pack_map. */
+int tmg_conv_pack_batched(const void* w, void* wpk, int64_t nbatch, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize,
+                          int64_t mode, const int64_t* map, tmg_stream_t st);
+
 /* `ngroups` identically shaped weight-gradient contractions in one launch (the per-layer coupling convolutions of a flow
  * level, flowAffine.py:49-55 under autograd: 15 small launches per level otherwise).  in_ptrs / in_desc / dims as
  * tmg_conv_wgrad, describing group 0; gtab: DEVICE int64 table [ngroups][3][4] = {pointer, pixel stride, channel offset,
