@@ -26,7 +26,9 @@ static inline int grid_for(size_t n, int cap = 4096) {
 // hh: [npix][C] interleaved (shift_j, r_j).  x2 -> y2 over C/2 channels.  logdet[b] += sum 2*softsign(r).
 __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ hh, int hs, int ho, const float* x2, int xs,
                                                            int xo, float* y2, int ys, int yo, float* __restrict__ rsave,
-                                                           float* __restrict__ logdet, int pix_per_img, int Ch, int reverse, int vec) {
+                                                           float* __restrict__ logdet, int pix_per_img, int Ch, int reverse, int vec,
+                                                           const float* x1, int x1s, float* y1, int y1s) {
+    // x1 / y1 (optional): the pass-through half of the coupling, copied here instead of in a launch of its own
     __shared__ float red[4];
     const int b = blockIdx.y;
     const size_t base = (size_t)b * pix_per_img;
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
             }
             *reinterpret_cast<float4*>(y2 + pix * ys + yo + j) = make_float4(oo[0], oo[1], oo[2], oo[3]);
             if (rsave) *reinterpret_cast<float4*>(rsave + pix * Ch + j) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+            if (y1) *reinterpret_cast<float4*>(y1 + pix * y1s + j) = *reinterpret_cast<const float4*>(x1 + pix * x1s + j);
         }
     } else
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
         else out = (xv + h2.x) * expf(sg);
         y2[pix * ys + yo + j] = out;
         if (rsave) rsave[pix * Ch + j] = r;
+        if (y1) y1[pix * y1s + j] = x1[pix * x1s + j];
         ld += sg;
     }
     const float tot = block_sum_256(ld, red);
@@ -862,20 +866,29 @@ extern "C" int tmg_c1_fwd_add(const void* const* in_ptrs, const int64_t* in_desc
 // C ABI
 // ---------------------------------------------------------------------------------------------
 // dims: [B, pix_per_img, Ch, reverse]; each *_d = [stride, off]
-extern "C" int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2,
-                                const int64_t* y_d, void* rsave, void* logdet, const int64_t* dims, hipStream_t st) {
+// As tmg_affine_apply; additionally copies the Ch pass-through channels x1 -> y1 (x1_d / y1_d = [pixel stride, 0]) in the
+// same pass (the reference's cat(x1, x2') at flowAffine.py:83,109).  x1 == null: no copy.
+extern "C" int tmg_affine_apply_pass(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2,
+                                     const int64_t* y_d, void* rsave, void* logdet, const void* x1, const int64_t* x1_d, void* y1,
+                                     const int64_t* y1_d, const int64_t* dims, hipStream_t st) {
     const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
-    const int vec = ((Ch & 3) == 0) && (((hh_d[0] | hh_d[1] | x_d[0] | x_d[1] | y_d[0] | y_d[1]) & 3) == 0) &&
-                    (((((uintptr_t)hh) | ((uintptr_t)x2) | ((uintptr_t)y2) | ((uintptr_t)rsave)) & 15) == 0);
+    int vec = ((Ch & 3) == 0) && (((hh_d[0] | hh_d[1] | x_d[0] | x_d[1] | y_d[0] | y_d[1]) & 3) == 0) &&
+              (((((uintptr_t)hh) | ((uintptr_t)x2) | ((uintptr_t)y2) | ((uintptr_t)rsave)) & 15) == 0);
+    if (x1 && (((x1_d[0] | y1_d[0]) & 3) || ((((uintptr_t)x1) | ((uintptr_t)y1)) & 15))) vec = 0;
     const size_t per = (size_t)ppi * (vec ? Ch / 4 : Ch);
     int gx = (int)((per + 1023) / 1024);  // >= 4 items per thread
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(affine_apply_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)hh, (int)hh_d[0], (int)hh_d[1],
                        (const float*)x2, (int)x_d[0], (int)x_d[1], (float*)y2, (int)y_d[0], (int)y_d[1], (float*)rsave, (float*)logdet,
-                       ppi, Ch, (int)dims[3], vec);
+                       ppi, Ch, (int)dims[3], vec, (const float*)x1, x1 ? (int)x1_d[0] : 0, x1 ? (float*)y1 : nullptr, x1 ? (int)y1_d[0] : 0);
     TMG_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2,
+                                const int64_t* y_d, void* rsave, void* logdet, const int64_t* dims, hipStream_t st) {
+    return tmg_affine_apply_pass(hh, hh_d, x2, x_d, y2, y_d, rsave, logdet, nullptr, nullptr, nullptr, nullptr, dims, st);
 }
 
 extern "C" int tmg_affine_bwd(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,

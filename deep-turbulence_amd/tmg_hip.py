@@ -26,7 +26,7 @@ c_vp = ctypes.c_void_p
 
 EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
-    "tmg_affine_apply", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
+    "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
 ]
@@ -322,10 +322,16 @@ def conv_dgrad_direct(dy, w, dx, ksize, stride, accumulate=False):
 # ------------------------------------------------------------------------------------------------
 # bandwidth-bound ops
 # ------------------------------------------------------------------------------------------------
-def affine_apply(hh, x2, y2, rsave, logdet, reverse):
+def affine_apply(hh, x2, y2, rsave, logdet, reverse, x1=None, y1=None):
+    """x1 / y1 (optional, Ch channels each): pass-through half copied in the same launch."""
     B, H, W, Ch = x2.shape
-    _chk(lib().tmg_affine_apply(_ptr(hh), _d2(hh), _ptr(x2), _d2(x2), _ptr(y2), _d2(y2), _ptr(rsave), _ptr(logdet),
-                                _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_apply")
+    if x1 is None:
+        _chk(lib().tmg_affine_apply(_ptr(hh), _d2(hh), _ptr(x2), _d2(x2), _ptr(y2), _d2(y2), _ptr(rsave), _ptr(logdet),
+                                    _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_apply")
+    else:
+        assert x1.shape == x2.shape and y1.shape == x2.shape
+        _chk(lib().tmg_affine_apply_pass(_ptr(hh), _d2(hh), _ptr(x2), _d2(x2), _ptr(y2), _d2(y2), _ptr(rsave), _ptr(logdet), _ptr(x1),
+                                         _d2(x1), _ptr(y1), _d2(y1), _i64(B, H * W, Ch, reverse), _stream()), "tmg_affine_apply_pass")
 
 
 def affine_bwd(gout, yref, rsave, g, gin, dhh, reverse, kappa=None):

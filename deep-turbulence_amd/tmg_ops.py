@@ -520,9 +520,8 @@ class LevelCouplingFn(torch.autograd.Function):
             hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             H.conv_fwd([x1, D], PZ[k], C, 3, 1, [hh], bias=bzs[k], kappa=kps[k], relu_in=True, pad_rep=True, add=Hc[..., k * C:(k + 1) * C])
             y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
-            H.masked_add(y[..., :ch], src=x1)
             r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
-            H.affine_apply(hh, tin[..., ch:], y[..., ch:], r, logdet, reverse)
+            H.affine_apply(hh, tin[..., ch:], y[..., ch:], r, logdet, reverse, x1=x1, y1=y[..., :ch])
             cur = _mix_fwd(y, Wm[k], bm[k], PM[k]) if reverse else y
             saved[k] = (xin, tin, D, r, y)
         del Hc, Dc

@@ -98,6 +98,11 @@ int tmg_prof_collect(double* out, int64_t nk);
  * dims = {B, pixels per image, C/2, reverse} */
 int tmg_affine_apply(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2, const int64_t* y_d,
                      void* rsave, void* logdet, const int64_t* dims, tmg_stream_t st);
+/* As tmg_affine_apply; also copies the Ch pass-through channels x1 -> y1 (x1_d / y1_d = {pixel stride, 0}) in the same pass
+ * (the reference's cat(x1, x2') at flowAffine.py:83,109); x1 == NULL: no copy. */
+int tmg_affine_apply_pass(const void* hh, const int64_t* hh_d, const void* x2, const int64_t* x_d, void* y2, const int64_t* y_d,
+                          void* rsave, void* logdet, const void* x1, const int64_t* x1_d, void* y1, const int64_t* y1_d,
+                          const int64_t* dims, tmg_stream_t st);
 int tmg_affine_bwd(const void* gout, const int64_t* go_d, const void* yref, const int64_t* yr_d, const void* rsave,
                    const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d, const int64_t* dims,
                    tmg_stream_t st);
