@@ -519,7 +519,7 @@ struct WgradP {
     int fstage;  // 1: every segment / dy is float4-addressable and offsets fit 24-bit multiplies -> lean staging path
     // grouped launch (tmg_conv_wgrad_grouped): group g = blockIdx.y / bpg reads its own input segments from gtab[g],
     // dy channels [g*dy_goff, +Cout) and writes dW + g*dw_gstride / dbias + g*db_gstride; null: one group
-    const long long* gtab;  // device: [ngroups][3][4] = {pointer, pixel stride, channel offset, channels}
+    const long long* gtab;  // device: [ngroups][4][4]: 3 input segments {pointer, pixel stride, channel offset, channels} + {dy pointer (0: shared dy), dy pixel stride, 0, 0}
     int bpg, dy_goff;
     long long dw_gstride;
     int db_gstride;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
             const float* sp1 = p.in[1].p; int ss1 = p.in[1].stride, so1 = p.in[1].off, sn1 = p.in[1].n;
             const float* sp2 = p.in[2].p; int ss2 = p.in[2].stride, so2 = p.in[2].off;
             if (p.gtab) {
-                const long long* gt = p.gtab + (size_t)grp * 12;
+                const long long* gt = p.gtab + (size_t)grp * 16;
                 sp0 = reinterpret_cast<const float*>(gt[0]); ss0 = (int)gt[1]; so0 = (int)gt[2]; sn0 = (int)gt[3];
                 sp1 = reinterpret_cast<const float*>(gt[4]); ss1 = (int)gt[5]; so1 = (int)gt[6]; sn1 = (int)gt[7];
                 sp2 = reinterpret_cast<const float*>(gt[8]); ss2 = (int)gt[9]; so2 = (int)gt[10];
@@ -713,8 +713,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     const int dc4 = tid & (NCO * 4 - 1), dm0 = tid >> DL;
     constexpr int dstep = NT >> DL;
     const bool dcv = co0 + 4 * dc4 < p.Cout;
-    const float* dptr = dcv ? p.dy.p + p.dy.off + grp * p.dy_goff + co0 + 4 * dc4 : g_tmg_zero_page;
-    const int dss = dcv ? p.dy.stride : 0;
+    // dy of this group: a channel slice of the shared tensor, or the group's own tensor (table row 3)
+    const float* dyb = p.dy.p + p.dy.off + grp * p.dy_goff;
+    int dys = p.dy.stride;
+    if (p.gtab && p.gtab[(size_t)grp * 16 + 12]) {
+        dyb = reinterpret_cast<const float*>(p.gtab[(size_t)grp * 16 + 12]);
+        dys = (int)p.gtab[(size_t)grp * 16 + 13];
+    }
+    const float* dptr = dcv ? dyb + co0 + 4 * dc4 : g_tmg_zero_page;
+    const int dss = dcv ? dys : 0;
     const unsigned ddst0 = 4u * (ldy_w + ((dc4 >> 2) * MPIX + dm0) * 16 + (dc4 & 3) * 4);
     unsigned oobm = 0;  // per-item out-of-image bits (only maintained when an input affine must not touch padding)
     float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1676,9 +1683,9 @@ extern "C" int tmg_conv_wgrad(const void* const* in_ptrs, const int64_t* in_desc
 
 // `ngroups` identically shaped weight-gradient contractions in ONE launch (the per-layer coupling convolutions of a flow
 // level: 15 launches of a few microseconds of MFMA work each otherwise).  in_ptrs / in_desc describe group 0 (geometry,
-// alignment); gtab is a DEVICE table [ngroups][3][4] of int64 {pointer, pixel stride, channel offset, channels} with every
-// group's input segments.  Group g reads dy channels [g*gdims[0], +Cout), accumulates into dW + g*gdims[1] floats and
-// dbias + g*gdims[2] floats.  Returns -100 when the shape cannot be grouped (caller issues per-group launches).
+// alignment); gtab is a DEVICE table [ngroups][4][4] of int64: rows 0-2 {pointer, pixel stride, channel offset, channels} of the
+// group's input segments, row 3 {dy pointer, dy pixel stride, 0, 0} or zeros.  Group g reads its own dy (row 3) or dy channels
+// [g*gdims[0], +Cout) of the shared tensor, accumulates into dW + g*gdims[1] floats and dbias + g*gdims[2] floats.  Returns -100 when the shape cannot be grouped (caller issues per-group launches).
 // ws must hold tmg_conv_wgrad_grouped_ws_floats(dims, ngroups) floats.
 extern "C" int tmg_conv_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* gtab,
                                       int64_t ngroups, const int64_t* gdims, const void* dy, const int64_t* dy_desc, void* dW,

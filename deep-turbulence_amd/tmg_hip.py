@@ -272,10 +272,14 @@ def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, 
 
 
 def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, stride, relu_in=False, pad_rep=False, cin_dst=0,
-                       cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0):
+                       cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0, group_dy=None):
     """One launch for len(group_inputs) identically shaped weight gradients.  group_inputs[g]: list of <= 3 NHWC segments;
-    dy: [B,H,W,>= G*Cg] with group g at channels [g*Cg, (g+1)*Cg); dW: [G, Cg, cin_dst, k, k] contiguous; dbias: [G, Cg] or
-    None.  Returns False when the library cannot group this shape (nothing was launched)."""
+    dy: [B,H,W,>= G*Cg] with group g at channels [g*Cg, (g+1)*Cg), or None with group_dy = list of G tensors [B,H,W,Cg]
+    of identical layout; dW: [G, Cg, cin_dst, k, k] contiguous; dbias: [G, Cg] or None.  Returns False when the library
+    cannot group this shape (nothing was launched)."""
+    if dy is None:
+        dy = group_dy[0]
+        assert all(t.shape == dy.shape and t.stride() == dy.stride() for t in group_dy)
     G = len(group_inputs)
     first = group_inputs[0]
     B, Hin, Win, _ = first[0].shape
@@ -290,6 +294,7 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
         for t in segs:
             row += list(seg(t))  # (pointer incl. the view's channel offset, pixel stride, 0, channels)
         row += [0, 0, 0, 0] * (3 - n_in)
+        row += ([seg(group_dy[len(rows)])[0], seg(group_dy[len(rows)])[1], 0, 0] if group_dy is not None else [0, 0, 0, 0])
         rows.append(row)
     gtab = torch.tensor(rows, dtype=torch.int64).to(dy.device, non_blocking=True)
     dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cg, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)

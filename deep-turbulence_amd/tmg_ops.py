@@ -454,12 +454,16 @@ def _mix_fwd(x, Wk, bk, packed=None):
     return y
 
 
-def _mix_bwd(x, dy, Wk, dWk, dbk, packed_t=None):
-    """Input gradient of _mix_fwd (returned) and weight / bias gradients (accumulated into dWk [C,C], dbk [C])."""
+def _mix_bwd(x, dy, Wk, dWk, dbk, packed_t=None, defer=None):
+    """Input gradient of _mix_fwd (returned) and weight / bias gradients (accumulated into dWk [C,C], dbk [C]).
+    defer: list collecting (x, dy) instead - the caller runs the weight gradients of a whole level as one grouped launch."""
     C = Wk.shape[0]
     dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     H.conv_fwd([dy], packed_t if packed_t is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 1), C, 1, 1, [dx])
-    H.conv_wgrad([x], dy, dWk, dbk, 1, 1)
+    if defer is not None:
+        defer.append((x, dy))
+    else:
+        H.conv_wgrad([x], dy, dWk, dbk, 1, 1)
     return dx
 
 
@@ -564,10 +568,12 @@ class LevelCouplingFn(torch.autograd.Function):
         PZt = H.conv_pack_batched(Wz, 1, ch + 4, (ch + 2, ch, Cc))          # input-gradient operands of all layers: one launch
         PMt = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 1)
         wg_in = [None] * NL
+        mix_wg = [None] * NL if grouped else None   # (input, upstream gradient) of every layer's 1x1 mix
         for k in (range(NL) if reverse else range(NL - 1, -1, -1)):
             xin, tin, D, r, y = saved[k]
             saved[k] = None
-            dto = _mix_bwd(y, dcur, Wm[k], dWm[k], dbm[k], PMt[k]) if reverse else dcur   # grad w.r.t. the tail output y
+            mdef = [] if grouped else None
+            dto = _mix_bwd(y, dcur, Wm[k], dWm[k], dbm[k], PMt[k], mdef) if reverse else dcur   # grad w.r.t. the tail output y
             dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)        # grad w.r.t. the tail input
             dhh = DH[..., k * C:(k + 1) * C]
             H.affine_bwd(dto[..., ch:], (tin if reverse else y)[..., ch:], r, g, dtin[..., ch:], dhh, reverse, kappa=kps[k])
@@ -584,7 +590,9 @@ class LevelCouplingFn(torch.autograd.Function):
             H.conv_rep_border_fix(dhh, wt, [G0, GD])
             H.dense2_bwd([x1, D], w1s[k], w2s[k], dW1[k], dW2[k], GD, D, [G0], [dtin[..., :ch]], ch, add0=dto[..., :ch], rows1=ch,
                          rows2=ch + 1, dd1=DD[..., k:k + 1], dd2=DD[..., NLp + k:NLp + k + 1], split2=ch, gap2=Cc)
-            dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k])
+            dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k], mdef)
+            if grouped:
+                mix_wg[k] = mdef[0]
             del xin, tin, D, r, y
         if grouped:
             if not H.conv_wgrad_grouped(wg_in, DH, C, dWz, dBz, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
@@ -593,6 +601,11 @@ class LevelCouplingFn(torch.autograd.Function):
                     H.conv_wgrad(wg_in[k], DH[..., k * C:(k + 1) * C], dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2,
                                  cin_valid=ch + 2, ci_split=ch, ci_off0=0, ci_off1=Cc)
             wg_in = None
+            # the 1x1 mix weight gradients of all layers: same trick, every group with its own upstream gradient tensor
+            if not H.conv_wgrad_grouped([[a] for a, _ in mix_wg], None, C, dWm.view(NL, C, C, 1, 1), dbm, 1, 1, group_dy=[g_ for _, g_ in mix_wg]):
+                for k in range(NL):
+                    H.conv_wgrad([mix_wg[k][0]], mix_wg[k][1], dWm[k], dbm[k], 1, 1)
+            mix_wg = None
         # conditioning side of the whole level: one input-gradient pass, three weight-gradient passes
         Gc = torch.empty(cond.shape, device=dev, dtype=torch.float32)
         wzc_t = H.conv_pack(Wzc, 1)

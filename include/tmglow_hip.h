@@ -180,8 +180,8 @@ int tmg_conv_pack_batched(const void* w, void* wpk, int64_t nbatch, int64_t Cout
 
 /* `ngroups` identically shaped weight-gradient contractions in one launch (the per-layer coupling convolutions of a flow
  * level, flowAffine.py:49-55 under autograd: 15 small launches per level otherwise).  in_ptrs / in_desc / dims as
- * tmg_conv_wgrad, describing group 0; gtab: DEVICE int64 table [ngroups][3][4] = {pointer, pixel stride, channel offset,
- * channels} of every group's input segments; gdims = {dy channel offset between groups, dW floats between groups, dbias
+ * tmg_conv_wgrad, describing group 0; gtab: DEVICE int64 table [ngroups][4][4]: rows 0-2 = {pointer, pixel stride, channel
+ * offset, channels} of the group's input segments, row 3 = {dy pointer, dy pixel stride, 0, 0} or zeros (shared dy); gdims = {dy channel offset between groups, dW floats between groups, dbias
  * floats between groups}.  -100: this shape cannot be grouped, issue per-group tmg_conv_wgrad calls instead. */
 int tmg_conv_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* gtab, int64_t ngroups,
                            const int64_t* gdims, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, void* ws,
