@@ -339,24 +339,41 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
                                                           int gs, int go, const float* __restrict__ v0, const float* __restrict__ v1,
                                                           const float* __restrict__ v2, const float* __restrict__ v3,
                                                           float* __restrict__ s0, float* __restrict__ s1, size_t npix, int C,
-                                                          int mode) {
+                                                          int mode, float v0_scale) {
+    // mode 0: s0 += sum (x - v0*v0_scale), s1 += sum (x - v0*v0_scale)^2   (v0 null: plain sums; v0 = channel sums and
+    //         v0_scale = 1/n: centred second pass without a separate mean kernel)
+    // mode 1: BatchNorm+ReLU backward sums (see bn_bwd_apply_kernel)
     __shared__ float l0[256], l1[256];
     const int tid = threadIdx.x;
     const int lanes = 256 / C > 0 ? 256 / C : 1;  // pixel lanes per block (C <= 256)
     const int c = tid % C, pl = tid / C;
     float a0 = 0.f, a1 = 0.f;
     if (pl < lanes) {
-        for (size_t pix = blockIdx.x * (size_t)lanes + pl; pix < npix; pix += (size_t)gridDim.x * lanes) {
-            const float xv = x[pix * xs + xo + c];
-            if (mode == 0) {
-                const float d = xv - (v0 ? v0[c] : 0.f);
-                a0 += d;
-                a1 += d * d;
-            } else {
-                const float u = xv * v0[c] + v1[c];
-                const float du = u > 0.f ? g[pix * gs + go + c] : 0.f;
-                a0 += du;
-                a1 += du * (xv - v2[c]) * v3[c];
+        const float off = (mode == 0 && v0) ? v0[c] * v0_scale : 0.f;
+        const size_t step = (size_t)gridDim.x * lanes;
+        // four pixels per iteration: the loads are independent, a one-pixel loop is a chain of exposed latencies
+        for (size_t pix = blockIdx.x * (size_t)lanes + pl; pix < npix; pix += 4 * step) {
+            float xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t pp = pix + u * step < npix ? pix + u * step : pix;
+                xv[u] = x[pp * xs + xo + c];
+                gv[u] = (mode != 0) ? g[pp * gs + go + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (pix + u * step < npix) {
+                    if (mode == 0) {
+                        const float d = xv[u] - off;
+                        a0 += d;
+                        a1 += d * d;
+                    } else {
+                        const float uu = xv[u] * v0[c] + v1[c];
+                        const float du = uu > 0.f ? gv[u] : 0.f;
+                        a0 += du;
+                        a1 += du * (xv[u] - v2[c]) * v3[c];
+                    }
+                }
             }
         }
     }
@@ -374,13 +391,35 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
     }
 }
 
+// Batch statistics -> everything the BatchNorm(+ReLU) fold needs, in one launch of C threads:
+//   mean = sum/n, var = centred_sq/n (biased), rstd, a = gamma*rstd, bsh = beta - mean*a  -> out[0..4][C]
+//   running_mean / running_var (optional) updated in place with `momentum`, the variance unbiased (n/(n-1)) as nn.BatchNorm2d.
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ csq, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ out, int C, float n, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = sum[c] / n, var = csq[c] / n;
+    const float rstd = rsqrtf(var + eps);
+    const float a = gamma[c] * rstd;
+    out[c] = mean;
+    out[C + c] = var;
+    out[2 * C + c] = rstd;
+    out[3 * C + c] = a;
+    out[4 * C + c] = beta[c] - mean * a;
+    if (rmean) {
+        rmean[c] = rmean[c] * (1.f - momentum) + momentum * mean;
+        rvar[c] = rvar[c] * (1.f - momentum) + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    }
+}
+
 // BatchNorm(+ReLU) input gradient:  u = x*a_c + b_c,  du = g*[u>0],
 //   dx = gamma_c * rstd_c * (du - m0_c - xhat * m1_c)     (m0 = mean du, m1 = mean du*xhat)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int xs, int xo, const float* __restrict__ g, int gs, int go,
                                     const float* __restrict__ a, const float* __restrict__ bsh, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ m0,
                                     const float* __restrict__ m1, float* __restrict__ dx, int ds, int dof, size_t npix, int C,
-                                    int accumulate) {
+                                    int accumulate, float m_scale) {
     const size_t total = npix * C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i / C;
@@ -389,7 +428,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int xs, int xo,
         const float u = xv * a[c] + bsh[c];
         const float du = u > 0.f ? g[pix * gs + go + c] : 0.f;
         const float xh = (xv - mean[c]) * rstd[c];
-        const float v = gamma[c] * rstd[c] * (du - m0[c] - xh * m1[c]);
+        const float v = gamma[c] * rstd[c] * (du - m0[c] * m_scale - xh * m1[c] * m_scale);
         float* d = dx + pix * ds + dof + c;
         *d = accumulate ? (*d + v) : v;
     }
@@ -986,7 +1025,7 @@ extern "C" int tmg_upsample_bwd(const void* dout, void* din, const int64_t* dims
     return 0;
 }
 
-// dims: [npix, C, mode]; s0/s1 accumulate (caller zeroes); C <= 256
+// dims: [npix, C, mode, divisor]; s0/s1 accumulate (caller zeroes); C <= 256
 extern "C" int tmg_chan_reduce(const void* x, const int64_t* x_d, const void* g, const int64_t* g_d, const void* v0, const void* v1,
                                const void* v2, const void* v3, void* s0, void* s1, const int64_t* dims, hipStream_t st) {
     const size_t npix = (size_t)dims[0];
@@ -999,7 +1038,7 @@ extern "C" int tmg_chan_reduce(const void* x, const int64_t* x_d, const void* g,
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(chan_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (int)x_d[0], (int)x_d[1],
                        (const float*)g, g ? (int)g_d[0] : 0, g ? (int)g_d[1] : 0, (const float*)v0, (const float*)v1, (const float*)v2,
-                       (const float*)v3, (float*)s0, (float*)s1, npix, C, (int)dims[2]);
+                       (const float*)v3, (float*)s0, (float*)s1, npix, C, (int)dims[2], dims[3] > 0 ? 1.0f / (float)dims[3] : 1.0f);
     TMG_CHECK_LAUNCH();
     return 0;
 }
@@ -1013,7 +1052,17 @@ extern "C" int tmg_bn_bwd_apply(const void* x, const int64_t* x_d, const void* g
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, st, (const float*)x, (int)x_d[0], (int)x_d[1],
                        (const float*)g, (int)g_d[0], (int)g_d[1], (const float*)a, (const float*)bsh, (const float*)mean,
                        (const float*)rstd, (const float*)gamma, (const float*)m0, (const float*)m1, (float*)dx, (int)dx_d[0],
-                       (int)dx_d[1], npix, C, (int)dims[2]);
+                       (int)dx_d[1], npix, C, (int)dims[2], dims[3] > 0 ? 1.0f / (float)dims[3] : 1.0f);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [C, n]; fl: {eps, momentum}; rmean / rvar may be null; out: [5][C] = mean, var, rstd, a, bsh (see bn_finalize_kernel)
+extern "C" int tmg_bn_finalize(const void* sum, const void* csq, const void* gamma, const void* beta, void* rmean, void* rvar, void* out,
+                               const int64_t* dims, const float* fl, hipStream_t st) {
+    const int C = (int)dims[0];
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)sum, (const float*)csq, (const float*)gamma,
+                       (const float*)beta, (float*)rmean, (float*)rvar, (float*)out, C, (float)dims[1], fl[0], fl[1]);
     TMG_CHECK_LAUNCH();
     return 0;
 }

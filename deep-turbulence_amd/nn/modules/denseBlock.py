@@ -27,17 +27,16 @@ class _DenseLayer(nn.Sequential):
         """xn: NHWC tensor or channel-slice view; returns the growth_rate new channels (NHWC)."""
         bn = self.norm1
         if self.training or not bn.track_running_stats:
-            mean, var, n = ops.batch_moments(xn.detach())
-            if bn.track_running_stats:
-                with torch.no_grad():
-                    m = bn.momentum
-                    bn.num_batches_tracked += 1
-                    bn.running_mean.mul_(1 - m).add_(m * mean)
-                    bn.running_var.mul_(1 - m).add_(m * var * (n / max(n - 1, 1)))
+            mean, rstd, a, bsh = ops.bn_batch_stats(xn.detach(), bn)
+            # a / bsh carry no autograd history: BNReLUConvFn's hand-written backward returns d(gamma), d(beta) itself
             training = True
         else:
-            mean, var, training = bn.running_mean, bn.running_var, False
-        return ops.BNReLUConvFn.apply(xn, bn.weight, bn.bias, self.conv1.weight, mean, var, bn.eps, training)
+            mean = bn.running_mean
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+            a = bn.weight.detach() * rstd
+            bsh = bn.bias.detach() - mean * a
+            training = False
+        return ops.BNReLUConvFn.apply(xn, bn.weight, bn.bias, self.conv1.weight, mean, rstd, a, bsh, training)
 
     def forward(self, x):
         xn = H.nhwc(x)

@@ -26,7 +26,7 @@ c_vp = ctypes.c_void_p
 
 EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
-    "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
+    "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
 ]
@@ -403,17 +403,26 @@ def upsample_bwd(dout, din):
     _chk(lib().tmg_upsample_bwd(_ptr(dout), _ptr(din), _i64(B, hi, wi, ho, wo, C), _stream()), "tmg_upsample_bwd")
 
 
-def chan_reduce(x, g, v0, v1, v2, v3, s0, s1, mode):
+def chan_reduce(x, g, v0, v1, v2, v3, s0, s1, mode, divisor=0):
+    """mode 0 with divisor > 0: v0 holds channel SUMS and v0/divisor is subtracted (centred second pass)."""
     B, H, W, C = x.shape
     gd = _d2(g) if g is not None else _i64(0, 0)
     _chk(lib().tmg_chan_reduce(_ptr(x), _d2(x), _ptr(g), gd, _ptr(v0), _ptr(v1), _ptr(v2), _ptr(v3), _ptr(s0), _ptr(s1),
-                               _i64(B * H * W, C, mode), _stream()), "tmg_chan_reduce")
+                               _i64(B * H * W, C, mode, divisor), _stream()), "tmg_chan_reduce")
 
 
-def bn_bwd_apply(x, g, a, bsh, mean, rstd, gamma, m0, m1, dx, accumulate):
+def bn_bwd_apply(x, g, a, bsh, mean, rstd, gamma, m0, m1, dx, accumulate, divisor=0):
+    """divisor > 0: m0, m1 are sums and are divided by it inside the kernel."""
     B, H, W, C = x.shape
     _chk(lib().tmg_bn_bwd_apply(_ptr(x), _d2(x), _ptr(g), _d2(g), _ptr(a), _ptr(bsh), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(m0),
-                                _ptr(m1), _ptr(dx), _d2(dx), _i64(B * H * W, C, accumulate), _stream()), "tmg_bn_bwd_apply")
+                                _ptr(m1), _ptr(dx), _d2(dx), _i64(B * H * W, C, accumulate, divisor), _stream()), "tmg_bn_bwd_apply")
+
+
+def bn_finalize(sums, csq, gamma, beta, running_mean, running_var, out, n, eps, momentum):
+    """out: [5, C] = mean, var, rstd, a, bsh; running_* (or None) updated in place."""
+    C = gamma.numel()
+    _chk(lib().tmg_bn_finalize(_ptr(sums), _ptr(csq), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(out), _i64(C, n),
+                               _flts([eps, momentum]), _stream()), "tmg_bn_finalize")
 
 
 def masked_add(dst, src=None, ref=None, add=None, accumulate=False):

@@ -98,12 +98,10 @@ class BNReLUConvFn(torch.autograd.Function):
     normalisation folded into the conv's input staging as a per-channel affine."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, mean, var, eps, training):
-        # mean / var: batch moments (training) or running moments (eval), computed by the caller
+    def forward(ctx, x, gamma, beta, weight, mean, rstd, a, bsh, training):
+        # mean / rstd and the folded affine a = gamma*rstd, bsh = beta - mean*a come from bn_batch_stats (training: batch
+        # moments, one fused kernel) or from the running moments (eval)
         x = x if x.stride(3) == 1 else x.contiguous()
-        rstd = torch.rsqrt(var + eps)
-        a = gamma * rstd
-        bsh = beta - mean * a
         B, Hh, Ww, _ = x.shape
         Cout = weight.shape[0]
         out = torch.empty((B, Hh, Ww, Cout), device=x.device, dtype=torch.float32)
@@ -124,17 +122,36 @@ class BNReLUConvFn(torch.autograd.Function):
         wpk_t = H.conv_pack(weight, 1)
         G = torch.empty((B, Hh, Ww, C), device=x.device, dtype=torch.float32)
         H.conv_fwd([dy], wpk_t, C, 3, 1, [G])
-        s0 = torch.zeros(C, device=x.device)
-        s1 = torch.zeros(C, device=x.device)
+        s = torch.zeros((3, C), device=x.device)  # sums of du, du*xhat, and a zero row for the eval-mode call
+        s0, s1 = s[0], s[1]
         H.chan_reduce(x, G, a, bsh, mean, rstd, s0, s1, 1)
         dgamma, dbeta = s1, s0
         dx = torch.empty((B, Hh, Ww, C), device=x.device, dtype=torch.float32)
         if ctx.training:
-            H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, s0 / n, s1 / n, dx, False)
+            H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, s0, s1, dx, False, divisor=n)
         else:
-            z = torch.zeros_like(s0)
-            H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, z, z, dx, False)
-        return dx, dgamma, dbeta, dW, None, None, None, None
+            H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, s[2], s[2], dx, False)
+        return dx, dgamma, dbeta, dW, None, None, None, None, None
+
+
+def bn_batch_stats(x, bn):
+    """Training-mode statistics of nn.BatchNorm2d `bn` on an NHWC tensor / channel-slice view: two-pass moments (sums, then
+    centred squares), then ONE kernel for mean, var, rstd, the folded affine and the momentum update of the running
+    statistics (the ~15 element-wise torch ops this replaces were ~40 % of the step's small launches).
+    -> (mean, rstd, a, bsh), each [C]."""
+    B, Hh, Ww, C = x.shape
+    n = B * Hh * Ww
+    acc = torch.zeros((4, C), device=x.device)
+    H.chan_reduce(x, None, None, None, None, None, acc[0], acc[1], 0)
+    H.chan_reduce(x, None, acc[0], None, None, None, acc[2], acc[3], 0, divisor=n)
+    out = torch.empty((5, C), device=x.device)
+    track = bn.track_running_stats
+    with torch.no_grad():
+        H.bn_finalize(acc[0], acc[3], bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
+                      bn.running_var if track else None, out, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+        if track:
+            bn.num_batches_tracked += 1
+    return out[0], out[2], out[3], out[4]
 
 
 def batch_moments(x):

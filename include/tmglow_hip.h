@@ -136,12 +136,18 @@ int tmg_upsample_fwd(const void* src, void* dst, const int64_t* dims, tmg_stream
 int tmg_upsample_bwd(const void* dout, void* din, const int64_t* dims, tmg_stream_t st);
 
 /* Per-channel sums over pixels: BatchNorm batch moments (mode 0) and backward sums (mode 1)
- * (nn.BatchNorm2d at denseBlock.py:49).  dims = {npix, C, mode} */
+ * (nn.BatchNorm2d at denseBlock.py:49).  dims = {npix, C, mode, divisor}: mode 0 subtracts v0[c]/divisor before summing
+ * (divisor 0: v0 as is) - the centred second pass takes the first pass's sums directly.  tmg_bn_bwd_apply: dims = {npix, C,
+ * accumulate, divisor} with m0, m1 divided by divisor. */
 int tmg_chan_reduce(const void* x, const int64_t* x_d, const void* g, const int64_t* g_d, const void* v0, const void* v1,
                     const void* v2, const void* v3, void* s0, void* s1, const int64_t* dims, tmg_stream_t st);
 int tmg_bn_bwd_apply(const void* x, const int64_t* x_d, const void* g, const int64_t* g_d, const void* a, const void* bsh,
                      const void* mean, const void* rstd, const void* gamma, const void* m0, const void* m1, void* dx,
                      const int64_t* dx_d, const int64_t* dims, tmg_stream_t st);
+/* Batch sums -> mean, biased var, rstd, a = gamma*rstd, bsh = beta - mean*a (out[5][C]) and the in-place momentum update of the
+ * running statistics (unbiased variance), one launch.  dims = {C, n}; fl = {eps, momentum}; rmean / rvar may be NULL. */
+int tmg_bn_finalize(const void* sum, const void* csq, const void* gamma, const void* beta, void* rmean, void* rvar, void* out,
+                    const int64_t* dims, const float* fl, tmg_stream_t st);
 
 /* dst (+)= src * [ref > 0] + add  over n channels: ReLU-mask / concat adjoints. dims = {npix,n,accumulate} */
 int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const int64_t* r_d, const void* add,

@@ -118,7 +118,22 @@ def test_bn_relu_conv():
     mean, var, n = ops.batch_moments(xd.detach())
     _close(mean, x.double().mean((0, 2, 3)), what="bn mean")
     _close(var, x.double().var((0, 2, 3), unbiased=False), what="bn var")
-    y = ops.BNReLUConvFn.apply(xd, gd, bd, wd, mean, var, 1e-5, True)
+    # the fused statistics kernel: same moments, folded affine, and nn.BatchNorm2d's running-statistics update
+    bn = torch.nn.BatchNorm2d(12).to(DEV)
+    ref_bn = torch.nn.BatchNorm2d(12).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        ref_bn.weight.copy_(gamma); ref_bn.bias.copy_(beta)
+    ref_bn.train()(x.double())
+    mean2, rstd, a, bsh = ops.bn_batch_stats(xd.detach(), bn)
+    _close(mean2, mean, what="fused mean")
+    _close(rstd, torch.rsqrt(var + 1e-5), what="fused rstd")
+    _close(a, gamma.to(DEV) * rstd, what="fused a")
+    _close(bsh, beta.to(DEV) - mean * a, what="fused bsh")
+    _close(bn.running_mean, ref_bn.running_mean, what="running mean")
+    _close(bn.running_var, ref_bn.running_var, what="running var")
+    assert int(bn.num_batches_tracked) == 1
+    y = ops.BNReLUConvFn.apply(xd, gd, bd, wd, mean2, rstd, a, bsh, True)
     _close(_back(y), yr, what="bnreluconv")
     (y * _nhwc(gy.float())).sum().backward()
     _close(_back(xd.grad), xr.grad, tol=1e-4, what="bn dx")
