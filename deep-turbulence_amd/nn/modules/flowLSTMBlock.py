@@ -201,9 +201,8 @@ class LSTMFLowBlock(nn.Module):
         use_weight = reverse if ts else not reverse
         if use_weight:
             W = P @ (lower @ upper)
-            with torch.no_grad():
-                for c in convs:
-                    c.log_s_old.copy_(c.log_s)
+            with torch.no_grad():  # the reference's W-cache key (glowConv.py:157,209-212), all layers in one launch
+                torch._foreach_copy_([c.log_s_old for c in convs], [c.log_s for c in convs])
         else:
             from nn.modules.glowConv import _TriInv
             W = _TriInv.apply(upper, True) @ (_TriInv.apply(lower, False) @ P.transpose(1, 2))
