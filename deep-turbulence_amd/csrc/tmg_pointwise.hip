@@ -520,6 +520,132 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(C1P p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Both growth-1 layers of a coupling network in one launch (denseBlock.py:135-152 with growth 1, two layers):
+//   d1 = conv3x3_zero(relu(t0); W1) + add1,   d2 = conv3x3_zero(relu(cat(t0, d1)); W2) + add2,   D = (d1, d2, 0, 0)
+// The input patch is staged once with halo 2; d1 is evaluated on the tile plus a one-pixel ring (two pixels per thread,
+// zero outside the image: the second conv zero-pads) into LDS, then d2 on the tile.  Halves the launches and the reads of
+// t0 against two c1_fwd_kernel launches.
+// ---------------------------------------------------------------------------------------------
+struct C1X2P {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg, vec4;
+    int B, Hin, Win;
+    int Cin;
+    const float* in_scale;
+    const float* in_shift;
+    int relu_in, pad_rep;
+    const float* w1;  // [rows][9]: input channel c < w_rows reads row c (+ w_gap if c >= w_split)
+    const float* w2;  // same mapping for the t0 channels; the d1 channel reads row w2_d1
+    int w_rows, w_split, w_gap, w2_d1;
+    const float* add1; int a1_stride, a1_off;
+    const float* add2; int a2_stride, a2_off;
+    float* out; int out_stride;  // float4 (d1, d2, 0, 0) per pixel
+    int TW_log2, tiles_x, tiles_y, KCH;
+};
+
+__global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = 256 >> TWl;
+    const int PW = TW + 4, PH = TH + 4;   // staged patch (halo 2)
+    const int RW = TW + 2, RH = TH + 2;   // d1 region (halo 1)
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int row = tid >> TWl, col = tid & (TW - 1);
+    const int Cpad = (p.Cin + 3) & ~3;
+    // this thread's two d1-region pixels (region index i -> (ry, rx)); the second may not exist
+    int ry[2], rx[2];
+    bool rok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 256;
+        rok[u] = i < RH * RW;
+        const int ii = rok[u] ? i : 0;
+        ry[u] = ii / RW;
+        rx[u] = ii - ry[u] * RW;
+    }
+    // all global operands of the epilogue up front (latency hides under the staging + compute)
+    const int oy = oy0 + row, ox = ox0 + col;
+    const bool own = oy < p.Hin && ox < p.Win;
+    const size_t opx = ((size_t)b * p.Hin + min(oy, p.Hin - 1)) * p.Win + min(ox, p.Win - 1);
+    const float a2v = *((p.add2 && own) ? p.add2 + opx * p.a2_stride + p.a2_off : tmg_zero_page);
+    float a1v[2];
+    bool rin[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int y = oy0 - 1 + ry[u], x = ox0 - 1 + rx[u];
+        rin[u] = rok[u] && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        const size_t px = ((size_t)b * p.Hin + min(max(y, 0), p.Hin - 1)) * p.Win + min(max(x, 0), p.Win - 1);
+        a1v[u] = *((p.add1 && rin[u]) ? p.add1 + px * p.a1_stride + p.a1_off : tmg_zero_page);
+    }
+    float acc1[2] = {0.f, 0.f}, acc2 = 0.f;
+    for (int c0 = 0; c0 < Cpad; c0 += p.KCH) {
+        const int kch = min(p.KCH, Cpad - c0);
+        const int CS = kch + 4;
+        float* lw1 = lds + PH * PW * CS;  // [9][kch]
+        float* lw2 = lw1 + 9 * p.KCH;     // [9][kch]
+        __syncthreads();
+        stage_patch_bf(p, lds, b, oy0 - 2, ox0 - 2, PH, PW, c0, kch, CS);
+        for (int i = tid; i < 9 * kch; i += 256) {
+            const int tap = i / kch, c = i - tap * kch;
+            const int cs = c0 + c;
+            const bool ok = cs < p.w_rows;
+            const size_t r = (size_t)(cs + (cs < p.w_split ? 0 : p.w_gap)) * 9 + tap;
+            lw1[i] = ok ? p.w1[r] : 0.f;
+            lw2[i] = ok ? p.w2[r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tyy = tap / 3, txx = tap - tyy * 3;
+            const float* w1p = lw1 + tap * kch;
+            const float* w2p = lw2 + tap * kch;
+            const float* p0 = lds + ((ry[0] + tyy) * PW + rx[0] + txx) * CS;          // region pixel + tap (patch = region - 1)
+            const float* p1 = lds + ((ry[1] + tyy) * PW + rx[1] + txx) * CS;
+            const float* pq = lds + ((row + 1 + tyy) * PW + col + 1 + txx) * CS;      // own pixel + tap
+            for (int c = 0; c < kch; c += 4) {
+                const float4 wa = *reinterpret_cast<const float4*>(w1p + c);
+                const float4 wb = *reinterpret_cast<const float4*>(w2p + c);
+                const float4 x0 = *reinterpret_cast<const float4*>(p0 + c);
+                const float4 x1 = *reinterpret_cast<const float4*>(p1 + c);
+                const float4 xq = *reinterpret_cast<const float4*>(pq + c);
+                acc1[0] += x0.x * wa.x + x0.y * wa.y + x0.z * wa.z + x0.w * wa.w;
+                acc1[1] += x1.x * wa.x + x1.y * wa.y + x1.z * wa.z + x1.w * wa.w;
+                acc2 += xq.x * wb.x + xq.y * wb.y + xq.z * wb.z + xq.w * wb.w;
+            }
+        }
+    }
+    // d1 on the ring-extended region: raw value at this thread's own pixel is needed for the output, relu(d1) for conv 2
+    __syncthreads();
+    float* ld1 = lds;  // [RH*RW] relu(d1), zero outside the image
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (rok[u]) ld1[tid + u * 256] = rin[u] ? fmaxf(acc1[u] + a1v[u], 0.f) : 0.f;
+    // raw d1 of the own pixel: region index of (row+1, col+1) belongs to some other thread -> recompute address, read raw via LDS too
+    float* ld1raw = lds + ((RH * RW + 3) & ~3);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (rok[u]) ld1raw[tid + u * 256] = acc1[u] + a1v[u];
+    __syncthreads();
+    float w2d[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w2d[tap] = p.w2[(size_t)p.w2_d1 * 9 + tap];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int tyy = tap / 3, txx = tap - tyy * 3;
+        acc2 += w2d[tap] * ld1[(row + tyy) * RW + col + txx];   // region index of own pixel + tap - 1 = (row + tyy, col + txx)
+    }
+    if (own) {
+        const float d1 = ld1raw[(row + 1) * RW + col + 1];
+        *reinterpret_cast<float4*>(p.out + opx * p.out_stride) = make_float4(d1, acc2 + a2v, 0.f, 0.f);
+    }
+}
+
 // Backward of the C_out = 1 layer.  ddm(p) = dd(p) * [dref(p) > 0]  (dref null -> no mask)
 //   G[p][ci]  += sum_tap w[ci][tap] * ddm(p - tap + 1)          (raw gradient w.r.t. the ReLU'd input)
 //   dW[ci][tap] += sum_p relu(in(p + tap - 1))[ci] * ddm(p)
@@ -1100,6 +1226,44 @@ static int c1_tile(int W, int H, int* twl) {
 
 // dims: [B,H,W,Cin,relu_in,w_rows,fill4,w_split,w_gap]; out_d = [stride, off]; w is [w_rows][9] (w_rows = 0 -> Cin);
 // fill4 = 1: out points at channel 0 of a 16-byte aligned 4-channel pixel and (value,0,0,0) is stored
+// Both growth-1 layers in one launch (see c1x2_fwd_kernel).  dims: [B,H,W,Cin,relu_in,w_rows,w_split,w_gap,w2_d1_row];
+// add1_d / add2_d / out_d = [stride, off]; out receives (d1, d2, 0, 0) per pixel as one float4 (16-byte aligned, off 0).
+extern "C" int tmg_c1x2_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2,
+                            const void* add1, const int64_t* add1_d, const void* add2, const int64_t* add2_d, void* out,
+                            const int64_t* out_d, const int64_t* dims, hipStream_t st) {
+    C1X2P p;
+    p.nseg = (int)nseg;
+    p.vec4 = 1;
+    fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.relu_in = (int)dims[4];
+    p.w_rows = (dims[5] > 0 && dims[5] < p.Cin) ? (int)dims[5] : p.Cin;
+    p.w_split = dims[6] > 0 ? (int)dims[6] : 0x7fffffff; p.w_gap = (int)dims[7]; p.w2_d1 = (int)dims[8];
+    if (p.Cin & 3) p.vec4 = 0;
+    p.pad_rep = 0; p.in_scale = nullptr; p.in_shift = nullptr;
+    p.w1 = (const float*)w1; p.w2 = (const float*)w2;
+    p.add1 = (const float*)add1; p.a1_stride = add1 ? (int)add1_d[0] : 0; p.a1_off = add1 ? (int)add1_d[1] : 0;
+    p.add2 = (const float*)add2; p.a2_stride = add2 ? (int)add2_d[0] : 0; p.a2_off = add2 ? (int)add2_d[1] : 0;
+    if ((out_d[0] & 3) || out_d[1] != 0 || (((uintptr_t)out) & 15)) return -2;
+    p.out = (float*)out; p.out_stride = (int)out_d[0];
+    c1_tile(p.Win, p.Hin, &p.TW_log2);
+    const int TW = 1 << p.TW_log2, TH = 256 >> p.TW_log2;
+    p.tiles_x = (p.Win + TW - 1) / TW;
+    p.tiles_y = (p.Hin + TH - 1) / TH;
+    const int Cpad = (p.Cin + 3) & ~3;
+    p.KCH = Cpad < 32 ? Cpad : 32;
+    size_t lds_floats = (size_t)(TH + 4) * (TW + 4) * (p.KCH + 4) + 18 * p.KCH;
+    const size_t d1_floats = 2 * (size_t)(((TH + 2) * (TW + 2) + 3) & ~3);
+    if (lds_floats < d1_floats) lds_floats = d1_floats;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c1x2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(c1x2_fwd_kernel, dim3(p.B * p.tiles_x * p.tiles_y), dim3(256), lds_floats * 4, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int tmg_c1_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w, void* out,
                           const int64_t* out_d, const int64_t* dims, hipStream_t st) {
     return tmg_c1_fwd_add(in_ptrs, in_desc, nseg, w, nullptr, nullptr, out, out_d, dims, st);

@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
+    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
 ]
 
 
@@ -440,6 +440,17 @@ def c1_fwd(inputs, w, out, relu_in=True, w_rows=0, fill4=False, add=None, w_spli
     ad = _d2(add) if add is not None else _i64(0, 0)
     _chk(lib().tmg_c1_fwd_add(ip, idesc, c_i64(n_in), _ptr(w), _ptr(add), ad, _ptr(out), _d2(out),
                               _i64(B, H, W, Cin, relu_in, w_rows, fill4, w_split, w_gap), _stream()), "tmg_c1_fwd_add")
+
+
+def c1x2_fwd(inputs, w1, w2, out, w_rows, w2_d1_row, add1=None, add2=None, w_split=0, w_gap=0, relu_in=True):
+    """Both growth-1 layers in one launch; out: [B,H,W,4] receives (d1, d2, 0, 0)."""
+    B, H, W, _ = inputs[0].shape
+    ip, idesc, n_in = _segs(inputs)
+    Cin = sum(t.shape[3] for t in inputs)
+    z = _i64(0, 0)
+    _chk(lib().tmg_c1x2_fwd(ip, idesc, c_i64(n_in), _ptr(w1), _ptr(w2), _ptr(add1), _d2(add1) if add1 is not None else z, _ptr(add2),
+                            _d2(add2) if add2 is not None else z, _ptr(out), _d2(out),
+                            _i64(B, H, W, Cin, relu_in, w_rows, w_split, w_gap, w2_d1_row), _stream()), "tmg_c1x2_fwd")
 
 
 def c1_bwd(inputs, w, dW, dd, dref, gsegs, relu_in=True):

@@ -536,8 +536,12 @@ class LevelCouplingFn(torch.autograd.Function):
             tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
             x1 = tin[..., :ch]
             D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-            H.c1_fwd([x1], w1s[k], D[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=Dc[..., k:k + 1])
-            H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=Dc[..., NLp + k:NLp + k + 1])
+            if ch % 4 == 0:
+                # both growth-1 layers in one launch (the conditioning parts arrive as add operands)
+                H.c1x2_fwd([x1], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., k:k + 1], add2=Dc[..., NLp + k:NLp + k + 1])
+            else:
+                H.c1_fwd([x1], w1s[k], D[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=Dc[..., k:k + 1])
+                H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=Dc[..., NLp + k:NLp + k + 1])
             hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             H.conv_fwd([x1, D], PZ[k], C, 3, 1, [hh], bias=bzs[k], kappa=kps[k], relu_in=True, pad_rep=True, add=Hc[..., k * C:(k + 1) * C])
             y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)

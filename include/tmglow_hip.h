@@ -153,6 +153,13 @@ int tmg_bn_finalize(const void* sum, const void* csq, const void* gamma, const v
 int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const int64_t* r_d, const void* add,
                    const int64_t* a_d, void* dst, const int64_t* d_d, const int64_t* dims, tmg_stream_t st);
 
+/* Both growth-1 layers of a coupling network in one launch: d1 = conv(relu(t0); w1) + add1, d2 = conv(relu(cat(t0, d1)); w2) +
+ * add2, out = (d1, d2, 0, 0) per pixel (denseBlock.py:135-152 with two layers of growth 1).  dims = {B,H,W,Cin,relu_in,w_rows,
+ * w_split,w_gap,w2_d1_row}: input channel c reads weight row c (+w_gap if c >= w_split) when c < w_rows; the d1 channel of the
+ * second layer reads row w2_d1_row of w2. */
+int tmg_c1x2_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2, const void* add1,
+                 const int64_t* add1_d, const void* add2, const int64_t* add2_d, void* out, const int64_t* out_d, const int64_t* dims,
+                 tmg_stream_t st);
 /* Growth-1 dense layer of the coupling network, C_out = 1 (denseBlock.py:135-138), forward and
  * backward (input gradient accumulated into g segments, weight gradient accumulated atomically).
  * dims = {B,H,W,Cin,relu_in,w_rows,fill4,w_split,w_gap} */

@@ -355,3 +355,30 @@ def test_grouped_weight_gradient_matches_per_group_launches(shape):
         _close(dW[k][:, ch + Cc:], w.grad[:, ch:], tol=3e-5, what="dW growth rows")
         assert float(dW[k][:, ch:ch + Cc].abs().max()) == 0.0  # the conditioning rows belong to the level-wide launch
         _close(dB[k], bb.grad, tol=3e-5, what="dbias")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 8, 32), (1, 9, 13, 4, 5), (3, 32, 8, 16, 32), (2, 40, 24, 64, 32)])
+def test_fused_growth_layers_match_two_launches(shape):
+    """tmg_c1x2_fwd (both growth-1 layers, one launch) against two tmg_c1_fwd launches and fp64 torch."""
+    import tmg_hip as H
+    B, Hh, Ww, ch, Cc = shape
+    g = torch.Generator().manual_seed(ch * 31 + Hh)
+    x = torch.randn(B, Hh, Ww, 2 * ch, generator=g).to(DEV)
+    x1 = x[..., :ch]
+    cin = ch + Cc
+    w1 = (0.3 * torch.randn(1, cin, 3, 3, generator=g)).to(DEV)
+    w2 = (0.3 * torch.randn(1, cin + 1, 3, 3, generator=g)).to(DEV)
+    Dc = torch.randn(B, Hh, Ww, 8, generator=g).to(DEV)
+    D = torch.full((B, Hh, Ww, 4), 7.0, device=DEV)
+    H.c1x2_fwd([x1], w1, w2, D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., 1:2], add2=Dc[..., 5:6])
+    D2 = torch.full((B, Hh, Ww, 4), 7.0, device=DEV)
+    H.c1_fwd([x1], w1, D2[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=Dc[..., 1:2])
+    H.c1_fwd([x1, D2], w2, D2[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=Dc[..., 5:6])
+    _close(D, D2, tol=2e-5, what="fused vs two launches")
+    xr = x1.permute(0, 3, 1, 2).double().cpu()
+    d1 = F.conv2d(F.relu(xr), w1[:, :ch].double().cpu(), padding=1) + Dc[..., 1:2].permute(0, 3, 1, 2).double().cpu()
+    w2x = torch.cat([w2[:, :ch], w2[:, ch + Cc:]], 1).double().cpu()
+    d2 = F.conv2d(F.relu(torch.cat([xr, d1], 1)), w2x, padding=1) + Dc[..., 5:6].permute(0, 3, 1, 2).double().cpu()
+    _close(D[..., 0:1].permute(0, 3, 1, 2), d1, tol=3e-5, what="d1")
+    _close(D[..., 1:2].permute(0, 3, 1, 2), d2, tol=3e-5, what="d2")
+    assert float(D[..., 2:].abs().max()) == 0.0
