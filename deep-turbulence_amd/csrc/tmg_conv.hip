@@ -260,19 +260,34 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
     const int G = gridDim.x;
     const int nmine = (int)blockIdx.x < p.ntiles ? (p.ntiles - (int)blockIdx.x + G - 1) / G : 0;
     const int nst = nmine * nchunks;
-    // (tile, chunk) cursors of the stage being issued / committed / computed
-    int ti = blockIdx.x, ci = 0, tc = blockIdx.x, cc = 0, tm = blockIdx.x, cm = 0;
-
-#define TMG_FW_ORIGIN(TILE)                  \
-    int b_, oy0_, ox0_;                      \
-    {                                        \
-        int t_ = (TILE);                     \
-        const int tx_ = t_ % p.tiles_x;      \
-        t_ /= p.tiles_x;                     \
-        const int ty_ = t_ % p.tiles_y;      \
-        b_ = t_ / p.tiles_y;                 \
-        oy0_ = ty_ * TH;                     \
-        ox0_ = tx_ * TW;                     \
+    // (tile, chunk) cursors of the stage being issued / committed / computed.  A tile index advances by G per step; its
+    // (tile x, tile y, sample) coordinates are carried along instead of being re-derived with two integer divisions at
+    // every use (each ~35 VALU instructions, and VALU cycles add to MFMA cycles).
+    int ci = 0, cc = 0, cm = 0;
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int Gb = G / tpi, Gy = (G - Gb * tpi) / p.tiles_x, Gx = G - Gb * tpi - Gy * p.tiles_x;
+    int ti_b = (int)blockIdx.x / tpi, ti_y = ((int)blockIdx.x - ti_b * tpi) / p.tiles_x, ti_x = (int)blockIdx.x - ti_b * tpi - ti_y * p.tiles_x;
+    int tm_b = ti_b, tm_y = ti_y, tm_x = ti_x;
+#define TMG_FW_ADVANCE(X, Y, B_)                                  \
+    {                                                             \
+        X += Gx;                                                  \
+        if (X >= p.tiles_x) { X -= p.tiles_x; ++Y; }              \
+        Y += Gy;                                                  \
+        if (Y >= p.tiles_y) { Y -= p.tiles_y; ++B_; }             \
+        B_ += Gb;                                                 \
+    }
+    // narrow register tiles keep this lane's bias quads in registers for the whole launch (wide ones have none to spare)
+    constexpr bool HB = MT * NTW <= 8;
+    float4 biasq[HB ? NTW : 1];
+    if (HB) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n0 = (ntile0 + j) * 16 + 4 * q;
+            float b4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = (p.bias && n0 + r < p.Cout) ? p.bias[n0 + r] : 0.f;
+            biasq[HB ? j : 0] = make_float4(b4[0], b4[1], b4[2], b4[3]);
+        }
     }
     // first B fragments of stage 0 (every later stage gets them from the previous stage's last iteration)
     float4 b0[NTW], b1[NTW];
@@ -308,11 +323,11 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                     *reinterpret_cast<float4*>(bb + u * pstep * CS * 4) = v;
                 }
             }
-            if (++cc == nchunks) { cc = 0; tc += G; }
+            if (++cc == nchunks) cc = 0;
         }
         // ---- issue the loads of stage k+2 ---------------------------------------------------------------------------
         if (k + 2 < nst) {
-            TMG_FW_ORIGIN(ti)
+            const int b_ = ti_b, oy0_ = ti_y * TH, ox0_ = ti_x * TW;
             const int c0 = ci * KCH, kch = min(KCH, p.Cin_pad - c0);
             const float* tptr = zero_page;
             int tss = 0;
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                 pv[u] = *reinterpret_cast<const float4*>(a_);
                 if (p.in_scale) oobm |= (oob ? 1u : 0u) << u;
             }
-            if (++ci == nchunks) { ci = 0; ti += G; }
+            if (++ci == nchunks) { ci = 0; TMG_FW_ADVANCE(ti_x, ti_y, ti_b) }
         }
         // ---- MFMA loop of stage k -----------------------------------------------------------------------------------
         if (k >= 0) {
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
             constexpr bool PREADD = MT * NTW <= 8;
             float4 addv[PREADD ? MT : 1][PREADD ? NTW : 1];
             if (PREADD && p.add.p && p.ovec4 && cm + 1 == nchunks) {
-                TMG_FW_ORIGIN(tm)
+                const int b_ = tm_b, oy0_ = tm_y * TH, ox0_ = tm_x * TW;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int m = (wm * MT + i) * 16 + li;
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
 #undef TMG_FW_BODY
             if (cm + 1 == nchunks) {
                 // epilogue: transposed C/D map: col = lane & 15 (pixel of the m-tile), row = (lane >> 4) * 4 + r (channel)
-                TMG_FW_ORIGIN(tm)
+                const int b_ = tm_b, oy0_ = tm_y * TH, ox0_ = tm_x * TW;
                 const float osc = out_scale_of(p.kappa);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
@@ -428,7 +443,9 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                             const int n0 = (ntile0 + j) * 16 + 4 * q;
                             if (n0 < p.Cout) {
                                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                                if (p.bias) {
+                                if (HB) {
+                                    v[0] += biasq[HB ? j : 0].x; v[1] += biasq[HB ? j : 0].y; v[2] += biasq[HB ? j : 0].z; v[3] += biasq[HB ? j : 0].w;
+                                } else if (p.bias) {
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) v[r] += (n0 + r < p.Cout) ? p.bias[n0 + r] : 0.f;
                                 }
@@ -476,14 +493,14 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                cm = 0; tm += G;
+                cm = 0; TMG_FW_ADVANCE(tm_x, tm_y, tm_b)
             } else {
                 ++cm;
             }
         }
         __syncthreads();  // the buffer just read may be overwritten next round; the one just written is complete
     }
-#undef TMG_FW_ORIGIN
+#undef TMG_FW_ADVANCE
 #undef TMG_FW_BOFF
 }
 
