@@ -232,11 +232,12 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // per-lane operand bases: A as float4 index into a buffer, B as float offset into a (tap, kb) slice of wpk
-    int abase[MT];
+    int abase[MT], mrc[MT];  // mrc: (row << 16) | col of this lane's pixel of m-tile i inside the tile (epilogue)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = (wm * MT + i) * 16 + li;
         abase[i] = ((m >> TWl) * PW + (m & (TW - 1))) * CS4 + q;
+        mrc[i] = ((m >> TWl) << 16) | (m & (TW - 1));
     }
     const int boff0 = li * 16 + 4 * q;  // + n-tile * 256 (scalar); tiles past the end repeat the last (dropped in the epilogue)
 #define TMG_FW_BOFF(J) (boff0 + min(ntile0 + (J), ntiles_total - 1) * 256)
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
         if (Y >= p.tiles_y) { Y -= p.tiles_y; ++B_; }             \
         B_ += Gb;                                                 \
     }
+    const float osc = out_scale_of(p.kappa);  // launch constant: read once, not in every tile's epilogue (a dependent load there)
     // narrow register tiles keep this lane's bias quads in registers for the whole launch (wide ones have none to spare)
     constexpr bool HB = MT * NTW <= 8;
     float4 biasq[HB ? NTW : 1];
@@ -386,9 +388,8 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                 const int b_ = tm_b, oy0_ = tm_y * TH, ox0_ = tm_x * TW;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int m = (wm * MT + i) * 16 + li;
-                    const int oy = min(oy0_ + (m >> TWl), p.Hout - 1), ox = min(ox0_ + (m & (TW - 1)), p.Wout - 1);
-                    const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
+                    const int oy = min(oy0_ + (mrc[i] >> 16), p.Hout - 1), ox = min(ox0_ + (mrc[i] & 0xffff), p.Wout - 1);
+                    const size_t opx = (size_t)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
                         const int n0 = min((ntile0 + j) * 16 + 4 * q, p.Cout - 4);
@@ -431,13 +432,11 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
             if (cm + 1 == nchunks) {
                 // epilogue: transposed C/D map: col = lane & 15 (pixel of the m-tile), row = (lane >> 4) * 4 + r (channel)
                 const int b_ = tm_b, oy0_ = tm_y * TH, ox0_ = tm_x * TW;
-                const float osc = out_scale_of(p.kappa);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int m = (wm * MT + i) * 16 + li;
-                    const int oy = oy0_ + (m >> TWl), ox = ox0_ + (m & (TW - 1));
+                    const int oy = oy0_ + (mrc[i] >> 16), ox = ox0_ + (mrc[i] & 0xffff);
                     if (oy < p.Hout && ox < p.Wout) {
-                        const size_t opx = ((size_t)b_ * p.Hout + oy) * p.Wout + ox;
+                        const size_t opx = (size_t)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);  // host: B*H < 2^24, W < 2^24
 #pragma unroll
                         for (int j = 0; j < NTW; ++j) {
                             const int n0 = (ntile0 + j) * 16 + 4 * q;
@@ -1280,7 +1279,9 @@ static int launch_fwd(const ConvP& p, int G, int gy, size_t lds_bytes, hipStream
 
 // Tile / chunk plan and launch of conv_fwd_kernel; -100 when the shape is not eligible (caller falls back to conv_mfma_kernel).
 static int conv_fwd_lean(ConvP p, hipStream_t st) {
-    if (p.stride != 1 || !p.vec4 || (p.Cin & 3) || (long)p.Hin * p.Win >= (1 << 24)) return -100;
+    if (p.stride != 1 || !p.vec4 || (p.Cin & 3) || (long)p.Hin * p.Win >= (1 << 24) || (long)p.B * p.Hout >= (1 << 24) ||
+        p.Wout >= (1 << 24) || (long)p.B * p.Hout * p.Wout >= (1L << 32))
+        return -100;
     for (int i = 0; i < p.nseg; ++i)
         if (p.in[i].stride >= (1 << 24) || (long)p.B * p.Hin * p.Win * p.in[i].stride >= (1L << 31)) return -100;
     // float4 epilogue: every output segment (and the add operand) addressable in channel quads
