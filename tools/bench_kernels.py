@@ -63,7 +63,7 @@ def main():
             name, t_f, fl / t_f / 1e9, t_d, fl / t_d / 1e9, t_w, fl / t_w / 1e9), flush=True)
 
 
-if __name__ == "__main__" and "tail" not in sys.argv and "d2" not in sys.argv:
+if __name__ == "__main__" and "tail" not in sys.argv and "d2" not in sys.argv and "d2f" not in sys.argv:
     main()
 
 
@@ -134,3 +134,29 @@ def bench_d2():
 
 if __name__ == "__main__" and "d2" in sys.argv:
     bench_d2()
+
+
+def bench_d2_fused():
+    """dense2 backward in the level-fused configuration (only the x1 half as input; conditioning handled level-wide)."""
+    dev = "cuda"
+    for lvl, (hw, C) in enumerate([(128, 16), (64, 32), (32, 64), (16, 128)], 1):
+        B, Cc = 64, 32
+        ch = C // 2
+        cin = ch + Cc
+        tin = torch.randn(B, hw, hw, C, device=dev)
+        D = torch.randn(B, hw, hw, 4, device=dev)
+        GD = torch.randn(B, hw, hw, 4, device=dev)
+        G0 = torch.randn(B, hw, hw, ch, device=dev)
+        dtin = torch.empty(B, hw, hw, C, device=dev)
+        dto = torch.randn(B, hw, hw, C, device=dev)
+        DD = torch.zeros(B, hw, hw, 32, device=dev)
+        w1, w2 = torch.randn(1, cin, 3, 3, device=dev), torch.randn(1, cin + 1, 3, 3, device=dev)
+        dW1, dW2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        x1 = tin[..., :ch]
+        t = timeit(lambda: H.dense2_bwd([x1, D], w1, w2, dW1, dW2, GD, D, [G0], [dtin[..., :ch]], ch, add0=dto[..., :ch], rows1=ch,
+                                        rows2=ch + 1, dd1=DD[..., 3:4], dd2=DD[..., 19:20], split2=ch, gap2=Cc))
+        print("dense2_bwd (fused cfg) L%d: %7.3f ms" % (lvl, t), flush=True)
+
+
+if __name__ == "__main__" and "d2f" in sys.argv:
+    bench_d2_fused()
