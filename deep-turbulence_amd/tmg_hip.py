@@ -280,6 +280,8 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
     if dy is None:
         dy = group_dy[0]
         assert all(t.shape == dy.shape and t.stride() == dy.stride() for t in group_dy)
+    if torch.cuda.is_current_stream_capturing():
+        return False  # the segment table is a host-to-device copy, which a graph capture cannot record: per-group launches
     G = len(group_inputs)
     first = group_inputs[0]
     B, Hin, Win, _ = first[0].shape
