@@ -805,6 +805,8 @@ struct D2BP {
     int TW_log2, tiles_x, tiles_y, ntiles, KCH;
 };
 
+// WG: with the weight gradients of both layers (false: the caller computes them with the MFMA weight-gradient kernel)
+template <bool WG>
 __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
     // grid = (pixel-tile shares, channel chunks): a block owns ONE chunk of <= KCH input channels (KCH*9 <= 256, one
     // weight-gradient output per thread) and walks its share of the 256-pixel tiles.
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
         lw2[i] = (c0 + c < p.rows2) ? p.w2[(size_t)(c0 + c + (c0 + c < p.split2 ? 0 : p.gap2)) * 9 + tap] : 0.f;
     }
     const int wo_tap = tid / kch, wo_c = tid - wo_tap * kch;   // this thread's weight-gradient output
-    const bool wo_ok = tid < kch * 9;
+    const bool wo_ok = WG && tid < kch * 9;
     const int wo_ky = wo_tap / 3, wo_kx = wo_tap - wo_ky * 3;
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -914,8 +916,13 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
         __syncthreads();
         if (p.dd1_out && blockIdx.y == 0 && own) {
             const size_t px_ = ((size_t)b * p.Hin + oy) * p.Win + ox;
-            p.dd1_out[px_ * p.dd_stride] = A1[(row + 1) * PW + col + 1];
-            p.dd2_out[px_ * p.dd_stride] = A2[(row + 2) * QW + col + 2];
+            const float d1v = A1[(row + 1) * PW + col + 1], d2v = A2[(row + 2) * QW + col + 2];
+            if (p.dd2_out == p.dd1_out + 1 && !(p.dd_stride & 1) && !(((uintptr_t)p.dd1_out) & 7)) {
+                *reinterpret_cast<float2*>(p.dd1_out + px_ * p.dd_stride) = make_float2(d1v, d2v);  // adjacent channels: one store
+            } else {
+                p.dd1_out[px_ * p.dd_stride] = d1v;
+                p.dd2_out[px_ * p.dd_stride] = d2v;
+            }
         }
         if (own && c0 < p.cin_nn) {
             float n1[9], n2[9];
@@ -980,7 +987,7 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
 #undef TMG_D2_QUAD
         }
         // weight gradients of both layers from the same staged activations: one (channel, tap) output per thread
-        if (wo_ok) {
+        if (WG && wo_ok) {
             float s1 = 0.f, s2 = 0.f;
             for (int r = 0; r < TH; ++r) {
                 const float* ip = lin + ((r + wo_ky) * PW + wo_kx) * CS + wo_c;
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
             wa2 += s2;
         }
     }
-    if (wo_ok) {
+    if (WG && wo_ok) {
         if (c0 + wo_c < p.rows1) atomicAdd(p.dW1 + (size_t)(c0 + wo_c) * 9 + wo_tap, wa1);
         if (c0 + wo_c < p.rows2) atomicAdd(p.dW2 + (size_t)(c0 + wo_c + (c0 + wo_c < p.split2 ? 0 : p.gap2)) * 9 + wo_tap, wa2);
     }
@@ -1379,14 +1386,16 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     const size_t lds_bytes = ((size_t)((QQ + 3) & ~3) + ((PP + 3) & ~3) + 18 * p.KCH + (size_t)PP * (p.KCH + 8)) * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     static const int d2_blocks = getenv("TMG_D2_BLOCKS") ? atoi(getenv("TMG_D2_BLOCKS")) : 1024;
     int gx = d2_blocks / nchunks;
     if (gx > p.ntiles) gx = p.ntiles;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(dense2_bwd_kernel, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
+    if (p.dW1) hipLaunchKernelGGL(dense2_bwd_kernel<true>, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
+    else hipLaunchKernelGGL(dense2_bwd_kernel<false>, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -579,12 +579,15 @@ class LevelCouplingFn(torch.autograd.Function):
         dWm = flat[o:o + NL * C * C].view(NL, C, C); o += NL * C * C
         dbm = flat[o:o + NL * C].view(NL, C)
         DH = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)     # exp(kappa_k) * dhh_k, all layers
-        DD = torch.zeros((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)    # (dd1_k | dd2_k), all layers
+        # masked gradients w.r.t. the growth channels, 4 channels per layer (dd1_k, dd2_k, 0, 0): float4-addressable slices for
+        # the grouped weight-gradient launch below
+        DD = torch.zeros((B, Hh, Ww, 4 * NL), device=dev, dtype=torch.float32)
         dcur = dy
         # The NL zero-conv weight gradients (x1 | D part) are independent of each other once DH holds every layer's
         # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
         # dominated by launch / pipeline-fill).  Their inputs stay alive until then (NL * C floats per pixel).
-        grouped = NL > 1 and ch + 4 <= 64 and os.environ.get("TMG_NO_GROUPED_WGRAD") is None
+        grouped = (NL > 1 and ch + 4 <= 64 and os.environ.get("TMG_NO_GROUPED_WGRAD") is None
+                   and not torch.cuda.is_current_stream_capturing())
         Wz = torch.stack(wzs)
         PZt = H.conv_pack_batched(Wz, 1, ch + 4, (ch + 2, ch, Cc))          # input-gradient operands of all layers: one launch
         PMt = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 1)
@@ -609,8 +612,9 @@ class LevelCouplingFn(torch.autograd.Function):
             wt = PZt[k]
             H.conv_fwd([dhh], wt, ch + 4, 3, 1, [G0, GD])
             H.conv_rep_border_fix(dhh, wt, [G0, GD])
-            H.dense2_bwd([x1, D], w1s[k], w2s[k], dW1[k], dW2[k], GD, D, [G0], [dtin[..., :ch]], ch, add0=dto[..., :ch], rows1=ch,
-                         rows2=ch + 1, dd1=DD[..., k:k + 1], dd2=DD[..., NLp + k:NLp + k + 1], split2=ch, gap2=Cc)
+            H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
+                         add0=dto[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2], split2=ch,
+                         gap2=Cc)
             dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k], mdef)
             if grouped:
                 mix_wg[k] = mdef[0]
@@ -621,6 +625,15 @@ class LevelCouplingFn(torch.autograd.Function):
                 for k in range(NL):
                     H.conv_wgrad(wg_in[k], DH[..., k * C:(k + 1) * C], dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2,
                                  cin_valid=ch + 2, ci_split=ch, ci_off0=0, ci_off1=Cc)
+            # x1 | d1 rows of the growth-layer weight gradients: same inputs, dy = this layer's (dd1, dd2, 0, 0) quad; row 0 of the
+            # result belongs to w1, row 1 to w2 (its column ch is the d1 input)
+            tmpX = torch.zeros((NL, 4, ch + 4, 3, 3), device=dev, dtype=torch.float32)
+            if not H.conv_wgrad_grouped(wg_in, DD, 4, tmpX, None, 3, 1, relu_in=True):
+                for k in range(NL):
+                    H.conv_wgrad(wg_in[k], DD[..., 4 * k:4 * k + 4], tmpX[k], None, 3, 1, relu_in=True)
+            dW1[:, 0, :ch] += tmpX[:, 0, :ch]
+            dW2[:, 0, :ch] += tmpX[:, 1, :ch]
+            dW2[:, 0, cin] += tmpX[:, 1, ch]
             wg_in = None
             # the 1x1 mix weight gradients of all layers: same trick, every group with its own upstream gradient tensor
             if not H.conv_wgrad_grouped([[a] for a, _ in mix_wg], None, C, dWm.view(NL, C, C, 1, 1), dbm, 1, 1, group_dy=[g_ for _, g_ in mix_wg]):
@@ -632,11 +645,16 @@ class LevelCouplingFn(torch.autograd.Function):
         wzc_t = H.conv_pack(Wzc, 1)
         H.conv_fwd([DH], wzc_t, Cc, 3, 1, [Gc])
         H.conv_rep_border_fix(DH, wzc_t, [Gc])
-        H.conv_fwd([DD], H.conv_pack(Wdc, 1), Cc, 3, 1, [Gc], accumulate=True)
+        Wd4 = torch.zeros((4 * NL, Cc, 3, 3), device=dev, dtype=torch.float32)   # rows 4k / 4k+1: cond columns of w1_k / w2_k
+        Wd4.view(NL, 4, Cc, 3, 3)[:, 0] = Wdc[:NL]
+        Wd4.view(NL, 4, Cc, 3, 3)[:, 1] = Wdc[NLp:NLp + NL]
+        H.conv_fwd([DD], H.conv_pack(Wd4, 1), Cc, 3, 1, [Gc], accumulate=True)
         H.masked_add(Gc, src=Gc, ref=cond)
         H.conv_wgrad([cond], DH, dWz, None, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=Cc, ci_off0=ch)
-        H.conv_wgrad([cond], DD[..., :NL], dW1, None, 3, 1, relu_in=True, cin_dst=cin, cin_valid=Cc, ci_off0=ch)
-        H.conv_wgrad([cond], DD[..., NLp:NLp + NL], dW2, None, 3, 1, relu_in=True, cin_dst=cin + 1, cin_valid=Cc, ci_off0=ch)
+        tmpC = torch.zeros((NL, 4, Cc, 3, 3), device=dev, dtype=torch.float32)   # one launch for both growth layers of all layers
+        H.conv_wgrad([cond], DD, tmpC.view(4 * NL, Cc, 3, 3), None, 3, 1, relu_in=True)
+        dW1[:, 0, ch:cin] += tmpC[:, 0]
+        dW2[:, 0, ch:cin] += tmpC[:, 1]
         # d(kappa_k) = <wz_k, dwz_k> + <bz_k, dbz_k> inside the clamp range (homogeneity of the zero conv in (W, b))
         Kp = torch.stack([kp.reshape(()) for kp in kps])
         dK = ((Wz * dWz).flatten(1).sum(1) + (torch.stack(bzs) * dBz).sum(1)) * ((Kp >= -4.0) & (Kp <= LOG4)).to(torch.float32)
