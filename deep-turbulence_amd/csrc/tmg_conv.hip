@@ -751,7 +751,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     }
 #define TMG_WG_ISSUE_F(TILE)                                                                                       \
     {                                                                                                             \
-        TMG_WG_ORIGIN(TILE)                                                                                       \
+        const int b_ = wi_b, oy0_ = wi_y * TH, ox0_ = wi_x * TW;  /* carried coordinates of tile k+2 */           \
         const int iy0_ = s * oy0_ - halo, ix0_ = s * ox0_ - halo;                                                 \
         const int tbv_ = b_ * p.Hin * p.Win * tss;          /* element offset of image b in this thread's segment */ \
         if (p.in_scale) oobm = 0;                                                                                 \
@@ -804,6 +804,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     const int G = gridDim.x;
     // Rotated tile loop (one ISSUE / COMMIT site): round k works on tile = blockIdx.x + k*G; rounds -2 and -1 only fill
     // the pipeline.
+    // coordinates of the tile whose loads are issued next (tile k+2), carried instead of two integer divisions per tile
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int Gb = G / tpi, Gy = (G - Gb * tpi) / p.tiles_x, Gx = G - Gb * tpi - Gy * p.tiles_x;
+    int wi_b = (int)blockIdx.x / tpi, wi_y = ((int)blockIdx.x - wi_b * tpi) / p.tiles_x, wi_x = (int)blockIdx.x - wi_b * tpi - wi_y * p.tiles_x;
     int k = -2;
     for (int tile = (int)blockIdx.x - 2 * G; tile < p.ntiles; tile += G, ++k) {
         // The item -> (pixel, channel) index math of the staging macros is tile-invariant; left alone the compiler hoists
@@ -813,7 +817,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
         asm volatile("" : "+v"(tid_i));
         if constexpr (LEAN) {
             if (k >= -1 && tile + G < p.ntiles && p.dbg != 2) TMG_WG_COMMIT_F(((k + 1) & 1) * bufw)  // tile k+1 (loaded a round ago)
-            if (tile + 2 * G < p.ntiles && p.dbg != 2) TMG_WG_ISSUE_F(p.dbg == 3 ? (int)blockIdx.x : tile + 2 * G)                   // tile k+2, in flight for a whole round
+            if (tile + 2 * G < p.ntiles && p.dbg != 2) {
+                TMG_WG_ISSUE_F(tile + 2 * G)  // tile k+2, in flight for a whole round
+                wi_x += Gx;
+                if (wi_x >= p.tiles_x) { wi_x -= p.tiles_x; ++wi_y; }
+                wi_y += Gy;
+                if (wi_y >= p.tiles_y) { wi_y -= p.tiles_y; ++wi_b; }
+                wi_b += Gb;
+            }
         } else {
             if (k >= -1 && tile + G < p.ntiles) TMG_WG_COMMIT(((k + 1) & 1) * bufw, tid_c)
             if (tile + 2 * G < p.ntiles) TMG_WG_ISSUE(tile + 2 * G, tid_i)
