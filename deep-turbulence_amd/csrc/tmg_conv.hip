@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
             // where the B prefetch of the last iteration points: first fragments of the next stage (or anything valid)
             const int c0n = (cm + 1 == nchunks) ? 0 : c0 + KCH;
             const float* wl_next = p.wpk + (size_t)(c0n >> 4) * kb_stride;
-            int tap = 0, kb = 0, tyy = 0, txx = 0;
+            int tap = 0, kb = 0, txx = 0;
             // Narrow register tiles: fetch the epilogue's `add` operand now, so that its latency hides under the MFMA loop
             // instead of stalling every tile's epilogue (the per-layer coupling convs are only a few microseconds per tile)
             // The MFMA operands are swapped (weights as A, pixels as B): the 16x16 result tile is transposed, lane (li, q)
@@ -397,17 +397,23 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                     }
                 }
             }
+            // (tap, kb) bookkeeping is carried as two scalars advanced by constants - the A offset into the patch and the B slice
+            // pointer - instead of being recomputed from (tap, kb) with 64-bit multiplies in every iteration (the narrow
+            // register tiles issue only 16 MFMAs per iteration, so ~25 scalar instructions of index math per iteration showed)
+            const size_t wtap_adv = tap_stride - (size_t)kbn * kb_stride;  // first slice of the next tap from the last of this
+            const int a_tap_adv = CS4 - 4 * kbn, a_row_adv = (PW - p.ksize) * CS4;
+            const float* wcur = wl;  // slice of the iteration whose B fragments are prefetched next
+            int aoffs = 0;
 #define TMG_FW_BODY(BC, BN)                                                                                          \
             {                                                                                                        \
-                const int aoffs = (tyy * PW + txx) * CS4 + kb * 4;                                                   \
                 float4 af[MT];                                                                                       \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) af[i] = lds4[abase[i] + aoffs];                       \
-                ++kb;                                                                                                \
+                ++kb; aoffs += 4; wcur += kb_stride;                                                                 \
                 if (kb == kbn) {                                                                                     \
-                    kb = 0; ++tap; ++txx;                                                                            \
-                    if (txx == p.ksize) { txx = 0; ++tyy; }                                                          \
+                    kb = 0; ++tap; ++txx; aoffs += a_tap_adv; wcur += wtap_adv;                                      \
+                    if (txx == p.ksize) { txx = 0; aoffs += a_row_adv; }                                             \
                 }                                                                                                    \
-                const float* wn_ = (tap == ntaps) ? wl_next : wl + tap * tap_stride + kb * kb_stride;                \
+                const float* wn_ = (tap == ntaps) ? wl_next : wcur;                                                  \
                 _Pragma("unroll") for (int j = 0; j < NTW; ++j) BN[j] = *reinterpret_cast<const float4*>(wn_ + TMG_FW_BOFF(j)); \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(BC[j].x, af[i].x, acc[i][j], 0, 0, 0);          \
