@@ -37,9 +37,11 @@ PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 
 
 def build_model(cfg, device):
+    import contextlib
     from nn.tmGlow import TMGlow
     C.seed_all(12345)
-    model = TMGlow(**C.build_kwargs(cfg))
+    with contextlib.redirect_stdout(sys.stderr):  # the constructor prints its parameter count (as the reference's does);
+        model = TMGlow(**C.build_kwargs(cfg))     # stdout carries exactly one JSON line
     C.perturb_(model, 7, 0.004, 0.02, 0.004)
     return model.to(device).train()
 
