@@ -657,7 +657,9 @@ class LevelCouplingFn(torch.autograd.Function):
         dW2[:, 0, ch:cin] += tmpC[:, 1]
         # d(kappa_k) = <wz_k, dwz_k> + <bz_k, dbz_k> inside the clamp range (homogeneity of the zero conv in (W, b))
         Kp = torch.stack([kp.reshape(()) for kp in kps])
-        dK = ((Wz * dWz).flatten(1).sum(1) + (torch.stack(bzs) * dBz).sum(1)) * ((Kp >= -4.0) & (Kp <= LOG4)).to(torch.float32)
+        # (the two inner products nearly cancel for small kappa gradients: accumulate them in fp64, the operands are parameter-sized)
+        dK = ((Wz.double() * dWz.double()).flatten(1).sum(1) + (torch.stack(bzs).double() * dBz.double()).sum(1)).float() \
+            * ((Kp >= -4.0) & (Kp <= LOG4)).to(torch.float32)
         grads = []
         for k in range(NL):
             grads += [dW1[k], dW2[k], dWz[k], dBz[k], dK[k].reshape(kps[k].shape)]
