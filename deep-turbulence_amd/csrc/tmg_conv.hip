@@ -576,14 +576,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     const int TWl = p.TW_log2, TW = 1 << TWl, TH = MPIX >> TWl;
     const int s = p.stride, halo = p.ksize >> 1, ntaps = p.ksize * p.ksize;
     const int PW = s * (TW - 1) + 1 + 2 * halo, PH = s * (TH - 1) + 1 + 2 * halo;
-    const int PHPW = PH * PW, plane = PHPW * 16;
+    // channel-tile planes are padded by one 64-byte row: consecutive planes then start 64 bytes apart modulo the 256-byte
+    // bank row, so the float4 stores of one pixel's quads (which go to different planes) do not collide (27 % of the LDS
+    // cycles were bank conflicts with unpadded planes, all from the staging stores)
+    const int PHPW = PH * PW, plane = PHPW * 16 + 16, dplane = MPIX * 16 + 16;
     const int cit0 = blockIdx.z * p.CITG;
     const int citn = min(p.CITG, (p.Cin_pad >> 4) - cit0);
     const int k4 = citn * 4;
     const int grp = p.gtab ? (int)blockIdx.y / p.bpg : 0;  // grouped launch: which (input segments, dy slice, dW slice)
     const int co0 = ((int)blockIdx.y - grp * p.bpg) * NCO * 16;
     const int ldy_w = citn * plane;           // word offset of the dy tile inside a buffer
-    const int bufw = p.CITG * plane + MPIX * NCO * 16;  // words per buffer
+    const int bufw = p.CITG * plane + NCO * dplane;  // words per buffer
     const int ksplit = p.ksplit;
 
     const int npairs = ntaps * citn;
@@ -666,14 +669,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
             if (it < pitems) {                                                                                    \
                 TMG_WG_PATCH_ITEM(it)                                                                             \
                 (void)py_; (void)px_;                                                                             \
-                *reinterpret_cast<float4*>(lds + (BW) + ((c4_ >> 2) * PHPW + pix_) * 16 + (c4_ & 3) * 4) = pv[u]; \
+                *reinterpret_cast<float4*>(lds + (BW) + (c4_ >> 2) * plane + pix_ * 16 + (c4_ & 3) * 4) = pv[u]; \
             }                                                                                                     \
         }                                                                                                         \
         _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                          \
             const int it = (TID) + u * NT;                                                                        \
             if (it < ditems) {                                                                                    \
                 const int m = it / (NCO * 4), c4 = it - m * (NCO * 4);                                            \
-                *reinterpret_cast<float4*>(lds + (BW) + ldy_w + ((c4 >> 2) * MPIX + m) * 16 + (c4 & 3) * 4) = dv[u]; \
+                *reinterpret_cast<float4*>(lds + (BW) + ldy_w + (c4 >> 2) * dplane + m * 16 + (c4 & 3) * 4) = dv[u]; \
                 /* NT % (NCO*4) == 0: c4 is the same for all of a thread's items -> per-thread bias partial */    \
                 bacc.x += dv[u].x; bacc.y += dv[u].y; bacc.z += dv[u].z; bacc.w += dv[u].w;                       \
             }                                                                                                     \
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     }
     const float* dptr = dcv ? dyb + co0 + 4 * dc4 : g_tmg_zero_page;
     const int dss = dcv ? dys : 0;
-    const unsigned ddst0 = 4u * (ldy_w + ((dc4 >> 2) * MPIX + dm0) * 16 + (dc4 & 3) * 4);
+    const unsigned ddst0 = 4u * (ldy_w + (dc4 >> 2) * dplane + dm0 * 16 + (dc4 & 3) * 4);
     unsigned oobm = 0;  // per-item out-of-image bits (only maintained when an input affine must not touch padding)
     float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LEAN && p.in_scale) {
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) aa[j] = 4u * (cbw + aoffw[j] + q * 16 + ((px0 >> TWl) * PW + (px0 & (TW - 1))) * 16);
 #pragma unroll
-                for (int n = 0; n < NCO; ++n) ba[n] = 4u * (cbw + ldy_w + (n * MPIX + px0 + q) * 16 + li);
+                for (int n = 0; n < NCO; ++n) ba[n] = 4u * (cbw + ldy_w + n * dplane + (px0 + q) * 16 + li);
 #define TMG_WG_LD(AV, BF, K)                                                                                     \
                 {                                                                                                \
                     _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = *(lds_cptr)(uintptr_t)(ba[n] + (K) * 256); \
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
                 {                                                                                              \
                     const int m_ = (KS) * 4 + q;                                                               \
                     const float* ab_ = lds + cbw + (((m_ >> TWl) * s) * PW + (m_ & (TW - 1)) * s) * 16;        \
-                    _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = lds[cbw + ldy_w + (n * MPIX + m_) * 16 + li]; \
+                    _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = lds[cbw + ldy_w + n * dplane + m_ * 16 + li]; \
                     _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = ab_[aoffw[j]];                      \
                 }
                 TMG_WG_LD(av, bfr, k0)
@@ -1568,7 +1571,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     // kernel limits: the patch of one tile fits the register window (7 float4 x 512 threads) and two LDS buffers fit
     auto fits = [&](int cg, int nc) {
         const int k4p = cg <= 1 ? 4 : (cg <= 2 ? 8 : 16);  // float4 slots per pixel as the lean staging path pads them
-        return PH * PW * k4p <= 7 * 512 && 2 * ((size_t)PH * PW * cg * 16 + (size_t)pl->MPIX * nc * 16) * 4 <= 160 * 1024;
+        return PH * PW * k4p <= 7 * 512 && 2 * ((size_t)(PH * PW * 16 + 16) * cg + (size_t)(pl->MPIX * 16 + 16) * nc) * 4 <= 160 * 1024;
     };
     int CITG = 1, NCO = 1, bestg = -1;
     for (auto& c : pref) {
@@ -1602,7 +1605,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
         for (int mp = 512; mp > 128; mp >>= 1) {
             const int th = mp >> twl, ph = th + 2 * halo;
             const int tiles = B * ((Wout + TW - 1) / TW) * ((Hout + th - 1) / th);
-            if (ph * PW * k4p <= 7 * 512 && 2 * ((size_t)ph * PW * pl->CITG * 16 + (size_t)mp * NCO * 16) * 4 <= 160 * 1024 &&
+            if (ph * PW * k4p <= 7 * 512 && 2 * ((size_t)(ph * PW * 16 + 16) * pl->CITG + (size_t)(mp * 16 + 16) * NCO) * 4 <= 160 * 1024 &&
                 tiles >= 4 * 256 / (pl->gy * pl->gz)) {
                 pl->MPIX = mp; pl->TH = th;
                 pl->tiles_y = (Hout + th - 1) / th;
@@ -1612,7 +1615,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
             }
         }
     }
-    pl->lds_bytes = 2 * ((size_t)PHe * PWe * pl->CITG * 16 + (size_t)pl->MPIX * NCO * 16) * 4;
+    pl->lds_bytes = 2 * ((size_t)(PHe * PWe * 16 + 16) * pl->CITG + (size_t)(pl->MPIX * 16 + 16) * NCO) * 4;
     if (pl->lds_bytes < 8192) pl->lds_bytes = 8192;  // the dbias fold reuses the first 8 KB
     if (pl->lds_bytes < (size_t)4 * pl->NP * NCO * 1024) pl->lds_bytes = (size_t)4 * pl->NP * NCO * 1024;  // cross-wave fold of the partial sums
     // pixel shares: one 512-thread block per CU, but >= 4 tiles per block (two rounds fill the pipeline)
