@@ -122,8 +122,8 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)  # >= 20 timed steps after 5 warm-up
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="M", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
