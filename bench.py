@@ -42,7 +42,7 @@ def build_model(cfg, device):
     C.seed_all(12345)
     with contextlib.redirect_stdout(sys.stderr):  # the constructor prints its parameter count (as the reference's does);
         model = TMGlow(**C.build_kwargs(cfg))     # stdout carries exactly one JSON line
-    C.perturb_(model, 7, 0.004, 0.02, 0.004)
+    C.perturb_(model, 7, *C.perturb_scales(cfg))
     return model.to(device).train()
 
 
@@ -54,7 +54,7 @@ def _cpu_baseline_worker(name, threads, B, max_steps, budget_s):
     torch.set_num_threads(threads)
     C.seed_all(12345)
     m = TMGlow(**C.build_kwargs(cfg))
-    C.perturb_(m, 7, 0.004, 0.02, 0.004)
+    C.perturb_(m, 7, *C.perturb_scales(cfg))
     P = O.params_from_state_dict(m.state_dict())
     del m
     params = list(O.trainable(P).values())
@@ -132,6 +132,9 @@ def main():
                     help="sample: the generative direction the reference trains through (the metric); forward: density direction "
                          "forward(x, y) with loss -mean(logp)/(noc*H*W), reported beside it (SURVEY 8-D)")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in one hipGraph and replay it (N=1 only)")
+    ap.add_argument("--mix", default=None, choices=["f32", "f16"],
+                    help="arithmetic of the 1x1 channel mixes: f32 MFMA (default) or fp16 operands / fp32 accumulation (default for "
+                         "cfg5, whose BASELINE.json line names fp16 MFMA 1x1 convs)")
     args = ap.parse_args()
 
     import tmg_dist
@@ -146,6 +149,9 @@ def main():
     dev = torch.device("cuda", local)
     cfg = CONFIGS[args.config]
     B = args.batch or DEFAULT_BATCH[args.config]
+    import tmg_ops
+    mix = args.mix or ("f16" if args.config == "cfg5" else "f32")
+    tmg_ops.set_mix_precision(mix)
     model = build_model(cfg, dev)
     tmg_dist.broadcast_parameters(model)
     bucket = tmg_dist.GradBucket(model.parameters()) if world > 1 else None
@@ -205,6 +211,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
     if not args.no_events:
         tmg_hip.prof_enable(True)
     t0 = time.perf_counter()
@@ -216,6 +223,7 @@ def main():
     if not args.no_events:
         prof = tmg_hip.prof_collect()
         tmg_hip.prof_enable(False)
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -240,11 +248,13 @@ def main():
     out = {"metric": "flow-field samples/sec (fwd+log-det+bwd), 64x256x256x4" if args.config == "M" else "flow-field samples/sec (fwd+log-det+bwd)",
            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": "f32" if mix == "f32" else "f32 (1x1 mixes: fp16 operands, fp32 accumulate)", "data": "synthetic",
            "config": {"workload": "tmglow %s: %s+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
                args.config, "sample()" if args.direction == "sample" else "forward(x,y)", Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
-               "global_batch": B * world, "parallelism": "dp%d" % world, "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
-           "roofline": roof}
+               "global_batch": B * world, "parallelism": "dp%d" % world, "world_size_observed": world,
+               "backend": (torch.distributed.get_backend() if world > 1 else None), "rank0_device": torch.cuda.get_device_name(dev) + " cuda:%d" % local,
+               "mix_precision": mix, "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
+           "peak_mem_gb": round(peak_gb, 2), "roofline": roof}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)
     print(json.dumps(out))

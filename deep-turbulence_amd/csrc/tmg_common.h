@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -288,6 +289,23 @@ __device__ __forceinline__ void stage_commit(const P& p, StageRegs<U>& R, float*
         NL_ -= ARR[0].n; PTR_ = ARR[1].p; STRIDE_ = ARR[1].stride; OFF_ = ARR[1].off;                     \
         if (NL_ >= ARR[1].n) { NL_ -= ARR[1].n; PTR_ = ARR[2].p; STRIDE_ = ARR[2].stride; OFF_ = ARR[2].off; } \
     }
+
+// One-time opt-in of a kernel to > 64 KB of dynamic LDS, per DEVICE: the attribute belongs to the (function, device) pair, so a
+// per-process flag would leave the second GPU of a multi-device process (the reference's thread-per-GPU replicas,
+// utils/parallel.py:222-231) without it.  hipGetDevice is a thread-local read.
+static inline void tmg_lds_optin(const void* fn, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.fetch_or(bit, std::memory_order_relaxed);
+}
+#define TMG_LDS_OPTIN(FN)                                              \
+    do {                                                               \
+        static std::atomic<uint64_t> done__{0};                        \
+        tmg_lds_optin(reinterpret_cast<const void*>(FN), done__);      \
+    } while (0)
 
 #define TMG_CHECK_LAUNCH()                          \
     do {                                            \

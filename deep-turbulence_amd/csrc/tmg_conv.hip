@@ -1268,12 +1268,7 @@ static inline int ilog2_ceil(int v) {
 
 template <int MT, int NTW, int WM, int WN>
 static int launch_conv(const ConvP& p, int gy, size_t lds_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, NTW, WM, WN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    TMG_LDS_OPTIN((&conv_mfma_kernel<MT, NTW, WM, WN>));
     dim3 grid(p.B * p.tiles_x * p.tiles_y, gy, 1);
     const int kid = (WM == 4 ? NTW - 1 : (WM == 2 ? NTW + 1 : NTW + 3));
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
@@ -1284,12 +1279,7 @@ static int launch_conv(const ConvP& p, int gy, size_t lds_bytes, hipStream_t st)
 
 template <int MT, int NTW, int WM, int WN>
 static int launch_fwd(const ConvP& p, int G, int gy, size_t lds_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<MT, NTW, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    TMG_LDS_OPTIN((&conv_fwd_kernel<MT, NTW, WM, WN>));
     const int kid = 11 + (WM == 8 ? NTW - 1 : (WM == 4 ? NTW + 1 : NTW + 3));
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_fwd_kernel<MT, NTW, WM, WN>), dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
@@ -1528,12 +1518,7 @@ extern "C" int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_de
 
 template <int NP, int NCO, bool LEAN>
 static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NP, NCO, LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    TMG_LDS_OPTIN((&conv_wgrad_kernel<NP, NCO, LEAN>));
     const int nco_i = NCO == 1 ? 0 : (NCO == 2 ? 1 : 2);
     const int kid = NP == 3 ? 8 + nco_i : 19 + ((NP - 5) / 2) * 3 + nco_i;
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);

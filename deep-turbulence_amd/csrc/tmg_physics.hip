@@ -160,12 +160,16 @@ struct PhysBP {
     float sd[3], mu[3];
     float dx, dy_, rho;
     float cp, cd, cl, cr;   // upstream * beta * 2 / count of each term (pressure, divergence, L2, rms)
+    const float* gup;       // optional DEVICE scalar multiplied onto the four coefficients (the upstream gradient of the loss
+                            // value, read here instead of on the host: no device->host synchronisation in the BPTT window)
 };
 
 __global__ __launch_bounds__(256) void phys_bwd_kernel(PhysBP p) {
     __shared__ float f[3][PT + 4][PT + 4];   // un-normalised fields, halo 2, zero outside the image
     __shared__ float S[6][PT + 2][PT + 2];   // adjoint sources on tile + halo 1
     const int n = blockIdx.z;
+    const float up_ = p.gup ? *p.gup : 1.f;
+    const float cp_ = up_ * p.cp, cd_ = up_ * p.cd, cl_ = up_ * p.cl, cr_ = up_ * p.cr;
     const int i0 = blockIdx.y * PT, j0 = blockIdx.x * PT;
     const int tid = threadIdx.x;
     const size_t plane = (size_t)p.H * p.W;
@@ -202,10 +206,10 @@ __global__ __launch_bounds__(256) void phys_bwd_kernel(PhysBP p) {
             const float raw_d = p.dx * (dvy / p.dy_ + dux / p.dx);
             const bool rin = (i >= 1 && i <= p.H - 2);
             if (rin && j >= 1 && j <= p.W - 2 && raw_p >= -1.f && raw_p <= 1.f) {
-                const float a_p = p.cp * raw_p * p.dx * p.dy_;
+                const float a_p = cp_ * raw_p * p.dx * p.dy_;
                 s1 = a_p * 2.f * ux_x; s2 = a_p * 2.f * uy_x; s3 = a_p * 2.f * ux_y; s4 = a_p * 2.f * uy_y; s5 = a_p / p.rho;
             }
-            if (rin && raw_d >= -1.f && raw_d <= 1.f) s6 = p.cd * raw_d * p.dx;
+            if (rin && raw_d >= -1.f && raw_d <= 1.f) s6 = cd_ * raw_d * p.dx;
         }
         S[0][li][lj] = s1; S[1][li][lj] = s2; S[2][li][lj] = s3; S[3][li][lj] = s4; S[4][li][lj] = s5; S[5][li][lj] = s6;
     }
@@ -243,8 +247,8 @@ __global__ __launch_bounds__(256) void phys_bwd_kernel(PhysBP p) {
         const size_t o = ((size_t)n * 3 + c) * plane + (size_t)i * p.W + j;
         const size_t ob = ((size_t)b_ * 3 + c) * plane + (size_t)i * p.W + j;
         const float yv = p.y[o];
-        float v = g[c] + p.cl * (yv - p.target[o]);
-        if (p.coef) v += p.cr * p.coef[ob] * (yv - p.mean[ob]);
+        float v = g[c] + cl_ * (yv - p.target[o]);
+        if (p.coef) v += cr_ * p.coef[ob] * (yv - p.mean[ob]);
         p.dy[o] = v;
     }
 }
@@ -283,9 +287,18 @@ extern "C" int tmg_phys_rms(const void* y, const void* trms, void* mean_out, voi
 }
 
 // dims = {N, T, H, W}; fl = {sd0..2, mu0..2, dx, dy, rho, cp, cd, cl, cr}
+extern "C" int tmg_phys_bwd_dev(const void* y, const void* target, const void* mean, const void* coef, void* dy, const void* upstream,
+                                const int64_t* dims, const float* fl, hipStream_t st);
 extern "C" int tmg_phys_bwd(const void* y, const void* target, const void* mean, const void* coef, void* dy, const int64_t* dims,
                             const float* fl, hipStream_t st) {
+    return tmg_phys_bwd_dev(y, target, mean, coef, dy, nullptr, dims, fl, st);
+}
+
+// as tmg_phys_bwd with the four coefficients additionally multiplied by the device scalar *upstream (NULL: 1)
+extern "C" int tmg_phys_bwd_dev(const void* y, const void* target, const void* mean, const void* coef, void* dy, const void* upstream,
+                                const int64_t* dims, const float* fl, hipStream_t st) {
     PhysBP p;
+    p.gup = (const float*)upstream;
     p.y = (const float*)y; p.target = (const float*)target; p.mean = (const float*)mean; p.coef = (const float*)coef; p.dy = (float*)dy;
     p.N = (int)dims[0]; p.T = (int)dims[1]; p.H = (int)dims[2]; p.W = (int)dims[3];
     for (int c = 0; c < 3; ++c) { p.sd[c] = fl[c]; p.mu[c] = fl[3 + c]; }

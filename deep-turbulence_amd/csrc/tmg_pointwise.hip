@@ -1261,11 +1261,7 @@ extern "C" int tmg_c1x2_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
     size_t lds_floats = (size_t)(TH + 4) * (TW + 4) * (p.KCH + 4) + 18 * p.KCH;
     const size_t d1_floats = 2 * (size_t)(((TH + 2) * (TW + 2) + 3) & ~3);
     if (lds_floats < d1_floats) lds_floats = d1_floats;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c1x2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    TMG_LDS_OPTIN((&c1x2_fwd_kernel));
     hipLaunchKernelGGL(c1x2_fwd_kernel, dim3(p.B * p.tiles_x * p.tiles_y), dim3(256), lds_floats * 4, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
@@ -1298,11 +1294,7 @@ extern "C" int tmg_c1_fwd_add(const void* const* in_ptrs, const int64_t* in_desc
     const int Cpad = (p.Cin + 3) & ~3;
     { const char* e = getenv("TMG_C1_KCH"); const int k = e ? atoi(e) : 32; p.KCH = Cpad < k ? Cpad : k; }
     const size_t lds_bytes = ((size_t)(TH + 2) * (TW + 2) * (p.KCH + 4) + 9 * p.KCH) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    TMG_LDS_OPTIN((&c1_fwd_kernel));
     hipLaunchKernelGGL(c1_fwd_kernel, dim3(p.B * p.tiles_x * p.tiles_y), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
@@ -1335,11 +1327,7 @@ extern "C" int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, in
     if ((Cpad + p.KCH - 1) / p.KCH > 8) return -2;  // Cin <= 256
     const int PP = (TH + 2) * (TW + 2);
     const size_t lds_bytes = ((size_t)((PP + 3) & ~3) + 9 * p.KCH + (size_t)PP * (p.KCH + 4)) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&c1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    TMG_LDS_OPTIN((&c1_bwd_kernel));
     int gx = p.ntiles < 1024 ? p.ntiles : 1024;
     hipLaunchKernelGGL(c1_bwd_kernel, dim3(gx), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
@@ -1384,12 +1372,8 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     const int nchunks = (Cpad + p.KCH - 1) / p.KCH;
     const int PP = (TH + 2) * (TW + 2), QQ = (TH + 4) * (TW + 4);
     const size_t lds_bytes = ((size_t)((QQ + 3) & ~3) + ((PP + 3) & ~3) + 18 * p.KCH + (size_t)PP * (p.KCH + 8)) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense2_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    TMG_LDS_OPTIN((&dense2_bwd_kernel<true>));
+    TMG_LDS_OPTIN((&dense2_bwd_kernel<false>));
     static const int d2_blocks = getenv("TMG_D2_BLOCKS") ? atoi(getenv("TMG_D2_BLOCKS")) : 1024;
     int gx = d2_blocks / nchunks;
     if (gx > p.ntiles) gx = p.ntiles;

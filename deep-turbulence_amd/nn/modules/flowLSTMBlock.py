@@ -53,6 +53,8 @@ class _BlockBase(nn.Module):
     def _mix(self, xn, reverse, mix=None):
         W, b = self._mix_params(reverse) if mix is None else mix
         c = W.shape[0]
+        if ops.mix_precision() != "f32":
+            return ops.MixFn.apply(xn, W, b)
         return ops.conv([xn], W.reshape(c, c, 1, 1), b, ksize=1)
 
 

@@ -17,6 +17,20 @@ from nn.modules.flowUtils import GaussianDiag
 from nn.modules.misc import UpsamplingLinear
 
 
+def _on_input_device(fn):
+    """Run a model entry point with its first tensor argument's GPU as the current device: the kernels launch on the current
+    device's stream, and the reference lets the model live on any cuda:N (main.py:72 `.to(args.src_device)`)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, x, *a, **k):
+        if x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(self, x, *a, **k)
+        return fn(self, x, *a, **k)
+    return wrapped
+
+
 def _conv3(cin, cout, stride):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False, padding_mode='zeros')
 
@@ -132,6 +146,7 @@ class TMGlow(nn.Module):
         cmean, clog_stddev = z_out.chunk(2, 1)
         return GaussianDiag(cmean, clog_stddev), c_out
 
+    @_on_input_device
     def forward(self, x, y, h_in=None, return_eps=False):
         """x -> z.  Returns (z, log_prior + log_det [B], h_out, eps | None) (reference :378-414)."""
         cprior, c_out = self._prior(x)
@@ -144,6 +159,7 @@ class TMGlow(nn.Module):
             eps = None
         return z, log_prior + log_det, h_out, eps
 
+    @_on_input_device
     def sample(self, x, h_in=None):
         """Conditional generation with freshly drawn latents; no top-prior term in the log-det (reference :417-440)."""
         cprior, c_out = self._prior(x)
@@ -151,6 +167,7 @@ class TMGlow(nn.Module):
         eps = [None for _ in range(len(self.glow_blocks))]
         return self.glow.reverse(z_samp, c_out, h_in, eps)
 
+    @_on_input_device
     def reconstruct(self, x, h_in, eps):
         """Generation from given latents, eps[-1] being the deepest (reference :442-467)."""
         cprior, c_out = self._prior(x)

@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtmglow_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip"]
+SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip"]
 _lib = None
 
 c_i64 = ctypes.c_int64
@@ -28,22 +28,38 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect",
+    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev",
 ]
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP sources for gfx950 into libtmglow_hip.so (in-tree)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "tmg_common.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """Compile the HIP sources for gfx950 into libtmglow_hip.so (in-tree).  One object per source (recompiled only when the
+    source or a header changed, all stale ones in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    headers = [os.path.join(CSRC, "tmg_common.h"), os.path.join(inc, "tmglow_hip.h")]
+    hmt = max(os.path.getmtime(h) for h in headers)
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-result",
-           "-I", os.path.join(os.path.dirname(_HERE), "include")] + srcs + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-I", inc]
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp, ob = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(ob)
+        if force or not os.path.exists(ob) or os.path.getmtime(ob) < max(os.path.getmtime(sp), hmt):
+            jobs.append([hipcc] + flags + ["-c", sp, "-o", ob])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])
     return LIB_PATH
 
 
@@ -112,9 +128,20 @@ def seg(t):
     return (t.data_ptr(), int(ps), 0, int(C))
 
 
+def check_device(t):
+    """Kernels launch on the CURRENT device's current stream: a tensor that lives on another GPU would be read through a
+    foreign pointer (fault, or silent peer traffic).  The model entry points (TMGlow.forward / sample / reconstruct) switch to
+    their input's device themselves; stand-alone modules must be called with their device current."""
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise RuntimeError("TM-Glow HIP op called with a tensor on %s while the current device is cuda:%d: wrap the call in "
+                           "`with torch.cuda.device(t.device):` (or torch.cuda.set_device once per process)"
+                           % (t.device, torch.cuda.current_device()))
+
+
 def nhwc(x):
     """API tensor [B,C,H,W] (any strides) -> internal [B,H,W,C] contiguous (free if channels_last)."""
     check_act(x)
+    check_device(x)
     return x.permute(0, 2, 3, 1).contiguous()
 
 
@@ -308,6 +335,15 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
         return False
     _chk(rc, "tmg_conv_wgrad_grouped")
     return True
+
+
+def mix_f16(x, W, bias, y, transposed=False):
+    """y = fp16(W) . fp16(x) + bias per pixel, fp32 accumulation (tmg_mix_f16); W: fp32 [C, C]; transposed: apply W^T."""
+    B, Hh, Ww, C = x.shape
+    check_act(W)
+    assert W.is_contiguous() and W.shape == (C, C) and y.shape == x.shape
+    _chk(lib().tmg_mix_f16(_ptr(x), _d2(x), _ptr(W), _ptr(bias), _ptr(y), _d2(y), _i64(B * Hh * Ww, C, 1 if transposed else 0), _stream()),
+         "tmg_mix_f16")
 
 
 def conv_rep_border_fix(dy, w, outs, kappa=None):
@@ -508,7 +544,8 @@ def phys_rms(y, trms, mean_out, coef_out, sum_out):
     _chk(lib().tmg_phys_rms(_ptr(y), _ptr(trms), _ptr(mean_out), _ptr(coef_out), _ptr(sum_out), _i64(B, T, chw), _stream()), "tmg_phys_rms")
 
 
-def phys_bwd(y, target, mean, coef, dyo, T, sd, mu, dx, dy, rho, cp, cd, cl, cr):
+def phys_bwd(y, target, mean, coef, dyo, T, sd, mu, dx, dy, rho, cp, cd, cl, cr, upstream=None):
+    """upstream: optional device scalar (fp32, 1 element) multiplied onto cp..cr inside the kernel."""
     N, _, Hh, Ww = y.shape
-    _chk(lib().tmg_phys_bwd(_ptr(y), _ptr(target), _ptr(mean), _ptr(coef), _ptr(dyo), _i64(N, T, Hh, Ww),
-                            _flts(list(sd) + list(mu) + [dx, dy, rho, cp, cd, cl, cr]), _stream()), "tmg_phys_bwd")
+    _chk(lib().tmg_phys_bwd_dev(_ptr(y), _ptr(target), _ptr(mean), _ptr(coef), _ptr(dyo), _ptr(upstream), _i64(N, T, Hh, Ww),
+                                _flts(list(sd) + list(mu) + [dx, dy, rho, cp, cd, cl, cr]), _stream()), "tmg_phys_bwd_dev")

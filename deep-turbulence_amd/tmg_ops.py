@@ -463,12 +463,59 @@ class CouplingTailFn(torch.autograd.Function):
         return dx, daux, dw1, dw2, dwz, dbz, dk, None, None
 
 
+# Arithmetic of the 1x1 channel mixes (ActNorm folded into the invertible 1x1 conv, glowConv.py:193-194 / :219-220):
+# "f32" (default) = fp32 MFMA through tmg_conv_fwd; "f16" = fp16 operands, fp32 accumulation (tmg_mix_f16), forward and input
+# gradient - the variant BASELINE.json configs[4] names.  Explicit opt-in: set_mix_precision("f16") or TMG_MIX_F16=1.  Weight
+# gradients stay fp32 in both modes.  The deviation of "f16" from "f32" is reported by tests/test_model_parity.py, separately
+# from the fp32 parity tolerances.
+_MIX_PRECISION = "f16" if os.environ.get("TMG_MIX_F16") else "f32"
+
+
+def set_mix_precision(kind):
+    global _MIX_PRECISION
+    if kind not in ("f32", "f16"):
+        raise ValueError("mix precision must be 'f32' or 'f16', got %r" % (kind,))
+    _MIX_PRECISION = kind
+
+
+def mix_precision():
+    return _MIX_PRECISION
+
+
+def _mix16_ok(C):
+    return _MIX_PRECISION == "f16" and C % 4 == 0 and C <= 256
+
+
 def _mix_fwd(x, Wk, bk, packed=None):
     """y = Wk x + bk per pixel (ActNorm folded into the invertible 1x1 conv).  packed: Wk already in operand order."""
     C = Wk.shape[0]
     y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    if _mix16_ok(C):
+        H.mix_f16(x, Wk.contiguous(), bk, y)
+        return y
     H.conv_fwd([x], packed if packed is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 0), C, 1, 1, [y], bias=bk)
     return y
+
+
+class MixFn(torch.autograd.Function):
+    """y = W x + b per pixel as one node in the selected mix precision (used by the blocks outside the level-fused node)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x if x.stride(3) == 1 else x.contiguous()
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        return _mix_fwd(x, W.detach(), b.detach() if b is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = W.shape[0]
+        dW = torch.zeros_like(W)
+        db = torch.zeros(C, device=W.device, dtype=torch.float32)
+        dx = _mix_bwd(x, dy, W, dW, db)
+        return dx, dW, (db if ctx.has_b else None)
 
 
 def _mix_bwd(x, dy, Wk, dWk, dbk, packed_t=None, defer=None):
@@ -476,7 +523,10 @@ def _mix_bwd(x, dy, Wk, dWk, dbk, packed_t=None, defer=None):
     defer: list collecting (x, dy) instead - the caller runs the weight gradients of a whole level as one grouped launch."""
     C = Wk.shape[0]
     dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-    H.conv_fwd([dy], packed_t if packed_t is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 1), C, 1, 1, [dx])
+    if _mix16_ok(C):
+        H.mix_f16(dy, Wk.contiguous(), None, dx, transposed=True)
+    else:
+        H.conv_fwd([dy], packed_t if packed_t is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 1), C, 1, 1, [dx])
     if defer is not None:
         defer.append((x, dy))
     else:

@@ -28,6 +28,20 @@ class DeviceLoader(object):
         self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
         self.input_noise_std, self.target_noise_std = input_noise_std, target_noise_std
         self.dataset = self.inputs  # len(loader.dataset) is used by the reference's prediction code (utils/utils.py:189)
+        self.rank, self.world, self._epoch = 0, 1, 0
+
+    def set_shard(self, rank, world):
+        """Data-parallel sharding: this rank yields rows rank::world of every global batch.  The permutation of an epoch is
+        drawn on the host from a generator seeded identically on all ranks (base seed from the global torch RNG at the time
+        of the call, which `main.py`'s seeding makes equal across ranks), so the ranks walk disjoint shards of the SAME
+        global batches - the reference's scatter of one batch across GPUs (parallel.py:118)."""
+        assert self.batch_size % world == 0, "global batch must be divisible by the number of GPUs"
+        self.rank, self.world = int(rank), int(world)
+        seed = [int(torch.initial_seed() % (2 ** 31))]
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.broadcast_object_list(seed, src=0)   # one permutation stream for all ranks even if their RNGs were seeded apart
+        self._seed = seed[0]
 
     def __len__(self):
         n = self.inputs.size(0)
@@ -35,9 +49,14 @@ class DeviceLoader(object):
 
     def __iter__(self):
         n = self.inputs.size(0)
-        order = torch.randperm(n, device=self.inputs.device) if self.shuffle else torch.arange(n, device=self.inputs.device)
+        if self.world > 1:
+            g = torch.Generator().manual_seed(self._seed + self._epoch)
+            self._epoch += 1
+            order = (torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)).to(self.inputs.device)
+        else:
+            order = torch.randperm(n, device=self.inputs.device) if self.shuffle else torch.arange(n, device=self.inputs.device)
         for i in range(len(self)):
-            idx = order[i * self.batch_size:(i + 1) * self.batch_size]
+            idx = order[i * self.batch_size:(i + 1) * self.batch_size][self.rank::self.world]
             x, y = self.inputs[idx], self.targets[idx]
             if self.input_noise_std:
                 x = x + self.input_noise_std * torch.randn_like(x)
@@ -176,3 +195,70 @@ class CylinderArrayLoader(TMGLowDataLoader):
         batch_size = min(batch_size, len(ntest))
         lo, hi = self._normalise(*self._load_cases(self.FILES, ntest, inUpscale))
         return DeviceLoader(lo, hi, torch.ones(lo.size(0)), batch_size, self.shuffle, False, device=self.device)
+
+
+class DataLoaderAuto(object):
+    """Loader factory keyed on `args.exp_type` (reference utils/dataLoader.py:476-538): same case selection, inlet
+    velocities, splits and up-scaling; returns (loader object, training loader, testing loader) as `main.py:86` expects.
+    The batches live on the model's device; under torchrun the TRAINING loader hands every rank its own shard of each
+    global batch (rank-strided, same seeded permutation on all ranks), the reference's `scatter` along dim 0."""
+
+    @classmethod
+    def init_data_loaders(cls, args, model, log):
+        if args.exp_type == 'backward-step':
+            return cls.setupBackwardStepLoaders(args, model, log)
+        if args.exp_type == 'cylinder-array':
+            return cls.setupCylinderLoaders(args, model, log)
+        raise AssertionError("Provided experiment name, {:s}, not supported .".format(args.exp_type))
+
+    @staticmethod
+    def _core(model):
+        return getattr(model, "module", model)
+
+    @classmethod
+    def _finish(cls, args, model, loader, make_train, make_test):
+        core = cls._core(model)
+        if args.epoch_start > 0:   # resumed run: the normalising constants ride in the model's buffers (reference :507-509)
+            loader.setNormalizingParams(core)
+            training_loader = make_train()
+        else:
+            training_loader = make_train()
+            loader.transferNormalizingParams(core)
+        return loader, _shard_for_rank(training_loader), make_test()
+
+    @classmethod
+    def setupBackwardStepLoaders(cls, args, model, log):
+        log.log('Setting up backward step loaders.')
+        cases = np.arange(0, 64, 1)
+        np.random.seed(args.seed)
+        np.random.shuffle(cases)
+        ntest = cases[-args.ntest:]
+        ntrain = np.linspace(0, 63, args.ntrain).astype(int)
+        u0 = np.linspace(1, 10, 64)
+        dev = next(cls._core(model).parameters()).device
+        ld = BackwardStepLoader(args.training_data_dir, args.testing_data_dir, log=log, device=dev)
+        return cls._finish(
+            args, model, ld,
+            lambda: ld.createTrainingLoader(ntrain, u0, tSplit=2, inUpscale=(1.34, 1.34), batch_size=args.batch_size,
+                                            tar_noise_std=args.noise_std),
+            lambda: ld.createTestingLoader(ntest, u0, inUpscale=(1.34, 1.34), batch_size=args.test_batch_size))
+
+    @classmethod
+    def setupCylinderLoaders(cls, args, model, log):
+        log.log('Setting up cylinder array loaders.')
+        ntest = np.arange(96, 96 + args.ntest, 1).astype(int)
+        ntrain = np.linspace(0, 95, args.ntrain).astype(int)
+        dev = next(cls._core(model).parameters()).device
+        ld = CylinderArrayLoader(args.training_data_dir, args.testing_data_dir, log=log, device=dev)
+        return cls._finish(args, model, ld,
+                           lambda: ld.createTrainingLoader(ntrain, tSplit=2, batch_size=args.batch_size),
+                           lambda: ld.createTestingLoader(ntest, batch_size=args.test_batch_size))
+
+
+def _shard_for_rank(loader):
+    """Under torch.distributed every rank takes rows rank::world of each global batch (the batch must divide evenly,
+    reference parallel.py:84-86)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        loader.set_shard(dist.get_rank(), dist.get_world_size())
+    return loader

@@ -201,6 +201,16 @@ int tmg_conv_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, i
                            int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
 int64_t tmg_conv_wgrad_grouped_ws_floats(const int64_t* dims, int64_t ngroups);
 
+/* ---- reduced-precision 1x1 channel mix (tmg_mix16.hip) ---------------------------------------------------------- */
+
+/* y = fp16(W) . fp16(x) + bias per pixel with fp32 accumulation on v_mfma_f32_16x16x16_f16: the "fp16 MFMA 1x1 conv" variant
+ * of BASELINE.json configs[4] for F.conv2d(x, W[C,C,1,1]) at glowConv.py:193-194 / :219-220 (activations stay fp32 in HBM and
+ * are rounded to fp16 in registers).  Opt-in; the default mix is tmg_conv_fwd with ksize 1 (fp32 MFMA).
+ * x_d / y_d = {pixel stride, channel offset}; W = fp32 [C][C] row-major; dims = {npix, C, transposed}: transposed != 0 applies
+ * W^T (the input gradient of the same mix).  C % 4 == 0, C <= 256. */
+int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d, const int64_t* dims,
+                tmg_stream_t st);
+
 /* ---- physics-constrained reverse-KL loss (tmg_physics.hip) ------------------------------ */
 
 /* Residual sums of TMGLowLoss (trainFlowParallel.py:121-177 / physicsConstrained.py:42-94): y, target = [N,3,H,W]
@@ -216,6 +226,10 @@ int tmg_phys_rms(const void* y, const void* trms, void* mean_out, void* coef_out
  * c* = upstream * beta * 2 / (element count of the term). */
 int tmg_phys_bwd(const void* y, const void* target, const void* mean, const void* coef, void* dy, const int64_t* dims,
                  const float* fl, tmg_stream_t st);
+/* tmg_phys_bwd with c* additionally multiplied by the DEVICE scalar *upstream (the gradient arriving on the loss value), so the
+ * host never reads it back (NULL: 1). */
+int tmg_phys_bwd_dev(const void* y, const void* target, const void* mean, const void* coef, void* dy, const void* upstream,
+                     const int64_t* dims, const float* fl, tmg_stream_t st);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,10 @@ CFG_TINY = dict(in_features=2, out_features=2, enc_blocks=[2, 2], glow_blocks=[3
                 cglow_upscale=2, growth_rate=4, init_features=8, rec_features=4, _in_hw=(8, 8), _up=2)
 CFG_TINY3 = dict(in_features=3, out_features=3, enc_blocks=[1, 2, 2], glow_blocks=[2, 3, 1], cond_features=5,
                  cglow_upscale=2, growth_rate=4, init_features=8, rec_features=6, _in_hw=(8, 16), _up=2)
+# five flow levels at tiny widths (the depth of BASELINE.json configs[4]); the deepest level works on 2x2 maps and the
+# encoder's last block on a single pixel (bilinear 1x1 -> 2x2, replicate padding of a 2x2 map)
+CFG_TINY5 = dict(in_features=2, out_features=2, enc_blocks=[1, 1, 1, 1, 1], glow_blocks=[2, 2, 2, 2, 2], cond_features=4,
+                 cglow_upscale=2, growth_rate=4, init_features=8, rec_features=4, _in_hw=(32, 32), _up=2)
 # BASELINE.json configs[0]: cylinder-wake, 32x32x2 -> 64x64x2, L=3, K=16 (CPU plumbing case)
 CFG1 = dict(in_features=2, out_features=2, enc_blocks=[4, 4, 4], glow_blocks=[16, 16, 16], cond_features=32,
             cglow_upscale=2, growth_rate=4, init_features=16, rec_features=64, _in_hw=(32, 32), _up=2)
@@ -69,6 +73,13 @@ def perturb_(model, seed, s_zero, s_norm, s_lu):
                 continue
             p.add_((scales[kind] * torch.randn(p.shape, generator=g)).to(p.device, p.dtype))
     return model
+
+
+def perturb_scales(cfg):
+    """Perturbation of the seeded default-width models (SURVEY 8-C recipe: 0.004 / 0.02 / 0.004).  Networks with five flow
+    levels (80 coupling layers, 256-channel mixes) need half of it: at the full recipe the reference arithmetic itself blows up
+    (fp64 oracle: max|z| = 3.6e3, fp32 reconstruct = NaN; at half: max|z| = 5.2, fp32-vs-fp64 error 2e-3)."""
+    return (0.002, 0.01, 0.002) if len(cfg["glow_blocks"]) >= 5 else (0.004, 0.02, 0.004)
 
 
 def loss_forward(logp, y):
@@ -155,6 +166,17 @@ def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_t
 LOADER_U0 = {0: 1.3, 1: 0.8}
 
 
+def write_synthetic_cylinder_data(directory, cases=(0, 1, 2), seed=97, T=6, hw=(5, 7), up=4):
+    """Cylinder-array cases in the reference's on-disk format (no inlet scaling; output = `up` x input)."""
+    import os
+    rs = np.random.RandomState(seed)
+    for case in cases:
+        lo = rs.standard_normal((T, 4, hw[0], hw[1])).astype(np.float32) * 0.7 + 0.1 * case
+        hi = rs.standard_normal((T, 4, hw[0] * up, hw[1] * up)).astype(np.float32) * 1.2 + 0.3
+        np.savez(os.path.join(directory, "cylinderArrayCoarse%d-[U,p].npz" % case), data=lo)
+        np.savez(os.path.join(directory, "cylinderArrayFine%d-[U,p].npz" % case), data=hi)
+
+
 def write_synthetic_step_data(directory, seed=4321, T=6, hw=(6, 8), up=2):
     """Two backward-step cases in the reference's on-disk format: `data` = [T, 4 (u_x,u_y,u_z,p), H, W] per file."""
     import os
@@ -164,3 +186,52 @@ def write_synthetic_step_data(directory, seed=4321, T=6, hw=(6, 8), up=2):
         hi = rs.standard_normal((T, 4, hw[0] * up, hw[1] * up)).astype(np.float32) * 1.5 - 0.25
         np.savez(os.path.join(directory, "backwardStepCoarse%d-[U,p].npz" % case), data=lo)
         np.savez(os.path.join(directory, "backwardStepFine%d-[U,p].npz" % case), data=hi)
+
+
+# ---- compact whole-model fixtures (cfg1, tiny5: weights re-created from seeds, big tensors stored as checksum + strided sample) ----
+GRAD_SAMPLE_STRIDE = 13
+
+
+def seeded_state_dict(model_cls, cfg, d, seed=12345, scales=(0.004, 0.02, 0.004)):
+    """Re-create the fixture's weights (torch/numpy seeds + perturbation recipe) and verify them against the stored checksums."""
+    seed_all(seed)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = model_cls(**build_kwargs(cfg))
+    perturb_(m, 7, *scales)
+    cs = tensor_checksums(m.state_dict())
+    for k, v in zip(d["sd_checksum_keys"], d["sd_checksum_vals"]):
+        assert abs(cs[str(k)] - v) <= 1e-6 * abs(v) + 1e-9, k
+    return m
+
+
+def assert_compact_field(d, key, got, what, atol=FIELD_ATOL, rtol=FIELD_RTOL):
+    """`key` stored in full, or as key#sum = (sum, sum|.|) and key#sample = every 97th entry."""
+    if key in d:
+        return assert_field(got, d[key], what, atol=atol, rtol=rtol)
+    flat = torch.as_tensor(got).detach().cpu().reshape(-1)
+    assert_field(flat[::97], d[key + "#sample"], what + " (sample)", atol=atol, rtol=rtol)
+    s = d[key + "#sum"]
+    f64 = flat.double()
+    n = flat.numel()
+    assert abs(float(f64.sum()) - s[0]) <= atol * n ** 0.5 * 4 + rtol * abs(s[1]) + 1e-9 * abs(s[1]), what + " (sum)"
+    assert abs(float(f64.abs().sum()) - s[1]) <= atol * n ** 0.5 * 4 + rtol * abs(s[1]) + 1e-9 * abs(s[1]), what + " (abs sum)"
+
+
+def assert_compact_grads(d, prefix, grads, what, norm_rtol=2e-3, global_tol=GRAD_GLOBAL_REL_L2, tensor_tol=GRAD_TENSOR_REL_MAX):
+    """grads: name -> tensor.  Checks per-tensor norms and every 13th entry of every gradient (direction, not only size)."""
+    keys = [str(k) for k in d[prefix + "gradnorm_keys"]]
+    assert all(k in grads and grads[k] is not None for k in keys), "%s: missing gradients" % what
+    for k, v in zip(keys, d[prefix + "gradnorm_vals"]):
+        n = float(torch.as_tensor(grads[k]).detach().double().norm())
+        assert abs(n - v) <= norm_rtol * v + 1e-7, (what, k, n, v)
+    if prefix + "gradsample" in d:
+        ref, o = d[prefix + "gradsample"], 0
+        got_s, ref_s = {}, {}
+        for k in keys:
+            g = torch.as_tensor(grads[k]).detach().cpu().reshape(-1)[::GRAD_SAMPLE_STRIDE]
+            got_s[k], ref_s[k] = g, ref[o:o + g.numel()]
+            o += g.numel()
+        assert o == ref.size, "%s: gradient sample layout" % what
+        assert_grads(got_s, ref_s, what + " (samples)", global_tol=global_tol, tensor_tol=tensor_tol)

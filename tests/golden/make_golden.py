@@ -45,7 +45,7 @@ def invalidate_w_cache(model):
             m.log_s_old.fill_(1.0e9)
 
 
-from common import (CFG_TINY, CFG_TINY3, CFG1, build_kwargs, perturb_, loss_forward, loss_reverse,  # noqa: E402
+from common import (CFG_TINY, CFG_TINY3, CFG_TINY5, CFG1, build_kwargs, perturb_, loss_forward, loss_reverse,  # noqa: E402
                     tensor_checksums, seed_all)
 
 
@@ -67,6 +67,9 @@ def states_to_np(states, prefix):
         out["%s%d.h" % (prefix, i)] = h.detach().numpy().copy()
         out["%s%d.c" % (prefix, i)] = c.detach().numpy().copy()
     return out
+
+
+GRAD_SAMPLE_STRIDE = 13   # compact fixtures keep every 13th entry of every gradient tensor (in named_parameters order)
 
 
 def _compact(d):
@@ -122,6 +125,7 @@ def model_case(ref, cfg, B, fname, store_weights=True, scales=(0.05, 0.1, 0.05),
     else:
         out["fwd.gradnorm_keys"] = np.array([k[len("fwd.grad."):] for k in gf])
         out["fwd.gradnorm_vals"] = np.array([float(np.sqrt((v.astype(np.float64) ** 2).sum())) for v in gf.values()])
+        out["fwd.gradsample"] = np.concatenate([v.reshape(-1)[::GRAD_SAMPLE_STRIDE] for v in gf.values()])
 
     # BatchNorm buffers advanced during the forward call: restore so both directions start equal
     model.load_state_dict(sd0)
@@ -143,6 +147,7 @@ def model_case(ref, cfg, B, fname, store_weights=True, scales=(0.05, 0.1, 0.05),
     else:
         out["rev.gradnorm_keys"] = np.array([k[len("rev.grad."):] for k in gr])
         out["rev.gradnorm_vals"] = np.array([float(np.sqrt((v.astype(np.float64) ** 2).sum())) for v in gr.values()])
+        out["rev.gradsample"] = np.concatenate([v.reshape(-1)[::GRAD_SAMPLE_STRIDE] for v in gr.values()])
     out["roundtrip_maxabs"] = np.array(float((y_rec.detach() - y).abs().max()))
     if compact:
         out = _compact(out)
@@ -345,6 +350,54 @@ def loader_case(fname):
     print("wrote", fname, {k: v.shape for k, v in out.items()})
 
 
+def cylinder_loader_case(fname):
+    """Row F4: the reference's CylinderArrayLoader (training: tSplit 2, drop_last; testing) and DataLoaderAuto's case selection
+    (`setupCylinderLoaders`) on synthetic files that tests/common.py writes again at test time."""
+    import tempfile
+    from types import SimpleNamespace
+    from common import write_synthetic_cylinder_data
+    sys.path.insert(0, REF)
+    from utils.dataLoader import CylinderArrayLoader, DataLoaderAuto
+
+    class _Quiet(object):
+        def log(self, *a, **k): pass
+        warning = error = info = log
+
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        write_synthetic_cylinder_data(d, cases=(0, 1, 2))
+        seed_all(778)
+        ld = CylinderArrayLoader(d, d, shuffle=False, log=_Quiet())
+        tr = ld.createTrainingLoader([0, 2, 1], tSplit=2, inUpscale=1, batch_size=4, tar_noise_std=0)
+        xs, ys, ss = zip(*[b for b in tr])
+        out["train.x"], out["train.y"], out["train.seed"] = torch.cat(xs).numpy(), torch.cat(ys).numpy(), torch.cat(ss).numpy()
+        out["train.nbatch"] = np.array([len(tr)])
+        for k in ("input_mean", "input_std", "output_mean", "output_std"):
+            out["norm." + k] = getattr(ld, k).numpy().copy()
+        te = ld.createTestingLoader([1, 2], batch_size=8)
+        xs, ys, us = zip(*[b for b in te])
+        out["test.x"], out["test.y"], out["test.u0"] = torch.cat(xs).numpy(), torch.cat(ys).numpy(), torch.cat(us).numpy()
+    # DataLoaderAuto: which cases it reads and what it hands back (main.py:86)
+    with tempfile.TemporaryDirectory() as d:
+        write_synthetic_cylinder_data(d, cases=(0, 47, 95, 96, 97), seed=98)
+        seed_all(779)
+        args = SimpleNamespace(exp_type='cylinder-array', ntrain=3, ntest=2, training_data_dir=d, testing_data_dir=d, epoch_start=0,
+                               batch_size=2, test_batch_size=2, noise_std=0.0, seed=1)
+        holder = SimpleNamespace(module=torch.nn.Linear(1, 1))   # transferNormalizingParams assigns the four buffers by attribute
+        auto, tr, te = DataLoaderAuto.init_data_loaders(args, holder, _Quiet())
+        out["auto.train.n"] = np.array([len(tr.dataset), len(tr)])
+        out["auto.test.n"] = np.array([len(te.dataset), len(te)])
+        out["auto.train.x_all"] = tr.dataset.inputs.numpy().copy()
+        out["auto.train.y_all"] = tr.dataset.targets.numpy().copy()
+        out["auto.train.seed_all"] = tr.dataset.lstm_seeds.numpy().copy()
+        out["auto.test.x_all"] = te.dataset.tensors[0].numpy().copy()
+        out["auto.test.y_all"] = te.dataset.tensors[1].numpy().copy()
+        for k in ("in_mu", "in_std", "out_mu", "out_std"):
+            out["auto.buf." + k] = getattr(holder.module, k).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print("wrote", fname, {k: v.shape for k, v in out.items()})
+
+
 def workspace_case(fname_zip):
     """Row F3: a workspace written by the reference's saveWorkspace for the tiny model + Adam (one step taken)."""
     import shutil
@@ -383,6 +436,17 @@ if __name__ == "__main__":
     if "loader" in sys.argv:
         loader_case("loader_case.npz")
         sys.exit(0)
+    if "cylinder" in sys.argv:
+        cylinder_loader_case("cylinder_loader_case.npz")
+        sys.exit(0)
+    if "tiny5" in sys.argv:
+        torch.set_num_threads(8)
+        model_case(ref, CFG_TINY5, 2, "tiny5_model.npz", store_weights=False, scales=(0.004, 0.02, 0.004), full_grads=False, compact=True)
+        sys.exit(0)
+    if "cfg1" in sys.argv:
+        torch.set_num_threads(8)
+        model_case(ref, CFG1, 2, "cfg1_model.npz", store_weights=False, scales=(0.004, 0.02, 0.004), full_grads=False, compact=True)
+        sys.exit(0)
     if "workspace" in sys.argv:
         workspace_case("ref_workspace7.zip")
         sys.exit(0)
@@ -392,6 +456,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     model_case(ref, CFG_TINY, 2, "tiny_model.npz")
     model_case(ref, CFG_TINY3, 3, "tiny3_model.npz", scales=(0.03, 0.05, 0.03))
+    model_case(ref, CFG_TINY5, 2, "tiny5_model.npz", store_weights=False, scales=(0.004, 0.02, 0.004), full_grads=False, compact=True)
     train_case(ref, CFG_TINY, 2, "tiny_train.npz")
     module_cases(ref, "modules.npz")
     init_checksum_case(ref, CFG1, "cfg1_init_checksums.npz")

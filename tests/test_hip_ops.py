@@ -382,3 +382,34 @@ def test_fused_growth_layers_match_two_launches(shape):
     _close(D[..., 0:1].permute(0, 3, 1, 2), d1, tol=3e-5, what="d1")
     _close(D[..., 1:2].permute(0, 3, 1, 2), d2, tol=3e-5, what="d2")
     assert float(D[..., 2:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C_,npix,slice_of", [(8, 37, 0), (12, 100, 0), (16, 4096, 0), (24, 333, 0), (32, 1000, 48), (48, 65, 0),
+                                               (64, 2048, 0), (80, 129, 0), (96, 257, 0), (128, 640, 160), (192, 33, 0), (256, 300, 0)])
+def test_mix_f16_kernel(C_, npix, slice_of):
+    """tmg_mix_f16 (fp16 operands, fp32 accumulation) against the same arithmetic spelled out in torch: operands rounded to
+    fp16, products and sums exact (fp64).  Every product of two fp16 numbers is exact in fp32, so only the fp32 summation
+    order separates the kernel from this reference: tolerance 2e-6 relative to max|y|.  Also W^T (the input-gradient form),
+    channel-slice inputs (pixel stride > C) and ragged pixel counts."""
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(C_ * 1000 + npix)
+    W = (torch.randn(C_, C_, generator=g) / math.sqrt(C_)).to(DEV)
+    b = torch.randn(C_, generator=g).to(DEV)
+    wide = slice_of or C_
+    buf = torch.randn(1, 1, npix, wide, generator=g).to(DEV)
+    x = buf[..., wide - C_:] if slice_of else buf          # channel-slice view: pixel stride `wide`
+    obuf = torch.full((1, 1, npix, wide), 7.0, device=DEV)
+    y = obuf[..., :C_] if slice_of else obuf
+    x16, W16 = x.half().double(), W.half().double()
+    for transposed in (False, True):
+        obuf.fill_(7.0)
+        H.mix_f16(x, W, None if transposed else b, y, transposed=transposed)
+        ref = x16 @ (W16 if transposed else W16.t()) + (0 if transposed else b.double())
+        _close(y, ref, tol=2e-6, what="mix_f16 C=%d transposed=%d" % (C_, transposed))
+        if slice_of:
+            assert bool((obuf[..., C_:] == 7.0).all()), "wrote outside its channel slice"
+    # and it must differ from the fp32 product by about fp16's rounding (2^-11 relative per operand), not by more
+    full = x.double() @ W.double().t() + b.double()
+    H.mix_f16(x, W, b, y)
+    dev = float((y.double() - full).abs().max()) / float(full.abs().max())
+    assert 1e-5 < dev < 5e-3, dev

@@ -57,19 +57,16 @@ def test_forward_reverse_and_grads_match_reference(name, cfg):
     assert float((yr.detach() - y).abs().max()) < 5e-4
 
 
-def test_cfg1_seeded_model_matches_reference():
-    """BASELINE configs[0] widths (L=3, K=16, Cc=32, R=64): weights are re-created from the seeds and the
-    perturbation recipe, checked by checksum against the reference's, then outputs are compared."""
+@pytest.mark.parametrize("name,cfg", [("cfg1_model.npz", C.CFG1), ("tiny5_model.npz", C.CFG_TINY5)])
+def test_seeded_models_match_reference(name, cfg):
+    """BASELINE configs[0] widths (cfg1: L=3, K=16, Cc=32, R=64) and a five-level model (depth of configs[4], deepest level on
+    2x2 maps, encoder down to one pixel): weights re-created from the seeds (checksums verified against the reference's),
+    then outputs, states, latents, per-tensor gradient norms and every 13th entry of every gradient against the values
+    recorded from the reference."""
     from nn.tmGlow import TMGlow
-    d = C.load_npz("cfg1_model.npz")
-    cfg = C.CFG1
-    L = 3
-    C.seed_all(12345)
-    m = TMGlow(**C.build_kwargs(cfg))
-    C.perturb_(m, 7, 0.004, 0.02, 0.004)
-    cs = C.tensor_checksums(m.state_dict())
-    for k, v in zip(d["sd_checksum_keys"], d["sd_checksum_vals"]):
-        assert abs(cs[str(k)] - v) <= 1e-6 * abs(v) + 1e-9, k
+    d = C.load_npz(name)
+    L = len(cfg["glow_blocks"])
+    m = C.seeded_state_dict(TMGlow, cfg, d)
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     m.to(DEV).train()
     x, y = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["y"]).to(DEV)
@@ -78,31 +75,161 @@ def test_cfg1_seeded_model_matches_reference():
     z, logp, h_out, eps = m.forward(x, y, h_in, return_eps=True)
     C.assert_field(z, d["fwd.z"], "z")
     C.assert_logdet(logp, d["fwd.logp"], "logp")
+    for i in range(L):
+        C.assert_compact_field(d, "fwd.h_out.%d.h" % i, h_out[i][0], "h_out", atol=C.STATE_ATOL)
+        C.assert_compact_field(d, "fwd.h_out.%d.c" % i, h_out[i][1], "c_out", atol=C.STATE_ATOL)
+    for i in range(L + 1):
+        C.assert_compact_field(d, "fwd.eps.%d" % i, eps[i], "eps%d" % i)
     C.loss_forward(logp, y).backward()
-    gn = {k: float(p.grad.double().norm()) for k, p in m.named_parameters() if p.grad is not None}
-    for k, v in zip(d["fwd.gradnorm_keys"], d["fwd.gradnorm_vals"]):
-        assert abs(gn[str(k)] - v) <= 1e-2 * v + 1e-7, (k, gn[str(k)], v)
+    C.assert_compact_grads(d, "fwd.", _grads(m), name + " fwd grads")
     m.load_state_dict(sd0)
     m.zero_grad()
-    yr, logdet, _ = m.reconstruct(x, h_in, [e.detach() for e in eps])
+    yr, logdet, h_out2 = m.reconstruct(x, h_in, [e.detach() for e in eps])
     C.assert_field(yr, d["rev.y"], "y_rec")
     C.assert_logdet(logdet, d["rev.logdet"], "logdet")
+    for i in range(L):
+        C.assert_compact_field(d, "rev.h_out.%d.h" % i, h_out2[i][0], "h_out", atol=C.STATE_ATOL)
     C.loss_reverse(yr, logdet).backward()
-    gn = {k: float(p.grad.double().norm()) for k, p in m.named_parameters() if p.grad is not None}
-    for k, v in zip(d["rev.gradnorm_keys"], d["rev.gradnorm_vals"]):
-        assert abs(gn[str(k)] - v) <= 1e-2 * v + 1e-7, (k, gn[str(k)], v)
+    C.assert_compact_grads(d, "rev.", _grads(m), name + " rev grads")
 
 
-@pytest.mark.parametrize("name,cfg,B,fatol,gtol", [("cfg2", C.CFG2, 2, C.FIELD_ATOL, (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX)),
-                                                  ("cfg3", C.CFG3, 1, 3e-3, (3e-3, 5e-2))])
-def test_baseline_configs_match_oracle(name, cfg, B, fatol, gtol):
-    """BASELINE configs[1] (64x64x3 -> 128x128x3, L=3) and configs[2] (non-square 64x128x4 -> 128x256x4, L=4) at the
-    default widths: forward, reconstruct and their gradients on the HIP path against the CPU oracle on the same seeded
-    weights (the oracle itself is pinned by the reference fixtures in tests/test_oracle_golden.py).  Field tolerance of
-    the 64-layer cfg3: the reference arithmetic's own fp32 noise there (oracle fp32 vs fp64, measured in the build
-    container) is 9.0e-4 on z (max|z| = 11.2), 1.9e-4 on the LSTM states, 6.4e-4 global / 1.2e-2 worst-tensor on the
-    gradients, so cfg3 is held to 3e-3 / 1.5e-3 / 3e-3 / 5e-2 (3-5x that floor); cfg2 (48 layers) holds the standard
-    tolerances of tests/common.py."""
+# cfg5 at a reduced field: the widths and the five levels of BASELINE configs[4] on a 64x64 output (level 5 works on 2x2 maps
+# with 256 channels); the full 512x512 field is covered by test_cfg5_full_size_properties
+CFG5_REDUCED = dict(C.CFG5, _in_hw=(32, 32))
+YARDSTICK = 3.0   # a quantity may deviate from the fp64 oracle by 3x what the reference's own fp32 arithmetic does
+
+
+def _maxabs(a, b):
+    return float((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max())
+
+
+def _grad_err(got, ref):
+    """(global relative L2, worst per-tensor relative max) of name -> tensor dicts against `ref`."""
+    num = den = worst = 0.0
+    for k, r in ref.items():
+        g = torch.as_tensor(got[k]).detach().cpu().double().reshape(-1)
+        r = torch.as_tensor(r).detach().cpu().double().reshape(-1)
+        num += float(((g - r) ** 2).sum())
+        den += float((r ** 2).sum())
+        if float(r.abs().max()) > 0:
+            worst = max(worst, float((g - r).abs().max()) / float(r.abs().max()))
+    return (num / max(den, 1e-300)) ** 0.5, worst
+
+
+def _oracle_pass(O, sd, cfg, x, y, seeds, dtype, eps=None):
+    """forward(+grads) and reconstruct(+grads) of the CPU oracle in `dtype`; eps: latents for the generative direction
+    (default: the forward pass's own)."""
+    H_, W_ = y.shape[2], y.shape[3]
+    P = O.params_from_state_dict(sd, dtype=dtype)
+    st = [(h.to(dtype), c.to(dtype)) for h, c in O.init_lstm_states(cfg, seeds, [H_, W_])]
+    xx, yy = x.to(dtype), y.to(dtype)
+    z, lp, ho, eo = O.tmglow_forward(P, cfg, xx, yy, st, return_eps=True, training=True)
+    C.loss_forward(lp, yy).backward()
+    gf = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
+    P = O.params_from_state_dict(sd, dtype=dtype)
+    e_in = [t.detach().to(dtype) for t in (eps if eps is not None else eo)]
+    yr, ld, ho2 = O.tmglow_reconstruct(P, cfg, xx, st, e_in, training=True)
+    C.loss_reverse(yr, ld).backward()
+    gr = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
+    det = lambda t: t.detach()  # noqa: E731
+    return dict(z=det(z), lp=det(lp), h=[(det(a), det(b)) for a, b in ho], eps=[det(t) for t in eo], gf=gf, y=det(yr), ld=det(ld),
+                h2=[(det(a), det(b)) for a, b in ho2], gr=gr)
+
+
+@pytest.mark.parametrize("name,cfg,B", [("cfg2", C.CFG2, 2), ("cfg3", C.CFG3, 1), ("M", C.CFG_M, 1), ("cfg5-64x64", CFG5_REDUCED, 2)])
+def test_baseline_configs_match_fp64_oracle(name, cfg, B):
+    """BASELINE configs[1] (64x64x3 -> 128x128x3, L=3), configs[2] (64x128x4 -> 128x256x4, L=4), the metric configuration M /
+    configs[3] (256x256x4, L=4) and configs[4]'s five-level network (reduced field) at the default widths: forward,
+    reconstruct and all gradients of the HIP path against the CPU oracle evaluated in FP64 on the same seeded weights.
+
+    Tolerance rule.  SURVEY 8-C states fp32 tolerances as 10x the reference's fp32-vs-fp64 noise measured on config 1; that
+    noise grows with depth and field size (48-80 coupling layers here), so every bound below is
+    max(stated tolerance, YARDSTICK x the error of the fp32 ORACLE against the same fp64 values), the fp32 oracle being the
+    reference's own arithmetic - measured here, in this test, not hard-coded.  The measured floors and the HIP errors are
+    printed (pytest -s) and written to gpurun_out/parity_<name>.json."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
+    import tmglow_oracle as O
+    from nn.tmGlow import TMGlow
+    import contextlib
+    import io
+    C.seed_all(12345)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, *C.perturb_scales(cfg))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(DEV).train()
+    h, w = cfg["_in_hw"]
+    H_, W_ = h * cfg["_up"], w * cfg["_up"]
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, cfg["in_features"], h, w, generator=g)
+    y = torch.randn(B, cfg["out_features"], H_, W_, generator=g)
+    seeds = torch.arange(B) + 3
+    r64 = _oracle_pass(O, sd, cfg, x, y, seeds, torch.float64)
+    r32 = _oracle_pass(O, sd, cfg, x, y, seeds, torch.float32, eps=r64["eps"])
+    # ---- HIP
+    st = m.initLSTMStates(seeds, [H_, W_])
+    z, lp, ho, e = m.forward(x.to(DEV), y.to(DEV), st, return_eps=True)
+    C.loss_forward(lp, y.to(DEV)).backward()
+    gf = {k: v.clone() for k, v in _grads(m).items()}
+    m.load_state_dict(sd)
+    m.zero_grad()
+    yr, ld, ho2 = m.reconstruct(x.to(DEV), st, [t.float().to(DEV) for t in r64["eps"]])
+    C.loss_reverse(yr, ld).backward()
+    gr = _grads(m)
+    rep = {}
+
+    def field(tag, got, key, stated):
+        ref = r64[key] if isinstance(key, str) else key[0]
+        o32 = r32[key] if isinstance(key, str) else key[1]
+        floor = _maxabs(o32, ref)
+        err = _maxabs(got, ref)
+        rep[tag] = {"hip_vs_fp64": err, "oracle_fp32_vs_fp64": floor, "stated": stated}
+        C.assert_field(got, ref, "%s %s" % (name, tag), atol=max(stated, YARDSTICK * floor), rtol=C.FIELD_RTOL)
+
+    def logdet(tag, got, key):
+        ref, o32 = r64[key], r32[key]
+        floor = float(((o32.double() - ref).abs() / ref.abs().clamp_min(1.0)).max())
+        err = float(((got.detach().cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max())
+        rep[tag] = {"hip_vs_fp64_rel": err, "oracle_fp32_vs_fp64_rel": floor, "stated": C.LOGDET_RTOL}
+        C.assert_logdet(got, ref, "%s %s" % (name, tag), rtol=max(C.LOGDET_RTOL, YARDSTICK * floor))
+
+    def grads(tag, got, key):
+        fl = _grad_err(r32[key], r64[key])
+        er = _grad_err(got, r64[key])
+        rep[tag] = {"hip_vs_fp64": er, "oracle_fp32_vs_fp64": fl, "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX)}
+        C.assert_grads(got, r64[key], "%s %s" % (name, tag), global_tol=max(C.GRAD_GLOBAL_REL_L2, YARDSTICK * fl[0]),
+                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, YARDSTICK * fl[1]))
+
+    try:
+        field("z", z, "z", C.FIELD_ATOL)
+        logdet("logp", lp, "lp")
+        for i, ((a, b_), (a64, b64), (a32, b32)) in enumerate(zip(ho, r64["h"], r32["h"])):
+            field("h%d" % i, a, (a64, a32), C.STATE_ATOL)
+            field("c%d" % i, b_, (b64, b32), C.STATE_ATOL)
+        for i, (ee, e64, e32) in enumerate(zip(e, r64["eps"], r32["eps"])):
+            field("eps%d" % i, ee, (e64, e32), C.FIELD_ATOL)
+        grads("forward grads", gf, "gf")
+        field("y", yr, "y", C.FIELD_ATOL)
+        logdet("logdet", ld, "ld")
+        for i, ((a, b_), (a64, b64), (a32, b32)) in enumerate(zip(ho2, r64["h2"], r32["h2"])):
+            field("rev h%d" % i, a, (a64, a32), C.STATE_ATOL)
+        grads("reverse grads", gr, "gr")
+    finally:
+        print("\nparity %s (B=%d): %s" % (name, B, json.dumps(rep, indent=1, default=float)))
+        out = os.path.join(C.ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "parity_%s.json" % name), "w") as f:
+                json.dump({"config": name, "batch": B, "yardstick": YARDSTICK, "quantities": rep}, f, indent=1, default=float)
+
+
+@pytest.mark.parametrize("name,cfg,B", [("cfg2", C.CFG2, 32), ("cfg3", C.CFG3, 64)])
+def test_stated_batches_match_oracle_on_a_subset(name, cfg, B):
+    """BASELINE configs[1] / configs[2] at their STATED batch sizes (32 / 64).  Samples are independent through the flow and
+    coupled only by the encoder's BatchNorm batch statistics, so the CPU oracle runs its encoder on the full batch (< 1 % of
+    the work) and the flow on the first two samples; the HIP path runs the whole batch."""
     import os
     import sys
     sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
@@ -115,36 +242,121 @@ def test_baseline_configs_match_oracle(name, cfg, B, fatol, gtol):
     m.to(DEV).train()
     h, w = cfg["_in_hw"]
     H_, W_ = h * cfg["_up"], w * cfg["_up"]
-    g = torch.Generator().manual_seed(31)
+    g = torch.Generator().manual_seed(77)
     x = torch.randn(B, cfg["in_features"], h, w, generator=g)
     y = torch.randn(B, cfg["out_features"], H_, W_, generator=g)
-    seeds = torch.arange(B) + 3
-    P = O.params_from_state_dict(sd)
-    st_o = O.init_lstm_states(cfg, seeds, [H_, W_])
-    zo, lpo, ho, eo = O.tmglow_forward(P, cfg, x, y, st_o, return_eps=True, training=True)
-    C.loss_forward(lpo, y).backward()
-    go = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
-    st = m.initLSTMStates(seeds, [H_, W_])
-    z, lp, ho2, e = m.forward(x.to(DEV), y.to(DEV), st, return_eps=True)
-    C.assert_field(z, zo.detach().numpy(), name + " z", atol=fatol)
-    C.assert_logdet(lp, lpo.detach().numpy(), name + " logp")
-    for (a, b_), (ao, bo) in zip(ho2, ho):
-        C.assert_field(a, ao.detach().numpy(), name + " h", atol=max(C.STATE_ATOL * 10, 0.5 * fatol))
-    C.loss_forward(lp, y.to(DEV)).backward()
-    C.assert_grads(_grads(m), {k: v.numpy() for k, v in go.items()}, name + " forward grads", global_tol=gtol[0], tensor_tol=gtol[1])
-    # generative direction with the oracle's latents
-    m.zero_grad()
-    for v in O.trainable(P).values():
-        v.grad = None
-    eps = [t.detach() for t in eo]
-    yo, ldo, _ = O.tmglow_reconstruct(P, cfg, x, st_o, eps, training=True)
-    C.loss_reverse(yo, ldo).backward()
-    go = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
-    yr, ld, _ = m.reconstruct(x.to(DEV), st, [t.to(DEV) for t in eps])
-    C.assert_field(yr, yo.detach().numpy(), name + " y", atol=fatol)
-    C.assert_logdet(ld, ldo.detach().numpy(), name + " logdet")
-    C.loss_reverse(yr, ld).backward()
-    C.assert_grads(_grads(m), {k: v.numpy() for k, v in go.items()}, name + " reverse grads", global_tol=gtol[0], tensor_tol=gtol[1])
+    seeds = torch.arange(B) + 11
+    n = 2
+    with torch.no_grad():
+        st = m.initLSTMStates(seeds, [H_, W_])
+        z, lp, ho, e = m.forward(x.to(DEV), y.to(DEV), st, return_eps=True)
+        m.load_state_dict(sd)
+        yr, ld, _ = m.reconstruct(x.to(DEV), st, e)
+        res = {}
+        for dt in (torch.float64, torch.float32):
+            P = O.params_from_state_dict(sd, dtype=dt, requires_grad=False)
+            z_out, c_out = O.encoder(P, cfg, x.to(dt), True)
+            cmean, clsd = z_out[:n].chunk(2, 1)
+            clsd = clsd.clamp(-10.0, O.LOG5)
+            sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
+            zo, ldo, _, eo = O.decoder_forward(P, cfg, y[:n].to(dt), [c[:n] for c in c_out], sto, True)
+            res[dt] = (zo, O.gauss_logp(cmean, clsd, zo) + ldo)
+    floor = _maxabs(res[torch.float32][0], res[torch.float64][0])
+    C.assert_field(z[:n], res[torch.float64][0], name + " z at the stated batch", atol=max(C.FIELD_ATOL, YARDSTICK * floor))
+    lfloor = float(((res[torch.float32][1].double() - res[torch.float64][1]).abs() / res[torch.float64][1].abs()).max())
+    C.assert_logdet(lp[:n], res[torch.float64][1], name + " logp at the stated batch", rtol=max(C.LOGDET_RTOL, YARDSTICK * lfloor))
+    assert float((yr - y.to(DEV)).abs().max()) < 2e-3   # forward -> reconstruct round trip over the whole batch
+
+
+def test_cfg5_full_size_properties():
+    """BASELINE configs[4] at its full field (512x512x4 output, five flow levels, default widths), batch 1, with the fp16-input
+    1x1 mixes that configuration names AND with the fp32 mixes: (i) forward -> reconstruct is the identity, (ii) forward
+    log-prob minus the top prior equals the generative direction's log-det on the same latents (appendix A.8), (iii) one
+    generative training step has finite gradients for every live parameter."""
+    import tmg_ops as ops
+    from nn.tmGlow import TMGlow
+    from nn.modules.flowUtils import GaussianDiag
+    cfg = C.CFG5
+    C.seed_all(12345)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, *C.perturb_scales(cfg))
+    m.to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 4, 256, 256, generator=g).to(DEV)
+    y = torch.randn(1, 4, 512, 512, generator=g).to(DEV)
+    h_in = m.initLSTMStates(torch.arange(1), [512, 512])
+    try:
+        for prec, rt_tol in (("f32", 1e-3), ("f16", 5e-2)):
+            ops.set_mix_precision(prec)
+            with torch.no_grad():
+                z, logp, h_out, eps = m.forward(x, y, h_in, return_eps=True)
+                yr, logdet, h_out2 = m.reconstruct(x, h_in, eps)
+                z_out, _ = m.encoder.forward(x)
+                cmean, clsd = z_out.chunk(2, 1)
+                top = GaussianDiag(cmean, clsd).log_prob(z)
+            assert z.shape == (1, 128, 16, 16) and yr.shape == y.shape and len(h_out) == 5
+            assert float((yr - y).abs().max()) < rt_tol, (prec, float((yr - y).abs().max()))
+            C.assert_logdet(logp - top, logdet, "cfg5 %s: forward logp - top prior vs reverse logdet" % prec,
+                            rtol=2e-5 if prec == "f32" else 2e-3, atol=1.0)
+            m.zero_grad()
+            ys, ld, _ = m.sample(x, h_in)
+            C.loss_reverse(ys, ld).backward()
+            gr = _grads(m)
+            assert len(gr) > 900 and all(bool(torch.isfinite(v).all()) for v in gr.values())
+    finally:
+        ops.set_mix_precision("f32")
+
+
+def test_fp16_mix_variant_deviation_is_reported_separately():
+    """The fp16-input / fp32-accumulate 1x1 mixes (BASELINE configs[4]; reference call sites glowConv.py:193-194, :219-220) are
+    outside the fp32 tolerances by construction: their deviation from this package's own fp32 path is measured
+    on the five-level network and bounded loosely (fp16 has 11 significant bits and the error compounds through 80 mixes);
+    the numbers go to gpurun_out/parity_fp16_mix.json."""
+    import json
+    import os
+    import tmg_ops as ops
+    from nn.tmGlow import TMGlow
+    cfg = CFG5_REDUCED
+    C.seed_all(12345)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, *C.perturb_scales(cfg))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(DEV).train()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 4, 32, 32, generator=g).to(DEV)
+    y = torch.randn(2, 4, 64, 64, generator=g).to(DEV)
+    st = m.initLSTMStates(torch.arange(2), [64, 64])
+    res = {}
+    try:
+        for prec in ("f32", "f16"):
+            ops.set_mix_precision(prec)
+            m.load_state_dict(sd)
+            m.zero_grad()
+            z, lp, _, e = m.forward(x, y, st, return_eps=True)
+            C.loss_forward(lp, y).backward()
+            gf = {k: v.clone() for k, v in _grads(m).items()}
+            m.load_state_dict(sd)
+            m.zero_grad()
+            eps_in = [t.detach() for t in (res["f32"]["e"] if prec == "f16" else e)]
+            yr, ld, _ = m.reconstruct(x, st, eps_in)
+            C.loss_reverse(yr, ld).backward()
+            res[prec] = dict(z=z.detach(), lp=lp.detach(), e=e, gf=gf, y=yr.detach(), ld=ld.detach(), gr=dict(_grads(m)))
+    finally:
+        ops.set_mix_precision("f32")
+    a, b = res["f16"], res["f32"]
+    rep = {"z_maxabs": _maxabs(a["z"], b["z"]), "z_scale": float(b["z"].abs().max()),
+           "logp_rel": float(((a["lp"] - b["lp"]).abs() / b["lp"].abs()).max()),
+           "y_maxabs": _maxabs(a["y"], b["y"]), "logdet_rel": float(((a["ld"] - b["ld"]).abs() / b["ld"].abs().clamp_min(1.0)).max()),
+           "forward_grads": _grad_err(a["gf"], b["gf"]), "reverse_grads": _grad_err(a["gr"], b["gr"])}
+    print("\nfp16-mix deviation from the fp32 HIP path:", json.dumps(rep, default=float))
+    out = os.path.join(C.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_fp16_mix.json"), "w") as f:
+            json.dump(rep, f, indent=1, default=float)
+    assert rep["z_maxabs"] > 0.0, "the fp16 variant must actually run (identical results mean the switch did nothing)"
+    assert rep["z_maxabs"] < 5e-2 * max(rep["z_scale"], 1.0) and rep["y_maxabs"] < 5e-2
+    assert rep["logp_rel"] < 2e-3 and rep["logdet_rel"] < 2e-3
+    assert rep["forward_grads"][0] < 5e-2 and rep["reverse_grads"][0] < 5e-2
 
 
 def test_flow_level_module_matches_reference():

@@ -37,6 +37,68 @@ def test_backward_step_loader_matches_reference(tmp_path):
     np.testing.assert_allclose(torch.cat(us).numpy(), g["test.u0"])
 
 
+def test_cylinder_loader_matches_reference(tmp_path):
+    """`CylinderArrayLoader` (reference utils/dataLoader.py:352-473): no inlet scaling, drop_last training batches, unit u0."""
+    from utils.dataLoader import CylinderArrayLoader
+    g = C.load_npz("cylinder_loader_case.npz")
+    C.write_synthetic_cylinder_data(str(tmp_path), cases=(0, 1, 2))
+    C.seed_all(778)
+    ld = CylinderArrayLoader(str(tmp_path), str(tmp_path), shuffle=False)
+    tr = ld.createTrainingLoader([0, 2, 1], tSplit=2, inUpscale=1, batch_size=4, tar_noise_std=0)
+    assert len(tr) == int(g["train.nbatch"][0])
+    xs, ys, ss = zip(*[b for b in tr])
+    np.testing.assert_allclose(torch.cat(xs).numpy(), g["train.x"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(torch.cat(ys).numpy(), g["train.y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(torch.cat(ss).numpy(), g["train.seed"])
+    for k in ("input_mean", "input_std", "output_mean", "output_std"):
+        np.testing.assert_allclose(getattr(ld, k).numpy(), g["norm." + k], rtol=1e-5, atol=1e-6)
+    te = ld.createTestingLoader([1, 2], batch_size=8)
+    xs, ys, us = zip(*[b for b in te])
+    np.testing.assert_allclose(torch.cat(xs).numpy(), g["test.x"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(torch.cat(ys).numpy(), g["test.y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(torch.cat(us).numpy(), g["test.u0"])
+
+
+def test_data_loader_auto_matches_reference(tmp_path):
+    """`DataLoaderAuto.init_data_loaders` (reference :476-538, what main.py:86 calls): case selection, splits, seeds and the
+    normalising constants handed to the model's buffers, against a capture of the reference's own factory."""
+    from utils.dataLoader import DataLoaderAuto
+    g = C.load_npz("cylinder_loader_case.npz")
+    C.write_synthetic_cylinder_data(str(tmp_path), cases=(0, 47, 95, 96, 97), seed=98)
+    C.seed_all(779)
+    args = SimpleNamespace(exp_type='cylinder-array', ntrain=3, ntest=2, training_data_dir=str(tmp_path), testing_data_dir=str(tmp_path),
+                           epoch_start=0, batch_size=2, test_batch_size=2, noise_std=0.0, seed=1)
+    holder = SimpleNamespace(module=torch.nn.Linear(1, 1))
+    log = SimpleNamespace(log=lambda *a, **k: None, warning=lambda *a, **k: None, error=lambda *a, **k: None)
+    auto, tr, te = DataLoaderAuto.init_data_loaders(args, holder, log)
+    assert [tr.inputs.size(0), len(tr)] == g["auto.train.n"].tolist() and [te.inputs.size(0), len(te)] == g["auto.test.n"].tolist()
+    np.testing.assert_allclose(tr.inputs.numpy(), g["auto.train.x_all"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tr.targets.numpy(), g["auto.train.y_all"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(tr.third.numpy(), g["auto.train.seed_all"])
+    np.testing.assert_allclose(te.inputs.numpy(), g["auto.test.x_all"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(te.targets.numpy(), g["auto.test.y_all"], rtol=1e-5, atol=1e-6)
+    for k in ("in_mu", "in_std", "out_mu", "out_std"):
+        np.testing.assert_allclose(getattr(holder.module, k).numpy(), g["auto.buf." + k], rtol=1e-5, atol=1e-6)
+    with pytest.raises(AssertionError):
+        DataLoaderAuto.init_data_loaders(SimpleNamespace(exp_type='nope'), holder, log)
+
+
+def test_sharded_loader_partitions_every_global_batch():
+    """Data-parallel sharding of `DeviceLoader`: the ranks' batches are disjoint and together are the global batches."""
+    from utils.dataLoader import DeviceLoader
+    t = torch.arange(24.).view(24, 1)
+    torch.manual_seed(3)
+    parts = []
+    for r in range(2):
+        ld = DeviceLoader(t, t, t, 8, True, True)
+        ld.set_shard(r, 2)
+        parts.append([b[0].flatten().tolist() for b in ld])
+    assert all(len(p) == 3 and all(len(b) == 4 for b in p) for p in parts)
+    for b0, b1 in zip(*parts):
+        assert not set(b0) & set(b1)
+    assert sorted(v for p in parts for b in p for v in b) == list(range(24))
+
+
 def test_loader_noise_and_batching(tmp_path):
     """tar_noise_std lands on the INPUT (the reference's positional-argument quirk), drawn per batch; drop_last rules."""
     from utils.dataLoader import BackwardStepLoader, DeviceLoader

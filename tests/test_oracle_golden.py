@@ -51,6 +51,42 @@ def test_model_forward_and_reverse_match_reference(name, cfg):
     assert float((yr.detach() - y).abs().max()) < 5e-4
 
 
+@pytest.mark.parametrize("name,cfg", [("cfg1_model.npz", C.CFG1), ("tiny5_model.npz", C.CFG_TINY5)])
+def test_seeded_models_match_reference(name, cfg):
+    """The oracle at BASELINE configs[0]'s default widths (cfg1: L=3, K=16, Cc=32, R=64) and on a five-level model (the depth of
+    configs[4]; the deepest level works on 2x2 maps): weights re-created from the seeds (checksums verified), outputs, states,
+    latents, per-tensor gradient norms and every 13th gradient entry against the values recorded from the reference."""
+    from nn.tmGlow import TMGlow
+    d = C.load_npz(name)
+    L = len(cfg["glow_blocks"])
+    m = C.seeded_state_dict(TMGlow, cfg, d)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"])
+    h_in = O.init_lstm_states(cfg, torch.arange(x.shape[0]), [y.shape[2], y.shape[3]])
+    for i, (h, c) in enumerate(h_in):
+        C.assert_compact_field(d, "h_in.%d.h" % i, h, "seeded h", atol=0, rtol=0)
+        C.assert_compact_field(d, "h_in.%d.c" % i, c, "seeded c", atol=0, rtol=0)
+    P = O.params_from_state_dict(sd)
+    z, logp, h_out, eps = O.tmglow_forward(P, cfg, x, y, h_in, return_eps=True)
+    C.assert_field(z, d["fwd.z"], "z")
+    C.assert_logdet(logp, d["fwd.logp"], "logp")
+    for i in range(L):
+        C.assert_compact_field(d, "fwd.h_out.%d.h" % i, h_out[i][0], "h_out", atol=C.STATE_ATOL)
+        C.assert_compact_field(d, "fwd.h_out.%d.c" % i, h_out[i][1], "c_out", atol=C.STATE_ATOL)
+    for i in range(L + 1):
+        C.assert_compact_field(d, "fwd.eps.%d" % i, eps[i], "eps%d" % i)
+    C.loss_forward(logp, y).backward()
+    C.assert_compact_grads(d, "fwd.", _grads(P), name + " fwd grads")
+    P = O.params_from_state_dict(sd)
+    yr, logdet, h_out2 = O.tmglow_reconstruct(P, cfg, x, h_in, [e.detach() for e in eps])
+    C.assert_field(yr, d["rev.y"], "y_rec")
+    C.assert_logdet(logdet, d["rev.logdet"], "logdet")
+    for i in range(L):
+        C.assert_compact_field(d, "rev.h_out.%d.h" % i, h_out2[i][0], "h_out", atol=C.STATE_ATOL)
+    C.loss_reverse(yr, logdet).backward()
+    C.assert_compact_grads(d, "rev.", _grads(P), name + " rev grads")
+
+
 def test_lstm_state_seeding_matches_reference():
     d = C.load_npz("tiny_model.npz")
     st = O.init_lstm_states(C.CFG_TINY, torch.arange(2), [16, 16])
