@@ -80,8 +80,14 @@ def test_seeded_models_match_reference(name, cfg):
         C.assert_compact_field(d, "fwd.h_out.%d.c" % i, h_out[i][1], "c_out", atol=C.STATE_ATOL)
     for i in range(L + 1):
         C.assert_compact_field(d, "fwd.eps.%d" % i, eps[i], "eps%d" % i)
+    # fp64 evaluation of the same case by the CPU oracle: measures the fp32 noise the reference-recorded gradients carry
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
+    import tmglow_oracle as O
+    r64 = _oracle_pass(O, sd0, cfg, x.cpu(), y.cpu(), torch.arange(B), torch.float64)
     C.loss_forward(logp, y).backward()
-    C.assert_compact_grads(d, "fwd.", _grads(m), name + " fwd grads")
+    C.assert_compact_grads(d, "fwd.", _grads(m), name + " fwd grads", truth=r64["gf"])
     m.load_state_dict(sd0)
     m.zero_grad()
     yr, logdet, h_out2 = m.reconstruct(x, h_in, [e.detach() for e in eps])
@@ -90,7 +96,7 @@ def test_seeded_models_match_reference(name, cfg):
     for i in range(L):
         C.assert_compact_field(d, "rev.h_out.%d.h" % i, h_out2[i][0], "h_out", atol=C.STATE_ATOL)
     C.loss_reverse(yr, logdet).backward()
-    C.assert_compact_grads(d, "rev.", _grads(m), name + " rev grads")
+    C.assert_compact_grads(d, "rev.", _grads(m), name + " rev grads", truth=r64["gr"])
 
 
 # cfg5 at a reduced field: the widths and the five levels of BASELINE configs[4] on a 64x64 output (level 5 works on 2x2 maps
@@ -302,7 +308,8 @@ def test_cfg5_full_size_properties():
             ys, ld, _ = m.sample(x, h_in)
             C.loss_reverse(ys, ld).backward()
             gr = _grads(m)
-            assert len(gr) > 900 and all(bool(torch.isfinite(v).all()) for v in gr.values())
+            live = [k for k, _ in m.named_parameters() if ".norm2." not in k]   # norm2 is dead in the reference
+            assert all(k in gr and bool(torch.isfinite(gr[k]).all()) for k in live), [k for k in live if k not in gr][:5]
     finally:
         ops.set_mix_precision("f32")
 
