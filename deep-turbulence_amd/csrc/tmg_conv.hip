@@ -536,7 +536,8 @@ struct WgradP {
     int TW_log2, TH;  // pixel tile (TH*TW == MPIX)
     int MPIX;
     int tiles_x, tiles_y, ntiles;
-    int CITG;  // input-channel tiles (of 16) handled per block group (grid.z walks the groups)
+    int CITG;  // input-channel tiles (of 16) a block group stages at most (LDS sizing)
+    int PPG;   // (input-channel tile, tap) pairs per block group: grid.z walks consecutive ranges of the tile-major pair list
     int dbg;     // timing experiments (TMG_WG_DBG): 1 = no MFMA loop, 2 = no staging
     int fstage;  // 1: every segment / dy is float4-addressable and offsets fit 24-bit multiplies -> lean staging path
     // grouped launch (tmg_conv_wgrad_grouped): group g = blockIdx.y / bpg reads its own input segments from gtab[g],
@@ -580,8 +581,13 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     // bank row, so the float4 stores of one pixel's quads (which go to different planes) do not collide (27 % of the LDS
     // cycles were bank conflicts with unpadded planes, all from the staging stores)
     const int PHPW = PH * PW, plane = PHPW * 16 + 16, dplane = MPIX * 16 + 16;
-    const int cit0 = blockIdx.z * p.CITG;
-    const int citn = min(p.CITG, (p.Cin_pad >> 4) - cit0);
+    // this group's pairs: [pair0, pair0 + npairs) of the list ordered (channel tile, tap); they touch channel tiles
+    // cit0 .. cit0 + citn - 1.  Ranges of equal length (not whole channel tiles) keep every group - hence every CU - equally
+    // loaded: 7 channel tiles x 9 taps = 63 pairs split 32 + 31 instead of 36 + 27.
+    const int pair0 = (int)blockIdx.z * p.PPG;
+    const int npairs = min(p.PPG, ntaps * (p.Cin_pad >> 4) - pair0);
+    const int cit0 = pair0 / ntaps;
+    const int citn = (pair0 + npairs - 1) / ntaps - cit0 + 1;
     const int k4 = citn * 4;
     const int grp = p.gtab ? (int)blockIdx.y / p.bpg : 0;  // grouped launch: which (input segments, dy slice, dW slice)
     const int co0 = ((int)blockIdx.y - grp * p.bpg) * NCO * 16;
@@ -589,7 +595,6 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     const int bufw = p.CITG * plane + NCO * dplane;  // words per buffer
     const int ksplit = p.ksplit;
 
-    const int npairs = ntaps * citn;
     f32x4 acc[NP][NCO];
 #pragma unroll
     for (int j = 0; j < NP; ++j)
@@ -601,8 +606,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     int aoffw[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int pid = min(ksplit ? j : w4 + 4 * j, npairs - 1);
-        const int tap = pid / citn, cit = pid - tap * citn;
+        const int gp = pair0 + min(ksplit ? j : w4 + 4 * j, npairs - 1);
+        const int citg = gp / ntaps, tap = gp - citg * ntaps, cit = citg - cit0;
         const int tyy = tap / p.ksize, txx = tap - tyy * p.ksize;
         aoffw[j] = cit * plane + (tyy * PW + txx) * 16 + li;
     }
@@ -824,79 +829,95 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
         int tid_c = tid, tid_i = tid;
         asm volatile("" : "+v"(tid_c));
         asm volatile("" : "+v"(tid_i));
-        if constexpr (LEAN) {
-            if (k >= -1 && tile + G < p.ntiles && p.dbg != 2) TMG_WG_COMMIT_F(((k + 1) & 1) * bufw)  // tile k+1 (loaded a round ago)
-            if (tile + 2 * G < p.ntiles && p.dbg != 2) {
-                TMG_WG_ISSUE_F(tile + 2 * G)  // tile k+2, in flight for a whole round
-                wi_x += Gx;
-                if (wi_x >= p.tiles_x) { wi_x -= p.tiles_x; ++wi_y; }
-                wi_y += Gy;
-                if (wi_y >= p.tiles_y) { wi_y -= p.tiles_y; ++wi_b; }
-                wi_b += Gb;
-            }
-        } else {
-            if (k >= -1 && tile + G < p.ntiles) TMG_WG_COMMIT(((k + 1) & 1) * bufw, tid_c)
-            if (tile + 2 * G < p.ntiles) TMG_WG_ISSUE(tile + 2 * G, tid_i)
+        // Staging of a round: tile k+1 (loaded a round ago) goes from registers to the idle LDS buffer, then the loads of tile
+        // k+2 are issued into those registers.  Neither touches the buffer the MFMA loop reads, so a wave may do it anywhere
+        // inside its round.
+#define TMG_WG_STAGE_ROUND                                                                                        \
+        if constexpr (LEAN) {                                                                                     \
+            if (k >= -1 && tile + G < p.ntiles && p.dbg != 2) TMG_WG_COMMIT_F(((k + 1) & 1) * bufw)              \
+            if (tile + 2 * G < p.ntiles && p.dbg != 2) {                                                          \
+                TMG_WG_ISSUE_F(tile + 2 * G)                                                                      \
+                wi_x += Gx;                                                                                       \
+                if (wi_x >= p.tiles_x) { wi_x -= p.tiles_x; ++wi_y; }                                             \
+                wi_y += Gy;                                                                                       \
+                if (wi_y >= p.tiles_y) { wi_y -= p.tiles_y; ++wi_b; }                                             \
+                wi_b += Gb;                                                                                       \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            if (k >= -1 && tile + G < p.ntiles) TMG_WG_COMMIT(((k + 1) & 1) * bufw, tid_c)                        \
+            if (tile + 2 * G < p.ntiles) TMG_WG_ISSUE(tile + 2 * G, tid_i)                                        \
         }
-        if (k >= 0 && p.dbg != 1) {
-            const int cbw = (k & 1) * bufw;
-            float av[NP], bfr[NCO], avn[NP], bfn[NCO];
-            if (fast) {
-                // 16-pixel units; fragment registers ping-pong between k-steps, LDS byte addresses are bumped in place
-                // once per unit, and the scheduling barriers keep "issue the next k-step's reads, then this k-step's MFMAs"
-                const int u0 = px0 >> 4, u1 = (px0 + npx) >> 4;
-                unsigned aa[NP], ba[NCO];
-#pragma unroll
-                for (int j = 0; j < NP; ++j) aa[j] = 4u * (cbw + aoffw[j] + q * 16 + ((px0 >> TWl) * PW + (px0 & (TW - 1))) * 16);
-#pragma unroll
-                for (int n = 0; n < NCO; ++n) ba[n] = 4u * (cbw + ldy_w + n * dplane + (px0 + q) * 16 + li);
-#define TMG_WG_LD(AV, BF, K)                                                                                     \
-                {                                                                                                \
-                    _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = *(lds_cptr)(uintptr_t)(ba[n] + (K) * 256); \
-                    _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = *(lds_cptr)(uintptr_t)(aa[j] + (K) * 256);  \
-                }
-                TMG_WG_LD(av, bfr, 0) TMG_SB
-                for (int u = u0; u < u1; ++u) {
-                    TMG_WG_LD(avn, bfn, 1) TMG_SB
-                    TMG_WG_MFMA(av, bfr) TMG_SB
-                    TMG_WG_LD(av, bfr, 2) TMG_SB
-                    TMG_WG_MFMA(avn, bfn) TMG_SB
-                    TMG_WG_LD(avn, bfn, 3) TMG_SB
-                    TMG_WG_MFMA(av, bfr) TMG_SB
-                    {
-                        const int un = min(u + 1, u1 - 1);  // the last unit re-reads its own first k-step (harmless)
-                        const int pa = u * 16, pb = un * 16;
-                        const int d = (((pb >> TWl) * PW + (pb & (TW - 1))) - ((pa >> TWl) * PW + (pa & (TW - 1)))) * 64;
-                        const int db = (pb - pa) * 64;
-#pragma unroll
-                        for (int j = 0; j < NP; ++j) aa[j] += d;
-#pragma unroll
-                        for (int n = 0; n < NCO; ++n) ba[n] += db;
-                    }
-                    TMG_WG_LD(av, bfr, 0) TMG_SB
-                    TMG_WG_MFMA(avn, bfn) TMG_SB
-                }
-#undef TMG_WG_LD
-            } else {
-                // generic walk (narrow tiles, stride 2): per-k-step addresses, reads one k-step ahead
-                const int k0 = px0 >> 2, k1 = (px0 + npx) >> 2;  // npx is a multiple of 8: an even number of k-steps
-#define TMG_WG_LD(AV, BF, KS)                                                                                  \
-                {                                                                                              \
-                    const int m_ = (KS) * 4 + q;                                                               \
-                    const float* ab_ = lds + cbw + (((m_ >> TWl) * s) * PW + (m_ & (TW - 1)) * s) * 16;        \
-                    _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = lds[cbw + ldy_w + n * dplane + m_ * 16 + li]; \
-                    _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = ab_[aoffw[j]];                      \
-                }
-                TMG_WG_LD(av, bfr, k0)
-                for (int ks = k0; ks < k1; ks += 2) {
-                    TMG_WG_LD(avn, bfn, ks + 1)
-                    TMG_WG_MFMA(av, bfr)
-                    TMG_WG_LD(av, bfr, min(ks + 2, k1 - 1))
-                    TMG_WG_MFMA(avn, bfn)
-                }
-#undef TMG_WG_LD
-            }
+#define TMG_WG_LDF(AV, BF, K)                                                                                     \
+        {                                                                                                         \
+            _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = *(lds_cptr)(uintptr_t)(ba[n] + (K) * 256);    \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = *(lds_cptr)(uintptr_t)(aa[j] + (K) * 256);     \
         }
+#define TMG_WG_LDG(AV, BF, KS)                                                                                    \
+        {                                                                                                         \
+            const int m_ = (KS) * 4 + q;                                                                          \
+            const float* ab_ = lds + cbw + (((m_ >> TWl) * s) * PW + (m_ & (TW - 1)) * s) * 16;                   \
+            _Pragma("unroll") for (int n = 0; n < NCO; ++n) BF[n] = lds[cbw + ldy_w + n * dplane + m_ * 16 + li]; \
+            _Pragma("unroll") for (int j = 0; j < NP; ++j) AV[j] = ab_[aoffw[j]];                                 \
+        }
+        // MFMA loop over the 16-pixel units [UA, UB) of this wave's share of tile k (fast path: fragment registers ping-pong
+        // between k-steps, LDS byte addresses are bumped in place once per unit, the scheduling barriers keep "issue the next
+        // k-step's reads, then this k-step's MFMAs") or over the k-steps [KA, KB) (generic walk for narrow tiles / stride 2:
+        // per-k-step addresses, reads one k-step ahead; KB - KA is even)
+#define TMG_WG_RUN(UA, UB, KA, KB)                                                                                \
+        if (k >= 0 && p.dbg != 1) {                                                                               \
+            const int cbw = (k & 1) * bufw;                                                                       \
+            float av[NP], bfr[NCO], avn[NP], bfn[NCO];                                                            \
+            if (fast) {                                                                                           \
+                const int ua_ = (UA), ub_ = (UB), pxa_ = ua_ * 16;                                                \
+                unsigned aa[NP], ba[NCO];                                                                         \
+                _Pragma("unroll") for (int j = 0; j < NP; ++j)                                                    \
+                    aa[j] = 4u * (cbw + aoffw[j] + q * 16 + ((pxa_ >> TWl) * PW + (pxa_ & (TW - 1))) * 16);       \
+                _Pragma("unroll") for (int n = 0; n < NCO; ++n)                                                   \
+                    ba[n] = 4u * (cbw + ldy_w + n * dplane + (pxa_ + q) * 16 + li);                               \
+                TMG_WG_LDF(av, bfr, 0) TMG_SB                                                                     \
+                for (int u = ua_; u < ub_; ++u) {                                                                 \
+                    TMG_WG_LDF(avn, bfn, 1) TMG_SB                                                                \
+                    TMG_WG_MFMA(av, bfr) TMG_SB                                                                   \
+                    TMG_WG_LDF(av, bfr, 2) TMG_SB                                                                 \
+                    TMG_WG_MFMA(avn, bfn) TMG_SB                                                                  \
+                    TMG_WG_LDF(avn, bfn, 3) TMG_SB                                                                \
+                    TMG_WG_MFMA(av, bfr) TMG_SB                                                                   \
+                    {                                                                                             \
+                        const int un = min(u + 1, ub_ - 1); /* the last unit re-reads its own first k-step */     \
+                        const int pa = u * 16, pb = un * 16;                                                      \
+                        const int d = (((pb >> TWl) * PW + (pb & (TW - 1))) - ((pa >> TWl) * PW + (pa & (TW - 1)))) * 64; \
+                        const int db = (pb - pa) * 64;                                                            \
+                        _Pragma("unroll") for (int j = 0; j < NP; ++j) aa[j] += d;                                \
+                        _Pragma("unroll") for (int n = 0; n < NCO; ++n) ba[n] += db;                              \
+                    }                                                                                             \
+                    TMG_WG_LDF(av, bfr, 0) TMG_SB                                                                 \
+                    TMG_WG_MFMA(avn, bfn) TMG_SB                                                                  \
+                }                                                                                                 \
+            } else {                                                                                              \
+                const int ka_ = (KA), kb_ = (KB);                                                                 \
+                if (ka_ < kb_) {                                                                                  \
+                    TMG_WG_LDG(av, bfr, ka_)                                                                      \
+                    for (int ks = ka_; ks < kb_; ks += 2) {                                                       \
+                        TMG_WG_LDG(avn, bfn, ks + 1)                                                              \
+                        TMG_WG_MFMA(av, bfr)                                                                      \
+                        TMG_WG_LDG(av, bfr, min(ks + 2, kb_ - 1))                                                 \
+                        TMG_WG_MFMA(avn, bfn)                                                                     \
+                    }                                                                                             \
+                }                                                                                                 \
+            }                                                                                                     \
+        }
+        // (Measured dead end: letting the second wave quartet stage in the MIDDLE of its MFMA loop, so that the two waves of a
+        // SIMD never stage at the same time, changes nothing - 5.16 against 5.06 ms on the level-1 gate gradient.  VALU work
+        // is not hidden by the other wave's MFMAs on the same SIMD; only less staging arithmetic would help.)
+        {
+            const int u0 = px0 >> 4, u1 = (px0 + npx) >> 4, k0 = px0 >> 2, k1 = (px0 + npx) >> 2;
+            TMG_WG_STAGE_ROUND
+            TMG_WG_RUN(u0, u1, k0, k1)
+        }
+#undef TMG_WG_LDF
+#undef TMG_WG_LDG
+#undef TMG_WG_RUN
+#undef TMG_WG_STAGE_ROUND
         __syncthreads();  // the buffer just read may be overwritten next round; the one just written is complete
     }
 #undef TMG_WG_MFMA
@@ -969,14 +990,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     for (int j = 0; j < NP; ++j) {
         const int pid = ksplit ? j : w4 + 4 * j;
         if (pid >= npairs) continue;
-        const int tap = pid / citn, cit = pid - tap * citn;
+        const int citg = (pair0 + pid) / ntaps, tap = pair0 + pid - citg * ntaps;
 #pragma unroll
         for (int n = 0; n < NCO; ++n) {
             const int co = co0 + n * 16 + li;
             if (co >= p.Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ci = (cit0 + cit) * 16 + q * 4 + r;
+                const int ci = citg * 16 + q * 4 + r;
                 if (ci < p.cin_valid)
                     atomicAdd(p.dW + ((size_t)co * p.cin_dst + ci + (ci < p.ci_split ? p.ci_off0 : p.ci_off1)) * ntaps + tap, acc[j][n][r] * osc);
             }
@@ -988,8 +1009,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
 // Fold the per-block slabs of conv_wgrad_kernel into dW / dbias.  grid = (ceil(items/256), xchunks):
 // each thread sums one accumulator float4 over a chunk of the pixel-share (x) dimension, then adds it to dW.
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
-                                         const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int CITG,
-                                         int cit_total, int Cin, int Cout, int ntaps, int xchunk, int cin_valid, int ci_split,
+                                         const float* __restrict__ kappa, int gx, int gy, int gz, int NP, int NCO, int PPG,
+                                         int pairs_total, int Cin, int Cout, int ntaps, int xchunk, int cin_valid, int ci_split,
                                          int ci_off0, int ci_off1, int ksplit, int bpg, long long dw_gstride, int db_gstride) {
     // gy counts the blocks in y of the wgrad launch; with groups (bpg < gy) block y belongs to group y / bpg
     const int nws = ksplit ? 1 : 4;  // wave copies per block that survive the in-block fold
@@ -1005,9 +1026,8 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
         const int wave = r_ % nws; r_ /= nws;
         const int z = r_ % gz;
         const int y = r_ / gz;
-        const int citn = min(CITG, cit_total - z * CITG);
         const int pid = ksplit ? j : wave + 4 * j;
-        if (pid < ntaps * citn) {
+        if (pid < min(PPG, pairs_total - z * PPG)) {
             const size_t per_x = (size_t)gy * gz * nws * NP * NCO * 64;
             const float4* src = reinterpret_cast<const float4*>(ws) + (((((size_t)y * gz + z) * nws + wave) * NP + j) * NCO + n) * 64 + lane;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1022,10 +1042,10 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
                     a.x += wgt * v[u].x; a.y += wgt * v[u].y; a.z += wgt * v[u].z; a.w += wgt * v[u].w;
                 }
             }
-            const int tap = pid / citn, cit = pid - tap * citn;
+            const int citg = (z * PPG + pid) / ntaps, tap = z * PPG + pid - citg * ntaps;
             const int grp = y / bpg;
             const int co = ((y - grp * bpg) * NCO + n) * 16 + (lane & 15);
-            const int ci = (z * CITG + cit) * 16 + (lane >> 4) * 4;
+            const int ci = citg * 16 + (lane >> 4) * 4;
             dW += (size_t)grp * dw_gstride;
             if (co < Cout) {
                 const float av[4] = {a.x, a.y, a.z, a.w};
@@ -1228,8 +1248,9 @@ static const char* const g_prof_names[] = {
     "conv_fwd_kernel<*,3,4,2>", "conv_fwd_kernel<*,4,4,2>", "conv_fwd_kernel<*,3,2,4>", "conv_fwd_kernel<*,4,2,4>",
     "conv_wgrad_kernel<5,1,*>", "conv_wgrad_kernel<5,2,*>", "conv_wgrad_kernel<5,4,*>",
     "conv_wgrad_kernel<7,1,*>", "conv_wgrad_kernel<7,2,*>", "conv_wgrad_kernel<7,4,*>",
-    "conv_wgrad_kernel<9,1,*>", "conv_wgrad_kernel<9,2,*>", "conv_wgrad_kernel<9,4,*>"};
-#define TMG_NPROF 28
+    "conv_wgrad_kernel<9,1,*>", "conv_wgrad_kernel<9,2,*>", "conv_wgrad_kernel<9,4,*>",
+    "conv_wgrad_kernel<8,1,*>", "conv_wgrad_kernel<8,2,*>", "conv_wgrad_kernel<8,4,*>"};
+#define TMG_NPROF 31
 
 struct ProfScope {
     ProfRec r; bool on; hipStream_t st;
@@ -1520,7 +1541,7 @@ template <int NP, int NCO, bool LEAN>
 static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_t st) {
     TMG_LDS_OPTIN((&conv_wgrad_kernel<NP, NCO, LEAN>));
     const int nco_i = NCO == 1 ? 0 : (NCO == 2 ? 1 : 2);
-    const int kid = NP == 3 ? 8 + nco_i : 19 + ((NP - 5) / 2) * 3 + nco_i;
+    const int kid = NP == 3 ? 8 + nco_i : (NP == 8 ? 28 + nco_i : 19 + ((NP - 5) / 2) * 3 + nco_i);
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO, LEAN>), grid, dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
@@ -1528,7 +1549,7 @@ static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_
 }
 
 struct WgradPlan {
-    int twl, TH, MPIX, tiles_x, tiles_y, ntiles, CITG, NCO, NP, ksplit, gx, gy, gz;
+    int twl, TH, MPIX, tiles_x, tiles_y, ntiles, CITG, PPG, NCO, NP, ksplit, gx, gy, gz;
     size_t lds_bytes, ws_floats;
 };
 
@@ -1576,8 +1597,21 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     pl->NCO = NCO;
     // <= 9 pairs: every wave owns all of them and an eighth of each tile's pixels; otherwise the pairs are dealt to 4 waves
     pl->ksplit = ntaps * pl->CITG <= (NCO == 4 ? 5 : 9);  // (NP, NCO) = (7|9, 4) would not fit the register file
-    const int np = pl->ksplit ? ntaps * pl->CITG : (ntaps * pl->CITG + 3) / 4;
-    pl->NP = np <= 3 ? 3 : (np <= 5 ? 5 : (np <= 7 ? 7 : 9));
+    pl->PPG = ntaps * pl->CITG;   // whole channel tiles per group ...
+    if (!pl->ksplit && ngroups > 1) {
+        // ... or equal ranges of the (channel tile, tap) pair list, rounded up to the 4 waves that share them, when that loads the
+        // groups more evenly and a range never spans more channel tiles than fit (registers / LDS)
+        const int tp = ntaps * cit, ppg = (((tp + ngroups - 1) / ngroups) + 3) & ~3;
+        int span = 0;
+        for (int g = 0; g * ppg < tp; ++g) {
+            const int a = g * ppg, b = (a + ppg < tp ? a + ppg : tp) - 1;
+            if (b / ntaps - a / ntaps + 1 > span) span = b / ntaps - a / ntaps + 1;
+        }
+        if (ppg < pl->PPG && (ngroups - 1) * ppg < tp && span <= 4 && fits(span, NCO)) { pl->PPG = ppg; pl->CITG = span; }
+    }
+    const int np = pl->ksplit ? pl->PPG : (pl->PPG + 3) / 4;
+    pl->NP = np <= 3 ? 3 : (np <= 5 ? 5 : (np <= 7 ? 7 : (np <= 8 ? 8 : 9)));
+    if (pl->NP == 8 && NCO == 4) pl->NP = 9;   // no (8, 4) instance
     if (np > 9) return -7;
     pl->gy = (cot + NCO - 1) / NCO;
     pl->gz = ngroups;
@@ -1650,6 +1684,7 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
     const int rc = plan_wgrad(p.B, p.Hout, p.Wout, p.ksize, p.stride, p.Cin, p.Cout, &pl);
     if (rc != 0) return rc;
     p.TW_log2 = pl.twl; p.TH = pl.TH; p.MPIX = pl.MPIX; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.CITG = pl.CITG;
+    p.PPG = pl.PPG;
     const int bpg = pl.gy;
     if (ngroups > 1) {
         // one launch for `ngroups` independent, identically shaped contractions: the groups share the pixel tiles' geometry,
@@ -1683,6 +1718,7 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
     TMG_WG_CASE(3, 1) TMG_WG_CASE(3, 2) TMG_WG_CASE(3, 4)
     TMG_WG_CASE(5, 1) TMG_WG_CASE(5, 2) TMG_WG_CASE(5, 4)
     TMG_WG_CASE(7, 1) TMG_WG_CASE(7, 2)
+    TMG_WG_CASE(8, 1) TMG_WG_CASE(8, 2)
     TMG_WG_CASE(9, 1) TMG_WG_CASE(9, 2)
 #undef TMG_WG_CASE
     if (lrc != 0) return lrc;
@@ -1691,7 +1727,7 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
         int xchunk = 32;
         const int xc = (pl.gx + xchunk - 1) / xchunk;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((items + 255) / 256, xc), dim3(256), 0, st, (const float*)p.ws, p.dW, p.dbias,
-                           p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.CITG, p.Cin_pad >> 4, p.cin_dst, p.Cout, p.ksize * p.ksize, xchunk,
+                           p.kappa, pl.gx, pl.gy, pl.gz, pl.NP, pl.NCO, pl.PPG, (p.Cin_pad >> 4) * p.ksize * p.ksize, p.cin_dst, p.Cout, p.ksize * p.ksize, xchunk,
                            p.cin_valid, p.ci_split, p.ci_off0, p.ci_off1, pl.ksplit, bpg, dw_gstride, db_gstride);
         TMG_CHECK_LAUNCH();
     }
