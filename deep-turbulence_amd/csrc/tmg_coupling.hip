@@ -1,0 +1,320 @@
+// tmg_coupling.hip -- the traffic-heavy part of an affine coupling layer in ONE launch, for the narrow flow levels (C <= 32
+// channels) where the per-op chain (zero conv -> coupling -> channel mix) is bound by HBM round trips of hh and y and by launch
+// ramps, not by arithmetic.
+//
+// Reference semantics (paths relative to /root/reference/tmglow/nn/modules/), t2 = cat(x1, cond, d1, d2):
+//   hh = (conv3x3_valid(pad_replicate(relu(t2))) + b) * exp(clamp(kappa, -4, ln 4))                  flowUtils.py:246-247
+//   shift = hh[0::2], r = hh[1::2], sg = 2 softsign(r)                                               flowAffine.py:76-83, :102-109
+//   forward: y2 = (x2 + shift) exp(sg)      reverse: y2 = x2 exp(-sg) - shift      logdet[b] += sum sg
+//   then (reverse direction) the folded ActNorm + invertible 1x1 mix: out = Wm [x1; y2] + bm       glowConv.py:207-222, actNorm.py:71-85
+// The growth layers d1, d2 (denseBlock.py:135-152) come from tmg_c1x2_fwd (vector-ALU work: fusing them in here as well made the
+// kernel VALU-bound - 2 100 vector instructions per thread and tile, 150 us per level-1 layer against 155 us for the unfused
+// chain); the conditioning map's share of the zero conv arrives pre-computed per level (hc: a conv is linear in its input
+// channels and every layer of a level sees the same map).
+//
+// One 256-thread block walks 16x16-pixel tiles, the loads of tile k+1 in flight while tile k computes:
+//   stage   relu(x1 | d1, d2) on the tile + 1 halo pixel into LDS, replicate padding by clamping the coordinates; raw x1 of the tile
+//   zero conv on the matrix cores (v_mfma_f32_16x16x4_f32): A = weights (16 output channels x 4 input channels, registers),
+//           B = activations (4 channels x 16 consecutive pixels of a tile row, one ds_read_b32 per fragment at base + immediate,
+//           conflict-free because LDS holds channel PAIRS per plane: [c/2][pixel][2]); a lane ends up with 4 consecutive hh
+//           channels of a pixel = two (shift, r) pairs, so the affine coupling runs in registers;
+//   mix     [x1; y2] is already laid out as the B operand of a second MFMA contraction (k-order chosen to match the
+//           accumulator layout, the weight fragments are permuted instead); out = Wm y + bm leaves as one float4 per lane.
+// HBM traffic per pixel: reads x (C + halo share of x1), D (4), hc (C); writes out (C), r (C/2), y2 (C/2).
+#include "tmg_common.h"
+#include <stdlib.h>
+
+struct CplFP {
+    const float* x; int xs;          // layer input, C channels: x1 = [0, ch), x2 = [ch, C)
+    float* out; int os;              // layer output (C channels)
+    float* rsave;                    // [npix][ch] softsign arguments r
+    float* y2save;                   // [npix][ch] transformed half (null: not stored)
+    const float* D;                  // [npix][4] raw (d1, d2, 0, 0)
+    const float* hc; int hcs;        // cond part of the zero conv, C channels, before bias / scale
+    const float* wz; int wz_rows;    // torch layout [C][wz_rows][3][3]; x1 channel c reads column c
+    int wz_d1col;                    // column of d1 (d2 = the next one)
+    const float* bz; const float* kappa;
+    const float* Wm; const float* bm;   // trailing channel mix [C][C], [C]; null: out = [x1 | y2]
+    float* logdet;                   // [B], accumulated
+    int B, H, W, C, reverse;
+    int tiles_x, tiles_y, ntiles;
+};
+
+// CT: 16-channel output tiles (C <= 16 CT); K4: input-channel quads of the zero conv = ch/4 + 1 (the last quad is d1, d2, 0, 0)
+template <int CT, int K4>
+__global__ __launch_bounds__(256, CT == 1 ? 3 : 1) void cpl_fwd_kernel(CplFP p) {
+    constexpr int CH4 = K4 - 1, CHP = 2 * CH4;        // x1 channel quads / pairs
+    constexpr int PW = 18, PP = PW * PW;              // staged patch (tile + halo 1)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // two tile buffers (a tile is committed while the other waves may still read the previous one: ONE barrier per tile), each
+    //   XQ [CHP + 1][PP][2]  relu(x1) pairs, then (relu d1, relu d2)       XR [CHP][256][2]  raw x1 of the tile
+    constexpr int BUFW = (CHP + 1) * PP * 2 + CHP * 256 * 2;
+    constexpr int ZPN = (5 * PW + 4) * 2;
+    float* ZP = lds + 2 * BUFW;                       // [ZPN] zeros: channels ch+2, ch+3 of the zero conv input (as large as the largest
+                                                      //       fragment offset: those lanes need no special case)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int C = p.C, ch = C >> 1;
+
+    // ---- per-block constants: weight fragments ----------------------------------------------------------------------
+    if (tid < ZPN) ZP[tid] = 0.f;
+    // zero-conv A fragments: A[i = li][k = q] of k-step (tap, s) = Wz[16 mt + li][column of channel 4 s + q][tap]
+    float wa[9][K4][CT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < K4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < CT; ++mt) {
+                const int co = 16 * mt + li, c = 4 * s + q;
+                int col = -1;
+                if (s < CH4) col = (c < ch) ? c : -1;
+                else if (q < 2) col = p.wz_d1col + q;
+                // (address select, not a guarded load: a load inside a divergent block is followed by s_waitcnt vmcnt(0), which made
+                // these 9 K4 CT loads a chain of L2 latencies - 25 us per block)
+                wa[t][s][mt] = *((co < C && col >= 0) ? p.wz + ((size_t)co * p.wz_rows + col) * 9 + t : tmg_zero_page);
+            }
+    // mix A fragments: k-steps 0 .. CH4-1 carry x1 channels 4 t + q; k-steps CH4 + 2 mt + e carry y2 channel 8 mt + 2 q + e
+    // (that is how the coupling leaves y2 in the accumulator registers)
+    constexpr int KM = CH4 + 2 * CT;
+    float wm[CT][KM];
+    float4 bmv[CT], bzv[CT];
+    const float osc = out_scale_of(p.kappa);
+#pragma unroll
+    for (int mo = 0; mo < CT; ++mo) {
+        const int co = 16 * mo + li;
+#pragma unroll
+        for (int t = 0; t < KM; ++t) {
+            int k;
+            if (t < CH4) k = (4 * t + q < ch) ? 4 * t + q : -1;
+            else {
+                const int mt = (t - CH4) >> 1, e = (t - CH4) & 1, j = 8 * mt + 2 * q + e;
+                k = (j < ch) ? ch + j : -1;
+            }
+            wm[mo][t] = *((p.Wm && co < C && k >= 0) ? p.Wm + (size_t)co * C + k : tmg_zero_page);
+        }
+        const int c4 = 16 * mo + 4 * q;
+        bmv[mo] = *reinterpret_cast<const float4*>((p.bm && c4 < C) ? p.bm + c4 : tmg_zero_page);
+        bzv[mo] = *reinterpret_cast<const float4*>((c4 < C) ? p.bz + c4 : tmg_zero_page);
+    }
+    __syncthreads();
+
+    // Tile pipeline: the global loads of tile k+1 are issued into registers right after tile k's staging barrier
+    constexpr int NIT = PP * K4;                      // staged float4 items of a tile: (patch pixel, channel quad)
+    constexpr int NPI = (NIT + 255) / 256;
+    float4 pv[NPI];
+#define TMG_CPL_ORIGIN(TILE)                                                  \
+    int b_, oy0_, ox0_;                                                       \
+    {                                                                         \
+        int t_ = (TILE);                                                      \
+        const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;                      \
+        const int ty_ = t_ % p.tiles_y;                                       \
+        b_ = t_ / p.tiles_y; oy0_ = ty_ * 16; ox0_ = tx_ * 16;                \
+    }
+#define TMG_CPL_ISSUE(TILE)                                                                                         \
+    {                                                                                                               \
+        TMG_CPL_ORIGIN(TILE)                                                                                        \
+        const size_t img_ = (size_t)b_ * p.H * p.W;                                                                 \
+        _Pragma("unroll") for (int u = 0; u < NPI; ++u) {                                                           \
+            const int i = min(tid + u * 256, NIT - 1);                                                              \
+            const int pp = i / K4, s_ = i - pp * K4;                                                                \
+            const int py = pp / PW, px = pp - py * PW;                                                              \
+            /* replicate padding: clamp the coordinates (flowUtils.py:246) */                                       \
+            const int gy = min(max(oy0_ - 1 + py, 0), p.H - 1), gx = min(max(ox0_ - 1 + px, 0), p.W - 1);           \
+            const size_t gp_ = img_ + (size_t)gy * p.W + gx;                                                        \
+            const float* a_ = s_ < CH4 ? (4 * s_ < ch ? p.x + gp_ * p.xs + 4 * s_ : tmg_zero_page) : p.D + gp_ * 4; \
+            pv[u] = *reinterpret_cast<const float4*>(a_);                                                           \
+        }                                                                                                           \
+    }
+    // a block owns a contiguous range of tiles (neighbouring tiles share halo lines in L2, and the log-det partial sums of an
+    // image stay in registers until the range moves on to the next image: one atomic per wave and image, not per tile)
+    const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t0 = (int)blockIdx.x * per, t1 = min(t0 + per, p.ntiles);
+    if (t0 < t1) TMG_CPL_ISSUE(t0)
+    int par = 0, ldb = -1;
+    float ldacc = 0.f;
+    for (int tile = t0; tile < t1; ++tile, par ^= 1) {
+        TMG_CPL_ORIGIN(tile)
+        const int b = b_, oy0 = oy0_, ox0 = ox0_;
+        const size_t img = (size_t)b * p.H * p.W;
+        float* XQ = lds + par * BUFW;
+        float* XR = XQ + (CHP + 1) * PP * 2;
+        // ---- commit the staged registers: relu(x1 | d1, d2) on the patch, raw x1 of the tile -------------------------------
+#pragma unroll
+        for (int u = 0; u < NPI; ++u) {
+            const int i = tid + u * 256;
+            if (i < NIT) {
+                const int pp = i / K4, s = i - pp * K4;
+                const int py = pp / PW, px = pp - py * PW;
+                const float4 v = pv[u];
+                *reinterpret_cast<float2*>(XQ + ((2 * s) * PP + pp) * 2) = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+                if (s < CH4) {
+                    *reinterpret_cast<float2*>(XQ + ((2 * s + 1) * PP + pp) * 2) = make_float2(fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    const int cy = py - 1, cx = px - 1;
+                    if (cy >= 0 && cy < 16 && cx >= 0 && cx < 16) {
+                        const int cp = cy * 16 + cx;
+                        *reinterpret_cast<float2*>(XR + ((2 * s) * 256 + cp) * 2) = make_float2(v.x, v.y);
+                        *reinterpret_cast<float2*>(XR + ((2 * s + 1) * 256 + cp) * 2) = make_float2(v.z, v.w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + 1 < t1) TMG_CPL_ISSUE(tile + 1)
+        // ---- this wave owns tile rows 4 wave .. 4 wave + 3, one 16-pixel n-tile each, walked by a ROLLED loop: one row's
+        //      accumulators and epilogue operands live at a time (registers buy occupancy here: the kernel waits on memory, and
+        //      with 4 rows unrolled it needed 200 VGPRs = 2 waves per SIMD); the next row's epilogue operands are in flight
+        //      while this row runs through the matrix cores
+        const int row0 = 4 * wave;
+        const float* xb = XQ + (((q >> 1) * PP + row0 * PW + li) * 2 + (q & 1));
+        const float* db = (q < 2) ? XQ + ((CHP * PP + row0 * PW + li) * 2 + q) : ZP;
+        const float* xrb = XR + (((q >> 1) * 256 + row0 * 16 + li) * 2 + (q & 1));
+        const int gx = ox0 + li, gxc = min(gx, p.W - 1);
+        float4 hcur[CT];
+        float2 xcur[CT];
+#define TMG_CPL_EPI_LOAD(HV, XV, NT)                                                                                 \
+        {                                                                                                            \
+            const int gy_ = min(oy0 + row0 + (NT), p.H - 1);                                                         \
+            const size_t gp_ = img + (size_t)gy_ * p.W + gxc;                                                        \
+            _Pragma("unroll") for (int mt = 0; mt < CT; ++mt) {                                                      \
+                const bool ok_ = 16 * mt + 4 * q < C;                                                                \
+                HV[mt] = *reinterpret_cast<const float4*>(ok_ ? p.hc + gp_ * p.hcs + 16 * mt + 4 * q : tmg_zero_page); \
+                XV[mt] = *reinterpret_cast<const float2*>(ok_ ? p.x + gp_ * p.xs + ch + 8 * mt + 2 * q : tmg_zero_page); \
+            }                                                                                                        \
+        }
+        TMG_CPL_EPI_LOAD(hcur, xcur, 0)
+        float ld = 0.f;
+#pragma unroll 1
+        for (int nt = 0; nt < 4; ++nt) {
+            float4 hnxt[CT];
+            float2 xnxt[CT];
+            TMG_CPL_EPI_LOAD(hnxt, xnxt, min(nt + 1, 3))
+            // zero conv: 9 taps x K4 quads, fragments at base + immediate
+            f32x4 acc[CT];
+#pragma unroll
+            for (int mt = 0; mt < CT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* xbn = xb + nt * (PW * 2);
+            const float* dbn = db + ((q < 2) ? nt * (PW * 2) : 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int tyy = t / 3, txx = t % 3;
+#pragma unroll
+                for (int s = 0; s < K4; ++s) {
+                    const float bf = (s < CH4) ? xbn[((2 * s) * PP + tyy * PW + txx) * 2] : dbn[(tyy * PW + txx) * 2];
+#pragma unroll
+                    for (int mt = 0; mt < CT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][s][mt], bf, acc[mt], 0, 0, 0);
+                }
+            }
+            // affine coupling in registers
+            const int gy = oy0 + row0 + nt;
+            const bool pin = gy < p.H && gx < p.W;
+            const size_t gp = img + (size_t)min(gy, p.H - 1) * p.W + gxc;
+            float y2r[CT][2];
+#pragma unroll
+            for (int mt = 0; mt < CT; ++mt) {
+                const float4 bz4 = bzv[mt], h4 = hcur[mt];
+                const float hh0 = (acc[mt][0] + h4.x + bz4.x) * osc, hh1 = (acc[mt][1] + h4.y + bz4.y) * osc;
+                const float hh2 = (acc[mt][2] + h4.z + bz4.z) * osc, hh3 = (acc[mt][3] + h4.w + bz4.w) * osc;
+                const float sg0 = 2.f * hh1 / (1.f + fabsf(hh1)), sg1 = 2.f * hh3 / (1.f + fabsf(hh3));
+                const float2 xv = xcur[mt];
+                float o0, o1;
+                if (p.reverse) { o0 = xv.x * expf(-sg0) - hh0; o1 = xv.y * expf(-sg1) - hh2; }
+                else           { o0 = (xv.x + hh0) * expf(sg0); o1 = (xv.y + hh2) * expf(sg1); }
+                const bool ok = pin && 8 * mt + 2 * q < ch;
+                y2r[mt][0] = ok ? o0 : 0.f;
+                y2r[mt][1] = ok ? o1 : 0.f;
+                if (ok) {
+                    ld += sg0 + sg1;
+                    *reinterpret_cast<float2*>(p.rsave + gp * ch + 8 * mt + 2 * q) = make_float2(hh1, hh3);
+                    if (p.y2save) *reinterpret_cast<float2*>(p.y2save + gp * ch + 8 * mt + 2 * q) = make_float2(o0, o1);
+                }
+            }
+            if (p.Wm) {
+                // channel mix: [x1; y2] is the B operand as it stands
+                f32x4 oacc[CT];
+#pragma unroll
+                for (int mo = 0; mo < CT; ++mo) oacc[mo] = (f32x4){bmv[mo].x, bmv[mo].y, bmv[mo].z, bmv[mo].w};
+                const float* xrn = xrb + nt * 32;
+#pragma unroll
+                for (int t = 0; t < KM; ++t) {
+                    const float bfm = (t < CH4) ? xrn[(2 * t) * 512] : y2r[(t - CH4) >> 1][(t - CH4) & 1];
+#pragma unroll
+                    for (int mo = 0; mo < CT; ++mo) oacc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[mo][t], bfm, oacc[mo], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mo = 0; mo < CT; ++mo)
+                    if (pin && 16 * mo + 4 * q < C)
+                        *reinterpret_cast<float4*>(p.out + gp * p.os + 16 * mo + 4 * q) = make_float4(oacc[mo][0], oacc[mo][1], oacc[mo][2], oacc[mo][3]);
+            } else {
+                // no trailing mix: out = [x1 | y2]
+                const int cpx = (row0 + nt) * 16 + li;
+#pragma unroll
+                for (int mt = 0; mt < CT; ++mt)
+                    if (pin && 8 * mt + 2 * q < ch) {
+                        *reinterpret_cast<float2*>(p.out + gp * p.os + ch + 8 * mt + 2 * q) = make_float2(y2r[mt][0], y2r[mt][1]);
+                        const int c = 8 * mt + 2 * q;
+                        *reinterpret_cast<float2*>(p.out + gp * p.os + c) = *reinterpret_cast<const float2*>(XR + ((c >> 1) * 256 + cpx) * 2);
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < CT; ++mt) { hcur[mt] = hnxt[mt]; xcur[mt] = xnxt[mt]; }
+        }
+#undef TMG_CPL_EPI_LOAD
+        if (b != ldb) {
+            if (ldb >= 0) {
+                ldacc = wave_sum(ldacc);
+                if (lane == 0) atomicAdd(p.logdet + ldb, ldacc);
+            }
+            ldb = b;
+            ldacc = 0.f;
+        }
+        ldacc += ld;
+    }
+    if (ldb >= 0) {
+        ldacc = wave_sum(ldacc);
+        if (lane == 0) atomicAdd(p.logdet + ldb, ldacc);
+    }
+#undef TMG_CPL_ISSUE
+#undef TMG_CPL_ORIGIN
+}
+
+template <int CT, int K4>
+static int launch_cpl_fwd(const CplFP& p, hipStream_t st) {
+    constexpr int CH4 = K4 - 1, CHP = 2 * CH4;
+    const size_t lds = (2 * ((size_t)(CHP + 1) * 324 * 2 + (size_t)CHP * 256 * 2) + (5 * 18 + 4) * 2) * sizeof(float);
+    if (lds > 64 * 1024) TMG_LDS_OPTIN((&cpl_fwd_kernel<CT, K4>));
+    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : 768;
+    const int grid = p.ntiles < gcap ? p.ntiles : gcap;
+    hipLaunchKernelGGL((cpl_fwd_kernel<CT, K4>), dim3(grid), dim3(256), lds, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// Zero conv + affine coupling + log-det (+ trailing channel mix) of one coupling layer in one launch (see the file header).
+// Tensors are NHWC fp32; every channel count / stride is a multiple of 4.
+// dims = {B, H, W, C, reverse, x pixel stride, out pixel stride, hc pixel stride, row length of wz, column of d1 in wz}.
+// Returns -100 when the shape is outside the kernel's envelope (C/2 a multiple of 4, 8 <= C <= 32): the caller uses the per-op path.
+extern "C" int tmg_coupling_fwd(const void* x, void* out, void* rsave, void* y2save, const void* D, const void* hc, const void* wz,
+                                const void* bz, const void* kappa, const void* Wm, const void* bm, void* logdet, const int64_t* dims,
+                                hipStream_t st) {
+    CplFP p;
+    p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.C = (int)dims[3]; p.reverse = (int)dims[4];
+    p.x = (const float*)x; p.xs = (int)dims[5];
+    p.out = (float*)out; p.os = (int)dims[6];
+    p.rsave = (float*)rsave; p.y2save = (float*)y2save; p.D = (const float*)D;
+    p.hc = (const float*)hc; p.hcs = (int)dims[7];
+    p.wz = (const float*)wz; p.wz_rows = (int)dims[8]; p.wz_d1col = (int)dims[9];
+    p.bz = (const float*)bz; p.kappa = (const float*)kappa; p.Wm = (const float*)Wm; p.bm = (const float*)bm;
+    p.logdet = (float*)logdet;
+    const int ch = p.C / 2;
+    if (p.C < 8 || p.C > 32 || (ch & 3) || (p.xs & 3) || (p.os & 3) || (p.hcs & 3)) return -100;
+    p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 15) / 16; p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    if (p.ntiles <= 0) return 0;
+    switch (ch / 4) {
+        case 1: return launch_cpl_fwd<1, 2>(p, st);   // C = 8
+        case 2: return launch_cpl_fwd<1, 3>(p, st);   // C = 16
+        case 3: return launch_cpl_fwd<2, 4>(p, st);   // C = 24
+        case 4: return launch_cpl_fwd<2, 5>(p, st);   // C = 32
+    }
+    return -100;
+}

@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtmglow_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip"]
+SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip", "tmg_coupling.hip"]
 _lib = None
 
 c_i64 = ctypes.c_int64
@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev",
+    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd",
 ]
 
 
@@ -334,6 +334,22 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
     if rc == -100:
         return False
     _chk(rc, "tmg_conv_wgrad_grouped")
+    return True
+
+
+def coupling_fwd(x, out, rsave, y2save, D, hc, wz, bz, kappa, Wm, bm, logdet, reverse, wz_d1col):
+    """Zero conv + affine coupling + log-det (+ trailing channel mix) of one coupling layer in one launch (tmg_coupling_fwd).
+    x / out: [B,H,W,C] NHWC (or channel-slice views); D: [B,H,W,4] from c1x2_fwd; hc: [B,H,W,C] view of the level's conditioning
+    contribution.  Returns False when the shape is outside the kernel's envelope (nothing was launched)."""
+    B, Hh, Ww, C = x.shape
+    sx, so, sh = seg(x), seg(out), seg(hc)
+    assert rsave.is_contiguous() and D.is_contiguous() and (y2save is None or y2save.is_contiguous()) and wz.is_contiguous()
+    dims = _i64(B, Hh, Ww, C, 1 if reverse else 0, sx[1], so[1], sh[1], wz.shape[1], wz_d1col)
+    rc = lib().tmg_coupling_fwd(c_vp(sx[0]), c_vp(so[0]), _ptr(rsave), _ptr(y2save), _ptr(D), c_vp(sh[0]), _ptr(wz), _ptr(bz), _ptr(kappa),
+                                _ptr(Wm), _ptr(bm), _ptr(logdet), dims, _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_coupling_fwd")
     return True
 
 

@@ -522,15 +522,16 @@ def _mix_bwd(x, dy, Wk, dWk, dbk, packed_t=None, defer=None):
     """Input gradient of _mix_fwd (returned) and weight / bias gradients (accumulated into dWk [C,C], dbk [C]).
     defer: list collecting (x, dy) instead - the caller runs the weight gradients of a whole level as one grouped launch."""
     C = Wk.shape[0]
-    dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    dx = torch.empty(dy.shape, device=dy.device, dtype=torch.float32)
     if _mix16_ok(C):
         H.mix_f16(dy, Wk.contiguous(), None, dx, transposed=True)
     else:
         H.conv_fwd([dy], packed_t if packed_t is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 1), C, 1, 1, [dx])
+    xs = x if isinstance(x, list) else [x]      # the mix input may be given as channel segments
     if defer is not None:
-        defer.append((x, dy))
+        defer.append((xs, dy))
     else:
-        H.conv_wgrad([x], dy, dWk, dbk, 1, 1)
+        H.conv_wgrad(xs, dy, dWk, dbk, 1, 1)
     return dx
 
 
@@ -581,8 +582,26 @@ class LevelCouplingFn(torch.autograd.Function):
         PM = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 0)
         saved = [None] * NL
         cur = x
+        # narrow levels: zero conv, coupling, log-det and - in the generative direction - the following channel mix are ONE launch
+        # (tmg_coupling_fwd) after the growth layers' launch; wide levels keep one launch per op
+        fuse = (8 <= C <= 32 and ch % 4 == 0 and _MIX_PRECISION == "f32" and os.environ.get("TMG_NO_FUSED_COUPLING") is None
+                and all(w.is_contiguous() for w in wts))
         for k in (range(NL - 1, -1, -1) if reverse else range(NL)):
             xin = cur
+            if fuse:
+                tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
+                D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
+                H.c1x2_fwd([tin[..., :ch]], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., k:k + 1], add2=Dc[..., NLp + k:NLp + k + 1])
+                out = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+                r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+                y2 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32) if reverse else None
+                ok = H.coupling_fwd(tin, out, r, y2, D, Hc[..., k * C:(k + 1) * C], wzs[k], bzs[k], kps[k], Wm[k] if reverse else None,
+                                    bm[k] if reverse else None, logdet, reverse, ch + Cc)
+                assert ok
+                cur = out
+                # the coupling output y: reverse -> (x1 of the input, y2) as two segments (never materialised), forward -> out
+                saved[k] = (xin, tin, D, r, [tin[..., :ch], y2] if reverse else out)
+                continue
             tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
             x1 = tin[..., :ch]
             D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
@@ -686,9 +705,9 @@ class LevelCouplingFn(torch.autograd.Function):
             dW2[:, 0, cin] += tmpX[:, 1, ch]
             wg_in = None
             # the 1x1 mix weight gradients of all layers: same trick, every group with its own upstream gradient tensor
-            if not H.conv_wgrad_grouped([[a] for a, _ in mix_wg], None, C, dWm.view(NL, C, C, 1, 1), dbm, 1, 1, group_dy=[g_ for _, g_ in mix_wg]):
+            if not H.conv_wgrad_grouped([a for a, _ in mix_wg], None, C, dWm.view(NL, C, C, 1, 1), dbm, 1, 1, group_dy=[g_ for _, g_ in mix_wg]):
                 for k in range(NL):
-                    H.conv_wgrad([mix_wg[k][0]], mix_wg[k][1], dWm[k], dbm[k], 1, 1)
+                    H.conv_wgrad(mix_wg[k][0], mix_wg[k][1], dWm[k], dbm[k], 1, 1)
             mix_wg = None
         # conditioning side of the whole level: one input-gradient pass, three weight-gradient passes
         Gc = torch.empty(cond.shape, device=dev, dtype=torch.float32)

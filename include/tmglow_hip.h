@@ -201,6 +201,23 @@ int tmg_conv_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, i
                            int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
 int64_t tmg_conv_wgrad_grouped_ws_floats(const int64_t* dims, int64_t ngroups);
 
+/* ---- fused affine coupling layer (tmg_coupling.hip) ---------------------------------------------------------------- */
+
+/* The traffic-heavy part of one affine coupling layer in ONE launch, for the narrow levels (8 <= C <= 32, C/2 a multiple of 4):
+ *   Conv2dZeros over relu(x1 | d1, d2) on the matrix cores (flowUtils.py:246-247, replicate padding) -> affine coupling +
+ *   per-sample log-det (flowAffine.py:76-83 forward, :102-109 reverse) -> optional trailing ActNorm + invertible 1x1 mix
+ *   out = Wm [x1; y2] + bm (glowConv.py:207-222 + actNorm.py:71-85, the reverse direction's order); Wm == NULL: out = [x1 | y2].
+ * D [npix][4] = raw (d1, d2, 0, 0) from tmg_c1x2_fwd.  The conditioning map's share of the zero conv is passed pre-computed
+ * (hc: C channels, before bias and scale; a conv is linear in its input channels and every layer of a level sees the same map).
+ * Saved for the backward pass: rsave [npix][C/2] (softsign arguments), y2save [npix][C/2] (transformed half; may be NULL).
+ * logdet[b] is accumulated.
+ * dims = {B, H, W, C, reverse, x pixel stride, out pixel stride, hc pixel stride, row length of wz, column of d1 in wz};
+ * wz in torch layout [C][rows][3][3].  Returns -100 when the shape is outside the kernel's envelope: use the per-op entry
+ * points instead. */
+int tmg_coupling_fwd(const void* x, void* out, void* rsave, void* y2save, const void* D, const void* hc, const void* wz,
+                     const void* bz, const void* kappa, const void* Wm, const void* bm, void* logdet, const int64_t* dims,
+                     tmg_stream_t st);
+
 /* ---- reduced-precision 1x1 channel mix (tmg_mix16.hip) ---------------------------------------------------------- */
 
 /* y = fp16(W) . fp16(x) + bias per pixel with fp32 accumulation on v_mfma_f32_16x16x16_f16: the "fp16 MFMA 1x1 conv" variant
