@@ -30,9 +30,9 @@ import torch  # noqa: E402
 
 import common as C  # noqa: E402
 
-CONFIGS = {"M": C.CFG_M, "cfg1": C.CFG1, "cfg2": C.CFG2, "cfg3": C.CFG3, "cfg5": C.CFG5, "tiny": C.CFG_TINY}
-DEFAULT_BATCH = {"M": 64, "cfg1": 8, "cfg2": 32, "cfg3": 64, "cfg5": 64, "tiny": 2}
-GFLOP_PER_SAMPLE = {"M": 63.72, "cfg1": 2.81, "cfg2": 12.95, "cfg3": 31.86, "cfg5": 267.45}  # SURVEY 8-D, fwd+bwd
+CONFIGS = {"M": C.CFG_M, "cfg1": C.CFG1, "cfg2": C.CFG2, "cfg3": C.CFG3, "cfg4": C.CFG_M, "cfg5": C.CFG5, "tiny": C.CFG_TINY}
+DEFAULT_BATCH = {"M": 64, "cfg1": 8, "cfg2": 32, "cfg3": 64, "cfg4": 32, "cfg5": 64, "tiny": 2}  # cfg4: global 256 over 8 GPUs
+GFLOP_PER_SAMPLE = {"M": 63.72, "cfg1": 2.81, "cfg2": 12.95, "cfg3": 31.86, "cfg4": 63.72, "cfg5": 267.45}  # SURVEY 8-D, fwd+bwd
 PEAK_FP32_MFMA_TF = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 
 

@@ -1,0 +1,77 @@
+"""Two data-parallel ranks of the HIP model on ONE device (TMG_SINGLE_DEVICE=1, gloo) against the same two shards processed one
+after the other in a single process with averaged gradients: exercises batch sharding, the parameter broadcast, rank-local LSTM
+states and the hook-driven bucketed gradient all-reduce of tmg_dist.GradBucket on device tensors (the RCCL path differs only
+in the backend string)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import common as C
+
+pytestmark = pytest.mark.gpu
+N_WINDOWS = 2
+
+
+def _single_process_two_shards():
+    from nn.tmGlow import TMGlow
+    dev = "cuda"
+    d = C.load_npz("tiny_train.npz")
+    cfg = C.CFG_TINY
+    L = len(cfg["glow_blocks"])
+    reps = []
+    for r in range(2):   # two replicas: shared trainable values (kept equal by the averaged update), own BatchNorm buffers
+        m = TMGlow(**C.build_kwargs(cfg))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in C.sub(d, "sd.").items()})
+        reps.append(m.to(dev).train())
+    params = [list(m.parameters()) for m in reps]
+    opts = [torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-8, amsgrad=True) for ps in params]
+    seeds = torch.from_numpy(d["seeds"])
+    keys = [reps[r].initLSTMStates(seeds[r:r + 1], [16, 16]) for r in range(2)]
+    states = [[(h.clone(), c.clone()) for h, c in keys[r]] for r in range(2)]
+    losses, gns = [], []
+    for a in range(N_WINDOWS):
+        xs_g = torch.from_numpy(d["xs"])[a]
+        ls = []
+        for r in range(2):
+            opts[r].zero_grad(set_to_none=True)
+            st, loss = states[r], 0.0
+            for t in range(xs_g.shape[0]):
+                eps = [torch.from_numpy(d["eps.%d.%d.%d" % (a, t, i)])[r:r + 1].to(dev) for i in range(L + 1)]
+                y, lp, st = reps[r].reconstruct(xs_g[t, r:r + 1].to(dev), st, eps)
+                loss = loss + C.loss_reverse(y, lp)
+            loss.backward()
+            ls.append(float(loss))
+            states[r] = [(0.5 * h.detach() + 0.5 * hk, 0.5 * c.detach() + 0.5 * ck) for (h, c), (hk, ck) in zip(st, keys[r])]
+        for p0, p1 in zip(*params):   # mean of the two shards' gradients on both replicas
+            if p0.grad is not None:
+                g = 0.5 * (p0.grad + p1.grad)
+                p0.grad, p1.grad = g, g.clone()
+        gn = torch.nn.utils.clip_grad_norm_([p for p in params[0] if p.grad is not None], float(d["max_grad_norm"]))
+        torch.nn.utils.clip_grad_norm_([p for p in params[1] if p.grad is not None], float(d["max_grad_norm"]))
+        for o in opts:
+            o.step()
+        losses.append(ls)
+        gns.append(float(gn))
+    return losses, gns, dict(reps[0].named_parameters())[str(d["log_s_key"])].detach().cpu()
+
+
+def test_two_ranks_on_one_device_match_single_process(tmp_path):
+    out = str(tmp_path / "res")
+    env = dict(os.environ, TMG_SINGLE_DEVICE="1", TMG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(C.ROOT, "tests", "dist_hip_worker.py"), out, str(N_WINDOWS)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [torch.load("%s.rank%d" % (out, k)) for k in range(2)]
+    losses, gns, log_s = _single_process_two_shards()
+    assert torch.equal(res[0]["log_s"], res[1]["log_s"])                       # replicas stay identical
+    C.assert_field(res[0]["log_s"], log_s, "log_s after the steps", atol=2e-6)
+    for k in range(2):
+        for a in range(N_WINDOWS):
+            assert abs(res[k]["loss"][a] - losses[a][k]) < 2e-5 * (1 + a)
+            assert abs(res[k]["gn"][a] - gns[a]) < 5e-4 * gns[a] * (1 + a)
+        assert res[k]["nbuckets"] > 1 and res[k]["hooked"] >= res[k]["nbuckets"] - 1
