@@ -63,12 +63,34 @@ class LSTMAffineCouplingLayer(nn.Module):
         self.out_conv = nn.Sequential()
         self.out_conv.add_module('zero_conv', Conv2dZeros(in_channels + 2, out_channels))
 
-    def run(self, xn, condn, state, reverse):
-        ch = xn.shape[3] // 2
-        out, h_next, c_next = self.resid_lstm.run([xn[..., :ch], condn], state)
+    def run(self, xn, condn, state, reverse, pad=0):
+        """pad > 0: xn is in the zero-padded layout [x1 | 0 x pad | x2 | 0 x pad] of LSTMFLowBlock (channel halves that are not a
+        multiple of 4); the weights get matching zero rows / columns / output channels, so every conv of the block sees
+        float4-addressable segments and the padding channels of the result stay exactly zero."""
+        chp = xn.shape[3] // 2
         db, zc = self.dense_nn.dense_block, self.out_conv.zero_conv
-        y, ld = ops.CouplingTailFn.apply(xn, out, db.denselayer1.conv1.weight, db.denselayer2.conv1.weight, zc.conv.weight,
-                                         zc.conv.bias, zc.scale, reverse, 1)
+        if pad == 0:
+            out, h_next, c_next = self.resid_lstm.run([xn[..., :chp], condn], state)
+            y, ld = ops.CouplingTailFn.apply(xn, out, db.denselayer1.conv1.weight, db.denselayer2.conv1.weight, zc.conv.weight,
+                                             zc.conv.bias, zc.scale, reverse, 1)
+            return y, ld, (h_next, c_next)
+        ch, dev = chp - pad, xn.device
+        z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)  # noqa: E731
+        ins = lambda w, at: torch.cat([w[:, :at], z(w.shape[0], pad, 3, 3), w[:, at:]], 1)  # noqa: E731  zero input rows at `at`
+        cell, oc = self.resid_lstm.convLSTM, self.resid_lstm.out_seq.LSTM_out_conv
+        cin = oc.weight.shape[0]                       # ch + cond channels: width of the block's feature map
+        x1 = xn[..., :chp]
+        if state is None:
+            h_cur, c_cur = z(*xn.shape[:3], cell.hidden_dim), None
+        else:
+            h_cur, c_cur = state
+        h_next, c_next = ops.ConvLSTMCellFn.apply(ins(cell.conv.weight, ch), cell.conv.bias, h_cur, c_cur, x1, condn)
+        ow = torch.cat([ins(oc.weight, ch), z(pad, oc.weight.shape[1] + pad, 3, 3)], 0)      # feature map widened by `pad` zero channels
+        out = ops.conv([x1, condn, h_next], ow, torch.cat([oc.bias, z(pad)]), relu_out=True)
+        w1 = torch.cat([db.denselayer1.conv1.weight, z(1, pad, 3, 3)], 1)
+        w2 = ins(db.denselayer2.conv1.weight, cin)                                             # before the d1 row
+        wz = torch.cat([ins(zc.conv.weight, cin), z(2 * pad, zc.conv.weight.shape[1] + pad, 3, 3)], 0)
+        y, ld = ops.CouplingTailFn.apply(xn, out, w1, w2, wz, torch.cat([zc.conv.bias, z(2 * pad)]), zc.scale, reverse, 1)
         return y, ld, (h_next, c_next)
 
     def _call(self, x, cond, rec_states, reverse):

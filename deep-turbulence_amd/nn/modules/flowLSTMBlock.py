@@ -106,14 +106,15 @@ class LSTMCouplingBlock(_BlockBase):
         self.conv = _make_conv(in_features, train_sampling, LUdecompose)
         self.coupling = LSTMAffineCouplingLayer(in_features, cond_features, rec_features)
 
-    def run(self, xn, condn, state, reverse, mix=None):
+    def run(self, xn, condn, state, reverse, mix=None, pad=0):
+        """pad > 0: xn and mix are in the zero-padded channel layout of LSTMFLowBlock._pad_x (then mix is given)."""
         if not isinstance(self.conv, InvertibleConv1x1LU):
             return _run_unfused(self, xn, condn, state, reverse)
         extra = self._mix_logdet(xn) if mix is None else 0.
         if reverse:
-            t, ld, st = self.coupling.run(xn, condn, state, True)
+            t, ld, st = self.coupling.run(xn, condn, state, True, pad=pad)
             return self._mix(t, True, mix), ld + extra, st
-        y, ld, st = self.coupling.run(self._mix(xn, False, mix), condn, state, False)
+        y, ld, st = self.coupling.run(self._mix(xn, False, mix), condn, state, False, pad=pad)
         return y, ld + extra, st
 
     def _call(self, x, cond, rec_states, reverse):
@@ -222,11 +223,59 @@ class LSTMFLowBlock(nn.Module):
         return Wm, bm, ld
 
     def _fusable(self, lm, xn):
-        """The level-fused node needs LU blocks throughout (lm), >= 1 non-LSTM layer and 16-byte aligned halves."""
+        """The level-fused node needs LU blocks throughout (lm) and >= 1 non-LSTM layer.  Halves that are not 16-byte aligned
+        (3-channel fields: C = 12 on the first level) run the same node on zero-padded channels, see _level_call."""
         if lm is None or self.n_layers < 2 or os.environ.get("TMG_NO_LEVEL_FUSION"):
             return False
         layers = list(self.revlayers._modules.values())[:-1]
-        return (xn.shape[3] // 2) % 4 == 0 and all(l.coupling.coupling_nn.zero_conv.logscale_factor == 1 for l in layers)
+        return xn.shape[3] % 2 == 0 and all(l.coupling.coupling_nn.zero_conv.logscale_factor == 1 for l in layers)
+
+    # ---- zero-padded channel layout --------------------------------------------------------------------------------
+    # When the channel half ch = C/2 is not a multiple of 4 (the reference's own data sets have 3 output channels: C = 12,
+    # ch = 6 on the first, largest level), every kernel of the fast path - float4 staging, the fused coupling launch, grouped
+    # weight gradients, the lean MFMA staging of the ConvLSTM convs - would be off.  The level then runs on the layout
+    # [x1 | 0.. | x2 | 0..] with ch rounded up to a multiple of 4: weights get zero rows / columns for the padding channels
+    # (plain differentiable torch ops on parameter-sized tensors), so the padding channels stay exactly zero through every
+    # layer (shift = 0, r = 0 => scale 1, log-det 0) and un-padding the result gives the un-padded computation.
+    @staticmethod
+    def _pad_x(xn, ch, pad):
+        B, Hh, Ww, _ = xn.shape
+        z = torch.zeros((B, Hh, Ww, pad), device=xn.device, dtype=torch.float32)
+        return torch.cat([xn[..., :ch], z, xn[..., ch:], z], 3)
+
+    @staticmethod
+    def _unpad_x(xp, ch, pad):
+        return torch.cat([xp[..., :ch], xp[..., ch + pad:2 * ch + pad]], 3)
+
+    @staticmethod
+    def _pad_mix(W, b, ch, pad):
+        """[K, C, C] / [K, C] channel-mix parameters -> padded layout (zero rows / columns / biases for the padding channels)."""
+        K, dev, chp = W.shape[0], W.device, ch + pad
+        idx = torch.cat([torch.arange(ch, device=dev), torch.arange(chp, chp + ch, device=dev)])
+        ar = torch.arange(K, device=dev)
+        Wp = torch.zeros((K, 2 * chp, 2 * chp), device=dev).index_put((ar[:, None, None], idx[None, :, None], idx[None, None, :]), W)
+        bp = torch.zeros((K, 2 * chp), device=dev).index_put((ar[:, None], idx[None, :]), b)
+        return Wp, bp
+
+    def _level_call(self, xn, condn, Wm, bm, layers, reverse, ch, pad):
+        """All non-LSTM coupling layers of the level as one LevelCouplingFn node; xn, Wm, bm already padded when pad > 0."""
+        wts = self._tail_weights(layers)
+        if pad == 0:
+            return ops.LevelCouplingFn.apply(xn, condn, Wm, bm, reverse, *wts)
+        NL, dev = len(layers), xn.device
+        z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)  # noqa: E731
+        w1 = torch.stack(wts[0::5])                     # [NL, 1, ch + Cc, 3, 3]
+        w2 = torch.stack(wts[1::5])                     # [NL, 1, ch + Cc + 1, 3, 3]
+        wz = torch.stack(wts[2::5])                     # [NL, C, ch + Cc + 2, 3, 3]
+        bz = torch.stack(wts[3::5])                     # [NL, C]
+        ins = lambda w: torch.cat([w[:, :, :ch], z(NL, w.shape[1], pad, 3, 3), w[:, :, ch:]], 2)  # noqa: E731  zero rows after x1's
+        w1p, w2p = ins(w1), ins(w2)
+        wzp = torch.cat([ins(wz), z(NL, 2 * pad, wz.shape[2] + pad, 3, 3)], 1)   # padding pairs (shift, r) = zero output channels
+        bzp = torch.cat([bz, z(NL, 2 * pad)], 1)
+        wp = []
+        for k in range(NL):
+            wp += [w1p[k], w2p[k], wzp[k], bzp[k], wts[5 * k + 4]]
+        return ops.LevelCouplingFn.apply(xn, condn, Wm, bm, reverse, *wp)
 
     @staticmethod
     def _tail_weights(layers):
@@ -251,19 +300,26 @@ class LSTMFLowBlock(nn.Module):
         logdet = 0. if lm is None else lm[2]
         out_states = []
         fused = self._fusable(lm, xn)
+        ch = xn.shape[3] // 2
+        pad = (-ch) % 4 if (lm is not None and xn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
+        Wm, bm = (None, None) if lm is None else (self._pad_mix(lm[0], lm[1], ch, pad) if pad else (lm[0], lm[1]))
+        if pad:
+            xn = self._pad_x(xn, ch, pad)
         if fused:
-            xn, dld = ops.LevelCouplingFn.apply(xn, condn, lm[0][:-1], lm[1][:-1], False, *self._tail_weights(layers[:-1]))
+            xn, dld = self._level_call(xn, condn, Wm[:-1], bm[:-1], layers[:-1], False, ch, pad)
             logdet = logdet + dld
         for i, layer in enumerate(layers):
             if fused and i < self.n_layers - 1:
                 continue
-            mix = None if lm is None else (lm[0][i], lm[1][i])
+            mix = None if lm is None else (Wm[i], bm[i])
             if i == self.n_layers - 1:
-                xn, dld, so = layer.run(xn, condn, st, False, mix)
+                xn, dld, so = layer.run(xn, condn, st, False, mix, pad=pad)
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
             else:
                 xn, dld = layer.run(xn, condn, False, mix)
             logdet = logdet + dld
+        if pad:
+            xn = self._unpad_x(xn, ch, pad)
         if self.do_split:
             z1, lp, eps = self.split(H.nchw(xn), return_eps=return_eps)
             return z1, logdet + lp, out_states, eps
@@ -282,16 +338,23 @@ class LSTMFLowBlock(nn.Module):
         if lm is not None:
             logdet = logdet + lm[2]
         fused = self._fusable(lm, yn)
+        ch = yn.shape[3] // 2
+        pad = (-ch) % 4 if (lm is not None and yn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
+        Wm, bm = (None, None) if lm is None else (self._pad_mix(lm[0], lm[1], ch, pad) if pad else (lm[0], lm[1]))
+        if pad:
+            yn = self._pad_x(yn, ch, pad)
         for i in range(len(layers) - 1, -1, -1):
-            mix = None if lm is None else (lm[0][i], lm[1][i])
+            mix = None if lm is None else (Wm[i], bm[i])
             if i == self.n_layers - 1:
-                yn, dld, so = layers[i].run(yn, condn, st, True, mix)
+                yn, dld, so = layers[i].run(yn, condn, st, True, mix, pad=pad)
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
             elif fused:
-                yn, dld = ops.LevelCouplingFn.apply(yn, condn, lm[0][:-1], lm[1][:-1], True, *self._tail_weights(layers[:-1]))
+                yn, dld = self._level_call(yn, condn, Wm[:-1], bm[:-1], layers[:-1], True, ch, pad)
                 logdet = logdet + dld
                 break
             else:
                 yn, dld = layers[i].run(yn, condn, True, mix)
             logdet = logdet + dld
+        if pad:
+            yn = self._unpad_x(yn, ch, pad)
         return H.nchw(self._squeeze_nhwc(yn, False)), logdet, out_states

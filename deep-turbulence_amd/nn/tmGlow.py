@@ -179,15 +179,29 @@ class TMGlow(nn.Module):
 
     def initLSTMStates(self, seeds, input_dim):
         """Per (level, sample) a fresh CPU generator with the sample's seed: hidden ~ U[-1,1], cell ~ N(0,1)
-        (reference :481-509).  Host RNG by construction, then one copy to the model's device."""
+        (reference :481-509).  Host RNG by construction (the streams are part of the reference's semantics), then one copy per
+        level to the model's device.  The (level, sample) draws are independent, so they run on a small thread pool (torch
+        releases the GIL inside rand / randn): at the metric shape and 64 samples this is 180 M numbers, 2 s single-threaded."""
+        from concurrent.futures import ThreadPoolExecutor
         device = next(self.parameters()).device
-        states = []
-        for i in range(len(self.glow_blocks)):
-            hs, cs = [], []
-            for j in range(seeds.size(0)):
-                gen = torch.Generator().manual_seed(int(seeds[j].item()))
-                dims = [1, self.rec_features, input_dim[0] // (2 ** (i + 1)), input_dim[1] // (2 ** (i + 1))]
-                hs.append(2 * torch.rand(dims, generator=gen) - 1)
-                cs.append(torch.randn(dims, generator=gen))
-            states.append((torch.cat(hs, dim=0).to(device), torch.cat(cs, dim=0).to(device)))
+        seed_list = [int(s) for s in seeds.tolist()]
+        L = len(self.glow_blocks)
+
+        def draw(job):
+            i, seed = job
+            gen = torch.Generator().manual_seed(seed)
+            dims = [1, self.rec_features, input_dim[0] // (2 ** (i + 1)), input_dim[1] // (2 ** (i + 1))]
+            h = 2 * torch.rand(dims, generator=gen) - 1
+            return h, torch.randn(dims, generator=gen)
+
+        jobs = [(i, seed) for i in range(L) for seed in seed_list]
+        if len(jobs) > 8:
+            with ThreadPoolExecutor(max_workers=min(16, len(jobs))) as ex:
+                res = list(ex.map(draw, jobs))
+        else:
+            res = [draw(j) for j in jobs]
+        states, n = [], len(seed_list)
+        for i in range(L):
+            part = res[i * n:(i + 1) * n]
+            states.append((torch.cat([p[0] for p in part], dim=0).to(device), torch.cat([p[1] for p in part], dim=0).to(device)))
         return states

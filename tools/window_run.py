@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""The trainer's real unit of work at the metric shape: one mini-batch of B samples
+through `TrainFlow.trainParallel` = a 10-step BPTT window of `model.sample` (256x256 output, 4 flow levels, K = 16, default
+widths; 3 output channels - the physics-constrained loss is defined on (u_x, u_y, p)) -> TMGLowLoss -> one backward through all
+ten time-steps -> clip -> Adam(amsgrad) -> state re-anchoring.  Prints one JSON line with the window time and the peak HBM use.
+
+    python tools/window_run.py [--batch 64] [--tsteps 10] [--windows 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import common as C  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--tsteps", type=int, default=10)
+    ap.add_argument("--windows", type=int, default=3)
+    ap.add_argument("--noc", type=int, default=3, choices=[3, 4],
+                    help="3: the trainer's real channel count, TrainFlow.trainParallel with the physics-constrained loss; 4: the metric "
+                         "configuration M (256x256x4) with bench.py's loss through tmg_dist.train_window (the physics loss is defined "
+                         "for 3 channels only)")
+    a = ap.parse_args()
+    import contextlib
+    from nn.tmGlow import TMGlow
+    from nn.trainFlowParallel import TrainFlow
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    cfg = dict(C.CFG_M, in_features=4, out_features=a.noc)   # backward-step trainer: nic = 4 (3 fields + inlet velocity), noc = 3
+    C.seed_all(12345)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(model, 7, *C.perturb_scales(cfg))
+    model.out_std, model.out_mu = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([0.0, 0.0, 0.0])
+    model.to(dev).train()
+    B, T = a.batch, a.tsteps
+    h, w = cfg["_in_hw"]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T * a.windows, 4, h, w, generator=g).to(dev)
+    if a.noc == 4:
+        import tmg_dist
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+        key = model.initLSTMStates(torch.arange(B), [2 * h, 2 * w])
+
+        def run():
+            st = [(hh.clone(), cc.clone()) for hh, cc in key]
+            tot = 0.0
+            for wi in range(a.windows):
+                loss, _, st, _ = tmg_dist.train_window(model, opt, [x[:, wi * T + t] for t in range(T)], st, key, C.loss_reverse,
+                                                       max_grad_norm=0.01)
+                tot = tot + loss
+            return tot
+        run()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.perf_counter()
+        loss = run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"what": "tmg_dist.train_window, %d BPTT window(s) of %d sample() steps, batch %d, config M (256x256x4, L=4, K=16), "
+                          "loss of bench.py summed over the steps, clip, Adam(amsgrad), state re-anchoring" % (a.windows, T, B),
+                          "seconds_per_window": round(dt / a.windows, 4), "sample_steps_per_s": round(B * T * a.windows / dt, 2),
+                          "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "loss_sum": float(loss),
+                          "warmup": "one untimed call of the same shape"}))
+        return
+    y = torch.randn(B, T * a.windows, 3, 2 * h, 2 * w, generator=g).to(dev)
+    seeds = torch.arange(B)
+    args = SimpleNamespace(beta=200.0, dx=2. / 64, dy=2. / 64, max_grad_norm=0.01)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    trainer = TrainFlow(args, model, [(x, y, seeds)], None)
+    # one call = `windows` BPTT windows of T steps each (trainParallel walks tmax // tback windows of a mini-batch); the first
+    # call is an untimed warm-up (the caching allocator grows to the window's working set with one hipMalloc per block)
+    trainer.trainParallel(model, opt, epoch=0)
+    torch.cuda.synchronize()
+    ti = time.perf_counter()
+    model.initLSTMStates(seeds, [2 * h, 2 * w])     # what trainParallel does once per mini-batch (host RNG streams of the reference)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - ti
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    loss = trainer.trainParallel(model, opt, epoch=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0 - t_init
+    peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    print(json.dumps({"what": "TrainFlow.trainParallel, %d BPTT window(s) of %d sample() steps, batch %d, 256x256x3 output, L=4, K=16" % (
+        a.windows, T, B), "seconds_per_window": round(dt / a.windows, 4), "sample_steps_per_s": round(B * T * a.windows / dt, 2),
+        "peak_mem_gb": round(peak, 2), "loss_sum": float(loss), "warmup": "one untimed call of the same shape",
+        "lstm_state_init_s_per_minibatch": round(t_init, 3), "note": "window time excludes the per-mini-batch host draw of the LSTM seed states "
+        "(reference tmGlow.py:481-509: CPU generators), reported beside it"}))
+
+
+if __name__ == "__main__":
+    main()
