@@ -307,6 +307,18 @@ static inline void tmg_lds_optin(const void* fn, std::atomic<uint64_t>& done) {
         tmg_lds_optin(reinterpret_cast<const void*>(FN), done__);      \
     } while (0)
 
+// Per-launch HIP-event timing (bench.py's roofline / bandwidth lines); the registry lives in tmg_conv.hip.  work = algorithmic
+// flops for matrix-core kernels, algorithmic HBM bytes for the bandwidth-bound classes (ids in g_prof_names there).
+extern "C" int tmg_prof_open(int kid, double work, hipStream_t st);
+extern "C" void tmg_prof_close(int slot, hipStream_t st);
+struct TmgProf {
+    int slot; hipStream_t st;
+    TmgProf(int kid, double work, hipStream_t s) : slot(tmg_prof_open(kid, work, s)), st(s) {}
+    ~TmgProf() { tmg_prof_close(slot, st); }
+};
+enum { TMG_PROF_CPL = 32, TMG_PROF_C1X2 = 33, TMG_PROF_D2B = 34, TMG_PROF_AFF = 35, TMG_PROF_AFFB = 36, TMG_PROF_LSTMF = 37,
+       TMG_PROF_LSTMB = 38, TMG_PROF_GAUSS = 39, TMG_PROF_RESAMPLE = 40, TMG_PROF_MIX16 = 41 };
+
 #define TMG_CHECK_LAUNCH()                          \
     do {                                            \
         hipError_t e__ = hipGetLastError();         \

@@ -1235,11 +1235,17 @@ __global__ void conv_dgrad_direct_kernel(const float* __restrict__ dy, int dy_st
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+#include <mutex>
 #include <vector>
-// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline line).
-struct ProfRec { hipEvent_t a, b; int kid; double flops; };
-static std::vector<ProfRec> g_prof;
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline line).  Events come from a pool that is
+// created when profiling is switched on (no hipEventCreate inside a timed region) and the registry is guarded by a mutex (the
+// reference drives one replica per host thread, utils/parallel.py:222-231).  Kernel ids < 32: matrix-core kernels, work =
+// algorithmic flops; ids >= 32: bandwidth-bound kernel classes, work = algorithmic HBM bytes.
+struct ProfRec { hipEvent_t a, b; int kid; double work; };
+static std::vector<ProfRec> g_prof;        // records in use: g_prof[0 .. g_prof_n)
+static size_t g_prof_n = 0;
 static int g_prof_on = 0;
+static std::mutex g_prof_mu;
 static const char* const g_prof_names[] = {
     "conv_mfma_kernel<4,1,4,1>", "conv_mfma_kernel<4,2,4,1>", "conv_mfma_kernel<4,3,4,1>", "conv_mfma_kernel<4,4,4,1>",
     "conv_mfma_kernel<4,3,2,2>", "conv_mfma_kernel<4,4,2,2>", "conv_mfma_kernel<4,3,1,4>", "conv_mfma_kernel<4,4,1,4>",
@@ -1249,32 +1255,63 @@ static const char* const g_prof_names[] = {
     "conv_wgrad_kernel<5,1,*>", "conv_wgrad_kernel<5,2,*>", "conv_wgrad_kernel<5,4,*>",
     "conv_wgrad_kernel<7,1,*>", "conv_wgrad_kernel<7,2,*>", "conv_wgrad_kernel<7,4,*>",
     "conv_wgrad_kernel<9,1,*>", "conv_wgrad_kernel<9,2,*>", "conv_wgrad_kernel<9,4,*>",
-    "conv_wgrad_kernel<8,1,*>", "conv_wgrad_kernel<8,2,*>", "conv_wgrad_kernel<8,4,*>"};
-#define TMG_NPROF 31
+    "conv_wgrad_kernel<8,1,*>", "conv_wgrad_kernel<8,2,*>", "conv_wgrad_kernel<8,4,*>",
+    "conv 1x1 (invertible channel mix, fp32 MFMA)",
+    "hbm: cpl_fwd_kernel (zero conv + coupling + mix)", "hbm: c1x2_fwd_kernel (growth layers)", "hbm: dense2_bwd_kernel",
+    "hbm: affine_apply_kernel", "hbm: affine_bwd_kernel", "hbm: lstm_pointwise_fwd_kernel", "hbm: lstm_pointwise_bwd_kernel",
+    "hbm: gauss_fwd/bwd_kernel", "hbm: checker / upsample", "hbm: mix16_kernel (fp16-input channel mix)"};
+#define TMG_NPROF 42
+
+// open / close a timed region around a launch; other translation units reach them through tmg_common.h's TmgProf
+extern "C" int tmg_prof_open(int kid, double work, hipStream_t st) {
+    if (!g_prof_on || (g_prof_on == 1 && kid >= 32)) return -1;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on || g_prof_n >= g_prof.size()) return -1;
+    ProfRec& r = g_prof[g_prof_n];
+    r.kid = kid; r.work = work;
+    (void)hipEventRecord(r.a, st);
+    return (int)g_prof_n++;
+}
+extern "C" void tmg_prof_close(int slot, hipStream_t st) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if ((size_t)slot < g_prof_n) (void)hipEventRecord(g_prof[slot].b, st);
+}
 
 struct ProfScope {
-    ProfRec r; bool on; hipStream_t st;
-    ProfScope(int kid, double flops, hipStream_t s) : on(g_prof_on != 0 && g_prof.size() < 400000), st(s) {
-        if (on) { r.kid = kid; r.flops = flops; (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); (void)hipEventRecord(r.a, st); }
-    }
-    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); } }
+    int slot; hipStream_t st;
+    ProfScope(int kid, double flops, hipStream_t s) : slot(tmg_prof_open(kid, flops, s)), st(s) {}
+    ~ProfScope() { tmg_prof_close(slot, st); }
 };
 
+// on = 1: time the matrix-core kernels (ids < 32); on = 2: also the bandwidth-bound classes; 0: off.  Clears the records and
+// (first time) creates the event pool.
 extern "C" int tmg_prof_enable(int64_t on) {
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    g_prof.clear();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_n = 0;
+    if (on) {
+        const size_t want = 65536;
+        while (g_prof.size() < want) {
+            ProfRec r;
+            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) break;
+            r.kid = 0; r.work = 0.0;
+            g_prof.push_back(r);
+        }
+    }
     g_prof_on = (int)on;
     return 0;
 }
 
-// out[kid*3 + {0,1,2}] = {launch count, total ms, total algorithmic flops}; returns number of kernel ids
+// out[kid*3 + {0,1,2}] = {launch count, total ms, total algorithmic work (flops or bytes)}; returns number of kernel ids
 extern "C" int tmg_prof_collect(double* out, int64_t nk) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < (int)nk * 3; ++i) out[i] = 0.0;
-    for (auto& r : g_prof) {
+    for (size_t i = 0; i < g_prof_n; ++i) {
+        ProfRec& r = g_prof[i];
         if (hipEventSynchronize(r.b) != hipSuccess) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-        if (r.kid < nk) { out[r.kid * 3] += 1.0; out[r.kid * 3 + 1] += ms; out[r.kid * 3 + 2] += r.flops; }
+        if (r.kid < nk) { out[r.kid * 3] += 1.0; out[r.kid * 3 + 1] += ms; out[r.kid * 3 + 2] += r.work; }
     }
     return TMG_NPROF;
 }
@@ -1301,7 +1338,7 @@ static int launch_conv(const ConvP& p, int gy, size_t lds_bytes, hipStream_t st)
 template <int MT, int NTW, int WM, int WN>
 static int launch_fwd(const ConvP& p, int G, int gy, size_t lds_bytes, hipStream_t st) {
     TMG_LDS_OPTIN((&conv_fwd_kernel<MT, NTW, WM, WN>));
-    const int kid = 11 + (WM == 8 ? NTW - 1 : (WM == 4 ? NTW + 1 : NTW + 3));
+    const int kid = p.ksize == 1 ? 31 : 11 + (WM == 8 ? NTW - 1 : (WM == 4 ? NTW + 1 : NTW + 3));
     ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_fwd_kernel<MT, NTW, WM, WN>), dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();

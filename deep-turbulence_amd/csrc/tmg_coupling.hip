@@ -285,6 +285,8 @@ static int launch_cpl_fwd(const CplFP& p, hipStream_t st) {
     if (lds > 64 * 1024) TMG_LDS_OPTIN((&cpl_fwd_kernel<CT, K4>));
     static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : 768;
     const int grid = p.ntiles < gcap ? p.ntiles : gcap;
+    // algorithmic HBM bytes: x (C), D (4), hc (C) read; out (C), r (C/2), y2 (C/2) written
+    TmgProf prof(TMG_PROF_CPL, 4.0 * p.B * (double)p.H * p.W * (3.0 * p.C + 4 + (p.y2save ? 1.0 : 0.5) * p.C), st);
     hipLaunchKernelGGL((cpl_fwd_kernel<CT, K4>), dim3(grid), dim3(256), lds, st, p);
     TMG_CHECK_LAUNCH();
     return 0;

@@ -99,6 +99,7 @@ static int launch_mix16(const Mix16P& p, hipStream_t st) {
     if (lds > 64 * 1024) TMG_LDS_OPTIN((&mix16_kernel<NT, NP>));
     const long groups = (p.npix + 64L * NP - 1) / (64L * NP);
     const int grid = (int)(groups < 2048 ? (groups < 1 ? 1 : groups) : 2048);
+    TmgProf prof(TMG_PROF_MIX16, 8.0 * (double)p.npix * p.C, st);   // x read, y written
     hipLaunchKernelGGL((mix16_kernel<NT, NP>), dim3(grid), dim3(256), lds, st, p);
     TMG_CHECK_LAUNCH();
     return 0;

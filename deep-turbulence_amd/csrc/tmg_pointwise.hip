@@ -1051,6 +1051,7 @@ extern "C" int tmg_affine_apply_pass(const void* hh, const int64_t* hh_d, const 
     int gx = (int)((per + 1023) / 1024);  // >= 4 items per thread
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
+    TmgProf prof(TMG_PROF_AFF, 4.0 * B * (double)ppi * Ch * (x1 ? 7 : 5), st);
     hipLaunchKernelGGL(affine_apply_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)hh, (int)hh_d[0], (int)hh_d[1],
                        (const float*)x2, (int)x_d[0], (int)x_d[1], (float*)y2, (int)y_d[0], (int)y_d[1], (float*)rsave, (float*)logdet,
                        ppi, Ch, (int)dims[3], vec, (const float*)x1, x1 ? (int)x1_d[0] : 0, x1 ? (float*)y1 : nullptr, x1 ? (int)y1_d[0] : 0);
@@ -1075,6 +1076,7 @@ extern "C" int tmg_affine_bwd_scaled(const void* gout, const int64_t* go_d, cons
                                      const void* kappa, const int64_t* dims, hipStream_t st) {
     const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
     const size_t npix = (size_t)B * ppi;
+    TmgProf prof(TMG_PROF_AFFB, 4.0 * (double)npix * Ch * 6, st);   // reads gout, yref, r; writes gin, dhh (2 Ch)
     hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid_for(npix * Ch)), dim3(256), 0, st, (const float*)gout, (int)go_d[0], (int)go_d[1],
                        (const float*)yref, (int)yr_d[0], (int)yr_d[1], (const float*)rsave, (const float*)g, (float*)gin, (int)gi_d[0],
                        (int)gi_d[1], (float*)dhh, (int)dh_d[0], (int)dh_d[1], ppi, Ch, npix, (int)dims[3], (const float*)kappa);
@@ -1087,6 +1089,7 @@ extern "C" int tmg_lstm_pointwise_fwd(void* gates, const void* c_prev, const int
                                       const int64_t* dims, hipStream_t st) {
     const size_t npix = (size_t)dims[0];
     const int R = (int)dims[1];
+    TmgProf prof(TMG_PROF_LSTMF, 4.0 * (double)npix * R * (c_prev ? 11 : 10), st);   // gates 4R read + 4R written, c_prev, c_next, h_next
     hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (float*)gates, (const float*)c_prev,
                        (int)cprev_d[0], (int)cprev_d[1], (float*)c_next, (float*)h_next, R, npix);
     TMG_CHECK_LAUNCH();
@@ -1097,6 +1100,7 @@ extern "C" int tmg_lstm_pointwise_bwd(void* acts, const void* c_prev, const int6
                                       const void* dc_in, void* dc_prev, const int64_t* dims, hipStream_t st) {
     const size_t npix = (size_t)dims[0];
     const int R = (int)dims[1];
+    TmgProf prof(TMG_PROF_LSTMB, 4.0 * (double)npix * R * (8 + (c_prev ? 1 : 0) + 1 + (dh ? 1 : 0) + (dc_in ? 1 : 0) + 1), st);
     hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (float*)acts, (const float*)c_prev,
                        (int)cprev_d[0], (int)cprev_d[1], (const float*)c_next, (const float*)dh, (const float*)dc_in, (float*)dc_prev, R,
                        npix);
@@ -1262,6 +1266,7 @@ extern "C" int tmg_c1x2_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
     const size_t d1_floats = 2 * (size_t)(((TH + 2) * (TW + 2) + 3) & ~3);
     if (lds_floats < d1_floats) lds_floats = d1_floats;
     TMG_LDS_OPTIN((&c1x2_fwd_kernel));
+    TmgProf prof(TMG_PROF_C1X2, 4.0 * p.B * (double)p.Hin * p.Win * (p.Cin + 4 + (p.add1 ? 1 : 0) + (p.add2 ? 1 : 0)), st);   // input once, D written
     hipLaunchKernelGGL(c1x2_fwd_kernel, dim3(p.B * p.tiles_x * p.tiles_y), dim3(256), lds_floats * 4, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
@@ -1378,6 +1383,7 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     int gx = d2_blocks / nchunks;
     if (gx > p.ntiles) gx = p.ntiles;
     if (gx < 1) gx = 1;
+    TmgProf prof(TMG_PROF_D2B, 4.0 * p.B * (double)p.Hin * p.Win * (3.0 * p.cin_nn + 4 + 4 + 4 + 2), st);   // x, G0 read, dx written; D, GD; add0 ~ included in 3 cin
     if (p.dW1) hipLaunchKernelGGL(dense2_bwd_kernel<true>, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
     else hipLaunchKernelGGL(dense2_bwd_kernel<false>, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();

@@ -78,14 +78,16 @@ def lib():
 
 
 def prof_enable(on):
-    lib().tmg_prof_enable(c_i64(1 if on else 0))
+    """False / 0: off; True / 1: time the matrix-core kernels; 2: also the bandwidth-bound kernel classes."""
+    lib().tmg_prof_enable(c_i64(int(on)))
 
 
 def prof_collect():
-    """{kernel name: (launches, total ms, total algorithmic flops)} of the event-timed contraction kernels."""
+    """{kernel name: (launches, total ms, total algorithmic work)} of the event-timed kernels: work = flops for the matrix-core
+    kernels, HBM bytes for the classes whose name starts with "hbm:"."""
     l = lib()
     l.tmg_prof_name.restype = ctypes.c_char_p
-    nk = 32
+    nk = 64
     buf = (ctypes.c_double * (3 * nk))()
     n = l.tmg_prof_collect(buf, c_i64(nk))
     out = {}

@@ -85,9 +85,11 @@ int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, const void* 
 int tmg_conv_dgrad_direct(const void* dy, const int64_t* dy_desc, const void* w, void* dx, const int64_t* dx_desc,
                           const int64_t* dims, tmg_stream_t st);
 
-/* Optional per-launch HIP-event timing of the contraction kernels on their launch stream (used by
- * bench.py's roofline line).  enable(1) clears and starts recording, enable(0) stops.
- * collect: out[kid*3+{0,1,2}] = {launches, total ms, total algorithmic flops}; returns #kernel ids. */
+/* Optional per-launch HIP-event timing on the launch stream (bench.py's roofline / bandwidth lines).  enable(1): time the
+ * matrix-core kernels; enable(2): also the bandwidth-bound kernel classes; enable(0): stop.  Enabling clears the records; the
+ * event pool is created on the first enable, never inside a timed region.
+ * collect: out[kid*3+{0,1,2}] = {launches, total ms, total algorithmic work}: flops for the matrix-core kernels, HBM bytes for
+ * the classes whose tmg_prof_name starts with "hbm:"; returns #kernel ids. */
 int tmg_prof_enable(int64_t on);
 int tmg_prof_collect(double* out, int64_t nk);
 
