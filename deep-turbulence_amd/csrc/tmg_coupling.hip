@@ -320,3 +320,257 @@ extern "C" int tmg_coupling_fwd(const void* x, void* out, void* rsave, void* y2s
     }
     return -100;
 }
+
+// =================================================================================================================================
+// Backward companion (generative direction, the one the reference trains through): channel-mix input gradient -> affine-coupling
+// backward -> zero-conv input gradient with the EXACT adjoint of the replicate padding, one launch per layer instead of
+// conv 1x1 (dgrad) + affine_bwd + conv 3x3 (dgrad) + border fix.
+//
+//   dto  = Wm^T dout                                     (glowConv.py:207-222 + actNorm.py:71-85 under autograd)
+//   dtin2 = dto2 e^{-sg};  da = -dto2;  dsg = -2 dto2 (tin2 e^{-sg}) + 2 g_b;  dr = dsg / (1 + |r|)^2      (flowAffine.py:102-109)
+//   dhh = e^kappa interleave(da, dr)                     -> DH (kept for the level-wide conditioning contractions and the weight gradients)
+//   G   = sum_p sum_t [clamp(p + t - 1) == q] Wz_t^T dhh(p)   over the channels (x1 | d1, d2)               (flowUtils.py:246-247)
+//
+// Phase A is pointwise: every 16 pixels of the tile + 1 halo pixel (324 pixels = 21 n-tiles dealt to the 4 waves) run through the
+// mix MFMA straight from global memory (B operand = one float4 of dout per lane; the k-order is permuted to match, as in
+// tmg_mix_f16), the coupling backward runs on the accumulator registers and leaves dhh in LDS as channel pairs.  Phase B is the
+// 3x3 transposed contraction over that LDS patch.  Replicate padding: an input position outside the image is a copy of its clamped
+// neighbour, so a border pixel q also collects the taps that would have landed on the ring: for the top image row the taps
+// (2, ux) applied to the data of row q.y itself (instead of q.y + 1), likewise bottom / left / right, plus one tap for each image
+// corner.  These extra MFMA steps are skipped (wave- / block-uniform branches) away from the border.
+struct CplBP {
+    const float* dout; int dos;      // gradient w.r.t. the layer output (C channels)
+    const float* x; int xs;          // layer input (tin): only tin2 = channels [ch, C) is read
+    const float* r;                  // [npix][ch] saved softsign arguments
+    const float* g;                  // [B] gradient arriving on the log-det (null: 0)
+    const float* Wm;                 // [C][C] trailing mix of the forward pass
+    const float* wz; int wz_rows, wz_d1col;
+    const float* kappa;
+    float* DH; int dhs;              // [npix] x C slice: e^kappa * dhh
+    float* dtin; int dts;            // [npix] x C: second half = dtin2; first half = dto1 (pass-through gradient, completed by dense2_bwd)
+    float* G0;                       // [npix][ch]
+    float* GD;                       // [npix][4]
+    int B, H, W, C;
+    int tiles_x, tiles_y, ntiles;
+};
+
+// CT = 16-channel tiles of C; MT = 16-channel tiles of the dgrad output (ch + 2 channels); KS = C / 4 channel quads of dhh
+template <int CT, int MT, int KS>
+__global__ __launch_bounds__(256, CT == 1 ? 2 : 1) void cpl_bwd_kernel(CplBP p) {
+    constexpr int PW = 18, PP = PW * PW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int C = p.C, ch = C >> 1;
+    float* DHL = lds;                                 // [ch][PP][2]: dhh pairs (da_j, dr_j) e^kappa on the tile + 1 halo pixel, zero outside the image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const float osc = out_scale_of(p.kappa);
+
+    // mix A fragments (transposed mix): k-step (h, e) carries dout channel 16 h + 4 q + e
+    float wmT[CT][4 * CT];
+#pragma unroll
+    for (int mo = 0; mo < CT; ++mo)
+#pragma unroll
+        for (int t = 0; t < 4 * CT; ++t) {
+            const int c = 16 * (t >> 2) + 4 * q + (t & 3), i = 16 * mo + li;
+            wmT[mo][t] = *((c < C && i < C) ? p.Wm + (size_t)c * C + i : tmg_zero_page);
+        }
+    // dgrad A fragments: A[i = li][k = q] of (tap u, quad s) = Wz[co = 4 s + q][col(i)][8 - u], rows i = (x1 | d1, d2)
+    float wa[9][KS][MT];
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int i = 16 * mt + li, co = 4 * s + q;
+                const int col = i < ch ? i : (i < ch + 2 ? p.wz_d1col + (i - ch) : -1);
+                wa[u][s][mt] = *((co < C && col >= 0) ? p.wz + ((size_t)co * p.wz_rows + col) * 9 + (8 - u) : tmg_zero_page);
+            }
+
+    const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t0 = (int)blockIdx.x * per, t1 = min(t0 + per, p.ntiles);
+    for (int tile = t0; tile < t1; ++tile) {
+        int t_ = tile;
+        const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
+        const int ty = t_ % p.tiles_y;
+        const int b = t_ / p.tiles_y;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+        const size_t img = (size_t)b * p.H * p.W;
+        const float gb = p.g ? p.g[b] : 0.f;
+        // ---- phase A: n-tiles of 16 region pixels (linear index) -------------------------------------------------------------
+#define TMG_CPLB_LOAD(DV, RV, TV, NT)                                                                                  \
+        {                                                                                                              \
+            const int rp_ = min((NT) * 16 + li, PP - 1);                                                               \
+            const int ry_ = rp_ / PW, rx_ = rp_ - ry_ * PW;                                                            \
+            const int gy_ = oy0 - 1 + ry_, gx_ = ox0 - 1 + rx_;                                                        \
+            const bool in_ = gy_ >= 0 && gy_ < p.H && gx_ >= 0 && gx_ < p.W;                                          \
+            const size_t gp_ = img + (size_t)min(max(gy_, 0), p.H - 1) * p.W + min(max(gx_, 0), p.W - 1);              \
+            _Pragma("unroll") for (int h = 0; h < CT; ++h) {                                                           \
+                const int c_ = 16 * h + 4 * q;                                                                         \
+                DV[h] = *reinterpret_cast<const float4*>((in_ && c_ < C) ? p.dout + gp_ * p.dos + c_ : tmg_zero_page);  \
+                /* the lanes whose accumulator quad of m-tile h is a dto2 quad (channel c_ >= ch) need r / tin2 of j0 = c_ - ch */ \
+                const bool two_ = in_ && c_ >= ch && c_ < C;                                                           \
+                RV[h] = *reinterpret_cast<const float4*>(two_ ? p.r + gp_ * ch + (c_ - ch) : tmg_zero_page);           \
+                TV[h] = *reinterpret_cast<const float4*>(two_ ? p.x + gp_ * p.xs + c_ : tmg_zero_page);                \
+            }                                                                                                          \
+        }
+        constexpr int NTA = (PP + 15) / 16;   // 21
+        float4 dcu[CT], rcu[CT], tcu[CT];
+        TMG_CPLB_LOAD(dcu, rcu, tcu, wave)
+#pragma unroll 1
+        for (int nt = wave; nt < NTA; nt += 4) {
+            float4 dnx[CT], rnx[CT], tnx[CT];
+            TMG_CPLB_LOAD(dnx, rnx, tnx, min(nt + 4, NTA - 1))
+            const int rp = nt * 16 + li;
+            const int ry = rp / PW, rx = rp - ry * PW;
+            const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
+            const bool inimg = rp < PP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const bool center = inimg && ry >= 1 && ry <= 16 && rx >= 1 && rx <= 16;
+            const size_t gp = img + (size_t)min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1);
+            f32x4 acc[CT];
+#pragma unroll
+            for (int mo = 0; mo < CT; ++mo) acc[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < CT; ++h) {
+                const float dv[4] = {dcu[h].x, dcu[h].y, dcu[h].z, dcu[h].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mo = 0; mo < CT; ++mo)
+                        acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wmT[mo][4 * h + e], dv[e], acc[mo], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mo = 0; mo < CT; ++mo) {
+                const int c = 16 * mo + 4 * q;
+                if (c < ch) {
+                    // pass-through half: dto1 -> first half of dtin (dense2_bwd adds the coupling network's share)
+                    if (center) *reinterpret_cast<float4*>(p.dtin + gp * p.dts + c) = make_float4(acc[mo][0], acc[mo][1], acc[mo][2], acc[mo][3]);
+                } else if (c < C) {
+                    const int j0 = c - ch;
+                    const float rr[4] = {rcu[mo].x, rcu[mo].y, rcu[mo].z, rcu[mo].w};
+                    const float tt[4] = {tcu[mo].x, tcu[mo].y, tcu[mo].z, tcu[mo].w};
+                    float di[4], da[4], dr[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float den = 1.f + fabsf(rr[e]);
+                        const float inv = expf(-2.f * rr[e] / den);
+                        const float go = acc[mo][e];
+                        di[e] = go * inv;
+                        da[e] = inimg ? -go * osc : 0.f;
+                        dr[e] = inimg ? osc * (-2.f * go * (tt[e] * inv) + 2.f * gb) / (den * den) : 0.f;
+                    }
+                    if (rp < PP) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) *reinterpret_cast<float2*>(DHL + ((j0 + e) * PP + rp) * 2) = make_float2(da[e], dr[e]);
+                    }
+                    if (center) {
+                        *reinterpret_cast<float4*>(p.dtin + gp * p.dts + c) = make_float4(di[0], di[1], di[2], di[3]);
+                        *reinterpret_cast<float4*>(p.DH + gp * p.dhs + 2 * j0) = make_float4(da[0], dr[0], da[1], dr[1]);
+                        *reinterpret_cast<float4*>(p.DH + gp * p.dhs + 2 * j0 + 4) = make_float4(da[2], dr[2], da[3], dr[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < CT; ++h) { dcu[h] = dnx[h]; rcu[h] = rnx[h]; tcu[h] = tnx[h]; }
+        }
+#undef TMG_CPLB_LOAD
+        __syncthreads();
+        // ---- phase B: transposed 3x3 contraction; this wave owns tile rows 4 wave .. 4 wave + 3 ------------------------------------
+        const int row0 = 4 * wave;
+        const float* hb = DHL + (((q >> 1) * PP + row0 * PW + li) * 2 + (q & 1));   // + plane 2 s, + (row + uy) * PW + ux
+        const int gx = ox0 + li;
+        const bool left = gx == 0, right = gx == p.W - 1;
+#pragma unroll 1
+        for (int nt = 0; nt < 4; ++nt) {
+            const int gy = oy0 + row0 + nt;
+            const float* hbn = hb + nt * (PW * 2);
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define TMG_CPLB_TAP(U, DY, DX, MASK)                                                                                  \
+            _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                           \
+                float bf = hbn[((2 * s) * PP + (1 + (DY)) * PW + 1 + (DX)) * 2];                                       \
+                bf = (MASK) ? bf : 0.f;                                                                                \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[U][s][mt], bf, acc[mt], 0, 0, 0);               \
+            }
+            // regular taps: G(q) += W^T_u dhh(q + u - 1)
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { TMG_CPLB_TAP(u, u / 3 - 1, u % 3 - 1, true) }
+            // replicate-padding adjoint (see the header): border rows / columns / corners collect the taps of the ring
+            if (gy == 0) {
+#pragma unroll
+                for (int ux = 0; ux < 3; ++ux) { TMG_CPLB_TAP(6 + ux, 0, ux - 1, true) }
+                if (ox0 == 0) { TMG_CPLB_TAP(8, 0, 0, left) }
+                if (ox0 + 16 >= p.W) { TMG_CPLB_TAP(6, 0, 0, right) }
+            }
+            if (gy == p.H - 1) {
+#pragma unroll
+                for (int ux = 0; ux < 3; ++ux) { TMG_CPLB_TAP(ux, 0, ux - 1, true) }
+                if (ox0 == 0) { TMG_CPLB_TAP(2, 0, 0, left) }
+                if (ox0 + 16 >= p.W) { TMG_CPLB_TAP(0, 0, 0, right) }
+            }
+            if (ox0 == 0) {
+#pragma unroll
+                for (int uy = 0; uy < 3; ++uy) { TMG_CPLB_TAP(3 * uy + 2, uy - 1, 0, left) }
+            }
+            if (ox0 + 16 >= p.W) {
+#pragma unroll
+                for (int uy = 0; uy < 3; ++uy) { TMG_CPLB_TAP(3 * uy, uy - 1, 0, right) }
+            }
+#undef TMG_CPLB_TAP
+            if (gy < p.H && gx < p.W) {
+                const size_t gp = img + (size_t)gy * p.W + gx;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int c = 16 * mt + 4 * q;
+                    const float4 v = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+                    if (c < ch) *reinterpret_cast<float4*>(p.G0 + gp * ch + c) = v;
+                    else if (c == ch) *reinterpret_cast<float4*>(p.GD + gp * 4) = v;   // (d1, d2, 0, 0): rows past ch + 1 carry zero weights
+                }
+            }
+        }
+        __syncthreads();   // the patch is rewritten by the next tile's phase A
+    }
+}
+
+template <int CT, int MT, int KS>
+static int launch_cpl_bwd(const CplBP& p, hipStream_t st) {
+    const size_t lds = (size_t)(p.C / 2) * 324 * 2 * sizeof(float);
+    if (lds > 64 * 1024) TMG_LDS_OPTIN((&cpl_bwd_kernel<CT, MT, KS>));
+    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : 768;
+    const int grid = p.ntiles < gcap ? p.ntiles : gcap;
+    // algorithmic HBM bytes: dout (C), r (C/2), tin2 (C/2) read; DH (C), dtin (C), G0 (C/2), GD (4) written
+    TmgProf prof(TMG_PROF_CPLB, 4.0 * p.B * (double)p.H * p.W * (4.5 * p.C + 4), st);
+    hipLaunchKernelGGL((cpl_bwd_kernel<CT, MT, KS>), dim3(grid), dim3(256), lds, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backward of tmg_coupling_fwd's generative-direction layer up to the coupling network's input gradients (see above).
+// dims = {B, H, W, C, dout pixel stride, x pixel stride, DH pixel stride, dtin pixel stride, row length of wz, column of d1 in wz}.
+// Returns -100 outside the envelope (8 <= C <= 32, C/2 a multiple of 4).
+extern "C" int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void* g, const void* Wm, const void* wz,
+                                const void* kappa, void* DH, void* dtin, void* G0, void* GD, const int64_t* dims, hipStream_t st) {
+    CplBP p;
+    p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.C = (int)dims[3];
+    p.dout = (const float*)dout; p.dos = (int)dims[4];
+    p.x = (const float*)x; p.xs = (int)dims[5];
+    p.r = (const float*)r; p.g = (const float*)g; p.Wm = (const float*)Wm;
+    p.wz = (const float*)wz; p.wz_rows = (int)dims[8]; p.wz_d1col = (int)dims[9];
+    p.kappa = (const float*)kappa;
+    p.DH = (float*)DH; p.dhs = (int)dims[6];
+    p.dtin = (float*)dtin; p.dts = (int)dims[7];
+    p.G0 = (float*)G0; p.GD = (float*)GD;
+    const int ch = p.C / 2;
+    if (p.C < 8 || p.C > 32 || (ch & 3) || (p.dos & 3) || (p.xs & 3) || (p.dhs & 3) || (p.dts & 3)) return -100;
+    p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 15) / 16; p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    if (p.ntiles <= 0) return 0;
+    switch (ch / 4) {
+        case 1: return launch_cpl_bwd<1, 1, 2>(p, st);   // C = 8:  outputs ch + 2 = 6
+        case 2: return launch_cpl_bwd<1, 1, 4>(p, st);   // C = 16: 10
+        case 3: return launch_cpl_bwd<2, 1, 6>(p, st);   // C = 24: 14
+        case 4: return launch_cpl_bwd<2, 2, 8>(p, st);   // C = 32: 18
+    }
+    return -100;
+}

@@ -28,7 +28,7 @@ EXPORTS = [
     "tmg_conv_pack", "tmg_conv_pack_map", "tmg_conv_fwd", "tmg_conv_fwd_add", "tmg_affine_bwd_scaled", "tmg_c1_fwd_add", "tmg_conv_wgrad", "tmg_conv_wgrad_ws_floats", "tmg_conv_rep_border_fix", "tmg_conv_dgrad_direct",
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
-    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd",
+    "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
 ]
 
 
@@ -352,6 +352,21 @@ def coupling_fwd(x, out, rsave, y2save, D, hc, wz, bz, kappa, Wm, bm, logdet, re
     if rc == -100:
         return False
     _chk(rc, "tmg_coupling_fwd")
+    return True
+
+
+def coupling_bwd(dout, x, r, g, Wm, wz, kappa, DH, dtin, G0, GD, wz_d1col):
+    """Mix input gradient + affine-coupling backward + zero-conv input gradient (exact replicate adjoint) of one generative-
+    direction coupling layer in one launch (tmg_coupling_bwd).  DH: [B,H,W,C] channel-slice view of the level's stash."""
+    B, Hh, Ww, C = dout.shape
+    sd, sx, sh, st = seg(dout), seg(x), seg(DH), seg(dtin)
+    assert r.is_contiguous() and G0.is_contiguous() and GD.is_contiguous() and Wm.is_contiguous() and wz.is_contiguous()
+    dims = _i64(B, Hh, Ww, C, sd[1], sx[1], sh[1], st[1], wz.shape[1], wz_d1col)
+    rc = lib().tmg_coupling_bwd(c_vp(sd[0]), c_vp(sx[0]), _ptr(r), _ptr(g), _ptr(Wm), _ptr(wz), _ptr(kappa), c_vp(sh[0]), c_vp(st[0]),
+                                _ptr(G0), _ptr(GD), dims, _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_coupling_bwd")
     return True
 
 

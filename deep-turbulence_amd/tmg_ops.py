@@ -620,6 +620,7 @@ class LevelCouplingFn(torch.autograd.Function):
             saved[k] = (xin, tin, D, r, y)
         del Hc, Dc
         ctx.saved = saved
+        ctx.fuse = fuse
         ctx.meta = (NL, NLp, reverse, ch, Cc)
         ctx.save_for_backward(cond, Wm, bm, Wzc, Wdc, *wts)
         return cur, logdet
@@ -665,6 +666,28 @@ class LevelCouplingFn(torch.autograd.Function):
         for k in (range(NL) if reverse else range(NL - 1, -1, -1)):
             xin, tin, D, r, y = saved[k]
             saved[k] = None
+            if reverse and ctx.fuse and os.environ.get("TMG_NO_FUSED_COUPLING_BWD") is None:
+                # one launch: mix input gradient -> coupling backward -> zero-conv input gradient (exact replicate adjoint)
+                dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+                G0 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+                GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
+                dhh = DH[..., k * C:(k + 1) * C]
+                ok = H.coupling_bwd(dcur, tin, r, g, Wm[k].contiguous(), wzs[k], kps[k], dhh, dtin, G0, GD, ch + Cc)
+                assert ok
+                x1 = tin[..., :ch]
+                if grouped:
+                    wg_in[k] = [x1, D]
+                    mix_wg[k] = (y, dcur)
+                else:
+                    H.conv_wgrad([x1, D], dhh, dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
+                                 ci_split=ch, ci_off0=0, ci_off1=Cc)
+                    H.conv_wgrad(y, dcur, dWm[k], dbm[k], 1, 1)
+                H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
+                             add0=dtin[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
+                             split2=ch, gap2=Cc)
+                dcur = dtin
+                del xin, tin, D, r, y
+                continue
             mdef = [] if grouped else None
             dto = _mix_bwd(y, dcur, Wm[k], dWm[k], dbm[k], PMt[k], mdef) if reverse else dcur   # grad w.r.t. the tail output y
             dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)        # grad w.r.t. the tail input

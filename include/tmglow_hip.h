@@ -220,6 +220,17 @@ int tmg_coupling_fwd(const void* x, void* out, void* rsave, void* y2save, const 
                      const void* bz, const void* kappa, const void* Wm, const void* bm, void* logdet, const int64_t* dims,
                      tmg_stream_t st);
 
+/* Backward of tmg_coupling_fwd's generative-direction layer up to the coupling network's input gradients, one launch:
+ *   dto = Wm^T dout (input gradient of the trailing mix, glowConv.py:207-222 under autograd) -> affine-coupling backward
+ *   (flowAffine.py:102-109) -> e^kappa dhh written to DH (C channels) -> input gradient of Conv2dZeros w.r.t. (x1 | d1, d2) with the
+ *   exact adjoint of its replicate padding (flowUtils.py:246-247): G0 [npix][C/2], GD [npix][4] = (d d1, d d2, 0, 0).
+ * dtin (C channels): second half = gradient w.r.t. the transformed input half, first half = dto1 (the pass-through gradient;
+ * tmg_dense2_bwd adds the coupling network's share on top).  g: [B] gradient arriving on the log-det (may be NULL).
+ * dims = {B, H, W, C, dout pixel stride, x pixel stride, DH pixel stride, dtin pixel stride, row length of wz, column of d1 in wz}.
+ * Returns -100 outside the envelope (8 <= C <= 32, C/2 a multiple of 4). */
+int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void* g, const void* Wm, const void* wz, const void* kappa,
+                     void* DH, void* dtin, void* G0, void* GD, const int64_t* dims, tmg_stream_t st);
+
 /* ---- reduced-precision 1x1 channel mix (tmg_mix16.hip) ---------------------------------------------------------- */
 
 /* y = fp16(W) . fp16(x) + bias per pixel with fp32 accumulation on v_mfma_f32_16x16x16_f16: the "fp16 MFMA 1x1 conv" variant
