@@ -212,25 +212,46 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    torch.cuda.reset_peak_memory_stats(dev)
+    # which matrix-core kernel dominates the step: two untimed steps with every contraction launch bracketed by HIP events;
+    # inside the timed region only THAT kernel keeps its events (a handful of pairs per step: timing all ~500 contraction
+    # launches of a step cost 2 % of the headline number)
+    prof_all, dom = {}, None
     if not args.no_events:
-        tmg_hip.prof_enable(True)
+        tmg_hip.prof_enable(1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof_all = tmg_hip.prof_collect()
+        tmg_hip.prof_enable(False)
+        cand = {k: v for k, v in prof_all.items() if not k.startswith("conv 1x1")}
+        if cand:
+            dom = max(cand.items(), key=lambda kv: kv[1][1])[0]
+    barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
+    if dom is not None:
+        tmg_hip.prof_enable(100 + tmg_hip.prof_kernel_id(dom))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = {}
+    prof, prof_steps = {}, {}
     if not args.no_events:
-        prof = tmg_hip.prof_collect()
+        live = tmg_hip.prof_collect()      # the dominant kernel, timed live inside the timed region
         tmg_hip.prof_enable(False)
+        prof = dict(prof_all)              # every other contraction kernel: from the two untimed steps before it
+        prof_steps = {k: 2 for k in prof}
+        prof.update(live)
+        prof_steps.update({k: args.steps for k in live})
         # the bandwidth-bound kernel classes are timed in a short pass of their own AFTER the timed region (their ~2 000 extra
         # event pairs per step would otherwise be charged to the headline number)
         tmg_hip.prof_enable(2)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        prof.update({k: v for k, v in tmg_hip.prof_collect().items() if k.startswith("hbm:")})
+        hb = {k: v for k, v in tmg_hip.prof_collect().items() if k.startswith("hbm:")}
+        prof.update(hb)
+        prof_steps.update({k: 3 for k in hb})
         tmg_hip.prof_enable(False)
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -245,13 +266,17 @@ def main():
     mix1 = prof.get("conv 1x1 (invertible channel mix, fp32 MFMA)")
     prof = {k: v for k, v in prof.items() if not k.startswith("hbm:")}
     if prof:
-        name, (cnt, ms, fl) = max(prof.items(), key=lambda kv: kv[1][1])
+        name = dom if dom in prof else max(prof.items(), key=lambda kv: kv[1][1] / prof_steps[kv[0]])[0]
+        cnt, ms, fl = prof[name]
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_MFMA_TF, 4), "traffic": None, "launches": cnt,
                 "avg_launch_us": round(1e3 * ms / max(cnt, 1), 2), "time_share_of_step": round(ms * 1e-3 / dt, 4),
-                "all_contraction_kernels": {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
-                                            for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+                "measured": "HIP events on the launch stream inside the timed region (this kernel only; the table below comes from "
+                            "two untimed steps with every contraction launch bracketed)",
+                "all_contraction_kernels": {k: {"launches_per_step": round(v[0] / prof_steps[k], 1), "ms_per_step": round(v[1] / prof_steps[k], 3),
+                                                "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
+                                            for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1] / prof_steps[kv[0]])}}
         roof["traffic"] = pmc_traffic(name) if args.config == "M" and B == 64 else None
         if args.config in GFLOP_PER_SAMPLE:
             e2e = value / world * GFLOP_PER_SAMPLE[args.config] / 1e3
@@ -269,12 +294,12 @@ def main():
            "peak_mem_gb": round(peak_gb, 2), "roofline": roof}
     if hbm:
         # bandwidth-bound kernel classes: algorithmic HBM bytes / HIP-event time on the launch stream, against the 8 TB/s HBM3E peak
-        out["hbm_kernel_classes"] = {k[5:]: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[2] / max(v[1], 1e-9) / 1e6, 1),
+        out["hbm_kernel_classes"] = {k[5:]: {"launches_per_step": round(v[0] / 3, 1), "ms_per_step": round(v[1] / 3, 3), "GB/s": round(v[2] / max(v[1], 1e-9) / 1e6, 1),
                                               "frac_of_8TBps": round(v[2] / max(v[1], 1e-9) / 1e6 / PEAK_HBM_GBS, 4)}
                                      for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}
     if mix1 and mix1[1] > 0:
         tf = mix1[2] / mix1[1] / 1e9
-        out["mix_1x1_mfma"] = {"launches": mix1[0], "ms": round(mix1[1], 3), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TF, 4),
+        out["mix_1x1_mfma"] = {"launches_per_step": mix1[0] / 2, "ms_per_step": round(mix1[1] / 2, 3), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TF, 4),
                                "note": "stand-alone 1x1 mixes only (wide levels, LSTM blocks); on the narrow levels the mix runs inside cpl_fwd_kernel"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)

@@ -1265,7 +1265,7 @@ static const char* const g_prof_names[] = {
 
 // open / close a timed region around a launch; other translation units reach them through tmg_common.h's TmgProf
 extern "C" int tmg_prof_open(int kid, double work, hipStream_t st) {
-    if (!g_prof_on || (g_prof_on == 1 && kid >= 32)) return -1;
+    if (!g_prof_on || (g_prof_on == 1 && kid >= 32) || (g_prof_on >= 100 && kid != g_prof_on - 100)) return -1;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof_n >= g_prof.size()) return -1;
     ProfRec& r = g_prof[g_prof_n];
@@ -1285,7 +1285,8 @@ struct ProfScope {
     ~ProfScope() { tmg_prof_close(slot, st); }
 };
 
-// on = 1: time the matrix-core kernels (ids < 32); on = 2: also the bandwidth-bound classes; 0: off.  Clears the records and
+// on = 1: time the matrix-core kernels (ids < 32); on = 2: also the bandwidth-bound classes; on = 100 + k: only kernel id k (what
+// bench.py uses inside its timed region: a handful of event pairs per step instead of hundreds); 0: off.  Clears the records and
 // (first time) creates the event pool.
 extern "C" int tmg_prof_enable(int64_t on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

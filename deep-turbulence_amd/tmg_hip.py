@@ -82,6 +82,16 @@ def prof_enable(on):
     lib().tmg_prof_enable(c_i64(int(on)))
 
 
+def prof_kernel_id(name):
+    """Kernel id of a name returned by prof_collect (for prof_enable(100 + id): time only that kernel)."""
+    l = lib()
+    l.tmg_prof_name.restype = ctypes.c_char_p
+    for k in range(64):
+        if l.tmg_prof_name(c_i64(k)).decode() == name:
+            return k
+    raise KeyError(name)
+
+
 def prof_collect():
     """{kernel name: (launches, total ms, total algorithmic work)} of the event-timed kernels: work = flops for the matrix-core
     kernels, HBM bytes for the classes whose name starts with "hbm:"."""

@@ -86,7 +86,7 @@ int tmg_conv_dgrad_direct(const void* dy, const int64_t* dy_desc, const void* w,
                           const int64_t* dims, tmg_stream_t st);
 
 /* Optional per-launch HIP-event timing on the launch stream (bench.py's roofline / bandwidth lines).  enable(1): time the
- * matrix-core kernels; enable(2): also the bandwidth-bound kernel classes; enable(0): stop.  Enabling clears the records; the
+ * matrix-core kernels; enable(2): also the bandwidth-bound kernel classes; enable(100 + k): only kernel id k; enable(0): stop.  Enabling clears the records; the
  * event pool is created on the first enable, never inside a timed region.
  * collect: out[kid*3+{0,1,2}] = {launches, total ms, total algorithmic work}: flops for the matrix-core kernels, HBM bytes for
  * the classes whose tmg_prof_name starts with "hbm:"; returns #kernel ids. */
