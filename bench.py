@@ -163,6 +163,9 @@ def main():
     g = torch.Generator().manual_seed(12345 + rank)
     x = torch.randn(B, cfg["in_features"], Hin, Win, generator=g).to(dev)
     states = model.initLSTMStates(torch.arange(B) + rank * B, [Hin * up, Win * up])
+    # the recurrent states a training loop carries are the model's own outputs (channels-last strides, re-anchored half-way to
+    # the seed states, trainFlowParallel.py:294-297); hand the seed states over in that layout too, once, outside the timed region
+    states = [(h.contiguous(memory_format=torch.channels_last), c.contiguous(memory_format=torch.channels_last)) for h, c in states]
 
     y_fwd = torch.randn(B, cfg["out_features"], Hin * up, Win * up, generator=g).to(dev) if args.direction == "forward" else None
 
