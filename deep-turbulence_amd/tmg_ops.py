@@ -619,11 +619,14 @@ class LevelCouplingFn(torch.autograd.Function):
             cur = _mix_fwd(y, Wm[k], bm[k], PM[k]) if reverse else y
             saved[k] = (xin, tin, D, r, y)
         del Hc, Dc
+        # the per-layer activations are module-owned buffers freed layer by layer during backward, hence a plain attribute
+        # instead of save_for_backward; the node hands out a VIEW of its last buffer, so the returned tensor (which owns the
+        # grad_fn -> ctx reference) is not itself an element of `saved`: no reference cycle when backward never runs
         ctx.saved = saved
         ctx.fuse = fuse
         ctx.meta = (NL, NLp, reverse, ch, Cc)
         ctx.save_for_backward(cond, Wm, bm, Wzc, Wdc, *wts)
-        return cur, logdet
+        return cur.view(cur.shape), logdet
 
     @staticmethod
     def backward(ctx, dy, dld):
@@ -632,6 +635,9 @@ class LevelCouplingFn(torch.autograd.Function):
         wts = ctx.saved_tensors[5:]
         w1s, w2s, wzs, bzs, kps = wts[0::5], wts[1::5], wts[2::5], wts[3::5], wts[4::5]
         saved = ctx.saved
+        if saved is None:
+            raise RuntimeError("LevelCouplingFn: the saved activations were released by a previous backward pass "
+                               "(a second backward through the same graph is not supported)")
         ctx.saved = None
         dy = dy.contiguous()
         B, Hh, Ww, C = dy.shape

@@ -686,3 +686,45 @@ def test_trainer_epoch_matches_oracle_loop():
         scale = float((0.05 * coef * gr).abs().max()) + 1e-12
         worst = max(worst, float((got - want).abs().max()) / scale)
     assert worst < 2e-2, worst  # updates agree to 2 % of the largest step taken in each tensor
+
+
+def test_trainer_test_loop_error_measure():
+    """`TrainFlow.test` (reference trainFlowParallel.py:313-382): un-normalisation with out_std / out_mu, sample mean over the
+    roll-outs, squared error summed over time-steps 1..tmax (step 0 excluded) and divided by ntest * tmax * H * W - checked
+    against the closed form for a model whose `sample` is replaced by a known function of the time-step; then one un-patched run
+    on the HIP path (finite, states re-anchored every 10 steps without error)."""
+    from types import SimpleNamespace
+    from nn.tmGlow import TMGlow
+    from nn.trainFlowParallel import TrainFlow
+    cfg = C.CFG_TINY3
+    B, T, (h, w) = 2, 13, cfg["_in_hw"]
+    Hh, Ww = h * cfg["_up"], w * cfg["_up"]
+    C.seed_all(11)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, 0.03, 0.05, 0.03)
+    m.out_std, m.out_mu = torch.tensor([1.5, 0.5, 2.0]), torch.tensor([0.1, -0.2, 0.3])
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, T, cfg["in_features"], h, w, generator=g)
+    tgt = torch.randn(B, T, 3, Hh, Ww, generator=g)
+    args = SimpleNamespace(beta=1.0, dx=0.1, dy=0.1, max_grad_norm=1.0, ntest=B, device=torch.device(DEV))
+    trainer = TrainFlow(args, m, None, [(x, tgt, torch.ones(B))])
+    # (i) closed form: the "model" predicts target + 0.25 * (t + 1) in normalised units
+    calls = {"t": 0}
+    real_sample = m.sample
+
+    def fake(x_t, states):
+        t = calls["t"] % T
+        calls["t"] += 1
+        return tgt[:, t].to(DEV) + 0.25 * (t + 1), torch.zeros(B, device=DEV), states
+
+    m.sample = fake
+    mse = trainer.test(m, samples=2, epoch=0, plot=False, tmax=T - 1)
+    sd = torch.tensor([1.5, 0.5, 2.0])
+    want = sum(float(((sd * 0.25 * (t + 1)) ** 2).sum()) * Hh * Ww * B for t in range(1, T)) / (B * (T - 1) * Hh * Ww)
+    assert abs(float(mse) - want) <= 1e-5 * want, (float(mse), want)
+    assert calls["t"] == 2 * T and m.training      # every step of both roll-outs; the model is put back into its previous mode
+    # (ii) the real path
+    m.sample = real_sample
+    mse = trainer.test(m, samples=1, epoch=0, plot=False, tmax=T - 1)
+    assert torch.isfinite(mse) and float(mse) > 0
