@@ -24,6 +24,12 @@
 #include "tmg_common.h"
 #include <stdlib.h>
 
+// exp and 1/x on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp): the IEEE-exact library forms cost ~10 vector
+// instructions each, and these kernels are bound by vector-instruction issue (1 900 per wave and tile against 180 MFMAs in the
+// backward kernel).  The results stay far inside the fp32 parity tolerances (exp feeds a factor in [e^-2, e^2]).
+__device__ __forceinline__ float cpl_exp(float v) { return __expf(v); }
+__device__ __forceinline__ float cpl_rcp(float v) { return __frcp_rn(v); }
+
 struct CplFP {
     const float* x; int xs;          // layer input, C channels: x1 = [0, ch), x2 = [ch, C)
     float* out; int os;              // layer output (C channels)
@@ -215,11 +221,11 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 1) void cpl_fwd_kernel(CplFP p) 
                 const float4 bz4 = bzv[mt], h4 = hcur[mt];
                 const float hh0 = (acc[mt][0] + h4.x + bz4.x) * osc, hh1 = (acc[mt][1] + h4.y + bz4.y) * osc;
                 const float hh2 = (acc[mt][2] + h4.z + bz4.z) * osc, hh3 = (acc[mt][3] + h4.w + bz4.w) * osc;
-                const float sg0 = 2.f * hh1 / (1.f + fabsf(hh1)), sg1 = 2.f * hh3 / (1.f + fabsf(hh3));
+                const float sg0 = 2.f * hh1 * cpl_rcp(1.f + fabsf(hh1)), sg1 = 2.f * hh3 * cpl_rcp(1.f + fabsf(hh3));
                 const float2 xv = xcur[mt];
                 float o0, o1;
-                if (p.reverse) { o0 = xv.x * expf(-sg0) - hh0; o1 = xv.y * expf(-sg1) - hh2; }
-                else           { o0 = (xv.x + hh0) * expf(sg0); o1 = (xv.y + hh2) * expf(sg1); }
+                if (p.reverse) { o0 = xv.x * cpl_exp(-sg0) - hh0; o1 = xv.y * cpl_exp(-sg1) - hh2; }
+                else           { o0 = (xv.x + hh0) * cpl_exp(sg0); o1 = (xv.y + hh2) * cpl_exp(sg1); }
                 const bool ok = pin && 8 * mt + 2 * q < ch;
                 y2r[mt][0] = ok ? o0 : 0.f;
                 y2r[mt][1] = ok ? o1 : 0.f;
@@ -452,12 +458,12 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 1) void cpl_bwd_kernel(CplBP p) 
                     float di[4], da[4], dr[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float den = 1.f + fabsf(rr[e]);
-                        const float inv = expf(-2.f * rr[e] / den);
+                        const float den = 1.f + fabsf(rr[e]), rden = cpl_rcp(den);
+                        const float inv = cpl_exp(-2.f * rr[e] * rden);
                         const float go = acc[mo][e];
                         di[e] = go * inv;
                         da[e] = inimg ? -go * osc : 0.f;
-                        dr[e] = inimg ? osc * (-2.f * go * (tt[e] * inv) + 2.f * gb) / (den * den) : 0.f;
+                        dr[e] = inimg ? osc * (-2.f * go * (tt[e] * inv) + 2.f * gb) * (rden * rden) : 0.f;
                     }
                     if (rp < PP) {
 #pragma unroll
