@@ -1609,7 +1609,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     // Decomposition: a block owns (CITG input-channel tiles x all taps) x (NCO output-channel tiles) of dW and a
     // strided share of the pixel tiles.  Prefer large register tiles (operand reuse); when the image is small,
     // fall back to smaller ones so that output groups x pixel shares still fill the chip with >= 4 tiles per block.
-    static const int pref[][2] = {{4, 2}, {3, 2}, {2, 2}, {4, 1}, {3, 1}, {1, 4}, {1, 2}, {2, 1}, {1, 1}};
+    static const int pref[][2] = {{4, 2}, {3, 2}, {2, 4}, {2, 2}, {4, 1}, {3, 1}, {1, 4}, {1, 2}, {2, 1}, {1, 1}};
     const int gmin = (1024 + pl->ntiles - 1) / pl->ntiles;
     const int halo = ksize >> 1;
     const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
@@ -1622,7 +1622,12 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     for (auto& c : pref) {
         int cg = c[0], nc = c[1];
         if (ntaps == 1) cg *= 4;  // 1x1: one pair per channel tile
-        if (cg > cit) cg = cit;
+        if (cg > cit) {
+            // few input-channel tiles, many output tiles (the level-wide conditioning contractions: 2 x 15..): spend the register
+            // tile on output channels - (2, 4) stages the same patch for twice the MFMA work of (2, 2)
+            if (cit <= 2 && cot >= 8 && nc < 4 && ntaps == 9) continue;
+            cg = cit;
+        }
         if (nc > cot) continue;
         while (cg > 1 && !fits(cg, nc)) --cg;
         if (!fits(cg, nc)) continue;
