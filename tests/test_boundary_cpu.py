@@ -74,3 +74,26 @@ def test_no_cpu_fallback():
         m.sample(torch.randn(1, 2, 8, 8))
     with pytest.raises(AssertionError):
         m.glow.forward(torch.zeros(1, 2, 16, 16), [None], None)
+
+
+def test_zero_padded_channel_layout_is_exact():
+    """Levels whose channel half is not a multiple of 4 (3-channel fields) run on [x1 | 0.. | x2 | 0..]: the padded mix applied to
+    the padded activations must reproduce the un-padded mix on the real channels and keep the padding channels exactly zero
+    (host-side helpers of LSTMFLowBlock; the kernels only ever see the padded, float4-aligned problem)."""
+    import torch
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock as B
+    g = torch.Generator().manual_seed(0)
+    for C_ in (12, 20, 6):
+        ch = C_ // 2
+        pad = (-ch) % 4
+        W, b = torch.randn(3, C_, C_, generator=g), torch.randn(3, C_, generator=g)
+        x = torch.randn(2, 5, 7, C_, generator=g)
+        xp = B._pad_x(x, ch, pad)
+        assert xp.shape[-1] == 2 * (ch + pad) and (ch + pad) % 4 == 0
+        assert torch.equal(B._unpad_x(xp, ch, pad), x)
+        Wp, bp = B._pad_mix(W, b, ch, pad)
+        for k in range(3):
+            yp = xp @ Wp[k].t() + bp[k]
+            y = x @ W[k].t() + b[k]
+            assert torch.allclose(B._unpad_x(yp, ch, pad), y, atol=1e-6)
+            assert float(yp[..., ch:ch + pad].abs().max()) == 0.0 and float(yp[..., 2 * ch + pad:].abs().max()) == 0.0
