@@ -310,6 +310,23 @@ def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, 
                               _ptr(kappa), _ptr(ws), c_i64(ws.numel() if ws is not None else 0), dims, _stream()), "tmg_conv_wgrad")
 
 
+_GTAB = {}
+
+
+def _segment_table(rows, device):
+    """Device copy of a grouped launch's segment table.  The table holds raw pointers of activations; in a steady training loop the
+    caching allocator hands out the same blocks step after step, so the same table recurs and its device copy is reused - no
+    pageable host-to-device copy (a synchronising one) per grouped launch.  The cache is bounded; a miss just copies."""
+    key = (device.index, tuple(tuple(r) for r in rows))
+    t = _GTAB.get(key)
+    if t is None:
+        if len(_GTAB) > 256:
+            _GTAB.clear()
+        t = torch.tensor(rows, dtype=torch.int64).to(device)
+        _GTAB[key] = t
+    return t
+
+
 def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, stride, relu_in=False, pad_rep=False, cin_dst=0,
                        cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0, group_dy=None):
     """One launch for len(group_inputs) identically shaped weight gradients.  group_inputs[g]: list of <= 3 NHWC segments;
@@ -337,7 +354,7 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
         row += [0, 0, 0, 0] * (3 - n_in)
         row += ([seg(group_dy[len(rows)])[0], seg(group_dy[len(rows)])[1], 0, 0] if group_dy is not None else [0, 0, 0, 0])
         rows.append(row)
-    gtab = torch.tensor(rows, dtype=torch.int64).to(dy.device, non_blocking=True)
+    gtab = _segment_table(rows, dy.device)
     dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cg, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
     ws = workspace(lib().tmg_conv_wgrad_grouped_ws_floats(dims, c_i64(G)), dy.device)
     gd = _i64(Cg, dW[0].numel(), dbias[0].numel() if dbias is not None else 0)

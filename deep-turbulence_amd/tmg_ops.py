@@ -80,7 +80,17 @@ class ConvFn(torch.autograd.Function):
                     H.conv_rep_border_fix(dy, wpk_t, dins, kappa=kappa)
             else:
                 assert ctx.n_in == 1 and not ctx.has_kappa and not pad_rep
-                H.conv_dgrad_direct(dy, weight, dins[0], ksize, stride)
+                Hin_, Win_ = inputs[0].shape[1], inputs[0].shape[2]
+                if stride == 2 and ksize == 3 and Hin_ % 2 == 0 and Win_ % 2 == 0:
+                    # stride-2 input gradient on the matrix cores: dx(i) = sum_k w[k] dy((i + 1 - k) / 2) over the even arguments
+                    # = a stride-1 correlation with the flipped taps over dy spread onto the even positions of a zero grid
+                    # (4x the minimal MFMA work, but these encoder convs have 8-32 channels: the scalar direct kernel spent
+                    # 260 us per call at 0.12 TB/s on them)
+                    up = torch.zeros((dy.shape[0], Hin_, Win_, dy.shape[3]), device=dy.device, dtype=torch.float32)
+                    up[:, ::2, ::2] = dy
+                    H.conv_fwd([up], H.conv_pack(weight, 1), inputs[0].shape[3], ksize, 1, dins)
+                else:
+                    H.conv_dgrad_direct(dy, weight, dins[0], ksize, stride)
             if relu_in:
                 for d, t in zip(dins, inputs):
                     H.masked_add(d, src=d, ref=t)
