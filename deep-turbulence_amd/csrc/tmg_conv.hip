@@ -1732,14 +1732,14 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
     const int bpg = pl.gy;
     if (ngroups > 1) {
         // one launch for `ngroups` independent, identically shaped contractions: the groups share the pixel tiles' geometry,
-        // blockIdx.y walks (group, output-channel block); a group must fit one input-channel block
-        if (pl.gz != 1) return -100;
+        // blockIdx.y walks (group, output-channel block)
+        // (blockIdx.z still walks the input-channel blocks of a group wider than one block)
         pl.gy = bpg * ngroups;
-        int gx = 256 / pl.gy;
+        int gx = 256 / (pl.gy * pl.gz);
         if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
         if (gx < 1) gx = 1;
         pl.gx = gx;
-        pl.ws_floats = (size_t)gx * pl.gy * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * pl.gy * 64;
+        pl.ws_floats = (size_t)gx * pl.gy * pl.gz * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * pl.gy * 64;
     }
     p.ws = (ws && (size_t)ws_floats >= pl.ws_floats && (((uintptr_t)ws) & 15) == 0) ? (float*)ws : nullptr;
     dim3 grid(pl.gx, pl.gy, pl.gz);
@@ -1802,10 +1802,10 @@ extern "C" int64_t tmg_conv_wgrad_grouped_ws_floats(const int64_t* dims, int64_t
     WgradPlan pl;
     if (plan_wgrad((int)dims[0], (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7], (int)dims[8], &pl) != 0) return 0;
     const int gy = pl.gy * (int)ngroups;
-    int gx = 256 / gy;
+    int gx = 256 / (gy * pl.gz);
     if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
     if (gx < 1) gx = 1;
-    return (int64_t)((size_t)gx * gy * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * gy * 64);
+    return (int64_t)((size_t)gx * gy * pl.gz * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * gy * 64);
 }
 
 // Replicate-padding fold for the 3x3 input gradient (see conv_rep_border_fix_kernel).

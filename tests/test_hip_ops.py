@@ -318,7 +318,7 @@ def test_physics_loss_matches_reference_fixture(tag):
     _close(phys.calcDivergence(hat[:, :2]), t("ustar"), what="ustar")
 
 
-@pytest.mark.parametrize("shape", [(4, 2, 16, 16, 8, 16, 32), (3, 1, 20, 12, 16, 32, 5), (5, 2, 32, 32, 32, 64, 32)])
+@pytest.mark.parametrize("shape", [(4, 2, 16, 16, 8, 16, 32), (3, 1, 20, 12, 16, 32, 5), (5, 2, 32, 32, 32, 64, 32), (3, 4, 16, 16, 64, 128, 32)])
 def test_grouped_weight_gradient_matches_per_group_launches(shape):
     """tmg_conv_wgrad_grouped (one launch, device segment table) against G separate tmg_conv_wgrad launches and against
     fp64 autograd; the destination mapping is the level node's (x1 | growth buffer rows of a wider weight tensor)."""
