@@ -1195,6 +1195,96 @@ __global__ void conv_rep_border_fix_kernel(BorderP p) {
     }
 }
 
+// The same fold on the matrix cores.  The scalar kernel above re-reads the operand per (pixel, channel): at the level-wide
+// conditioning contraction (240..1920 dy channels) that was 3 GB of L2 reads per launch for 1.6 GFLOP of work.  Here the border
+// pixels are the GEMM's N dimension: they are sorted into 8 classes (left / right / top / bottom edge without corners, 4 corners),
+// a wave owns 16 pixels of ONE class, so its pixels share the class's list of (operand tap, source offset) pairs and every
+// operand fragment read from L2 serves 16 pixels.  D = Wt[tap] (16 channels x 4 k) x dy(source pixel)^T (4 k x 16 pixels), both
+// operands straight from global memory (16-byte loads, no LDS), accumulated over pairs x dy channels; lane (pixel, q) then
+// adds its 4 consecutive channels onto dx with one float4 read-modify-write.
+struct BorderMP {
+    BorderP b;
+    int tile0[9];   // first 16-pixel tile of class c (tile0[8] = total)
+    int cnt[8];     // pixels of class c per image
+};
+
+// pairs of class c: entry = operand tap | (dy + 1) << 4 | (dx + 1) << 6 ; classes: 0 L, 1 R, 2 T, 3 B, 4 TL, 5 TR, 6 BL, 7 BR
+#define TMG_BP(TAP, DY, DX) ((unsigned)(TAP) | ((unsigned)((DY) + 1) << 4) | ((unsigned)((DX) + 1) << 6))
+static __device__ const unsigned g_border_pairs[8][8] = {
+    {3, TMG_BP(2, -1, 0), TMG_BP(5, 0, 0), TMG_BP(8, 1, 0)},
+    {3, TMG_BP(0, -1, 0), TMG_BP(3, 0, 0), TMG_BP(6, 1, 0)},
+    {3, TMG_BP(6, 0, -1), TMG_BP(7, 0, 0), TMG_BP(8, 0, 1)},
+    {3, TMG_BP(0, 0, -1), TMG_BP(1, 0, 0), TMG_BP(2, 0, 1)},
+    {7, TMG_BP(6, 0, -1), TMG_BP(7, 0, 0), TMG_BP(8, 0, 1), TMG_BP(2, -1, 0), TMG_BP(5, 0, 0), TMG_BP(8, 1, 0), TMG_BP(8, 0, 0)},
+    {7, TMG_BP(6, 0, -1), TMG_BP(7, 0, 0), TMG_BP(8, 0, 1), TMG_BP(0, -1, 0), TMG_BP(3, 0, 0), TMG_BP(6, 1, 0), TMG_BP(6, 0, 0)},
+    {7, TMG_BP(0, 0, -1), TMG_BP(1, 0, 0), TMG_BP(2, 0, 1), TMG_BP(2, -1, 0), TMG_BP(5, 0, 0), TMG_BP(8, 1, 0), TMG_BP(2, 0, 0)},
+    {7, TMG_BP(0, 0, -1), TMG_BP(1, 0, 0), TMG_BP(2, 0, 1), TMG_BP(0, -1, 0), TMG_BP(3, 0, 0), TMG_BP(6, 1, 0), TMG_BP(0, 0, 0)}};
+#undef TMG_BP
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
+    const BorderP& p = m.b;
+    const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const float osc = out_scale_of(p.kappa);
+    const size_t tap_stride = (size_t)p.KB * p.Npad * 16, kb_stride = (size_t)p.Npad * 16;
+    for (int t = (int)blockIdx.x * 4 + wave; t < m.tile0[8]; t += (int)gridDim.x * 4) {
+        int c = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) c += (t >= m.tile0[k]) ? 1 : 0;
+        const int cnt = m.cnt[c];
+        const int i = (t - m.tile0[c]) * 16 + li;          // this lane's pixel of the class
+        const bool pv = i < p.B * cnt;
+        const int b = pv ? i / cnt : 0, j = pv ? i - b * cnt : 0;
+        int qy, qx;
+        if (c == 0) { qy = 1 + j; qx = 0; }
+        else if (c == 1) { qy = 1 + j; qx = p.W - 1; }
+        else if (c == 2) { qy = 0; qx = 1 + j; }
+        else if (c == 3) { qy = p.H - 1; qx = 1 + j; }
+        else { qy = (c & 2) ? p.H - 1 : 0; qx = (c & 1) ? p.W - 1 : 0; }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int npairs = (int)g_border_pairs[c][0];
+        for (int e = 0; e < npairs; ++e) {
+            const unsigned ent = g_border_pairs[c][1 + e];
+            const int sy = qy + (int)((ent >> 4) & 3u) - 1, sx = qx + (int)((ent >> 6) & 3u) - 1;
+            const bool sv = pv && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+            const float* src = p.dy + (((size_t)b * p.H + (sv ? sy : 0)) * p.W + (sv ? sx : 0)) * p.dy_stride + p.dy_off + 4 * q;
+            const float* wt = p.wpk + (size_t)(ent & 15u) * tap_stride + li * 16 + 4 * q;
+            for (int kb = 0; kb < p.KB; ++kb) {
+                const float4 x4 = (sv && kb * 16 + 4 * q < p.Cdy) ? *reinterpret_cast<const float4*>(src + kb * 16)
+                                                                 : *reinterpret_cast<const float4*>(g_tmg_zero_page);
+                float4 w4[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) w4[n] = *reinterpret_cast<const float4*>(wt + (size_t)kb * kb_stride + n * 256);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].x, x4.x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].y, x4.y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].z, x4.z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].w, x4.w, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        if (pv) {
+            const size_t opx = ((size_t)b * p.H + qy) * p.W + qx;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int n0 = n * 16 + 4 * q;
+                if (n0 < p.Cx) {
+                    int nl = n0;
+                    TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
+                    float4* dst = reinterpret_cast<float4*>(optr + opx * ostride + ooff + nl);
+                    float4 o = *dst;
+                    o.x += acc[n][0] * osc; o.y += acc[n][1] * osc; o.z += acc[n][2] * osc; o.w += acc[n][3] * osc;
+                    *dst = o;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic direct input-gradient (any stride) for the encoder's two stride-2 convs (tiny FLOPs).
 // dx[b,iy,ix,ci] = sum_{ky,kx,co : iy+pad-ky = s*oy, ix+pad-kx = s*ox} W[co][ci][ky][kx] * dy[b,oy,ox,co]
@@ -1826,6 +1916,35 @@ extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, c
     if (p.H == 1 && p.W == 1) p.nborder = 1;
     else if (p.H == 1) p.nborder = p.W;
     else p.nborder = 2 * p.W + (p.W > 1 ? 2 : 1) * (p.H - 2);
+    // matrix-core path: images with an interior (H, W >= 2), float4-addressable dy and dx segments, <= 6 channel tiles
+    bool mf = p.H >= 2 && p.W >= 2 && (p.Cdy & 3) == 0 && (((p.dy_stride | p.dy_off) & 3) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
+              (p.Cx & 3) == 0 && p.Npad <= 96;
+    for (int i = 0; i < (int)nout; ++i)
+        if (((p.out[i].stride | p.out[i].off | p.out[i].n) & 3) || (((uintptr_t)p.out[i].p) & 15)) mf = false;
+    static const int no_mf = getenv("TMG_BORDER_SCALAR") ? 1 : 0;
+    if (mf && !no_mf) {
+        BorderMP m;
+        m.b = p;
+        const int cnt[8] = {p.H - 2, p.H - 2, p.W - 2, p.W - 2, 1, 1, 1, 1};
+        int t0 = 0;
+        for (int c = 0; c < 8; ++c) {
+            m.cnt[c] = cnt[c] > 0 ? cnt[c] : 1;
+            m.tile0[c] = t0;
+            t0 += cnt[c] > 0 ? (p.B * cnt[c] + 15) / 16 : 0;
+        }
+        m.tile0[8] = t0;
+        const int blocks = (t0 + 3) / 4 < 2048 ? (t0 + 3) / 4 : 2048;
+        switch (p.Npad >> 4) {
+            case 1: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<1>, dim3(blocks), dim3(256), 0, st, m); break;
+            case 2: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<2>, dim3(blocks), dim3(256), 0, st, m); break;
+            case 3: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<3>, dim3(blocks), dim3(256), 0, st, m); break;
+            case 4: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<4>, dim3(blocks), dim3(256), 0, st, m); break;
+            case 5: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<5>, dim3(blocks), dim3(256), 0, st, m); break;
+            default: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<6>, dim3(blocks), dim3(256), 0, st, m); break;
+        }
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t total = (size_t)p.B * p.nborder * p.Cx;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv_rep_border_fix_kernel, dim3(blocks), dim3(256), 0, st, p);

@@ -37,6 +37,9 @@ CONV_CASES = [
     (2, 16, 16, [16, 32, 64], 256, 3, 1, False, False, True, False, False),
     (2, 16, 16, [20, 64], 40, 3, 1, False, False, True, False, True),
     (2, 8, 8, [64, 32, 4], 128, 3, 1, True, True, True, True, False),
+    (2, 40, 72, [8, 4], 16, 3, 1, True, True, True, True, False),     # several tiles per image, partial tiles on two sides
+    (3, 1, 8, [8], 16, 3, 1, True, True, True, False, False),         # one-row image: top and bottom ring fold onto the same pixels
+    (2, 5, 1, [4], 8, 3, 1, True, True, False, False, False),
     (2, 16, 16, [8], 16, 3, 2, True, False, False, False, False),
     (3, 10, 6, [5], 9, 3, 2, True, False, False, False, False),
     (2, 16, 16, [16], 16, 1, 1, False, False, True, False, False),

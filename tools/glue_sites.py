@@ -47,3 +47,21 @@ for e in prof.events():
         sites[key] += 1
 for (name, where), n in sites.most_common(45):
     print("%5d  %-16s %s" % (n, name, where[:110]))
+
+print("---- autograd nodes / aten ops of the step by call count")
+ka = prof.key_averages()
+for e in sorted(ka, key=lambda e: -e.count)[:70]:
+    print("%5d  %-60s cpu %8.1f us  dev %8.1f us" % (e.count, e.key[:60], e.cpu_time_total, e.device_time_total))
+
+print("---- parents of the fill / copy / cat launches")
+chains = collections.Counter()
+for e in prof.events():
+    if e.name in ("aten::fill_", "aten::copy_", "aten::cat", "aten::add", "aten::mul", "aten::add_") and e.device_time_total > 0:
+        names = []
+        q = e.cpu_parent
+        while q is not None and len(names) < 4:
+            names.append(q.name[:48])
+            q = q.cpu_parent
+        chains[(e.name, " < ".join(names))] += 1
+for (n, c), k in chains.most_common(40):
+    print("%5d  %-12s %s" % (k, n, c))
