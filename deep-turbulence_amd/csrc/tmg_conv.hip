@@ -1206,6 +1206,7 @@ struct BorderMP {
     BorderP b;
     int tile0[9];   // first 16-pixel tile of class c (tile0[8] = total)
     int cnt[8];     // pixels of class c per image
+    int ksplit;     // waves sharing one tile's dy-channel range (long contractions over few border pixels)
 };
 
 // pairs of class c: entry = operand tap | (dy + 1) << 4 | (dx + 1) << 6 ; classes: 0 L, 1 R, 2 T, 3 B, 4 TL, 5 TR, 6 BL, 7 BR
@@ -1224,11 +1225,16 @@ static __device__ const unsigned g_border_pairs[8][8] = {
 template <int NT>
 __global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
     const BorderP& p = m.b;
+    constexpr int U = NT <= 3 ? 4 : 2;   // k-blocks whose operand loads are in flight together (the chain is latency-bound)
     const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const float osc = out_scale_of(p.kappa);
     const size_t tap_stride = (size_t)p.KB * p.Npad * 16, kb_stride = (size_t)p.Npad * 16;
-    for (int t = (int)blockIdx.x * 4 + wave; t < m.tile0[8]; t += (int)gridDim.x * 4) {
+    const int S = m.ksplit, KBs = (p.KB + S - 1) / S;
+    for (int item = (int)blockIdx.x * 4 + wave; item < m.tile0[8] * S; item += (int)gridDim.x * 4) {
+        const int t = item / S, ks = item - t * S;
+        const int kb0 = ks * KBs, kb1 = min(p.KB, kb0 + KBs);
+        if (kb0 >= kb1) continue;
         int c = 0;
 #pragma unroll
         for (int k = 1; k < 8; ++k) c += (t >= m.tile0[k]) ? 1 : 0;
@@ -1252,19 +1258,26 @@ __global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
             const bool sv = pv && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
             const float* src = p.dy + (((size_t)b * p.H + (sv ? sy : 0)) * p.W + (sv ? sx : 0)) * p.dy_stride + p.dy_off + 4 * q;
             const float* wt = p.wpk + (size_t)(ent & 15u) * tap_stride + li * 16 + 4 * q;
-            for (int kb = 0; kb < p.KB; ++kb) {
-                const float4 x4 = (sv && kb * 16 + 4 * q < p.Cdy) ? *reinterpret_cast<const float4*>(src + kb * 16)
-                                                                 : *reinterpret_cast<const float4*>(g_tmg_zero_page);
-                float4 w4[NT];
+            for (int kb = kb0; kb < kb1; kb += U) {
+                float4 x4[U], w4[U][NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) w4[n] = *reinterpret_cast<const float4*>(wt + (size_t)kb * kb_stride + n * 256);
+                for (int u = 0; u < U; ++u) {
+                    const int kk = kb + u;
+                    x4[u] = (sv && kk < kb1 && kk * 16 + 4 * q < p.Cdy) ? *reinterpret_cast<const float4*>(src + kk * 16)
+                                                                        : *reinterpret_cast<const float4*>(g_tmg_zero_page);
+                    const float* wk = wt + (size_t)min(kk, kb1 - 1) * kb_stride;   // past the range: any valid slice (x4 is zero)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].x, x4.x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].y, x4.y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].z, x4.z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].w, x4.w, acc[n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n) w4[u][n] = *reinterpret_cast<const float4*>(wk + n * 256);
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[u][n].x, x4[u].x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[u][n].y, x4[u].y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[u][n].z, x4[u].z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[u][n].w, x4[u].w, acc[n], 0, 0, 0);
+                    }
             }
         }
         if (pv) {
@@ -1275,10 +1288,16 @@ __global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
                 if (n0 < p.Cx) {
                     int nl = n0;
                     TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
-                    float4* dst = reinterpret_cast<float4*>(optr + opx * ostride + ooff + nl);
-                    float4 o = *dst;
-                    o.x += acc[n][0] * osc; o.y += acc[n][1] * osc; o.z += acc[n][2] * osc; o.w += acc[n][3] * osc;
-                    *dst = o;
+                    float* dst = optr + opx * ostride + ooff + nl;
+                    if (S > 1) {
+                        // the dy channels of this pixel are split over S waves: hardware float adds (a few thousand border pixels)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + r, acc[n][r] * osc);
+                    } else {
+                        float4 o = *reinterpret_cast<float4*>(dst);
+                        o.x += acc[n][0] * osc; o.y += acc[n][1] * osc; o.z += acc[n][2] * osc; o.w += acc[n][3] * osc;
+                        *reinterpret_cast<float4*>(dst) = o;
+                    }
                 }
             }
         }
@@ -1933,7 +1952,13 @@ extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, c
             t0 += cnt[c] > 0 ? (p.B * cnt[c] + 15) / 16 : 0;
         }
         m.tile0[8] = t0;
-        const int blocks = (t0 + 3) / 4 < 2048 ? (t0 + 3) / 4 : 2048;
+        // enough waves to fill the chip: split the dy channels of a tile over several waves when there are few tiles
+        int S = (4096 + t0 - 1) / t0;
+        if (S > p.KB / 4) S = p.KB / 4;
+        if (S < 1) S = 1;
+        m.ksplit = S;
+        const long items = (long)t0 * S;
+        const int blocks = (int)((items + 3) / 4 < 4096 ? (items + 3) / 4 : 4096);
         switch (p.Npad >> 4) {
             case 1: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<1>, dim3(blocks), dim3(256), 0, st, m); break;
             case 2: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<2>, dim3(blocks), dim3(256), 0, st, m); break;
