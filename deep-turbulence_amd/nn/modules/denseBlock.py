@@ -7,6 +7,17 @@ import tmg_hip as H
 import tmg_ops as ops
 
 
+def drop_features(owner, yn, name='dropout'):
+    """The reference's optional `nn.Dropout3d` after a conv, applied to the NCHW VIEW of the NHWC activation: the very same
+    torch module, so its semantics on a 4-D input (whole samples are dropped: torch reads [N,C,H,W] as an un-batched
+    [C,D,H,W]) and its random-number consumption are the reference's by construction.  Off the hot path (rate 0 everywhere
+    the paper trains); an element-wise torch op, no kernel of ours."""
+    drop = getattr(owner, name, None)
+    if drop is None:
+        return yn
+    return drop(yn.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+
+
 class _DenseLayer(nn.Sequential):
     """BN -> ReLU -> 3x3 conv (growth_rate outputs), concatenated onto the input.  BatchNorm's
     per-channel affine and the ReLU are folded into the conv kernel's input staging; the batch moments
@@ -17,11 +28,11 @@ class _DenseLayer(nn.Sequential):
         super().__init__()
         if bottleneck and in_features > bn_size * growth_rate:
             raise NotImplementedError("bottleneck dense layers are not on the TM-Glow path (reference denseBlock.py:37-47)")
-        if drop_rate > 0:
-            raise NotImplementedError("dropout is not on the TM-Glow path (drop_rate is 0 in every config)")
         self.add_module('norm1', nn.BatchNorm2d(in_features))
         self.add_module('conv1', nn.Conv2d(in_features, growth_rate, kernel_size=(2 * padding + 1), stride=1, padding=padding,
                                            bias=False, padding_mode='zeros'))
+        if drop_rate > 0:
+            self.add_module('dropout', nn.Dropout3d(p=drop_rate))   # reference :54-55 (main.py --drop-rate)
 
     def grow(self, xn):
         """xn: NHWC tensor or channel-slice view; returns the growth_rate new channels (NHWC)."""
@@ -36,7 +47,7 @@ class _DenseLayer(nn.Sequential):
             a = bn.weight.detach() * rstd
             bsh = bn.bias.detach() - mean * a
             training = False
-        return ops.BNReLUConvFn.apply(xn, bn.weight, bn.bias, self.conv1.weight, mean, rstd, a, bsh, training)
+        return drop_features(self, ops.BNReLUConvFn.apply(xn, bn.weight, bn.bias, self.conv1.weight, mean, rstd, a, bsh, training))
 
     def forward(self, x):
         xn = H.nhwc(x)
@@ -81,13 +92,13 @@ class _DenseLayerNoNorm(nn.Sequential):
         super().__init__()
         if bottleneck and in_features > bn_size * growth_rate:
             raise NotImplementedError("bottleneck dense layers are not on the TM-Glow path")
-        if drop_rate > 0:
-            raise NotImplementedError("dropout is not on the TM-Glow path")
         self.add_module('conv1', nn.Conv2d(in_features, growth_rate, kernel_size=(2 * padding + 1), stride=1, padding=padding,
                                            bias=False, padding_mode='zeros'))
+        if drop_rate > 0:
+            self.add_module('dropout', nn.Dropout3d(p=drop_rate))   # reference :139-140
 
     def grow(self, inputs):
-        return ops.conv(inputs, self.conv1.weight, relu_in=True)
+        return drop_features(self, ops.conv(inputs, self.conv1.weight, relu_in=True))
 
     def forward(self, x):
         xn = H.nhwc(x)

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 import tmg_hip as H
 import tmg_ops as ops
-from nn.modules.denseBlock import DenseBlock
+from nn.modules.denseBlock import DenseBlock, drop_features
 from nn.modules.flowLSTMBlock import LSTMFLowBlock
 from nn.modules.flowUtils import GaussianDiag
 from nn.modules.misc import UpsamplingLinear
@@ -53,7 +53,7 @@ class Encoder(nn.Module):
                 trans = nn.Sequential()
                 trans.add_module('conv1', _conv3(self.num_feat, self.num_feat // 2, 2))
                 if drop_rate > 0:
-                    raise NotImplementedError("dropout is not on the TM-Glow path")
+                    trans.add_module('dropout1', nn.Dropout3d(p=drop_rate))   # reference :183-184
                 block.add_module('encode_conv{}'.format(i), trans)
                 self.num_feat = self.num_feat // 2
             block.add_module('encode_dense_block{}'.format(i),
@@ -77,7 +77,7 @@ class Encoder(nn.Module):
         for i, block in enumerate(self.encoding_blocks):
             mods = list(block._modules.values())
             if i > 0:
-                out = ops.conv([out], mods[0].conv1.weight, stride=2, relu_in=True)
+                out = drop_features(mods[0], ops.conv([out], mods[0].conv1.weight, stride=2, relu_in=True), 'dropout1')
             out = mods[-1].run(out)
             c0 = ops.conv([out], self.cond_convs[i][0].weight)
             c_out.append(ops.UpsampleFn.apply(c0, up))

@@ -50,3 +50,44 @@ def loadWorkspace(args, file_dir, file_name="nsWorkspace", file_id=0):
             raise FileNotFoundError('{} holds no {}'.format(path, _model_entry(file_id)))
         state = torch.load(io.BytesIO(z.read(_model_entry(file_id))), map_location='cpu', weights_only=False)
     return args, state['state_dict'], state['optimizer']
+
+
+def modelPred(args, model, testing_loader, log, samples=1, stride=1, tmax=1):
+    """Roll the model out over the test set for post-processing (reference utils/utils.py:151-235, the plotting scripts'
+    entry): `samples` independent roll-outs of `tmax` steps per test case, every `stride`-th step kept, everything
+    un-normalised and scaled back by the case's inlet velocity u0 (velocities x u0, pressure x u0^2).
+
+    Returns (ypred [samples, N, tmax // stride, C, H, W], ytarget [N, T, C, H, W], yinput [N, T, 3, h, w]) on the CPU.
+    The recurrent states are re-anchored half-way to their seed states every 20 steps, as the reference does."""
+    core = getattr(model, "module", model)
+    core.eval()
+    dev = torch.device(args.device) if getattr(args, "device", None) is not None else next(core.parameters()).device
+    shp = (1, -1, 1, 1)
+    in_std, in_mu = core.in_std.to(dev).view(shp), core.in_mu.to(dev).view(shp)
+    out_std, out_mu = core.out_std.to(dev).view(shp), core.out_mu.to(dev).view(shp)
+    nkeep = tmax // stride
+    preds, targets, inputs = [], [], []
+    with torch.no_grad():
+        for mbIdx, (input0, target0, u0) in enumerate(testing_loader):
+            log.log('Running mini-batch {:d}/{:d}'.format(mbIdx + 1, len(testing_loader)))
+            u = u0.to(dev).view(-1, 1, 1, 1, 1)
+            u = torch.cat((u, u, u ** 2), dim=2)                      # [N,1,3,1,1]: (ux, uy, p) scales
+            inp = input0.to(dev)
+            tgt = u * (out_std * target0.to(dev) + out_mu)
+            inputs.append((u * (in_std * inp[:, :, :3] + in_mu)).cpu())
+            targets.append(tgt.cpu())
+            mb = torch.full((samples, inp.size(0), nkeep) + tuple(tgt.shape[2:]), 10000.0, device=dev, dtype=inp.dtype)
+            for i in range(samples):
+                log.log('Running sample {:d}.'.format(i))
+                seeds = torch.LongTensor(inp.size(0)).random_(0, int(1e8))
+                key = core.initLSTMStates(seeds, [tgt.size(-2), tgt.size(-1)])
+                h0 = [(h.clone(), c.clone()) for h, c in key]
+                for tstep in range(tmax):
+                    y0, _logp, h0 = core.sample(inp[:, tstep], h0)
+                    if tstep % stride == 0 and tstep // stride < nkeep:
+                        mb[i, :, tstep // stride] = u[:, 0] * (out_std * y0 + out_mu)
+                    if tstep % 20 == 0:
+                        h0 = [(0.5 * h + 0.5 * hk, 0.5 * c + 0.5 * ck) for (h, c), (hk, ck) in zip(h0, key)]
+            log.log('Number of elements unset: {}'.format(int((mb > 10000).sum())))
+            preds.append(mb.cpu())
+    return torch.cat(preds, dim=1), torch.cat(targets, dim=0), torch.cat(inputs, dim=0)

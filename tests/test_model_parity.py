@@ -728,3 +728,87 @@ def test_trainer_test_loop_error_measure():
     m.sample = real_sample
     mse = trainer.test(m, samples=1, epoch=0, plot=False, tmax=T - 1)
     assert torch.isfinite(mse) and float(mse) > 0
+
+
+def test_model_pred_rollout_layout_and_scaling():
+    """`utils.utils.modelPred` (reference utils/utils.py:151-235): shapes of the three returned tensors, every `stride`-th step
+    kept, un-normalisation and the inlet-velocity scaling (u0, u0, u0^2) - against the closed form for a patched `sample`,
+    then one un-patched roll-out on the HIP path."""
+    from types import SimpleNamespace
+    from nn.tmGlow import TMGlow
+    from utils.utils import modelPred
+    cfg = C.CFG_TINY3
+    B, T, (h, w) = 3, 6, cfg["_in_hw"]
+    Hh, Ww = h * cfg["_up"], w * cfg["_up"]
+    C.seed_all(12)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 8, 0.03, 0.05, 0.03)
+    m.out_std, m.out_mu = torch.tensor([1.5, 0.5, 2.0]), torch.tensor([0.1, -0.2, 0.3])
+    m.in_std, m.in_mu = torch.tensor([2.0, 3.0, 0.5]), torch.tensor([0.5, 0.0, -1.0])
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, cfg["in_features"], h, w, generator=g)
+    tgt = torch.randn(B, T, 3, Hh, Ww, generator=g)
+    u0 = torch.tensor([1.0, 2.0, 0.5])
+    loader = [(x[:2], tgt[:2], u0[:2]), (x[2:], tgt[2:], u0[2:])]
+    log = SimpleNamespace(log=lambda *a, **k: None)
+    args = SimpleNamespace(device=torch.device(DEV))
+    calls = {"t": 0}
+    real_sample = m.sample
+
+    def fake(x_t, states):
+        t = calls["t"] % 4
+        calls["t"] += 1
+        return torch.full((x_t.size(0), 3, Hh, Ww), float(t), device=DEV), torch.zeros(x_t.size(0), device=DEV), states
+
+    m.sample = fake
+    yp, yt, yi = modelPred(args, m, loader, log, samples=2, stride=2, tmax=4)
+    assert tuple(yp.shape) == (2, B, 2, 3, Hh, Ww) and tuple(yt.shape) == (B, T, 3, Hh, Ww) and tuple(yi.shape) == (B, T, 3, h, w)
+    sc = torch.stack([u0, u0, u0 ** 2], 1)                                       # [B,3]
+    sd, mu = torch.tensor([1.5, 0.5, 2.0]), torch.tensor([0.1, -0.2, 0.3])
+    for k, t in enumerate((0, 2)):                                               # kept steps
+        want = (sc * (sd * t + mu)).view(1, B, 3, 1, 1).expand(2, B, 3, Hh, Ww)
+        assert torch.allclose(yp[:, :, k], want, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(yt, sc.view(B, 1, 3, 1, 1) * (sd.view(1, 1, 3, 1, 1) * tgt + mu.view(1, 1, 3, 1, 1)), rtol=1e-5, atol=1e-6)
+    isd, imu = torch.tensor([2.0, 3.0, 0.5]), torch.tensor([0.5, 0.0, -1.0])
+    assert torch.allclose(yi, sc.view(B, 1, 3, 1, 1) * (isd.view(1, 1, 3, 1, 1) * x[:, :, :3] + imu.view(1, 1, 3, 1, 1)), rtol=1e-5, atol=1e-6)
+    m.sample = real_sample
+    yp, _, _ = modelPred(args, m, loader, log, samples=1, stride=1, tmax=3)
+    assert tuple(yp.shape) == (1, B, 3, 3, Hh, Ww) and torch.isfinite(yp).all() and not (yp > 9999).any()
+
+
+def test_encoder_dropout_option():
+    """`--drop-rate` (reference main.py:71 -> denseBlock.py:54-55, tmGlow.py:183-184: nn.Dropout3d after the encoder's dense-layer
+    and transition convs).  Evaluation mode is the rate-0 model exactly; training mode runs forward + backward on the HIP path with
+    the mask torch draws for an un-batched 4-D input (whole samples of a feature map dropped, survivors scaled by 1 / (1 - p))."""
+    from nn.tmGlow import TMGlow
+    cfg = C.CFG_TINY3
+    (h, w) = cfg["_in_hw"]
+    C.seed_all(13)
+    kw = C.build_kwargs(cfg)
+    m0 = TMGlow(**kw)
+    C.perturb_(m0, 9, 0.03, 0.05, 0.03)
+    m1 = TMGlow(**dict(kw, drop_rate=0.5))
+    m1.load_state_dict(m0.state_dict(), strict=True)     # dropout adds no parameters or buffers
+    m0, m1 = m0.to(DEV).eval(), m1.to(DEV).eval()
+    assert any(isinstance(mod, torch.nn.Dropout3d) for mod in m1.modules())
+    B = 4
+    x = torch.randn(B, cfg["in_features"], h, w, generator=torch.Generator().manual_seed(6)).to(DEV)
+    st = m0.initLSTMStates(torch.arange(B), [h * cfg["_up"], w * cfg["_up"]])
+    torch.manual_seed(3)
+    y0, ld0, _ = m0.sample(x, st)
+    torch.manual_seed(3)
+    y1, ld1, _ = m1.sample(x, st)
+    assert torch.equal(y0, y1) and torch.equal(ld0, ld1)
+    m1.train()
+    # the mask semantics on one dense layer: each sample's new channels are either zero or 2x the rate-0 values
+    layer1 = m1.encoder.encoding_blocks[0][-1].denselayer1
+    layer0 = m0.train().encoder.encoding_blocks[0][-1].denselayer1
+    a = torch.randn(B, 6, 6, layer0.norm1.num_features, device=DEV)
+    ref = layer0.grow(a)
+    out = layer1.grow(a)
+    for b in range(B):
+        assert bool((out[b] == 0).all()) or torch.allclose(out[b], 2.0 * ref[b], rtol=1e-5, atol=1e-6)
+    y, ld, _ = m1.sample(x, st)
+    C.loss_reverse(y, ld).backward()
+    assert torch.isfinite(y).all() and all(p.grad is None or torch.isfinite(p.grad).all() for p in m1.parameters())
