@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtmglow_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip", "tmg_coupling.hip"]
+SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip", "tmg_coupling.hip", "tmg_wino.hip"]
 _lib = None
 
 c_i64 = ctypes.c_int64
@@ -29,6 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd",
 ]
 
 
@@ -235,6 +236,38 @@ def conv_fwd(inputs, wpk, Cout, ksize, stride, outs, bias=None, kappa=None, in_s
         return
     _chk(lib().tmg_conv_fwd(ip, idesc, c_i64(n_in), _ptr(wpk), _ptr(bias), _ptr(kappa), _ptr(in_scale), _ptr(in_shift), op, odesc,
                             c_i64(n_out), dims, _stream()), "tmg_conv_fwd")
+
+
+def wino_eligible(Cin, Cout, ksize, stride):
+    """Shapes the Winograd F(2x2, 3x3) kernel takes over from the direct implicit GEMM: 3x3 / stride 1 with many output
+    channels (the matrix-pipe-bound contractions).  TMG_NO_WINOGRAD=1 keeps everything on the direct kernel."""
+    return (ksize == 3 and stride == 1 and Cout >= 64 and Cout % 4 == 0 and Cin % 4 == 0 and Cin >= 16
+            and os.environ.get("TMG_NO_WINOGRAD") is None)
+
+
+def conv_wino_pack(w):
+    """Winograd operand U = G g G^T of a [Cout, Cin, 3, 3] weight: [16][Cin_pad/16][Cout_pad][16] floats."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    assert w.shape[2] == 3 and w.shape[3] == 3
+    w = w.contiguous()
+    U = torch.empty(16 * ((Cin + 15) // 16 * 16) * ((Cout + 15) // 16 * 16), device=w.device, dtype=torch.float32)
+    _chk(lib().tmg_conv_wino_pack(_ptr(w), _ptr(U), c_i64(Cout), c_i64(Cin), _stream()), "tmg_conv_wino_pack")
+    return U
+
+
+def conv_wino_fwd(inputs, U, Cout, out, bias=None, relu_in=False, pad_rep=False):
+    """out = conv3x3(pad(act(cat(inputs)))) + bias through the Winograd kernel; False when the shape is outside its envelope
+    (nothing was launched: the caller runs conv_fwd with the direct operand)."""
+    B, Hin, Win, _ = inputs[0].shape
+    ip, idesc, n_in = _segs(inputs)
+    Cin = sum(t.shape[3] for t in inputs)
+    assert out.shape[3] == Cout and out.shape[1] == Hin and out.shape[2] == Win
+    rc = lib().tmg_conv_wino_fwd(ip, idesc, c_i64(n_in), _ptr(U), _ptr(bias), _ptr(out), _d2(out),
+                                 _i64(B, Hin, Win, Cin, Cout, relu_in, pad_rep), _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_conv_wino_fwd")
+    return True
 
 
 _SIDE = {}

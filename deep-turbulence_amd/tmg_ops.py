@@ -254,7 +254,11 @@ class ConvLSTMCellFn(torch.autograd.Function):
         R = R4 // 4
         dev = weight.device
         gates = torch.empty((B, Hh, Ww, R4), device=dev, dtype=torch.float32)
-        H.conv_fwd(list(inputs) + [h_cur], H.conv_pack(weight, 0), R4, 3, 1, [gates], bias=bias)
+        segs = list(inputs) + [h_cur]
+        # the widest contraction of the path (Cin + R -> 4R channels): Winograd F(2x2, 3x3) when the shape is in its envelope
+        if not (H.wino_eligible(sum(t.shape[3] for t in segs), R4, 3, 1)
+                and H.conv_wino_fwd(segs, H.conv_wino_pack(weight), R4, gates, bias=bias)):
+            H.conv_fwd(segs, H.conv_pack(weight, 0), R4, 3, 1, [gates], bias=bias)
         c_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
         h_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
         H.lstm_pointwise_fwd(gates, c_cur, c_next, h_next)
@@ -583,7 +587,8 @@ class LevelCouplingFn(torch.autograd.Function):
         Wdc[:NL] = torch.stack(w1s)[:, 0, ch:cin]
         Wdc[NLp:NLp + NL] = torch.stack(w2s)[:, 0, ch:cin]
         Hc = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)
-        H.conv_fwd([cond], H.conv_pack(Wzc, 0), NL * C, 3, 1, [Hc], relu_in=True, pad_rep=True)
+        if not (H.wino_eligible(Cc, NL * C, 3, 1) and H.conv_wino_fwd([cond], H.conv_wino_pack(Wzc), NL * C, Hc, relu_in=True, pad_rep=True)):
+            H.conv_fwd([cond], H.conv_pack(Wzc, 0), NL * C, 3, 1, [Hc], relu_in=True, pad_rep=True)
         Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
         H.conv_fwd([cond], H.conv_pack(Wdc, 0), 2 * NLp, 3, 1, [Dc], relu_in=True)
         logdet = torch.zeros(B, device=dev, dtype=torch.float32)

@@ -416,3 +416,36 @@ def test_mix_f16_kernel(C_, npix, slice_of):
     H.mix_f16(x, W, b, y)
     dev = float((y.double() - full).abs().max()) / float(full.abs().max())
     assert 1e-5 < dev < 5e-3, dev
+
+
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, [16, 32, 64], 256, False, False, True),    # the gate-conv pattern: three segments, bias, zero padding
+    (2, 16, 12, [32], 240, True, True, False),             # the conditioning contraction: ReLU on the way in, replicate padding
+    (1, 9, 21, [8, 32, 64], 256, False, False, True),      # 104 input channels (last chunk half full), partial tiles on both axes
+    (2, 8, 8, [32], 1920, True, True, False),              # several output-channel blocks
+    (3, 5, 3, [16], 64, False, True, True),                # image smaller than a tile
+    (1, 32, 48, [64, 64], 128, True, False, True),         # several tiles per image, two full chunks per tile
+])
+def test_winograd_conv_matches_fp64(case):
+    """tmg_conv_wino_fwd (Winograd F(2x2,3x3) on the fp32 matrix cores) against fp64 F.conv2d, at the direct kernel's tolerance,
+    and against the direct kernel itself."""
+    import tmg_hip as H
+    B, Hh, Ww, segs, Cout, relu_in, pad_rep, has_b = case
+    g = torch.Generator().manual_seed(sum(segs) + Cout + Hh)
+    xs = [torch.randn(B, Hh, Ww, c, generator=g) for c in segs]
+    w = 0.2 * torch.randn(Cout, sum(segs), 3, 3, generator=g)
+    b = 0.3 * torch.randn(Cout, generator=g) if has_b else None
+    t = torch.cat(xs, 3).permute(0, 3, 1, 2).double()
+    if relu_in:
+        t = F.relu(t)
+    t = F.pad(t, (1, 1, 1, 1), mode="replicate" if pad_rep else "constant")
+    ref = F.conv2d(t, w.double(), b.double() if has_b else None).permute(0, 2, 3, 1)
+    xd = [x.to(DEV) for x in xs]
+    wd, bd = w.to(DEV), (b.to(DEV) if has_b else None)
+    out = torch.full((B, Hh, Ww, Cout), float("nan"), device=DEV)
+    assert H.wino_eligible(sum(segs), Cout, 3, 1)
+    assert H.conv_wino_fwd(xd, H.conv_wino_pack(wd), Cout, out, bias=bd, relu_in=relu_in, pad_rep=pad_rep)
+    _close(out, ref, what="winograd conv")
+    direct = torch.empty_like(out)
+    H.conv_fwd(xd, H.conv_pack(wd, 0), Cout, 3, 1, [direct], bias=bd, relu_in=relu_in, pad_rep=pad_rep)
+    _close(out, direct.double(), what="winograd vs direct")

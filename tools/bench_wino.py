@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Winograd vs direct 3x3 contraction on the path's widest shapes (GPU only): milliseconds and direct-algorithm TFLOP/s."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import tmg_hip as H  # noqa: E402
+
+dev = torch.device("cuda")
+CASES = [(64, 128, 128, [8, 32, 64], 256, False, False, True), (64, 128, 128, [32], 240, True, True, False),
+         (64, 64, 64, [16, 32, 64], 256, False, False, True), (64, 64, 64, [32], 480, True, True, False),
+         (64, 32, 32, [32], 960, True, True, False), (64, 16, 16, [32], 1920, True, True, False)]
+for B, Hh, Ww, segs, Cout, relu, rep, hb in CASES:
+    xs = [torch.randn(B, Hh, Ww, c, device=dev) for c in segs]
+    w = 0.1 * torch.randn(Cout, sum(segs), 3, 3, device=dev)
+    b = torch.randn(Cout, device=dev) if hb else None
+    out = torch.empty(B, Hh, Ww, Cout, device=dev)
+    U, Wp = H.conv_wino_pack(w), H.conv_pack(w, 0)
+    fl = 2.0 * B * Hh * Ww * Cout * sum(segs) * 9
+
+    def t(fn, n=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+    tw = t(lambda: H.conv_wino_fwd(xs, U, Cout, out, bias=b, relu_in=relu, pad_rep=rep))
+    td = t(lambda: H.conv_fwd(xs, Wp, Cout, 3, 1, [out], bias=b, relu_in=relu, pad_rep=rep))
+    print("%4dx%-4d %4d -> %4d   winograd %7.3f ms (%6.1f TF)   direct %7.3f ms (%6.1f TF)" % (Hh, Ww, sum(segs), Cout, tw, fl / tw / 1e9, td, fl / td / 1e9))
