@@ -31,13 +31,15 @@ struct WinoP {
     const float* U;                  // [16 pos][Cin_pad/16][Npad][16]
     const float* bias;               // [Cout] or null
     int relu_in, pad_rep;
-    float* out; int ostride, ooff;
+    TmgOSeg out[TMG_MAX_OUT_SEG];    // up to 3 output segments (the concatenated Cout channels)
     int tiles_x, tiles_y, ntiles;    // 8x16-pixel tiles of the whole batch
     int nchunks;                     // 32-channel chunks per tile
 };
 
 // U = G g G^T per (output channel, input channel):  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Kpad, int Npad) {
+// mode 0: forward operand, K = Cin, N = Cout, g = w[n][k].   mode 1: input-gradient operand (the transposed conv): K = Cout,
+// N = the first `nvalid` input channels, g = w[k][n] with the taps flipped.
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int K, int N, int Kpad, int Npad, int mode) {
     const size_t total = (size_t)Kpad * Npad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c16 = i & 15;
@@ -49,7 +51,11 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = (k < Cin && n < Cout) ? w[((size_t)n * Cin + k) * 9 + a * 3 + b] : 0.f;
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.f;
+                if (k < K && n < N) v = mode == 0 ? w[((size_t)n * Cin + k) * 9 + a * 3 + b] : w[((size_t)k * Cin + n) * 9 + (2 - a) * 3 + (2 - b)];
+                g[a][b] = v;
+            }
         float t[4][3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -70,12 +76,15 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-// w: torch layout [Cout][Cin][3][3]; U: [16][Cin_pad/16][Npad][16] floats (Cin_pad = Cin rounded to 16, Npad = Cout rounded to 16)
-extern "C" int tmg_conv_wino_pack(const void* w, void* U, int64_t Cout, int64_t Cin, hipStream_t st) {
-    const int Kpad = ((int)Cin + 15) & ~15, Npad = ((int)Cout + 15) & ~15;
+// w: torch layout [Cout][Cin][3][3]; U: [16][Kpad/16][Npad][16] floats.  mode 0: K = Cin, N = Cout (forward).  mode 1: K = Cout,
+// N = nvalid (<= Cin; 0 -> Cin): the operand of the input gradient w.r.t. the first N input channels.  Kpad / Npad: rounded to 16.
+extern "C" int tmg_conv_wino_pack(const void* w, void* U, int64_t Cout, int64_t Cin, int64_t mode, int64_t nvalid, hipStream_t st) {
+    const int K = mode == 0 ? (int)Cin : (int)Cout;
+    const int N = mode == 0 ? (int)Cout : (int)(nvalid > 0 && nvalid < Cin ? nvalid : Cin);
+    const int Kpad = (K + 15) & ~15, Npad = (N + 15) & ~15;
     const size_t total = (size_t)Kpad * Npad;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (float*)U, (int)Cout, (int)Cin, Kpad, Npad);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (float*)U, (int)Cout, (int)Cin, K, N, Kpad, Npad, (int)mode);
     TMG_CHECK_LAUNCH();
     return 0;
 }
@@ -302,12 +311,14 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                         if (ntile0 + n < ntt && n0 < p.Cout) {
                             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
+                            int nl = n0;
+                            TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
 #pragma unroll
                             for (int o = 0; o < 4; ++o) {
                                 const int oy = oyb + (o >> 1), ox = oxb + (o & 1);
                                 if (oy < p.Hin && ox < p.Win) {
                                     const size_t opx = ((size_t)b_ * p.Hin + oy) * p.Win + ox;
-                                    *reinterpret_cast<float4*>(p.out + opx * p.ostride + p.ooff + n0) =
+                                    *reinterpret_cast<float4*>(optr + opx * ostride + ooff + nl) =
                                         make_float4(Y[o][m][n][0] + bv.x, Y[o][m][n][1] + bv.y, Y[o][m][n][2] + bv.z, Y[o][m][n][3] + bv.w);
                                 }
                             }
@@ -330,15 +341,15 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
 }
 
 // out = conv3x3_stride1(pad(act(in))) + bias with the Winograd operand of tmg_conv_wino_pack.
-// dims = {B, H, W, Cin, Cout, relu_in, pad_replicate}; in_desc = {stride, off, n} per segment; out_desc = {stride, off}.
-// Envelope: float4-addressable segments and output, Cin % 4 == 0, Cout % 4 == 0, Cout >= 64; returns -100 outside it (the caller
+// dims = {B, H, W, Cin, Cout, relu_in, pad_replicate}; in_desc / out_desc = {stride, off, n} per segment (<= 3 each).
+// Envelope: float4-addressable segments, Cin % 4 == 0, Cout % 4 == 0, Cout >= 64; returns -100 outside it (the caller
 // uses tmg_conv_fwd).
 extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
-                                 void* out, const int64_t* out_desc, const int64_t* dims, hipStream_t st) {
+                                 void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, hipStream_t st) {
     WinoP p;
     p.nseg = (int)nseg;
-    if (p.nseg < 1 || p.nseg > TMG_MAX_IN_SEG) return -3;
-    int csum = 0;
+    if (p.nseg < 1 || p.nseg > TMG_MAX_IN_SEG || nout < 1 || nout > TMG_MAX_OUT_SEG) return -3;
+    int csum = 0, osum = 0;
     bool ok = true;
     for (int i = 0; i < TMG_MAX_IN_SEG; ++i) p.in[i] = TmgSeg{nullptr, 0, 0, 0};
     for (int i = 0; i < p.nseg; ++i) {
@@ -346,11 +357,16 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
         if (((p.in[i].stride | p.in[i].off | p.in[i].n) & 3) || (((uintptr_t)in_ptrs[i]) & 15)) ok = false;
         csum += p.in[i].n;
     }
+    for (int i = 0; i < TMG_MAX_OUT_SEG; ++i) p.out[i] = TmgOSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < (int)nout; ++i) {
+        p.out[i] = TmgOSeg{(float*)out_ptrs[i], (int)out_desc[3 * i], (int)out_desc[3 * i + 1], (int)out_desc[3 * i + 2]};
+        if (((p.out[i].stride | p.out[i].off | p.out[i].n) & 3) || (((uintptr_t)out_ptrs[i]) & 15)) ok = false;
+        osum += p.out[i].n;
+    }
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.Cout = (int)dims[4];
     p.relu_in = (int)dims[5]; p.pad_rep = (int)dims[6];
-    if (csum != p.Cin) return -3;
-    p.out = (float*)out; p.ostride = (int)out_desc[0]; p.ooff = (int)out_desc[1];
-    if (((p.ostride | p.ooff) & 3) || (((uintptr_t)out) & 15) || (p.Cout & 3) || (p.Cin & 3) || p.Cout < 64) ok = false;
+    if (csum != p.Cin || osum != p.Cout) return -3;
+    if ((p.Cout & 3) || (p.Cin & 3) || p.Cout < 64) ok = false;
     if (bias && (((uintptr_t)bias) & 15)) ok = false;
     if (!ok) return -100;
     p.Cin_pad = (p.Cin + 15) & ~15;
@@ -370,4 +386,308 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
     hipLaunchKernelGGL(wino_fwd_kernel, dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
+}
+
+// =================================================================================================================================
+// Few output channels (<= 48), many input channels: the input gradients of the contractions above (4R -> Cin gate gradient, 15 C
+// -> Cc conditioning gradient) and the ConvLSTM block's narrow convs.  With only NTN <= 4 output-channel tiles there is no work to
+// give eight waves along N; instead the 16 Winograd positions are dealt to the waves, two each (wave w: xi = w >> 1, nu = 2 (w & 1)
+// and + 1), every wave running the whole input-channel contraction for its positions on the same 32 Winograd tiles:
+//   * no V buffer: a lane builds its V fragment (4 channels of one tile at one position) from the raw patch in LDS - a position of
+//     B^T d B has four non-zero terms, and the wave's two positions share the row combination: 6 float4 reads + 5 float4 adds;
+//   * no per-chunk output transform: the accumulators M_pos run over ALL input channels of the tile;
+//   * after the last chunk the waves drop M_pos into LDS and all 512 threads apply A^T M A, bias / ReLU, and store.
+// =================================================================================================================================
+struct WinoNP {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg;
+    int B, Hin, Win;
+    int Cin, Cin_pad, Cout, Npad;
+    const float* U; const float* bias;
+    int relu_in, pad_rep, relu_out;
+    TmgOSeg out[TMG_MAX_OUT_SEG];
+    int tiles_x, tiles_y, ntiles, nchunks;
+};
+
+template <int NTN>
+__global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 512;
+    constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    constexpr int KC = 32, CS = KC + 8, RAWW = PP * CS;
+    constexpr int NC = NTN * 16 + (NTN < 3 ? 4 : 0);   // row stride (words) of the M buffer [16 pos][32 tiles][NC] (3 tiles: no room to pad)
+    float* Mb = lds + 2 * RAWW;
+    constexpr int UPI = (PP * (KC / 4) + NT - 1) / NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int KB = p.Cin_pad >> 4;
+    const size_t kb_stride = (size_t)p.Npad * 16, pos_stride = (size_t)KB * p.Npad * 16;
+    const int xi = wave >> 1, par = wave & 1;
+    const int pos0 = xi * 4 + 2 * par;
+    const int boff = li * 16 + 4 * q;
+    // row combination of this wave's xi: u = d[ra] + sg d[rb]   (B^T rows: r0 - r2, r1 + r2, r2 - r1, r1 - r3)
+    const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float sg = xi == 1 ? 1.f : -1.f;
+    // per-lane raw-patch word offsets of the tile's pixel (row ra / rb, column par) for the two m-tiles, + 4 q (channel quad)
+    int offa[2], offb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int wt = 16 * m + li, ty = wt >> 3, tx = wt & 7;
+        offa[m] = ((2 * ty + ra) * PW + 2 * tx + par) * CS + 4 * q;
+        offb[m] = ((2 * ty + rb) * PW + 2 * tx + par) * CS + 4 * q;
+    }
+
+    const int pc4 = tid & 7, ppix0 = tid >> 3;
+    unsigned pyx[UPI];
+#pragma unroll
+    for (int u = 0; u < UPI; ++u) {
+        const int pix = min(ppix0 + u * 64, PP - 1);
+        const int py = pix / PW, px = pix - py * PW;
+        pyx[u] = ((unsigned)py << 16) | (unsigned)px;
+    }
+    float4 pv[UPI];
+
+    const int G = gridDim.x;
+    const int nmine = (int)blockIdx.x < p.ntiles ? (p.ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int nchunks = p.nchunks, nst = nmine * nchunks;
+    int ci = 0, cm = 0;
+    int ti = blockIdx.x, tm = blockIdx.x;
+
+    f32x4 acc[2][2][NTN];   // [position of the wave][m-tile][n-tile]
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NTN; ++n) acc[e][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // U fragments (2 positions x NTN tiles per 16-channel group) in a ring over the groups, RD - 1 groups ahead of the MFMAs: a group
+    // is only 16 NTN MFMAs per wave, one group of lead does not cover the L2 latency (three tiles: registers allow no more)
+    constexpr int RD = NTN <= 2 ? 4 : 2;
+    float4 bq[RD][2][NTN];
+    const int ngrp = 2 * nchunks;   // groups per tile (those past Cin_pad read a clamped slice against zero V fragments)
+#define TMG_WN_LOADG(SLOT, GI)                                                                                        \
+    {                                                                                                                 \
+        const int kb_ = min((GI), KB - 1);                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                               \
+            const float* up_ = p.U + (size_t)(pos0 + e) * pos_stride + (size_t)kb_ * kb_stride + boff;                \
+            _Pragma("unroll") for (int n = 0; n < NTN; ++n) bq[SLOT][e][n] = *reinterpret_cast<const float4*>(up_ + n * 256); \
+        }                                                                                                             \
+    }
+    if (nst > 0) {
+#pragma unroll
+        for (int d = 0; d < RD - 1; ++d) TMG_WN_LOADG(d, d % ngrp)
+    }
+
+    for (int k = -2; k < nst; ++k) {
+        if (k >= -1 && k + 1 < nst) {
+            float* rb_ = lds + ((k + 1) & 1) * RAWW;
+#pragma unroll
+            for (int u = 0; u < UPI; ++u) {
+                if (ppix0 + u * 64 < PP) {
+                    float4 v = pv[u];
+                    if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(rb_ + (ppix0 + u * 64) * CS + 4 * pc4) = v;
+                }
+            }
+        }
+        if (k + 2 < nst) {
+            int t_ = ti;
+            const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
+            const int ty_ = t_ % p.tiles_y;
+            const int b_ = t_ / p.tiles_y;
+            const int iy0 = ty_ * TH - 1, ix0 = tx_ * TW - 1;
+            const float* tptr = tmg_zero_page;
+            int tss = 0;
+            {
+                int cl = ci * KC + 4 * pc4;
+                if (cl < p.Cin) {
+                    const float* sp = p.in[0].p;
+                    int ss = p.in[0].stride, so = p.in[0].off;
+                    if (cl >= p.in[0].n) {
+                        cl -= p.in[0].n;
+                        sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+                        if (cl >= p.in[1].n) {
+                            cl -= p.in[1].n;
+                            sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+                        }
+                    }
+                    tptr = sp + so + cl;
+                    tss = ss;
+                }
+            }
+            const size_t tbv = (size_t)b_ * p.Hin * p.Win;
+#pragma unroll
+            for (int u = 0; u < UPI; ++u) {
+                const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);
+                const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
+                const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);
+                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (tbv + (size_t)iyc * p.Win + ixc) * tss;
+                pv[u] = *reinterpret_cast<const float4*>(a_);
+            }
+            if (++ci == nchunks) { ci = 0; ti += G; }
+        }
+        if (k >= 0) {
+            const float* rbuf = lds + (k & 1) * RAWW;
+#define TMG_WN_COMPUTE(PH)                                                                                            \
+            {                                                                                                         \
+                _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                       \
+                    const int SL = (2 * (PH) + g) & (RD - 1), SN = (2 * (PH) + g + RD - 1) & (RD - 1);   /* constants after unrolling */ \
+                    {                                                                                                 \
+                        int gi_ = 2 * cm + g + RD - 1;                                                                \
+                        if (gi_ >= ngrp) gi_ -= ngrp;                                                                 \
+                        if (gi_ >= ngrp) gi_ -= ngrp;                                                                 \
+                        TMG_WN_LOADG(SN, gi_)                                                                         \
+                    }                                                                                                 \
+                    float4 va[2], vb[2];   /* V fragments of the wave's two positions, per m-tile */                  \
+                    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                   \
+                        float4 u_[3];                                                                                 \
+                        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                               \
+                            const float4 da = *reinterpret_cast<const float4*>(rbuf + offa[m] + c * CS + g * 16);     \
+                            const float4 db = *reinterpret_cast<const float4*>(rbuf + offb[m] + c * CS + g * 16);     \
+                            u_[c] = make_float4(fmaf(db.x, sg, da.x), fmaf(db.y, sg, da.y), fmaf(db.z, sg, da.z), fmaf(db.w, sg, da.w)); \
+                        }                                                                                             \
+                        /* columns par .. par + 2 are loaded: nu 0 = c0 - c2, nu 1 = c1 + c2 | nu 2 = c2 - c1, nu 3 = c1 - c3 */ \
+                        if (par == 0) {                                                                               \
+                            va[m] = make_float4(u_[0].x - u_[2].x, u_[0].y - u_[2].y, u_[0].z - u_[2].z, u_[0].w - u_[2].w); \
+                            vb[m] = make_float4(u_[1].x + u_[2].x, u_[1].y + u_[2].y, u_[1].z + u_[2].z, u_[1].w + u_[2].w); \
+                        } else {                                                                                      \
+                            va[m] = make_float4(u_[1].x - u_[0].x, u_[1].y - u_[0].y, u_[1].z - u_[0].z, u_[1].w - u_[0].w); \
+                            vb[m] = make_float4(u_[0].x - u_[2].x, u_[0].y - u_[2].y, u_[0].z - u_[2].z, u_[0].w - u_[2].w); \
+                        }                                                                                             \
+                    }                                                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NTN; ++n) {   \
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][0][n].x, va[m].x, acc[0][m][n], 0, 0, 0); \
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][1][n].x, vb[m].x, acc[1][m][n], 0, 0, 0); \
+                    }                                                                                                 \
+                    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NTN; ++n) {   \
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][0][n].y, va[m].y, acc[0][m][n], 0, 0, 0); \
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][1][n].y, vb[m].y, acc[1][m][n], 0, 0, 0); \
+                    }                                                                                                 \
+                    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NTN; ++n) {   \
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][0][n].z, va[m].z, acc[0][m][n], 0, 0, 0); \
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][1][n].z, vb[m].z, acc[1][m][n], 0, 0, 0); \
+                    }                                                                                                 \
+                    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NTN; ++n) {   \
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][0][n].w, va[m].w, acc[0][m][n], 0, 0, 0); \
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[SL][1][n].w, vb[m].w, acc[1][m][n], 0, 0, 0); \
+                    }                                                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }
+            if (k & 1) TMG_WN_COMPUTE(1) else TMG_WN_COMPUTE(0)
+#undef TMG_WN_COMPUTE
+            if (cm + 1 == nchunks) {
+                // ---- M_pos -> LDS, then A^T M A over the positions by all threads ----------------------------------------------
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < NTN; ++n) {
+                            *reinterpret_cast<float4*>(Mb + ((pos0 + e) * 32 + 16 * m + li) * NC + 16 * n + 4 * q) =
+                                make_float4(acc[e][m][n][0], acc[e][m][n][1], acc[e][m][n][2], acc[e][m][n][3]);
+                            acc[e][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                __syncthreads();
+                int t_ = tm;
+                const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
+                const int ty_ = t_ % p.tiles_y;
+                const int b_ = t_ / p.tiles_y;
+                constexpr int QN = NTN * 4;   // channel quads
+                for (int it = tid; it < 32 * QN; it += NT) {
+                    const int wt = it / QN, c4 = it - wt * QN;
+                    const int n0 = 4 * c4;
+                    if (n0 >= p.Cout) continue;
+                    const float* mp_ = Mb + wt * NC + n0;
+                    float4 z[2][4];   // [oy][nu]: row pass  z0 = M0 + M1 + M2, z1 = M1 - M2 - M3
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu) {
+                        const float4 m0 = *reinterpret_cast<const float4*>(mp_ + (0 * 4 + nu) * 32 * NC);
+                        const float4 m1 = *reinterpret_cast<const float4*>(mp_ + (1 * 4 + nu) * 32 * NC);
+                        const float4 m2 = *reinterpret_cast<const float4*>(mp_ + (2 * 4 + nu) * 32 * NC);
+                        const float4 m3 = *reinterpret_cast<const float4*>(mp_ + (3 * 4 + nu) * 32 * NC);
+                        z[0][nu] = make_float4(m0.x + m1.x + m2.x, m0.y + m1.y + m2.y, m0.z + m1.z + m2.z, m0.w + m1.w + m2.w);
+                        z[1][nu] = make_float4(m1.x - m2.x - m3.x, m1.y - m2.y - m3.y, m1.z - m2.z - m3.z, m1.w - m2.w - m3.w);
+                    }
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
+                    int nl = n0;
+                    TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                        for (int ox = 0; ox < 2; ++ox) {
+                            const float4 za = z[oy][0], zb = z[oy][1], zc = z[oy][2], zd = z[oy][3];
+                            float4 y = ox == 0 ? make_float4(za.x + zb.x + zc.x, za.y + zb.y + zc.y, za.z + zb.z + zc.z, za.w + zb.w + zc.w)
+                                               : make_float4(zb.x - zc.x - zd.x, zb.y - zc.y - zd.y, zb.z - zc.z - zd.z, zb.w - zc.w - zd.w);
+                            y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+                            if (p.relu_out) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                            const int py = ty_ * TH + 2 * (wt >> 3) + oy, px = tx_ * TW + 2 * (wt & 7) + ox;
+                            if (py < p.Hin && px < p.Win)
+                                *reinterpret_cast<float4*>(optr + (((size_t)b_ * p.Hin + py) * p.Win + px) * ostride + ooff + nl) = y;
+                        }
+                }
+                cm = 0; tm += G;
+            } else {
+                ++cm;
+            }
+        }
+        __syncthreads();
+    }
+#undef TMG_WN_LOADG
+}
+
+template <int NTN>
+static int launch_wino_nn(const WinoNP& p, int G, hipStream_t st) {
+    const size_t lds_bytes = (size_t)(2 * 180 * 40 + 16 * 32 * (NTN * 16 + (NTN < 3 ? 4 : 0))) * sizeof(float);
+    TMG_LDS_OPTIN((&wino_nn_kernel<NTN>));
+    TmgProf prof(TMG_PROF_WINO, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);
+    hipLaunchKernelGGL((wino_nn_kernel<NTN>), dim3(G), dim3(512), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// The Winograd contraction for FEW output channels (Cout <= 64) and many input channels: same operand format and descriptors as
+// tmg_conv_wino_fwd, up to 3 output segments (out_desc = {stride, off, n} each), dims = {B,H,W,Cin,Cout,relu_in,pad_replicate,relu_out}.
+// Returns -100 outside its envelope (float4-addressable operands, channel counts multiples of 4, Cin >= 64, Cout <= 48).
+extern "C" int tmg_conv_wino_narrow(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
+                                    void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, hipStream_t st) {
+    WinoNP p;
+    p.nseg = (int)nseg;
+    if (p.nseg < 1 || p.nseg > TMG_MAX_IN_SEG || nout < 1 || nout > TMG_MAX_OUT_SEG) return -3;
+    int csum = 0, osum = 0;
+    bool ok = true;
+    for (int i = 0; i < TMG_MAX_IN_SEG; ++i) p.in[i] = TmgSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < p.nseg; ++i) {
+        p.in[i] = TmgSeg{(const float*)in_ptrs[i], (int)in_desc[3 * i], (int)in_desc[3 * i + 1], (int)in_desc[3 * i + 2]};
+        if (((p.in[i].stride | p.in[i].off | p.in[i].n) & 3) || (((uintptr_t)in_ptrs[i]) & 15)) ok = false;
+        csum += p.in[i].n;
+    }
+    for (int i = 0; i < TMG_MAX_OUT_SEG; ++i) p.out[i] = TmgOSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < (int)nout; ++i) {
+        p.out[i] = TmgOSeg{(float*)out_ptrs[i], (int)out_desc[3 * i], (int)out_desc[3 * i + 1], (int)out_desc[3 * i + 2]};
+        if (((p.out[i].stride | p.out[i].off | p.out[i].n) & 3) || (((uintptr_t)out_ptrs[i]) & 15)) ok = false;
+        osum += p.out[i].n;
+    }
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.Cout = (int)dims[4];
+    p.relu_in = (int)dims[5]; p.pad_rep = (int)dims[6]; p.relu_out = (int)dims[7];
+    if (csum != p.Cin || osum != p.Cout) return -3;
+    if ((p.Cout & 3) || (p.Cin & 3) || p.Cout > 48 || p.Cin < 64) ok = false;   // 48: the M buffer of 4 channel tiles does not fit LDS
+    if (bias && (((uintptr_t)bias) & 15)) ok = false;
+    if (!ok) return -100;
+    p.Cin_pad = (p.Cin + 15) & ~15;
+    p.Npad = (p.Cout + 15) & ~15;
+    p.U = (const float*)U; p.bias = (const float*)bias;
+    p.tiles_x = (p.Win + 15) / 16; p.tiles_y = (p.Hin + 7) / 8;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    p.nchunks = (p.Cin_pad + 31) / 32;
+    if (p.ntiles <= 0) return 0;
+    const int G = p.ntiles < 256 ? p.ntiles : 256;
+    switch (p.Npad >> 4) {
+        case 1: return launch_wino_nn<1>(p, G, st);
+        case 2: return launch_wino_nn<2>(p, G, st);
+        default: return launch_wino_nn<3>(p, G, st);
+    }
 }

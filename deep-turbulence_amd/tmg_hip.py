@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow",
 ]
 
 
@@ -245,29 +245,75 @@ def wino_eligible(Cin, Cout, ksize, stride):
             and os.environ.get("TMG_NO_WINOGRAD") is None)
 
 
-def conv_wino_pack(w):
-    """Winograd operand U = G g G^T of a [Cout, Cin, 3, 3] weight: [16][Cin_pad/16][Cout_pad][16] floats."""
+def wino_narrow_eligible(Cin, Cout):
+    """Shapes of the few-output-channel Winograd kernel (the input gradients of the wide contractions, the ConvLSTM block's
+    narrow convs): 3x3 / stride 1, Cout <= 48, Cin >= 64."""
+    return Cout <= 48 and Cout % 4 == 0 and Cin % 4 == 0 and Cin >= 64 and os.environ.get("TMG_NO_WINOGRAD") is None
+
+
+def conv_wino_pack(w, mode=0, nvalid=0):
+    """Winograd operand U = G g G^T of a [Cout, Cin, 3, 3] weight: [16][K_pad/16][N_pad][16] floats.  mode 0: forward (K = Cin,
+    N = Cout); mode 1: input gradient w.r.t. the first `nvalid` input channels (K = Cout, N = nvalid or Cin), taps flipped."""
     Cout, Cin = w.shape[0], w.shape[1]
     assert w.shape[2] == 3 and w.shape[3] == 3
     w = w.contiguous()
-    U = torch.empty(16 * ((Cin + 15) // 16 * 16) * ((Cout + 15) // 16 * 16), device=w.device, dtype=torch.float32)
-    _chk(lib().tmg_conv_wino_pack(_ptr(w), _ptr(U), c_i64(Cout), c_i64(Cin), _stream()), "tmg_conv_wino_pack")
+    K, N = (Cin, Cout) if mode == 0 else (Cout, nvalid if 0 < nvalid < Cin else Cin)
+    U = torch.empty(16 * ((K + 15) // 16 * 16) * ((N + 15) // 16 * 16), device=w.device, dtype=torch.float32)
+    _chk(lib().tmg_conv_wino_pack(_ptr(w), _ptr(U), c_i64(Cout), c_i64(Cin), c_i64(mode), c_i64(nvalid), _stream()), "tmg_conv_wino_pack")
     return U
 
 
-def conv_wino_fwd(inputs, U, Cout, out, bias=None, relu_in=False, pad_rep=False):
-    """out = conv3x3(pad(act(cat(inputs)))) + bias through the Winograd kernel; False when the shape is outside its envelope
-    (nothing was launched: the caller runs conv_fwd with the direct operand)."""
+def conv_wino_narrow(inputs, U, Cout, outs, bias=None, relu_in=False, pad_rep=False, relu_out=False):
+    """Few output channels: outs = list of <= 3 NHWC tensors / channel-slice views forming the Cout channels.  False when the
+    shape is outside the kernel's envelope (nothing was launched)."""
     B, Hin, Win, _ = inputs[0].shape
     ip, idesc, n_in = _segs(inputs)
+    op, odesc, n_out = _segs(outs)
     Cin = sum(t.shape[3] for t in inputs)
-    assert out.shape[3] == Cout and out.shape[1] == Hin and out.shape[2] == Win
-    rc = lib().tmg_conv_wino_fwd(ip, idesc, c_i64(n_in), _ptr(U), _ptr(bias), _ptr(out), _d2(out),
+    assert sum(t.shape[3] for t in outs) == Cout
+    rc = lib().tmg_conv_wino_narrow(ip, idesc, c_i64(n_in), _ptr(U), _ptr(bias), op, odesc, c_i64(n_out),
+                                    _i64(B, Hin, Win, Cin, Cout, relu_in, pad_rep, relu_out), _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_conv_wino_narrow")
+    return True
+
+
+def conv_wino_fwd(inputs, U, Cout, outs, bias=None, relu_in=False, pad_rep=False):
+    """outs = conv3x3(pad(act(cat(inputs)))) + bias through the Winograd kernel (outs: tensor or list of <= 3 segments); False when
+    the shape is outside its envelope (nothing was launched: the caller runs conv_fwd with the direct operand)."""
+    if isinstance(outs, torch.Tensor):
+        outs = [outs]
+    B, Hin, Win, _ = inputs[0].shape
+    ip, idesc, n_in = _segs(inputs)
+    op, odesc, n_out = _segs(outs)
+    Cin = sum(t.shape[3] for t in inputs)
+    assert sum(t.shape[3] for t in outs) == Cout and outs[0].shape[1] == Hin and outs[0].shape[2] == Win
+    rc = lib().tmg_conv_wino_fwd(ip, idesc, c_i64(n_in), _ptr(U), _ptr(bias), op, odesc, c_i64(n_out),
                                  _i64(B, Hin, Win, Cin, Cout, relu_in, pad_rep), _stream())
     if rc == -100:
         return False
     _chk(rc, "tmg_conv_wino_fwd")
     return True
+
+
+def conv3x3_auto(inputs, weight, Cout, outs, bias=None, relu_in=False, pad_rep=False, relu_out=False, dgrad=False, nvalid=0):
+    """A plain 3x3 / stride-1 contraction (no kappa / add / accumulate) through the fastest kernel that takes the shape: Winograd
+    (wide or narrow) when eligible, the direct implicit GEMM otherwise.  dgrad: the input gradient of a conv with this weight
+    ([K = weight.shape[0] dy channels] -> the first `nvalid` (0: all) input channels).  Returns the direct mode-1 operand when it
+    had to pack one (callers of replicate-padded convs reuse it for the border fold), else None."""
+    Cin = sum(t.shape[3] for t in inputs)
+    mode = 1 if dgrad else 0
+    if not relu_out and wino_eligible(Cin, Cout, 3, 1):
+        if conv_wino_fwd(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep):
+            return None
+    if wino_narrow_eligible(Cin, Cout):
+        if conv_wino_narrow(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep,
+                            relu_out=relu_out):
+            return None
+    wpk = conv_pack(weight, mode, nvalid, (nvalid, 1 << 30, 0)) if (dgrad and nvalid) else conv_pack(weight, mode)
+    conv_fwd(inputs, wpk, Cout, 3, 1, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep, relu_out=relu_out)
+    return wpk
 
 
 _SIDE = {}

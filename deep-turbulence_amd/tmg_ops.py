@@ -35,9 +35,11 @@ class ConvFn(torch.autograd.Function):
         Cout = weight.shape[0]
         Ho, Wo = _out_hw(Hin, Win, stride)
         out = torch.empty((B, Ho, Wo, Cout), device=weight.device, dtype=torch.float32)
-        wpk = H.conv_pack(weight, 0)
-        H.conv_fwd(list(inputs), wpk, Cout, ksize, stride, [out], bias=bias, kappa=kappa, relu_in=relu_in, pad_rep=pad_rep,
-                   relu_out=relu_out)
+        if ksize == 3 and stride == 1 and kappa is None:
+            H.conv3x3_auto(list(inputs), weight, Cout, [out], bias=bias, relu_in=relu_in, pad_rep=pad_rep, relu_out=relu_out)
+        else:
+            H.conv_fwd(list(inputs), H.conv_pack(weight, 0), Cout, ksize, stride, [out], bias=bias, kappa=kappa, relu_in=relu_in,
+                       pad_rep=pad_rep, relu_out=relu_out)
         ctx.opts = opts
         ctx.n_in = len(inputs)
         ctx.has_bias = bias is not None
@@ -73,11 +75,14 @@ class ConvFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[4:]):
             dins = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in inputs]
             if stride == 1:
-                wpk_t = H.conv_pack(weight, 1)
                 cin = sum(t.shape[3] for t in inputs)
-                H.conv_fwd([dy], wpk_t, cin, ksize, 1, dins, kappa=kappa)
+                if ksize == 3 and kappa is None:
+                    wpk_t = H.conv3x3_auto([dy], weight, cin, dins, dgrad=True)
+                else:
+                    wpk_t = H.conv_pack(weight, 1)
+                    H.conv_fwd([dy], wpk_t, cin, ksize, 1, dins, kappa=kappa)
                 if pad_rep and ksize == 3:
-                    H.conv_rep_border_fix(dy, wpk_t, dins, kappa=kappa)
+                    H.conv_rep_border_fix(dy, wpk_t if wpk_t is not None else H.conv_pack(weight, 1), dins, kappa=kappa)
             else:
                 assert ctx.n_in == 1 and not ctx.has_kappa and not pad_rep
                 Hin_, Win_ = inputs[0].shape[1], inputs[0].shape[2]
@@ -256,9 +261,7 @@ class ConvLSTMCellFn(torch.autograd.Function):
         gates = torch.empty((B, Hh, Ww, R4), device=dev, dtype=torch.float32)
         segs = list(inputs) + [h_cur]
         # the widest contraction of the path (Cin + R -> 4R channels): Winograd F(2x2, 3x3) when the shape is in its envelope
-        if not (H.wino_eligible(sum(t.shape[3] for t in segs), R4, 3, 1)
-                and H.conv_wino_fwd(segs, H.conv_wino_pack(weight), R4, gates, bias=bias)):
-            H.conv_fwd(segs, H.conv_pack(weight, 0), R4, 3, 1, [gates], bias=bias)
+        H.conv3x3_auto(segs, weight, R4, [gates], bias=bias)
         c_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
         h_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
         H.lstm_pointwise_fwd(gates, c_cur, c_next, h_next)
@@ -291,7 +294,7 @@ class ConvLSTMCellFn(torch.autograd.Function):
         if last >= 0:
             nch = sum(t.shape[3] for t in segs[:last + 1])
             dins[:last + 1] = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in segs[:last + 1]]
-            H.conv_fwd([dg], H.conv_pack(weight, 1, nch, (nch, 1 << 30, 0)), nch, 3, 1, dins[:last + 1])
+            H.conv3x3_auto([dg], weight, nch, dins[:last + 1], dgrad=True, nvalid=nch)
         return (dW, db, dins[-1], dc_prev if ctx.has_c else None) + tuple(dins[:-1])
 
 
@@ -587,8 +590,7 @@ class LevelCouplingFn(torch.autograd.Function):
         Wdc[:NL] = torch.stack(w1s)[:, 0, ch:cin]
         Wdc[NLp:NLp + NL] = torch.stack(w2s)[:, 0, ch:cin]
         Hc = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)
-        if not (H.wino_eligible(Cc, NL * C, 3, 1) and H.conv_wino_fwd([cond], H.conv_wino_pack(Wzc), NL * C, Hc, relu_in=True, pad_rep=True)):
-            H.conv_fwd([cond], H.conv_pack(Wzc, 0), NL * C, 3, 1, [Hc], relu_in=True, pad_rep=True)
+        H.conv3x3_auto([cond], Wzc, NL * C, [Hc], relu_in=True, pad_rep=True)
         Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
         H.conv_fwd([cond], H.conv_pack(Wdc, 0), 2 * NLp, 3, 1, [Dc], relu_in=True)
         logdet = torch.zeros(B, device=dev, dtype=torch.float32)
@@ -755,9 +757,8 @@ class LevelCouplingFn(torch.autograd.Function):
             mix_wg = None
         # conditioning side of the whole level: one input-gradient pass, three weight-gradient passes
         Gc = torch.empty(cond.shape, device=dev, dtype=torch.float32)
-        wzc_t = H.conv_pack(Wzc, 1)
-        H.conv_fwd([DH], wzc_t, Cc, 3, 1, [Gc])
-        H.conv_rep_border_fix(DH, wzc_t, [Gc])
+        wzc_t = H.conv3x3_auto([DH], Wzc, Cc, [Gc], dgrad=True)
+        H.conv_rep_border_fix(DH, wzc_t if wzc_t is not None else H.conv_pack(Wzc, 1), [Gc])
         Wd4 = torch.zeros((4 * NL, Cc, 3, 3), device=dev, dtype=torch.float32)   # rows 4k / 4k+1: cond columns of w1_k / w2_k
         Wd4.view(NL, 4, Cc, 3, 3)[:, 0] = Wdc[:NL]
         Wd4.view(NL, 4, Cc, 3, 3)[:, 1] = Wdc[NLp:NLp + NL]

@@ -67,11 +67,18 @@ int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t
  * convLSTM.py:72-74, and the level-wide conditioning contraction) as Winograd F(2x2, 3x3): 2.25x fewer matrix-core operations,
  * fp32 throughout.  tmg_conv_wino_pack builds the operand U = G g G^T, [16][Cin_pad/16][Cout_pad][16] floats, from the torch-layout
  * weight [Cout][Cin][3][3]; tmg_conv_wino_fwd computes out = conv(pad(act(cat(in)))) + bias.
- * in_desc = {stride, off, n} per segment, out_desc = {stride, off}, dims = {B,H,W,Cin,Cout,relu_in,pad_replicate}.
+ * in_desc / out_desc = {stride, off, n} per segment (<= 3 each), dims = {B,H,W,Cin,Cout,relu_in,pad_replicate}.
  * Returns -100 (nothing launched) outside its envelope: float4-addressable operands, Cin % 4 == 0, Cout % 4 == 0, Cout >= 64. */
-int tmg_conv_wino_pack(const void* w, void* U, int64_t Cout, int64_t Cin, tmg_stream_t st);
+int tmg_conv_wino_pack(const void* w, void* U, int64_t Cout, int64_t Cin, int64_t mode, int64_t nvalid, tmg_stream_t st);
 int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
-                      void* out, const int64_t* out_desc, const int64_t* dims, tmg_stream_t st);
+                      void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
+/* tmg_conv_wino_pack: mode 0 = forward operand (K = Cin, N = Cout); mode 1 = operand of the input gradient w.r.t. the first
+ * `nvalid` input channels (0: all), K = Cout, N = nvalid, taps flipped - what autograd's conv2d backward contracts with.
+ * tmg_conv_wino_narrow: the same Winograd contraction for FEW output channels (Cout <= 48, Cin >= 64): the input gradients of the
+ * wide contractions and the ConvLSTM block's narrow convs (convLSTM.py:150-152).  Up to 3 output segments (out_desc = {stride,
+ * off, n} each); dims = {B,H,W,Cin,Cout,relu_in,pad_replicate,relu_out}.  -100 outside the envelope. */
+int tmg_conv_wino_narrow(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
+                         void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
 
 /* dW[Cout][Cin][k][k] += scale * sum_pixels act(in)(p*s+tap) (x) dy(p) ; dbias += scale * sum dy.
  * (accumulating: caller zero-fills; per-block partial sums go through the scratch `ws` and a reduce kernel.)  Replaces the autograd weight-gradient of the convs above.

@@ -444,8 +444,44 @@ def test_winograd_conv_matches_fp64(case):
     wd, bd = w.to(DEV), (b.to(DEV) if has_b else None)
     out = torch.full((B, Hh, Ww, Cout), float("nan"), device=DEV)
     assert H.wino_eligible(sum(segs), Cout, 3, 1)
-    assert H.conv_wino_fwd(xd, H.conv_wino_pack(wd), Cout, out, bias=bd, relu_in=relu_in, pad_rep=pad_rep)
+    assert H.conv_wino_fwd(xd, H.conv_wino_pack(wd), Cout, [out[..., :32], out[..., 32:]], bias=bd, relu_in=relu_in, pad_rep=pad_rep)
     _close(out, ref, what="winograd conv")
     direct = torch.empty_like(out)
     H.conv_fwd(xd, H.conv_pack(wd, 0), Cout, 3, 1, [direct], bias=bd, relu_in=relu_in, pad_rep=pad_rep)
     _close(out, direct.double(), what="winograd vs direct")
+
+
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, 256, [8, 32], True, False, False),        # gate input gradient: 4R dy channels -> the first 40 input channels, two outputs
+    (2, 16, 12, 240, [32], True, False, False),           # conditioning gradient: 15 C -> Cc (last chunk half full)
+    (1, 9, 21, 104, [40], False, True, True),             # forward operand, bias + ReLU out, partial tiles
+    (2, 8, 8, 1920, [32], True, False, False),            # long contraction
+    (3, 5, 3, 64, [16], False, True, False),              # image smaller than a tile, one channel tile
+])
+def test_winograd_narrow_matches_fp64(case):
+    """tmg_conv_wino_narrow (few output channels: the waves split the 16 Winograd positions) with the forward operand and with the
+    input-gradient operand (mode 1: transposed weight, flipped taps, channel prefix), against fp64 torch."""
+    import tmg_hip as H
+    B, Hh, Ww, K, outs_c, dgrad, has_b, relu_out = case
+    N = sum(outs_c)
+    g = torch.Generator().manual_seed(K + N + Hh)
+    x = torch.randn(B, Hh, Ww, K, generator=g)
+    if dgrad:
+        # weight of the forward conv: [Cout = K][Cin >= N]; the gradient w.r.t. its first N input channels
+        cin_full = N + 8
+        w = 0.2 * torch.randn(K, cin_full, 3, 3, generator=g)
+        ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1)[:, :N].permute(0, 2, 3, 1)
+        U = H.conv_wino_pack(w.to(DEV), 1, N)
+    else:
+        w = 0.2 * torch.randn(N, K, 3, 3, generator=g)
+        b = 0.3 * torch.randn(N, generator=g) if has_b else None
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double() if has_b else None, padding=1)
+        if relu_out:
+            ref = F.relu(ref)
+        ref = ref.permute(0, 2, 3, 1)
+        U = H.conv_wino_pack(w.to(DEV))
+    bd = b.to(DEV) if (not dgrad and has_b) else None
+    outs = [torch.full((B, Hh, Ww, c), float("nan"), device=DEV) for c in outs_c]
+    assert H.wino_narrow_eligible(K, N)
+    assert H.conv_wino_narrow([x.to(DEV)], U, N, outs, bias=bd, relu_out=relu_out)
+    _close(torch.cat(outs, 3), ref, what="narrow winograd")

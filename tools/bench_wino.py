@@ -30,6 +30,29 @@ for B, Hh, Ww, segs, Cout, relu, rep, hb in CASES:
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / n
-    tw = t(lambda: H.conv_wino_fwd(xs, U, Cout, out, bias=b, relu_in=relu, pad_rep=rep))
+    tw = t(lambda: H.conv_wino_fwd(xs, U, Cout, [out], bias=b, relu_in=relu, pad_rep=rep))
     td = t(lambda: H.conv_fwd(xs, Wp, Cout, 3, 1, [out], bias=b, relu_in=relu, pad_rep=rep))
     print("%4dx%-4d %4d -> %4d   winograd %7.3f ms (%6.1f TF)   direct %7.3f ms (%6.1f TF)" % (Hh, Ww, sum(segs), Cout, tw, fl / tw / 1e9, td, fl / td / 1e9))
+
+print("few output channels (input gradients):")
+for B, Hh, Ww, K, N in [(64, 128, 128, 256, 40), (64, 128, 128, 240, 32), (64, 64, 64, 256, 48), (64, 64, 64, 480, 32), (64, 32, 32, 960, 32),
+                        (64, 16, 16, 1920, 32), (64, 128, 128, 104, 40)]:
+    x = torch.randn(B, Hh, Ww, K, device=dev)
+    w = 0.1 * torch.randn(K, N, 3, 3, device=dev)      # forward weight [Cout = K][Cin = N]: dgrad contracts K -> N
+    out = torch.empty(B, Hh, Ww, N, device=dev)
+    U, Wp = H.conv_wino_pack(w, 1), H.conv_pack(w, 1)
+    fl = 2.0 * B * Hh * Ww * K * N * 9
+
+    def t(fn, n=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+    tw = t(lambda: H.conv_wino_narrow([x], U, N, [out]))
+    td = t(lambda: H.conv_fwd([x], Wp, N, 3, 1, [out]))
+    print("%4dx%-4d %4d -> %4d   winograd %7.3f ms (%6.1f TF)   direct %7.3f ms (%6.1f TF)" % (Hh, Ww, K, N, tw, fl / tw / 1e9, td, fl / td / 1e9))
