@@ -317,7 +317,7 @@ struct TmgProf {
     ~TmgProf() { tmg_prof_close(slot, st); }
 };
 enum { TMG_PROF_CPL = 32, TMG_PROF_C1X2 = 33, TMG_PROF_D2B = 34, TMG_PROF_AFF = 35, TMG_PROF_AFFB = 36, TMG_PROF_LSTMF = 37,
-       TMG_PROF_LSTMB = 38, TMG_PROF_GAUSS = 39, TMG_PROF_RESAMPLE = 40, TMG_PROF_MIX16 = 41, TMG_PROF_CPLB = 42, TMG_PROF_WINO = 43 };
+       TMG_PROF_LSTMB = 38, TMG_PROF_GAUSS = 39, TMG_PROF_RESAMPLE = 40, TMG_PROF_MIX16 = 41, TMG_PROF_CPLB = 42, TMG_PROF_WINO = 43, TMG_PROF_WINO_WG = 44 };
 
 #define TMG_CHECK_LAUNCH()                          \
     do {                                            \

@@ -1370,8 +1370,9 @@ static const char* const g_prof_names[] = {
     "hbm: affine_apply_kernel", "hbm: affine_bwd_kernel", "hbm: lstm_pointwise_fwd_kernel", "hbm: lstm_pointwise_bwd_kernel",
     "hbm: gauss_fwd/bwd_kernel", "hbm: checker / upsample", "hbm: mix16_kernel (fp16-input channel mix)",
     "hbm: cpl_bwd_kernel (mix dgrad + coupling backward + zero-conv dgrad)",
-    "wino_fwd_kernel (3x3 conv, Winograd F(2x2,3x3), fp32 MFMA; direct-algorithm flops)"};
-#define TMG_NPROF 44
+    "wino_fwd / wino_nn_kernel (3x3 conv, Winograd F(2x2,3x3), fp32 MFMA; direct-algorithm flops)",
+    "wino_wgrad_kernel (3x3 weight gradient, Winograd F(3x3,2x2), fp32 MFMA; direct-algorithm flops)"};
+#define TMG_NPROF 45
 
 // open / close a timed region around a launch; other translation units reach them through tmg_common.h's TmgProf
 extern "C" int tmg_prof_open(int kid, double work, hipStream_t st) {

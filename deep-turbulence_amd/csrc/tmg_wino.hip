@@ -691,3 +691,354 @@ extern "C" int tmg_conv_wino_narrow(const void* const* in_ptrs, const int64_t* i
         default: return launch_wino_nn<3>(p, G, st);
     }
 }
+
+// =================================================================================================================================
+// Weight gradient as Winograd F(3x3, 2x2): the 3x3 taps of dW are the "outputs", a 2x2 tile of dy is the "filter":
+//     dW[ci][co] = A'^T { sum_tiles (B^T x B)[ci] (.) (G' dy G'^T)[co] } A'
+//     G' = [[1,0],[.5,.5],[.5,-.5],[0,1]],  A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]],  B^T as in the forward kernels
+// (the transposition of F(2x2, 3x3): same interpolation points).  16 contractions over the Winograd tiles per (ci, co) pair instead of
+// 9 taps x 4 pixels: 2.25x fewer MFMA operations for the largest kernels of the step (the gate-conv and conditioning weight gradients).
+//
+// A 512-thread block owns CIT x NCO channel tiles (<= 64 x 64 channels) of all 16 positions and a strided share of the 8x16-pixel
+// tiles; wave w owns positions (xi = w >> 1, nu = 2 (w & 1) and + 1) and builds its operand fragments straight from the raw
+// activations in LDS (one channel per lane): x^ = 6 reads + 5 vector ops per channel tile, dy^ = 4 reads + 6 ops.  Per k-step (4
+// Winograd tiles) a wave issues 2 CIT NCO MFMAs.  Raw tiles are register-prefetched one tile ahead (single LDS buffer).  The
+// per-block partial sums go to a slab; wino_wgrad_reduce_kernel folds the slabs, applies A'^T . A' and adds the 9 taps onto dW.
+// =================================================================================================================================
+struct WinoWP {
+    TmgSeg in[TMG_MAX_IN_SEG];
+    int nseg;
+    int B, Hin, Win;
+    int Cin, Cout;
+    int relu_in, pad_rep;
+    const float* dy; int dy_stride, dy_off;
+    float* ws;        // [gx][gy][gz][8 waves][2][CIT][NCO][64 lanes][4] partial sums, then [gx][gy][64] bias partials
+    int want_bias;
+    int tiles_x, tiles_y, ntiles;
+};
+
+template <int CIT, int NCO>
+__global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 512;
+    constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    constexpr int CSX = CIT * 16 + 8, CSD = NCO * 16 + 8;   // pixel strides (words): 2 CS = 16 (mod 32) -> the two tile columns a
+                                                            // half-wave reads fall on disjoint bank halves
+    float* XR = lds;                // [PP][CSX] raw (activated) input patch
+    float* DR = lds + PP * CSX;     // [128][CSD] raw dy tile
+    constexpr int KX = CIT <= 1 ? 4 : (CIT <= 2 ? 8 : 16), KXL = CIT <= 1 ? 2 : (CIT <= 2 ? 3 : 4);   // float4 slots per pixel (2^n)
+    constexpr int KD = NCO <= 1 ? 4 : (NCO <= 2 ? 8 : 16), KDL = NCO <= 1 ? 2 : (NCO <= 2 ? 3 : 4);
+    constexpr int UX = (PP * KX + NT - 1) / NT, UD = (128 * KD + NT - 1) / NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int xi = wave >> 1, par = wave & 1;
+    const int ci0 = (int)blockIdx.z * CIT * 16, co0 = (int)blockIdx.y * NCO * 16;
+    // row combination of xi for the input transform: u = x[ra] + sg x[rb]; G' row of xi for dy: e = g0 dy[0] + g1 dy[1]
+    const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float sg = xi == 1 ? 1.f : -1.f;
+    const float g0 = xi == 0 ? 1.f : (xi == 3 ? 0.f : 0.5f), g1 = xi == 0 ? 0.f : (xi == 1 ? 0.5f : (xi == 2 ? -0.5f : 1.f));
+    // per-lane word offsets for k-step 0 (tiles 0..3 of tile-row 0: tile q): x rows ra / rb at column 2 q + par; dy pixel (0, 2 q)
+    const int oxa = (ra * PW + 2 * q + par) * CSX + li, oxb = (rb * PW + 2 * q + par) * CSX + li;
+    const int od = (2 * q) * CSD + li;
+
+    // ---- staging: a thread owns one channel quad of every (NT / K)-th pixel --------------------------------------------------------
+    const int xc4 = tid & (KX - 1), xpix0 = tid >> KXL;
+    constexpr int xstep = NT >> KXL;
+    const float* xptr = tmg_zero_page;
+    int xss = 0;
+    {
+        int cl = ci0 + 4 * xc4;
+        if (xc4 < CIT * 4 && cl < p.Cin) {
+            const float* sp = p.in[0].p;
+            int ss = p.in[0].stride, so = p.in[0].off;
+            if (cl >= p.in[0].n) {
+                cl -= p.in[0].n;
+                sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+                if (cl >= p.in[1].n) {
+                    cl -= p.in[1].n;
+                    sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+                }
+            }
+            xptr = sp + so + cl;
+            xss = ss;
+        }
+    }
+    unsigned pyx[UX];
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+        const int pix = min(xpix0 + u * xstep, PP - 1);
+        const int py = pix / PW, px = pix - py * PW;
+        pyx[u] = ((unsigned)py << 16) | (unsigned)px;
+    }
+    const int dc4 = tid & (KD - 1), dpix0 = tid >> KDL;
+    constexpr int dstep = NT >> KDL;
+    const bool dcv = dc4 < NCO * 4 && co0 + 4 * dc4 < p.Cout;
+    const float* dptr = dcv ? p.dy + p.dy_off + co0 + 4 * dc4 : tmg_zero_page;
+    const int dss = dcv ? p.dy_stride : 0;
+    float4 xv[UX], dv[UD];
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#define TMG_WW_ISSUE(TILE)                                                                                            \
+    {                                                                                                                 \
+        int t_ = (TILE);                                                                                              \
+        const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;                                                              \
+        const int ty_ = t_ % p.tiles_y;                                                                               \
+        const int b_ = t_ / p.tiles_y;                                                                                \
+        const int iy0 = ty_ * TH - 1, ix0 = tx_ * TW - 1;                                                             \
+        const size_t ib = (size_t)b_ * p.Hin * p.Win;                                                                 \
+        _Pragma("unroll") for (int u = 0; u < UX; ++u) {                                                              \
+            const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);                             \
+            const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);                             \
+            const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);                                                  \
+            const float* a_ = (oob || xpix0 + u * xstep >= PP) ? tmg_zero_page : xptr + (ib + (size_t)iyc * p.Win + ixc) * xss; \
+            xv[u] = *reinterpret_cast<const float4*>(a_);                                                             \
+        }                                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                              \
+            const int m = dpix0 + u * dstep;                                                                          \
+            const int oy = ty_ * TH + (m >> 4), ox = tx_ * TW + (m & 15);                                             \
+            const bool inb = m < 128 && oy < p.Hin && ox < p.Win;                                                     \
+            const float* a_ = inb ? dptr + (ib + (size_t)oy * p.Win + ox) * dss : tmg_zero_page;                      \
+            dv[u] = *reinterpret_cast<const float4*>(a_);                                                             \
+        }                                                                                                             \
+    }
+
+    f32x4 acc[2][CIT][NCO];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+            for (int n = 0; n < NCO; ++n) acc[e][i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int G = gridDim.x;
+    if ((int)blockIdx.x < p.ntiles) TMG_WW_ISSUE((int)blockIdx.x)
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += G) {
+        // ---- commit the prefetched tile, then put the next one in flight ---------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            if (xc4 < CIT * 4 && xpix0 + u * xstep < PP) {
+                float4 v = xv[u];
+                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(XR + (xpix0 + u * xstep) * CSX + 4 * xc4) = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UD; ++u) {
+            if (dc4 < NCO * 4 && dpix0 + u * dstep < 128) {
+                *reinterpret_cast<float4*>(DR + (dpix0 + u * dstep) * CSD + 4 * dc4) = dv[u];
+                bacc.x += dv[u].x; bacc.y += dv[u].y; bacc.z += dv[u].z; bacc.w += dv[u].w;
+            }
+        }
+        __syncthreads();
+        if (tile + G < p.ntiles) TMG_WW_ISSUE(tile + G)
+        // ---- 8 k-steps of 4 Winograd tiles: tile index 4 s + q -> tile row s >> 1, tile column 4 (s & 1) + q -------------------
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int sx = ((2 * (s >> 1)) * PW + 8 * (s & 1)) * CSX;          // patch offset of the k-step's first tile
+            const int sd = ((2 * (s >> 1)) * 16 + 8 * (s & 1)) * CSD;
+            float xa[2][CIT], dh[2][NCO];
+#pragma unroll
+            for (int i = 0; i < CIT; ++i) {
+                float u_[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) u_[c] = fmaf(XR[oxb + sx + c * CSX + 16 * i], sg, XR[oxa + sx + c * CSX + 16 * i]);
+                if (par == 0) { xa[0][i] = u_[0] - u_[2]; xa[1][i] = u_[1] + u_[2]; }
+                else          { xa[0][i] = u_[1] - u_[0]; xa[1][i] = u_[0] - u_[2]; }
+            }
+#pragma unroll
+            for (int n = 0; n < NCO; ++n) {
+                const float* dp_ = DR + od + sd + 16 * n;
+                const float e0 = fmaf(dp_[16 * CSD], g1, g0 * dp_[0]), e1 = fmaf(dp_[17 * CSD], g1, g0 * dp_[CSD]);
+                if (par == 0) { dh[0][n] = e0; dh[1][n] = 0.5f * (e0 + e1); }
+                else          { dh[0][n] = 0.5f * (e0 - e1); dh[1][n] = e1; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                for (int n = 0; n < NCO; ++n) {
+                    acc[0][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][i], dh[0][n], acc[0][i][n], 0, 0, 0);
+                    acc[1][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][i], dh[1][n], acc[1][i][n], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#undef TMG_WW_ISSUE
+    // ---- partial sums -> this block's slab (accumulator order, coalesced float4 stores) ---------------------------------------------
+    const size_t bl = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+    float4* slab = reinterpret_cast<float4*>(p.ws) + ((bl * 8 + wave) * (2 * CIT * NCO)) * 64 + lane;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+            for (int n = 0; n < NCO; ++n)
+                slab[((e * CIT + i) * NCO + n) * 64] = make_float4(acc[e][i][n][0], acc[e][i][n][1], acc[e][i][n][2], acc[e][i][n][3]);
+    if (p.want_bias && blockIdx.z == 0) {
+        // dbias partial of this block: thread t holds the sum of channel quad t % KD over its pixels
+        __syncthreads();
+        *reinterpret_cast<float4*>(lds + tid * 4) = bacc;
+        __syncthreads();
+        if (tid < NCO * 16) {
+            const int c4 = tid >> 2, e = tid & 3;
+            float bs = 0.f;
+            for (int t = c4; t < NT; t += KD) bs += lds[t * 4 + e];
+            float* wsb = p.ws + (size_t)gridDim.x * gridDim.y * gridDim.z * 8 * (2 * CIT * NCO) * 256;
+            wsb[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 + tid] = bs;
+        }
+    }
+}
+
+// Fold the slabs of wino_wgrad_kernel over the pixel shares, apply A'^T . A' and add the 9 taps onto dW (+ the bias sums onto dbias).
+// One thread per (channel-tile pair, lane): 4 input channels x 1 output channel, all 16 positions.
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias, int gx, int gy, int gz,
+                                         int CIT, int NCO, int Cin, int Cout, int cin_dst, int cin_valid, int ci_split, int ci_off0,
+                                         int ci_off1) {
+    const int per = CIT * NCO * 64;
+    const int total = gy * gz * per;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) {
+        const int lane = t & 63;
+        int r_ = t >> 6;
+        const int n = r_ % NCO; r_ /= NCO;
+        const int i = r_ % CIT; r_ /= CIT;
+        const int bz = r_ % gz, by = r_ / gz;
+        const int li = lane & 15, q = lane >> 4;
+        float4 m[16];
+#pragma unroll
+        for (int pz = 0; pz < 16; ++pz) m[pz] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int bx = 0; bx < gx; ++bx) {
+            const size_t bl = ((size_t)bx * gy + by) * gz + bz;
+#pragma unroll
+            for (int pz = 0; pz < 16; ++pz) {
+                const int w = pz >> 1, e = pz & 1;   // position pz = 4 xi + nu lives in wave (xi, nu >> 1) = pz >> 1, slot nu & 1
+                const float4 v = reinterpret_cast<const float4*>(ws)[((bl * 8 + w) * (2 * CIT * NCO) + (e * CIT + i) * NCO + n) * 64 + lane];
+                m[pz].x += v.x; m[pz].y += v.y; m[pz].z += v.z; m[pz].w += v.w;
+            }
+        }
+        const int co = (by * NCO + n) * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = (bz * CIT + i) * 16 + 4 * q + r;
+            if (co >= Cout || ci >= Cin || ci >= cin_valid) continue;
+            float M[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 v = m[a * 4 + b];
+                    M[a][b] = r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w));
+                }
+            // A'^T M: rows  t0 = M0 + M1 + M2, t1 = M1 - M2, t2 = M1 + M2 - M3 ; then the same along the columns
+            float T[3][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                T[0][b] = M[0][b] + M[1][b] + M[2][b];
+                T[1][b] = M[1][b] - M[2][b];
+                T[2][b] = M[1][b] + M[2][b] - M[3][b];
+            }
+            float* dst = dW + ((size_t)co * cin_dst + ci + (ci < ci_split ? ci_off0 : ci_off1)) * 9;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                dst[a * 3 + 0] += T[a][0] + T[a][1] + T[a][2];
+                dst[a * 3 + 1] += T[a][1] - T[a][2];
+                dst[a * 3 + 2] += T[a][1] + T[a][2] - T[a][3];
+            }
+        }
+    }
+    if (dbias && t < gy * 64) {
+        const int by = t >> 6, c = t & 63;
+        const int co = by * NCO * 16 + c;
+        if (c < NCO * 16 && co < Cout) {
+            const float* wsb = ws + (size_t)gx * gy * gz * 8 * (2 * CIT * NCO) * 256;
+            float s = 0.f;
+            for (int bx = 0; bx < gx; ++bx) s += wsb[((size_t)bx * gy + by) * 64 + c];
+            dbias[co] += s;
+        }
+    }
+}
+
+struct WinoWPlan { int CIT, NCO, gx, gy, gz; size_t ws_floats; };
+
+static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, WinoWPlan* pl) {
+    const int cit = (Cin + 15) >> 4, cot = (Cout + 15) >> 4;
+    if (cit < 2 || cot < 2) return -100;
+    pl->gz = (cit + 3) / 4;
+    const int citg = (cit + pl->gz - 1) / pl->gz;
+    pl->CIT = citg <= 2 ? 2 : 4;
+    pl->gy = (cot + 3) / 4;
+    const int cotg = (cot + pl->gy - 1) / pl->gy;
+    pl->NCO = cotg <= 2 ? 2 : (cotg == 3 ? 3 : 4);
+    const int ntiles = B * ((W + 15) / 16) * ((H + 7) / 8);
+    int gx = 256 / (pl->gy * pl->gz);
+    if (gx > ntiles / 2) gx = ntiles / 2;
+    if (gx < 1) gx = 1;
+    pl->gx = gx;
+    pl->ws_floats = (size_t)gx * pl->gy * pl->gz * 8 * (2 * pl->CIT * pl->NCO) * 256 + (size_t)gx * pl->gy * 64;
+    return 0;
+}
+
+// scratch floats tmg_conv_wino_wgrad wants for dims = {B,H,W,Cin,Cout,...} (0: shape not eligible)
+extern "C" int64_t tmg_conv_wino_wgrad_ws_floats(const int64_t* dims) {
+    WinoWPlan pl;
+    if (plan_wino_wgrad((int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], &pl) != 0) return 0;
+    return (int64_t)pl.ws_floats;
+}
+
+template <int CIT, int NCO>
+static int launch_wino_wgrad(const WinoWP& p, const WinoWPlan& pl, hipStream_t st) {
+    const size_t lds_bytes = (size_t)(180 * (CIT * 16 + 8) + 128 * (NCO * 16 + 8)) * sizeof(float);
+    TMG_LDS_OPTIN((&wino_wgrad_kernel<CIT, NCO>));
+    TmgProf prof(TMG_PROF_WINO_WG, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);
+    hipLaunchKernelGGL((wino_wgrad_kernel<CIT, NCO>), dim3(pl.gx, pl.gy, pl.gz), dim3(512), lds_bytes < 8192 ? 8192 : lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW[Cout][cin_dst][3][3] += sum_pixels act(in)(p + tap) (x) dy(p)  and  dbias += sum dy, for 3x3 / stride-1 / padding-1 convs with
+// >= 32 input and output channels, as Winograd F(3x3, 2x2).  dims = {B,H,W,Cin,Cout,relu_in,pad_replicate,cin_dst,cin_valid,ci_split,
+// ci_off0,ci_off1} (destination mapping as tmg_conv_wgrad); dy_desc = {stride, off}; ws: >= tmg_conv_wino_wgrad_ws_floats(dims) floats.
+// Returns -100 outside the envelope (nothing launched).
+extern "C" int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* dy, const int64_t* dy_desc,
+                                   void* dW, void* dbias, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st) {
+    WinoWP p;
+    p.nseg = (int)nseg;
+    if (p.nseg < 1 || p.nseg > TMG_MAX_IN_SEG) return -3;
+    int csum = 0;
+    bool ok = true;
+    for (int i = 0; i < TMG_MAX_IN_SEG; ++i) p.in[i] = TmgSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < p.nseg; ++i) {
+        p.in[i] = TmgSeg{(const float*)in_ptrs[i], (int)in_desc[3 * i], (int)in_desc[3 * i + 1], (int)in_desc[3 * i + 2]};
+        if (((p.in[i].stride | p.in[i].off | p.in[i].n) & 3) || (((uintptr_t)in_ptrs[i]) & 15)) ok = false;
+        csum += p.in[i].n;
+    }
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.Cout = (int)dims[4];
+    p.relu_in = (int)dims[5]; p.pad_rep = (int)dims[6];
+    const int cin_dst = dims[7] > 0 ? (int)dims[7] : p.Cin;
+    const int cin_valid = dims[8] > 0 ? (int)dims[8] : (cin_dst < p.Cin ? cin_dst : p.Cin);
+    const int ci_split = dims[9] > 0 ? (int)dims[9] : 0x7fffffff;
+    const int ci_off0 = (int)dims[10], ci_off1 = (int)dims[11];
+    if (csum != p.Cin) return -3;
+    p.dy = (const float*)dy; p.dy_stride = (int)dy_desc[0]; p.dy_off = (int)dy_desc[1];
+    if (((p.dy_stride | p.dy_off) & 3) || (((uintptr_t)dy) & 15) || (p.Cin & 3) || (p.Cout & 3)) ok = false;
+    WinoWPlan pl;
+    if (!ok || plan_wino_wgrad(p.B, p.Hin, p.Win, p.Cin, p.Cout, &pl) != 0) return -100;
+    if (!ws || (size_t)ws_floats < pl.ws_floats || (((uintptr_t)ws) & 15)) return -100;
+    p.ws = (float*)ws;
+    p.want_bias = dbias ? 1 : 0;
+    p.tiles_x = (p.Win + 15) / 16; p.tiles_y = (p.Hin + 7) / 8;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    if (p.ntiles <= 0) return 0;
+    int rc = -7;
+#define TMG_WW_CASE(C_, N_) if (pl.CIT == C_ && pl.NCO == N_) rc = launch_wino_wgrad<C_, N_>(p, pl, st);
+    TMG_WW_CASE(2, 2) TMG_WW_CASE(2, 3) TMG_WW_CASE(2, 4) TMG_WW_CASE(4, 2) TMG_WW_CASE(4, 3) TMG_WW_CASE(4, 4)
+#undef TMG_WW_CASE
+    if (rc != 0) return rc;
+    const int total = pl.gy * pl.gz * pl.CIT * pl.NCO * 64;
+    const int tb = total > pl.gy * 64 ? total : pl.gy * 64;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((tb + 127) / 128), dim3(128), 0, st, (const float*)p.ws, (float*)dW, (float*)dbias, pl.gx,
+                       pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid, ci_split, ci_off0, ci_off1);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats",
 ]
 
 
@@ -383,10 +383,36 @@ def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, 
     _, Hout, Wout, Cout = dy.shape
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
+    if (ksize == 3 and stride == 1 and kappa is None and in_scale is None and use_ws and Cin >= 32
+            and (Cout >= 128 or (Cout >= 32 and Cin >= 64 and B * Hin * Win >= (1 << 20)))
+            and os.environ.get("TMG_NO_WINOGRAD") is None and os.environ.get("TMG_NO_WINOGRAD_WGRAD") is None
+            # Winograd F(3x3, 2x2), 2.25x fewer matrix-core operations.  Measured per call site at config M: it wins wherever the
+            # contraction is matrix-pipe bound (many output channels, or many pixels x input channels) and loses to the direct kernel
+            # on the small ones (its 16-position slabs make the reduce step the larger part)
+            and conv_wino_wgrad(inputs, dy, dW, dbias, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)):
+        return
     dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cout, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
     ws = workspace(lib().tmg_conv_wgrad_ws_floats(dims), dy.device) if use_ws else None
     _chk(lib().tmg_conv_wgrad(ip, idesc, c_i64(n_in), _ptr(in_scale), _ptr(in_shift), _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
                               _ptr(kappa), _ptr(ws), c_i64(ws.numel() if ws is not None else 0), dims, _stream()), "tmg_conv_wgrad")
+
+
+def conv_wino_wgrad(inputs, dy, dW, dbias, relu_in=False, pad_rep=False, cin_dst=0, cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0):
+    """3x3 / stride-1 weight gradient as Winograd F(3x3, 2x2) (tmg_conv_wino_wgrad); False when the shape is outside the kernel's
+    envelope (nothing was launched).  conv_wgrad routes the large contractions here."""
+    B, Hin, Win, _ = inputs[0].shape
+    Cout = dy.shape[3]
+    ip, idesc, n_in = _segs(inputs)
+    Cin = sum(t.shape[3] for t in inputs)
+    wd = _i64(B, Hin, Win, Cin, Cout, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
+    need = lib().tmg_conv_wino_wgrad_ws_floats(wd)
+    if need > 0:
+        ws = workspace(need, dy.device)
+        rc = lib().tmg_conv_wino_wgrad(ip, idesc, c_i64(n_in), _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias), _ptr(ws), c_i64(ws.numel()), wd, _stream())
+        if rc != -100:
+            _chk(rc, "tmg_conv_wino_wgrad")
+            return True
+    return False
 
 
 _GTAB = {}

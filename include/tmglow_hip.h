@@ -80,6 +80,14 @@ int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_
 int tmg_conv_wino_narrow(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
                          void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
 
+/* The large 3x3 / stride-1 weight gradients (>= 32 input and output channels) as Winograd F(3x3, 2x2): dW[Cout][cin_dst][3][3] +=
+ * sum_pixels act(in)(p + tap) (x) dy(p), dbias += sum dy.  dims = {B,H,W,Cin,Cout,relu_in,pad_replicate,cin_dst,cin_valid,ci_split,
+ * ci_off0,ci_off1} (destination mapping as tmg_conv_wgrad), dy_desc = {stride, off}; ws = scratch of at least
+ * tmg_conv_wino_wgrad_ws_floats(dims) floats (0: shape not eligible).  Returns -100 outside the envelope (nothing launched). */
+int64_t tmg_conv_wino_wgrad_ws_floats(const int64_t* dims);
+int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* dy, const int64_t* dy_desc,
+                        void* dW, void* dbias, void* ws, int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
+
 /* dW[Cout][Cin][k][k] += scale * sum_pixels act(in)(p*s+tap) (x) dy(p) ; dbias += scale * sum dy.
  * (accumulating: caller zero-fills; per-block partial sums go through the scratch `ws` and a reduce kernel.)  Replaces the autograd weight-gradient of the convs above.
  * dims = {B,Hin,Win,Hout,Wout,ksize,stride,Cin,Cout,relu_in,pad_replicate,cin_dst,cin_valid,ci_split,ci_off0,ci_off1};

@@ -485,3 +485,38 @@ def test_winograd_narrow_matches_fp64(case):
     assert H.wino_narrow_eligible(K, N)
     assert H.conv_wino_narrow([x.to(DEV)], U, N, outs, bias=bd, relu_out=relu_out)
     _close(torch.cat(outs, 3), ref, what="narrow winograd")
+
+
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, [8, 32, 64], 256, False, False, True),     # gate weight gradient: 104 input channels (two channel groups), bias
+    (2, 16, 12, [32], 240, True, True, False),             # conditioning weight gradient into a wider destination
+    (1, 9, 21, [8, 32, 64], 40, False, False, True),       # three output-channel tiles, partial tiles on both axes
+    (3, 8, 8, [64], 32, True, False, False),
+    (2, 24, 40, [48], 96, False, True, True),              # several tiles per block share
+])
+def test_winograd_weight_gradient_matches_fp64(case):
+    """tmg_conv_wino_wgrad (Winograd F(3x3, 2x2) on the fp32 matrix cores) against fp64 autograd, at the direct
+    kernel's tolerance, including the destination-column mapping of the level node."""
+    import tmg_hip as H
+    B, Hh, Ww, segs, Cout, relu_in, pad_rep, has_b = case
+    Cin = sum(segs)
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + Ww)
+    xs = [torch.randn(B, Hh, Ww, c, generator=g) for c in segs]
+    dy = torch.randn(B, Hh, Ww, Cout, generator=g)
+    t = torch.cat(xs, 3).permute(0, 3, 1, 2).double()
+    if relu_in:
+        t = F.relu(t)
+    t = F.pad(t, (1, 1, 1, 1), mode="replicate" if pad_rep else "constant")
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(t, w, b) * dy.permute(0, 3, 1, 2).double()).sum().backward()
+    off = 5 if len(segs) == 1 else 0                          # single-segment cases land in columns [off, off + Cin) of a wider tensor
+    dW = torch.zeros(Cout, Cin + 2 * off, 3, 3, device=DEV)
+    dB = torch.zeros(Cout, device=DEV) if has_b else None
+    assert H.conv_wino_wgrad([x.to(DEV) for x in xs], dy.to(DEV), dW, dB, relu_in=relu_in, pad_rep=pad_rep,
+                             cin_dst=Cin + 2 * off, cin_valid=Cin, ci_off0=off)
+    _close(dW[:, off:off + Cin], w.grad, tol=5e-5, what="winograd dW")
+    if off:
+        assert float(dW[:, :off].abs().max()) == 0.0 and float(dW[:, off + Cin:].abs().max()) == 0.0
+    if has_b:
+        _close(dB, b.grad, tol=5e-5, what="winograd dbias")

@@ -56,3 +56,27 @@ for B, Hh, Ww, K, N in [(64, 128, 128, 256, 40), (64, 128, 128, 240, 32), (64, 6
     tw = t(lambda: H.conv_wino_narrow([x], U, N, [out]))
     td = t(lambda: H.conv_fwd([x], Wp, N, 3, 1, [out]))
     print("%4dx%-4d %4d -> %4d   winograd %7.3f ms (%6.1f TF)   direct %7.3f ms (%6.1f TF)" % (Hh, Ww, K, N, tw, fl / tw / 1e9, td, fl / td / 1e9))
+
+print("weight gradients:")
+for B, Hh, Ww, segs, Cout in [(64, 128, 128, [8, 32, 64], 256), (64, 128, 128, [32], 240), (64, 64, 64, [16, 32, 64], 256), (64, 64, 64, [32], 480),
+                              (64, 32, 32, [32], 960), (64, 16, 16, [32], 1920), (64, 128, 128, [8, 32, 64], 40)]:
+    xs = [torch.randn(B, Hh, Ww, c, device=dev) for c in segs]
+    dy = torch.randn(B, Hh, Ww, Cout, device=dev)
+    dW = torch.zeros(Cout, sum(segs), 3, 3, device=dev)
+    fl = 2.0 * B * Hh * Ww * Cout * sum(segs) * 9
+
+    def t(fn, n=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+    tw = t(lambda: H.conv_wino_wgrad(xs, dy, dW, None))
+    os.environ["TMG_NO_WINOGRAD"] = "1"
+    td = t(lambda: H.conv_wgrad(xs, dy, dW, None, 3, 1))
+    del os.environ["TMG_NO_WINOGRAD"]
+    print("%4dx%-4d %4d -> %4d   winograd %7.3f ms (%6.1f TF)   direct %7.3f ms (%6.1f TF)" % (Hh, Ww, sum(segs), Cout, tw, fl / tw / 1e9, td, fl / td / 1e9))
