@@ -891,70 +891,82 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
 }
 
 // Fold the slabs of wino_wgrad_kernel over the pixel shares, apply A'^T . A' and add the 9 taps onto dW (+ the bias sums onto dbias).
-// One thread per (channel-tile pair, lane): 4 input channels x 1 output channel, all 16 positions.
-__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias, int gx, int gy, int gz,
-                                         int CIT, int NCO, int Cin, int Cout, int cin_dst, int cin_valid, int ci_split, int ci_off0,
-                                         int ci_off1) {
-    const int per = CIT * NCO * 64;
-    const int total = gy * gz * per;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < total) {
-        const int lane = t & 63;
-        int r_ = t >> 6;
-        const int n = r_ % NCO; r_ /= NCO;
-        const int i = r_ % CIT; r_ /= CIT;
-        const int bz = r_ % gz, by = r_ / gz;
-        const int li = lane & 15, q = lane >> 4;
-        float4 m[16];
+// One 256-thread block per pair of channel tiles: thread (lane, group g) sums the slabs bx = g, g + 4, ... for its 4 input channels x 1
+// output channel at all 16 positions, transforms its partial sum (the tap transform is linear), the four groups meet in LDS and group
+// 0 adds the result onto dW.  (A single serial walk over all gx slabs per thread left the chip idle for 120 us per launch.)
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
+                                                                int gx, int gy, int gz, int CIT, int NCO, int Cin, int Cout, int cin_dst,
+                                                                int cin_valid, int ci_split, int ci_off0, int ci_off1) {
+    __shared__ float red[3][64][37];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    int r_ = blockIdx.x;
+    const int n = r_ % NCO; r_ /= NCO;
+    const int i = r_ % CIT; r_ /= CIT;
+    const int bz = r_ % gz, by = r_ / gz;
+    const int li = lane & 15, q = lane >> 4;
+    float4 m[16];
 #pragma unroll
-        for (int pz = 0; pz < 16; ++pz) m[pz] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int bx = 0; bx < gx; ++bx) {
-            const size_t bl = ((size_t)bx * gy + by) * gz + bz;
+    for (int pz = 0; pz < 16; ++pz) m[pz] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int bx = grp; bx < gx; bx += 4) {
+        const size_t bl = ((size_t)bx * gy + by) * gz + bz;
 #pragma unroll
-            for (int pz = 0; pz < 16; ++pz) {
-                const int w = pz >> 1, e = pz & 1;   // position pz = 4 xi + nu lives in wave (xi, nu >> 1) = pz >> 1, slot nu & 1
-                const float4 v = reinterpret_cast<const float4*>(ws)[((bl * 8 + w) * (2 * CIT * NCO) + (e * CIT + i) * NCO + n) * 64 + lane];
-                m[pz].x += v.x; m[pz].y += v.y; m[pz].z += v.z; m[pz].w += v.w;
-            }
+        for (int pz = 0; pz < 16; ++pz) {
+            const int w = pz >> 1, e = pz & 1;   // position pz = 4 xi + nu lives in wave (xi, nu >> 1) = pz >> 1, slot nu & 1
+            const float4 v = reinterpret_cast<const float4*>(ws)[((bl * 8 + w) * (2 * CIT * NCO) + (e * CIT + i) * NCO + n) * 64 + lane];
+            m[pz].x += v.x; m[pz].y += v.y; m[pz].z += v.z; m[pz].w += v.w;
         }
+    }
+    float tap[4][9];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float M[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float4 v = m[a * 4 + b];
+                M[a][b] = r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w));
+            }
+        // A'^T M: rows  t0 = M0 + M1 + M2, t1 = M1 - M2, t2 = M1 + M2 - M3 ; then the same along the columns
+        float T[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            T[0][b] = M[0][b] + M[1][b] + M[2][b];
+            T[1][b] = M[1][b] - M[2][b];
+            T[2][b] = M[1][b] + M[2][b] - M[3][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            tap[r][a * 3 + 0] = T[a][0] + T[a][1] + T[a][2];
+            tap[r][a * 3 + 1] = T[a][1] - T[a][2];
+            tap[r][a * 3 + 2] = T[a][1] + T[a][2] - T[a][3];
+        }
+    }
+    if (grp > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) red[grp - 1][lane][r * 9 + k] = tap[r][k];
+    }
+    __syncthreads();
+    if (grp == 0) {
         const int co = (by * NCO + n) * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = (bz * CIT + i) * 16 + 4 * q + r;
             if (co >= Cout || ci >= Cin || ci >= cin_valid) continue;
-            float M[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float4 v = m[a * 4 + b];
-                    M[a][b] = r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w));
-                }
-            // A'^T M: rows  t0 = M0 + M1 + M2, t1 = M1 - M2, t2 = M1 + M2 - M3 ; then the same along the columns
-            float T[3][4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                T[0][b] = M[0][b] + M[1][b] + M[2][b];
-                T[1][b] = M[1][b] - M[2][b];
-                T[2][b] = M[1][b] + M[2][b] - M[3][b];
-            }
             float* dst = dW + ((size_t)co * cin_dst + ci + (ci < ci_split ? ci_off0 : ci_off1)) * 9;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                dst[a * 3 + 0] += T[a][0] + T[a][1] + T[a][2];
-                dst[a * 3 + 1] += T[a][1] - T[a][2];
-                dst[a * 3 + 2] += T[a][1] + T[a][2] - T[a][3];
-            }
+            for (int k = 0; k < 9; ++k) dst[k] += tap[r][k] + red[0][lane][r * 9 + k] + red[1][lane][r * 9 + k] + red[2][lane][r * 9 + k];
         }
     }
-    if (dbias && t < gy * 64) {
-        const int by = t >> 6, c = t & 63;
-        const int co = by * NCO * 16 + c;
-        if (c < NCO * 16 && co < Cout) {
+    if (dbias && bz == 0 && i == 0 && n == 0 && threadIdx.x < NCO * 16) {
+        const int c = threadIdx.x, co = by * NCO * 16 + c;
+        if (co < Cout) {
             const float* wsb = ws + (size_t)gx * gy * gz * 8 * (2 * CIT * NCO) * 256;
-            float s = 0.f;
-            for (int bx = 0; bx < gx; ++bx) s += wsb[((size_t)bx * gy + by) * 64 + c];
-            dbias[co] += s;
+            float s_ = 0.f;
+            for (int bx = 0; bx < gx; ++bx) s_ += wsb[((size_t)bx * gy + by) * 64 + c];
+            dbias[co] += s_;
         }
     }
 }
@@ -1035,10 +1047,8 @@ extern "C" int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in
     TMG_WW_CASE(2, 2) TMG_WW_CASE(2, 3) TMG_WW_CASE(2, 4) TMG_WW_CASE(4, 2) TMG_WW_CASE(4, 3) TMG_WW_CASE(4, 4)
 #undef TMG_WW_CASE
     if (rc != 0) return rc;
-    const int total = pl.gy * pl.gz * pl.CIT * pl.NCO * 64;
-    const int tb = total > pl.gy * 64 ? total : pl.gy * 64;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((tb + 127) / 128), dim3(128), 0, st, (const float*)p.ws, (float*)dW, (float*)dbias, pl.gx,
-                       pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid, ci_split, ci_off0, ci_off1);
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(256), 0, st, (const float*)p.ws, (float*)dW,
+                       (float*)dbias, pl.gx, pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid, ci_split, ci_off0, ci_off1);
     TMG_CHECK_LAUNCH();
     return 0;
 }
