@@ -101,20 +101,32 @@ def cpu_baseline(name, hard_timeout_s=240, max_steps=12, budget_s=25.0):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_traffic_per_launch.json:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, launch-weighted over the template instances the event id groups)."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic_per_launch.json")
+    """HBM bytes per launch of the event class `kernel` from the committed rocprofv3 PMC passes (profiles/r2_traffic_per_launch.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, launch-weighted over the kernels / template instances the class groups)."""
+    path = os.path.join(ROOT, "profiles", "r2_traffic_per_launch.json")
     if not os.path.exists(path):
         return None
     tab = json.load(open(path))
-    base, _, tail = kernel.partition("<")
-    want = tail.rstrip(">").split(",")
+    if kernel.startswith("wino_fwd"):
+        pats = [("wino_fwd_kernel", None), ("wino_nn_kernel", None)]
+    elif kernel.startswith("wino_wgrad"):
+        pats = [("wino_wgrad_kernel", None)]
+    else:
+        base, _, tail = kernel.partition("<")
+        pats = [(base, tail.rstrip(">").split(","))]
     tot = n = 0
     for k, v in tab.items():
-        if not isinstance(v, dict) or not k.startswith(base + "<"):
+        if not isinstance(v, dict):
             continue
-        have = [a.strip() for a in k[len(base) + 1:].rstrip(">").split(",")]
-        if len(have) == len(want) and all(w == "*" or w == h for w, h in zip(want, have)):
+        for base, want in pats:
+            if not k.startswith(base):
+                continue
+            if want is not None:
+                if not k.startswith(base + "<"):
+                    continue
+                have = [a.strip() for a in k[len(base) + 1:].rstrip(">").split(",")]
+                if not (len(have) == len(want) and all(w == "*" or w == h for w, h in zip(want, have))):
+                    continue
             tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None
@@ -284,6 +296,13 @@ def main():
                 "all_contraction_kernels": {k: {"launches_per_step": round(v[0] / prof_steps[k], 1), "ms_per_step": round(v[1] / prof_steps[k], 3),
                                                 "tflops": round(v[2] / max(v[1], 1e-9) / 1e9, 2)}
                                             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1] / prof_steps[kv[0]])}}
+        if name.startswith("wino"):
+            # Winograd kernels: `achieved` counts the ALGORITHMIC (direct 3x3) flops of the contraction, of which the minimal-
+            # filtering form executes 16 / 36 on the matrix cores - so it can exceed the MFMA peak; the pipe's own utilisation
+            # is the executed rate
+            roof["algorithm"] = "Winograd F(2x2,3x3) / F(3x3,2x2): 16 matrix-core multiplies per 36 algorithmic ones"
+            roof["mfma_executed_tflops"] = round(ach * 16.0 / 36.0, 3)
+            roof["mfma_executed_frac"] = round(ach * 16.0 / 36.0 / PEAK_FP32_MFMA_TF, 4)
         roof["traffic"] = pmc_traffic(name) if args.config == "M" and B == 64 else None
         if args.config in GFLOP_PER_SAMPLE:
             e2e = value / world * GFLOP_PER_SAMPLE[args.config] / 1e3

@@ -7,7 +7,6 @@ tag=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 mkdir -p "$R/gpurun_out"
-python3 "$R/bench.py" > "$R/gpurun_out/${tag}_bench_config_M.json" 2> "$R/gpurun_out/${tag}_bench_config_M.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${tag}_stats" -o s -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-events > "$R/gpurun_out/${tag}_stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/${tag}_pmc_fetch" -o f -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-events > "$R/gpurun_out/${tag}_pmc_fetch.log" 2>&1
@@ -15,6 +14,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/
 cd "$R"
 python3 tools/traffic_json.py "gpurun_out/${tag}_pmc_fetch" "gpurun_out/${tag}_pmc_write" "gpurun_out/${tag}_traffic_per_launch.json"
 cp "$(ls gpurun_out/${tag}_stats/*kernel_stats.csv | head -1)" "gpurun_out/${tag}_kernel_stats_config_M.csv"
+# the bench line reads the per-launch traffic of its dominant kernel from profiles/: put this round's table there first
+cp "gpurun_out/${tag}_traffic_per_launch.json" "profiles/${tag}_traffic_per_launch.json"
+python3 "$R/bench.py" > "$R/gpurun_out/${tag}_bench_config_M.json" 2> "$R/gpurun_out/${tag}_bench_config_M.err"
 python3 - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]
