@@ -1376,7 +1376,8 @@ static const char* const g_prof_names[] = {
 
 // open / close a timed region around a launch; other translation units reach them through tmg_common.h's TmgProf
 extern "C" int tmg_prof_open(int kid, double work, hipStream_t st) {
-    if (!g_prof_on || (g_prof_on == 1 && kid >= 32) || (g_prof_on >= 100 && kid != g_prof_on - 100)) return -1;
+    // mode 1: matrix-core kernels only (ids < 32 and the Winograd classes 43, 44); mode 2: + the bandwidth-bound classes 32..42
+    if (!g_prof_on || (g_prof_on == 1 && kid >= 32 && kid < 43) || (g_prof_on >= 100 && kid != g_prof_on - 100)) return -1;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof_n >= g_prof.size()) return -1;
     ProfRec& r = g_prof[g_prof_n];
