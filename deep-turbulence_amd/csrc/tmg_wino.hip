@@ -429,13 +429,17 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
     // row combination of this wave's xi: u = d[ra] + sg d[rb]   (B^T rows: r0 - r2, r1 + r2, r2 - r1, r1 - r3)
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sg = xi == 1 ? 1.f : -1.f;
-    // per-lane raw-patch word offsets of the tile's pixel (row ra / rb, column par) for the two m-tiles, + 4 q (channel quad)
+    // column pass without selects: patch columns in the order (c0, c1, c2) for nu = (0, 1), (c2, c3, c1) for nu = (2, 3): both position
+    // pairs are (u0 - u2, u1 s1 + u2), s1 = +1 / -1 (wave-uniform offsets and a sign instead of computing both variants)
+    const int cc[3] = {par ? 2 : 0, par ? 3 : 1, par ? 1 : 2};
+    const float s1 = par ? -1.f : 1.f;
+    // per-lane raw-patch word offsets of the tile's pixel (row ra / rb, column 0) for the two m-tiles, + 4 q (channel quad)
     int offa[2], offb[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int wt = 16 * m + li, ty = wt >> 3, tx = wt & 7;
-        offa[m] = ((2 * ty + ra) * PW + 2 * tx + par) * CS + 4 * q;
-        offb[m] = ((2 * ty + rb) * PW + 2 * tx + par) * CS + 4 * q;
+        offa[m] = ((2 * ty + ra) * PW + 2 * tx) * CS + 4 * q;
+        offb[m] = ((2 * ty + rb) * PW + 2 * tx) * CS + 4 * q;
     }
 
     const int pc4 = tid & 7, ppix0 = tid >> 3;
@@ -543,18 +547,12 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
                     _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                   \
                         float4 u_[3];                                                                                 \
                         _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                               \
-                            const float4 da = *reinterpret_cast<const float4*>(rbuf + offa[m] + c * CS + g * 16);     \
-                            const float4 db = *reinterpret_cast<const float4*>(rbuf + offb[m] + c * CS + g * 16);     \
+                            const float4 da = *reinterpret_cast<const float4*>(rbuf + offa[m] + cc[c] * CS + g * 16); \
+                            const float4 db = *reinterpret_cast<const float4*>(rbuf + offb[m] + cc[c] * CS + g * 16); \
                             u_[c] = make_float4(fmaf(db.x, sg, da.x), fmaf(db.y, sg, da.y), fmaf(db.z, sg, da.z), fmaf(db.w, sg, da.w)); \
                         }                                                                                             \
-                        /* columns par .. par + 2 are loaded: nu 0 = c0 - c2, nu 1 = c1 + c2 | nu 2 = c2 - c1, nu 3 = c1 - c3 */ \
-                        if (par == 0) {                                                                               \
-                            va[m] = make_float4(u_[0].x - u_[2].x, u_[0].y - u_[2].y, u_[0].z - u_[2].z, u_[0].w - u_[2].w); \
-                            vb[m] = make_float4(u_[1].x + u_[2].x, u_[1].y + u_[2].y, u_[1].z + u_[2].z, u_[1].w + u_[2].w); \
-                        } else {                                                                                      \
-                            va[m] = make_float4(u_[1].x - u_[0].x, u_[1].y - u_[0].y, u_[1].z - u_[0].z, u_[1].w - u_[0].w); \
-                            vb[m] = make_float4(u_[0].x - u_[2].x, u_[0].y - u_[2].y, u_[0].z - u_[2].z, u_[0].w - u_[2].w); \
-                        }                                                                                             \
+                        va[m] = make_float4(u_[0].x - u_[2].x, u_[0].y - u_[2].y, u_[0].z - u_[2].z, u_[0].w - u_[2].w); \
+                        vb[m] = make_float4(fmaf(u_[1].x, s1, u_[2].x), fmaf(u_[1].y, s1, u_[2].y), fmaf(u_[1].z, s1, u_[2].z), fmaf(u_[1].w, s1, u_[2].w)); \
                     }                                                                                                 \
                     __builtin_amdgcn_sched_barrier(0);                                                                \
                     _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NTN; ++n) {   \
@@ -738,9 +736,20 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sg = xi == 1 ? 1.f : -1.f;
     const float g0 = xi == 0 ? 1.f : (xi == 3 ? 0.f : 0.5f), g1 = xi == 0 ? 0.f : (xi == 1 ? 0.5f : (xi == 2 ? -0.5f : 1.f));
-    // per-lane word offsets for k-step 0 (tiles 0..3 of tile-row 0: tile q): x rows ra / rb at column 2 q + par; dy pixel (0, 2 q)
-    const int oxa = (ra * PW + 2 * q + par) * CSX + li, oxb = (rb * PW + 2 * q + par) * CSX + li;
+    // Column pass without selects: with the patch columns taken in the order (c0, c1, c2) for nu = (0, 1) and (c2, c3, c1) for
+    // nu = (2, 3), both position pairs are (u0 - u2, u1 * s1 + u2) with s1 = +1 / -1 - a wave-uniform choice of three LDS base
+    // addresses and one sign instead of computing both variants and selecting (the compiler if-converts `par ? a : b`).
+    const int cc0 = par ? 2 : 0, cc1 = par ? 3 : 1, cc2 = par ? 1 : 2;
+    const float s1 = par ? -1.f : 1.f;
+    // per-lane word offsets for k-step 0 (tiles 0..3 of tile-row 0: tile q): x rows ra / rb at columns 2 q + cc*; dy pixel (0, 2 q)
+    const int oxa0 = (ra * PW + 2 * q + cc0) * CSX + li, oxa1 = (ra * PW + 2 * q + cc1) * CSX + li, oxa2 = (ra * PW + 2 * q + cc2) * CSX + li;
+    const int oxb0 = (rb * PW + 2 * q + cc0) * CSX + li, oxb1 = (rb * PW + 2 * q + cc1) * CSX + li, oxb2 = (rb * PW + 2 * q + cc2) * CSX + li;
     const int od = (2 * q) * CSD + li;
+    // dy^ of the wave's two positions as ONE linear form of the 2x2 dy tile: (G' dy G'^T)[xi][nu] = sum_ab G'[xi][a] G'[nu][b] dy[a][b]
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float gn0a = par ? 0.5f : 1.f, gn0b = par ? -0.5f : 0.f;   // G' row of the first nu (0 or 2)
+    const float gn1a = par ? 0.f : 0.5f, gn1b = par ? 1.f : 0.5f;    // G' row of the second nu (1 or 3)
+    const f2 k00 = {g0 * gn0a, g0 * gn1a}, k01 = {g0 * gn0b, g0 * gn1b}, k10 = {g1 * gn0a, g1 * gn1a}, k11 = {g1 * gn0b, g1 * gn1b};
 
     // ---- staging: a thread owns one channel quad of every (NT / K)-th pixel --------------------------------------------------------
     const int xc4 = tid & (KX - 1), xpix0 = tid >> KXL;
@@ -840,18 +849,17 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
             float xa[2][CIT], dh[2][NCO];
 #pragma unroll
             for (int i = 0; i < CIT; ++i) {
-                float u_[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) u_[c] = fmaf(XR[oxb + sx + c * CSX + 16 * i], sg, XR[oxa + sx + c * CSX + 16 * i]);
-                if (par == 0) { xa[0][i] = u_[0] - u_[2]; xa[1][i] = u_[1] + u_[2]; }
-                else          { xa[0][i] = u_[1] - u_[0]; xa[1][i] = u_[0] - u_[2]; }
+                const float u0 = fmaf(XR[oxb0 + sx + 16 * i], sg, XR[oxa0 + sx + 16 * i]);
+                const float u1 = fmaf(XR[oxb1 + sx + 16 * i], sg, XR[oxa1 + sx + 16 * i]);
+                const float u2 = fmaf(XR[oxb2 + sx + 16 * i], sg, XR[oxa2 + sx + 16 * i]);
+                xa[0][i] = u0 - u2;
+                xa[1][i] = fmaf(u1, s1, u2);
             }
 #pragma unroll
             for (int n = 0; n < NCO; ++n) {
                 const float* dp_ = DR + od + sd + 16 * n;
-                const float e0 = fmaf(dp_[16 * CSD], g1, g0 * dp_[0]), e1 = fmaf(dp_[17 * CSD], g1, g0 * dp_[CSD]);
-                if (par == 0) { dh[0][n] = e0; dh[1][n] = 0.5f * (e0 + e1); }
-                else          { dh[0][n] = 0.5f * (e0 - e1); dh[1][n] = e1; }
+                const f2 d_ = k00 * dp_[0] + k01 * dp_[CSD] + k10 * dp_[16 * CSD] + k11 * dp_[17 * CSD];
+                dh[0][n] = d_.x; dh[1][n] = d_.y;
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
