@@ -558,17 +558,22 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int row = tid >> TWl, col = tid & (TW - 1);
     const int Cpad = (p.Cin + 3) & ~3;
-    // this thread's two d1-region pixels (region index i -> (ry, rx)); the second may not exist
+    // this thread's d1-region pixels: [0] its OWN pixel (region coordinates (row + 1, col + 1): the conv-1 and conv-2 sums then read the
+    // same patch values - the kernel is bound by LDS reads, a third of them were this duplicate), [1] one pixel of the one-pixel ring
+    // around the tile for the first 2 (RW + RH) - 4 threads (top row, bottom row, left column, right column)
     int ry[2], rx[2];
     bool rok[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = tid + u * 256;
-        rok[u] = i < RH * RW;
-        const int ii = rok[u] ? i : 0;
-        ry[u] = ii / RW;
-        rx[u] = ii - ry[u] * RW;
+    ry[0] = row + 1; rx[0] = col + 1; rok[0] = true;
+    {
+        const int nring = 2 * RW + 2 * (RH - 2);
+        rok[1] = tid < nring;
+        int i = rok[1] ? tid : 0;
+        if (i < RW) { ry[1] = 0; rx[1] = i; }
+        else if (i < 2 * RW) { ry[1] = RH - 1; rx[1] = i - RW; }
+        else if (i < 2 * RW + RH - 2) { ry[1] = 1 + i - 2 * RW; rx[1] = 0; }
+        else { ry[1] = 1 + i - (2 * RW + RH - 2); rx[1] = RW - 1; }
     }
+    const bool ring_wave = (tid & ~63) < 2 * RW + 2 * (RH - 2);   // wave-uniform: does any lane of this wave own a ring pixel
     // all global operands of the epilogue up front (latency hides under the staging + compute)
     const int oy = oy0 + row, ox = ox0 + col;
     const bool own = oy < p.Hin && ox < p.Win;
@@ -605,18 +610,18 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
             const int tyy = tap / 3, txx = tap - tyy * 3;
             const float* w1p = lw1 + tap * kch;
             const float* w2p = lw2 + tap * kch;
-            const float* p0 = lds + ((ry[0] + tyy) * PW + rx[0] + txx) * CS;          // region pixel + tap (patch = region - 1)
-            const float* p1 = lds + ((ry[1] + tyy) * PW + rx[1] + txx) * CS;
-            const float* pq = lds + ((row + 1 + tyy) * PW + col + 1 + txx) * CS;      // own pixel + tap
+            const float* p0 = lds + ((ry[0] + tyy) * PW + rx[0] + txx) * CS;          // own pixel + tap (region pixel + tap; patch = region - 1)
+            const float* p1 = lds + ((ry[1] + tyy) * PW + rx[1] + txx) * CS;          // ring pixel + tap
             for (int c = 0; c < kch; c += 4) {
                 const float4 wa = *reinterpret_cast<const float4*>(w1p + c);
                 const float4 wb = *reinterpret_cast<const float4*>(w2p + c);
                 const float4 x0 = *reinterpret_cast<const float4*>(p0 + c);
-                const float4 x1 = *reinterpret_cast<const float4*>(p1 + c);
-                const float4 xq = *reinterpret_cast<const float4*>(pq + c);
                 acc1[0] += x0.x * wa.x + x0.y * wa.y + x0.z * wa.z + x0.w * wa.w;
-                acc1[1] += x1.x * wa.x + x1.y * wa.y + x1.z * wa.z + x1.w * wa.w;
-                acc2 += xq.x * wb.x + xq.y * wb.y + xq.z * wb.z + xq.w * wb.w;
+                acc2 += x0.x * wb.x + x0.y * wb.y + x0.z * wb.z + x0.w * wb.w;
+                if (ring_wave) {
+                    const float4 x1 = *reinterpret_cast<const float4*>(p1 + c);
+                    acc1[1] += x1.x * wa.x + x1.y * wa.y + x1.z * wa.z + x1.w * wa.w;
+                }
             }
         }
     }
@@ -625,12 +630,8 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
     float* ld1 = lds;  // [RH*RW] relu(d1), zero outside the image
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        if (rok[u]) ld1[tid + u * 256] = rin[u] ? fmaxf(acc1[u] + a1v[u], 0.f) : 0.f;
-    // raw d1 of the own pixel: region index of (row+1, col+1) belongs to some other thread -> recompute address, read raw via LDS too
-    float* ld1raw = lds + ((RH * RW + 3) & ~3);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-        if (rok[u]) ld1raw[tid + u * 256] = acc1[u] + a1v[u];
+        if (rok[u]) ld1[ry[u] * RW + rx[u]] = rin[u] ? fmaxf(acc1[u] + a1v[u], 0.f) : 0.f;
+    const float d1own = acc1[0] + a1v[0];   // raw d1 of the own pixel
     __syncthreads();
     float w2d[9];
 #pragma unroll
@@ -640,10 +641,7 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
         const int tyy = tap / 3, txx = tap - tyy * 3;
         acc2 += w2d[tap] * ld1[(row + tyy) * RW + col + txx];   // region index of own pixel + tap - 1 = (row + tyy, col + txx)
     }
-    if (own) {
-        const float d1 = ld1raw[(row + 1) * RW + col + 1];
-        *reinterpret_cast<float4*>(p.out + opx * p.out_stride) = make_float4(d1, acc2 + a2v, 0.f, 0.f);
-    }
+    if (own) *reinterpret_cast<float4*>(p.out + opx * p.out_stride) = make_float4(d1own, acc2 + a2v, 0.f, 0.f);
 }
 
 // Backward of the C_out = 1 layer.  ddm(p) = dd(p) * [dref(p) > 0]  (dref null -> no mask)
