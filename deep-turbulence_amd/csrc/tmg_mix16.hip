@@ -127,3 +127,113 @@ extern "C" int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, con
         default: return launch_mix16<16, 1>(p, st);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same mix in full fp32 (v_mfma_f32_16x16x4_f32), for the stand-alone mixes of the wide levels and the ConvLSTM blocks: tensors
+// of 8-64 MB with K = C <= 256, i.e. a bandwidth / latency kernel.  The general conv kernel spent ~20 us per launch on them (512-
+// thread persistent blocks, LDS-staged patch, packed-operand launch beforehand); here a wave streams 16-pixel groups straight
+// from global memory (B fragment = one float4 per lane and 16 channels) against the weight held in LDS ([ci/4][co][4] floats, read
+// as float4 = four k-steps), no packing launch.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NT, int NP>
+__global__ __launch_bounds__(256) void mix32_kernel(Mix16P p) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float4* Wl = reinterpret_cast<float4*>(smem_raw);   // [NT*4][CP]: (ci quad, co) -> 4 floats
+    constexpr int CP = NT * 16;
+    const int C = p.C;
+    for (int i = threadIdx.x; i < NT * 4 * CP; i += 256) {
+        const int kq = i / CP, co = i - kq * CP;
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = 4 * kq + e;
+            f[e] = (co < C && ci < C) ? (p.transposed ? p.W[(size_t)ci * C + co] : p.W[(size_t)co * C + ci]) : 0.f;
+        }
+        Wl[i] = make_float4(f[0], f[1], f[2], f[3]);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, lq = lane >> 4;
+    float4 bv[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        const int c = mt * 16 + 4 * lq;
+        bv[mt] = (p.bias && c < C) ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const long group = 16L * NP;
+    for (long g0 = ((long)blockIdx.x * 4 + wave) * group; g0 < p.npix; g0 += (long)gridDim.x * 4 * group) {
+        float4 xv[NP][NT];
+#pragma unroll
+        for (int np = 0; np < NP; ++np)
+#pragma unroll
+            for (int ks = 0; ks < NT; ++ks) {
+                const long px = g0 + np * 16 + l16;
+                const int c = ks * 16 + 4 * lq;
+                const float* a = (px < p.npix && c < C) ? p.x + (size_t)px * p.xs + c : tmg_zero_page;
+                xv[np][ks] = *reinterpret_cast<const float4*>(a);
+            }
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const long px = g0 + np * 16 + l16;
+            f32x4 acc[NT];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) acc[mt] = (f32x4){bv[mt].x, bv[mt].y, bv[mt].z, bv[mt].w};
+#pragma unroll
+            for (int ks = 0; ks < NT; ++ks) {
+                // step e of channel block ks contracts channels 16 ks + 4 lq + e on both operands: the weight fragment is component e
+                // of the lane's LDS quad (co = l16, quad lq), the pixel fragment component e of its global quad (pixel l16, quad lq);
+                // the output tiles are the inner loop so that consecutive MFMAs hit different accumulators
+                float4 a[NT];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) a[mt] = Wl[(ks * 4 + lq) * CP + mt * 16 + l16];
+                const float4 b = xv[np][ks];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b.x, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b.y, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b.z, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b.w, acc[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                const int c = mt * 16 + 4 * lq;
+                if (px < p.npix && c < C)
+                    *reinterpret_cast<float4*>(p.y + (size_t)px * p.ys + c) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+            }
+        }
+    }
+}
+
+template <int NT, int NP>
+static int launch_mix32(const Mix16P& p, hipStream_t st) {
+    const size_t lds = (size_t)NT * 4 * NT * 16 * sizeof(float4);
+    if (lds > 64 * 1024) TMG_LDS_OPTIN((&mix32_kernel<NT, NP>));
+    const long groups = (p.npix + 64L * NP - 1) / (64L * NP);
+    const int grid = (int)(groups < 2048 ? (groups < 1 ? 1 : groups) : 2048);
+    TmgProf prof(31, 2.0 * (double)p.npix * p.C * p.C, st);   // the "conv 1x1 (invertible channel mix, fp32 MFMA)" class: flops
+    hipLaunchKernelGGL((mix32_kernel<NT, NP>), dim3(grid), dim3(256), lds, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// y = W x + bias per pixel in fp32 on the matrix cores; arguments as tmg_mix_f16.  C % 4 == 0, C <= 128 (the weight tile lives in LDS).
+extern "C" int tmg_mix_f32(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d,
+                           const int64_t* dims, hipStream_t st) {
+    Mix16P p;
+    p.x = static_cast<const float*>(x) + x_d[1]; p.xs = (int)x_d[0];
+    p.y = static_cast<float*>(y) + y_d[1]; p.ys = (int)y_d[0];
+    p.W = static_cast<const float*>(W); p.bias = static_cast<const float*>(bias);
+    p.npix = (long)dims[0]; p.C = (int)dims[1]; p.transposed = (int)dims[2];
+    if (p.C < 4 || p.C % 4 || p.C > 128 || p.xs % 4 || p.ys % 4 || x_d[1] % 4 || y_d[1] % 4) return -1;
+    if (p.npix <= 0) return 0;
+    switch ((p.C + 15) / 16) {
+        case 1: return launch_mix32<1, 8>(p, st);
+        case 2: return launch_mix32<2, 4>(p, st);
+        case 3: return launch_mix32<3, 2>(p, st);
+        case 4: return launch_mix32<4, 2>(p, st);
+        case 5: case 6: return launch_mix32<6, 1>(p, st);
+        default: return launch_mix32<8, 1>(p, st);
+    }
+}

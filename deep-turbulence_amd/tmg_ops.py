@@ -510,6 +510,8 @@ def _mix_fwd(x, Wk, bk, packed=None):
     if _mix16_ok(C):
         H.mix_f16(x, Wk.contiguous(), bk, y)
         return y
+    if os.environ.get("TMG_NO_MIX32") is None and x.stride(3) == 1 and H.mix_f32(x, Wk.contiguous(), bk, y):
+        return y
     H.conv_fwd([x], packed if packed is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 0), C, 1, 1, [y], bias=bk)
     return y
 
@@ -542,7 +544,7 @@ def _mix_bwd(x, dy, Wk, dWk, dbk, packed_t=None, defer=None):
     dx = torch.empty(dy.shape, device=dy.device, dtype=torch.float32)
     if _mix16_ok(C):
         H.mix_f16(dy, Wk.contiguous(), None, dx, transposed=True)
-    else:
+    elif not (os.environ.get("TMG_NO_MIX32") is None and H.mix_f32(dy, Wk.contiguous(), None, dx, transposed=True)):
         H.conv_fwd([dy], packed_t if packed_t is not None else H.conv_pack(Wk.reshape(C, C, 1, 1), 1), C, 1, 1, [dx])
     xs = x if isinstance(x, list) else [x]      # the mix input may be given as channel segments
     if defer is not None:

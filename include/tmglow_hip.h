@@ -265,6 +265,10 @@ int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void*
  * W^T (the input gradient of the same mix).  C % 4 == 0, C <= 256. */
 int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d, const int64_t* dims,
                 tmg_stream_t st);
+/* The same mix in full fp32 (v_mfma_f32_16x16x4_f32) for C <= 128: the stand-alone 1x1 mixes (wide flow levels, ConvLSTM blocks)
+ * without the general conv kernel's patch staging and operand-packing launch.  Arguments as tmg_mix_f16. */
+int tmg_mix_f32(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d,
+                const int64_t* dims, tmg_stream_t st);
 
 /* ---- physics-constrained reverse-KL loss (tmg_physics.hip) ------------------------------ */
 

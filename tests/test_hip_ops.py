@@ -520,3 +520,25 @@ def test_winograd_weight_gradient_matches_fp64(case):
         assert float(dW[:, :off].abs().max()) == 0.0 and float(dW[:, off + Cin:].abs().max()) == 0.0
     if has_b:
         _close(dB, b.grad, tol=5e-5, what="winograd dbias")
+
+
+@pytest.mark.parametrize("C_,npix,slice_of", [(16, 1000, 0), (32, 4096, 0), (64, 777, 96), (128, 2048, 0), (24, 513, 40), (96, 300, 0)])
+def test_mix_f32_kernel(C_, npix, slice_of):
+    """tmg_mix_f32 (the stand-alone 1x1 mix in fp32 on the matrix cores) against fp64: W and W^T, bias, channel-slice views
+    (pixel stride > C), ragged pixel counts; nothing written outside the channel slice."""
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(C_ * 77 + npix)
+    W = (torch.randn(C_, C_, generator=g) / math.sqrt(C_)).to(DEV)
+    b = torch.randn(C_, generator=g).to(DEV)
+    wide = slice_of or C_
+    buf = torch.randn(1, 1, npix, wide, generator=g).to(DEV)
+    x = buf[..., wide - C_:] if slice_of else buf
+    obuf = torch.full((1, 1, npix, wide), 7.0, device=DEV)
+    y = obuf[..., :C_] if slice_of else obuf
+    for transposed in (False, True):
+        obuf.fill_(7.0)
+        assert H.mix_f32(x, W, None if transposed else b, y, transposed=transposed)
+        ref = x.double() @ (W.double() if transposed else W.double().t()) + (0 if transposed else b.double())
+        _close(y, ref, tol=2e-6, what="mix_f32 C=%d transposed=%d" % (C_, transposed))
+        if slice_of:
+            assert bool((obuf[..., C_:] == 7.0).all()), "wrote outside its channel slice"
