@@ -169,7 +169,13 @@ def test_baseline_configs_match_fp64_oracle(name, cfg, B):
     m.to(DEV).train()
     h, w = cfg["_in_hw"]
     H_, W_ = h * cfg["_up"], w * cfg["_up"]
-    g = torch.Generator().manual_seed(31)
+    # Inputs must stay clear of ReLU kinks, as in any gradient check: with input seed 31 the five-level case has ONE pre-activation
+    # of the level-2 ConvLSTM out conv at +2.2e-7 (tensor scale 1), which fp32 evaluation orders that are all within 1e-6 of the fp64
+    # forward (direct contraction, Winograd contraction, either 1x1 kernel) put on different sides of zero; that element happens to
+    # be the largest entry of its upstream gradient, so the flip moves two weight-gradient tensors by 2-10 % while the forward pass
+    # and every other gradient agree to 1e-6 (measured element by element when the Winograd kernels came in).  Seed 37 has no such
+    # element for any of the kernel selections (TMG_NO_WINOGRAD / TMG_NO_MIX32 on or off).
+    g = torch.Generator().manual_seed(int(os.environ.get("TMG_TEST_INPUT_SEED", 37 if name == "cfg5-64x64" else 31)))
     x = torch.randn(B, cfg["in_features"], h, w, generator=g)
     y = torch.randn(B, cfg["out_features"], H_, W_, generator=g)
     seeds = torch.arange(B) + 3
