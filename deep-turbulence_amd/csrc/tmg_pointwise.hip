@@ -1398,3 +1398,174 @@ extern "C" int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void*
     TMG_CHECK_LAUNCH();
     return 0;
 }
+
+// =================================================================================================================================
+// Parameter-side folding of a flow level: ActNorm + PLU-parameterised invertible 1x1 conv of ALL K layers -> the [K,C,C] mix matrices
+// and [K,C] biases the coupling kernels consume, and the backward of that map - two launches per level instead of the ~70 tiny
+// torch launches (stack / mask / diag_embed / bmm / scale and their autograd) the same arithmetic cost before.
+//   lower = l (.) strictly-lower mask + I,  upper = u (.) strictly-upper mask + diag(exp(log_s) sign_s) + 0.01 I      (glowConv.py:151-160)
+//   W = P lower upper                                                                                           (glowConv.py:161)
+//   reverse: Wm = diag(1/a) W, bm = -b / a          forward: Wm = W diag(a), bm = W b                           (actNorm.py:66-83 folded)
+//   ld = hw (sgn sum log_s + sum log|a|)
+// Parameters stay the module's own per-layer tensors: the kernels read them through a device pointer table [K][5] (l, u, log_s, a, b;
+// a / b null: no ActNorm); P enters as the row permutation perm[k][i] (row i of W = row perm of lower upper).
+// =================================================================================================================================
+struct LuFoldP {
+    const long long* tab;     // [K][5] pointers
+    const float* sign_s;      // [K][C]
+    const int* perm;          // [K][C]: P[i][perm[i]] = 1
+    const int* iperm;         // [K][C]: inverse
+    int K, C, reverse;
+    float sgn, hw;
+};
+
+__device__ __forceinline__ float lu_lower(const float* l, int C, int r, int k) { return k < r ? l[r * C + k] : (k == r ? 1.f : 0.f); }
+__device__ __forceinline__ float lu_upper(const float* u, const float* ls, const float* sg, int C, int k, int j) {
+    return k < j ? u[k * C + j] : (k == j ? expf(ls[k]) * sg[k] + 0.01f : 0.f);
+}
+
+__global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __restrict__ W, float* __restrict__ Wm, float* __restrict__ bm,
+                                                          float* __restrict__ ld) {
+    const int C = p.C, k = blockIdx.y;
+    const long long* t = p.tab + (size_t)k * 5;
+    const float* l = reinterpret_cast<const float*>(t[0]);
+    const float* u = reinterpret_cast<const float*>(t[1]);
+    const float* ls = reinterpret_cast<const float*>(t[2]);
+    const float* a = reinterpret_cast<const float*>(t[3]);
+    const float* b = reinterpret_cast<const float*>(t[4]);
+    const float* sg = p.sign_s + (size_t)k * C;
+    const int* perm = p.perm + (size_t)k * C;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * C; e += gridDim.x * 256) {
+        const int i = e / C, j = e - i * C, r = perm[i];
+        float acc = 0.f;
+        const int kmax = min(r, j);
+        for (int q = 0; q <= kmax; ++q) acc += lu_lower(l, C, r, q) * lu_upper(u, ls, sg, C, q, j);
+        W[((size_t)k * C + i) * C + j] = acc;
+        Wm[((size_t)k * C + i) * C + j] = p.reverse ? acc / (a ? a[i] : 1.f) : acc * (a ? a[j] : 1.f);
+    }
+    if (blockIdx.x == 0) {
+        // biases need whole rows of W: recomputed here from the factors (C <= 256: a few thousand flops per thread)
+        for (int i = threadIdx.x; i < C; i += 256) {
+            float v;
+            if (p.reverse) v = b ? -b[i] / (a ? a[i] : 1.f) : 0.f;
+            else {
+                v = 0.f;
+                if (b) {
+                    const int r = perm[i];
+                    for (int j = 0; j < C; ++j) {
+                        float acc = 0.f;
+                        const int kmax = min(r, j);
+                        for (int q = 0; q <= kmax; ++q) acc += lu_lower(l, C, r, q) * lu_upper(u, ls, sg, C, q, j);
+                        v += acc * b[j];
+                    }
+                }
+            }
+            bm[(size_t)k * C + i] = v;
+        }
+        if (k == 0) {
+            // scalar log-det of all K mixes (one block: K C <= 4096 terms)
+            __shared__ float red[4];
+            float s = 0.f;
+            for (int e = threadIdx.x; e < p.K * C; e += 256) {
+                const int kk = e / C, i = e - kk * C;
+                const long long* tt = p.tab + (size_t)kk * 5;
+                const float* aa = reinterpret_cast<const float*>(tt[3]);
+                s += p.sgn * reinterpret_cast<const float*>(tt[2])[i] + (aa ? logf(fabsf(aa[i])) : 0.f);
+            }
+            const float tot = block_sum_256(s, red);
+            if (threadIdx.x == 0) ld[0] = tot * p.hw;
+        }
+    }
+}
+
+// Backward: dWm [K,C,C], dbm [K,C], dld (device scalar) -> dl, du [K,C,C] (zero outside the masks), dlog_s, da, db [K,C].
+__global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const float* __restrict__ W, const float* __restrict__ dWm,
+                                                          const float* __restrict__ dbm, const float* __restrict__ dld, float* __restrict__ dl,
+                                                          float* __restrict__ du, float* __restrict__ dlogs, float* __restrict__ da,
+                                                          float* __restrict__ db) {
+    const int C = p.C, k = blockIdx.y;
+    const long long* t = p.tab + (size_t)k * 5;
+    const float* l = reinterpret_cast<const float*>(t[0]);
+    const float* u = reinterpret_cast<const float*>(t[1]);
+    const float* ls = reinterpret_cast<const float*>(t[2]);
+    const float* a = reinterpret_cast<const float*>(t[3]);
+    const float* b = reinterpret_cast<const float*>(t[4]);
+    const float* sg = p.sign_s + (size_t)k * C;
+    const int* iperm = p.iperm + (size_t)k * C;
+    const float* dWk = dWm + (size_t)k * C * C;
+    const float* dbk = dbm ? dbm + (size_t)k * C : nullptr;
+    const float g = dld ? dld[0] : 0.f;
+    // gradient w.r.t. W (before the ActNorm fold) at row i, column j
+#define TMG_LU_DW(I, J) (p.reverse ? dWk[(I) * C + (J)] / (a ? a[I] : 1.f) : dWk[(I) * C + (J)] * (a ? a[J] : 1.f) + ((dbk && b) ? dbk[I] * b[J] : 0.f))
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < C * C; e += gridDim.x * 256) {
+        const int x = e / C, y = e - x * C;
+        float vl = 0.f, vu = 0.f;
+        if (x > y) {
+            // dlower[x][y] = sum_j M[x][j] upper[y][j], M = P^T dW: M[x][j] = dW[iperm[x]][j]; upper[y][j] = 0 for j < y
+            const int i = iperm[x];
+            for (int j = y; j < C; ++j) vl += TMG_LU_DW(i, j) * lu_upper(u, ls, sg, C, y, j);
+        } else {
+            // dupper[x][y] = sum_r lower[r][x] M[r][y]; lower[r][x] = 0 for r < x
+            for (int r = x; r < C; ++r) vu += lu_lower(l, C, r, x) * TMG_LU_DW(iperm[r], y);
+        }
+        dl[((size_t)k * C + x) * C + y] = vl;
+        du[((size_t)k * C + x) * C + y] = x < y ? vu : 0.f;
+        if (x == y) dlogs[(size_t)k * C + x] = vu * expf(ls[x]) * sg[x] + p.sgn * p.hw * g;
+    }
+    if (blockIdx.x == 0) {
+        const float* Wk = W + (size_t)k * C * C;
+        for (int i = threadIdx.x; i < C; i += 256) {
+            float va = 0.f, vb = 0.f;
+            if (a) {
+                if (p.reverse) {
+                    // Wm = W / a_i, bm = -b_i / a_i
+                    float s = 0.f;
+                    for (int j = 0; j < C; ++j) s += dWk[i * C + j] * Wk[i * C + j];
+                    va = -s / (a[i] * a[i]) + ((dbk && b) ? dbk[i] * b[i] / (a[i] * a[i]) : 0.f) + g * p.hw / a[i];
+                } else {
+                    // Wm = W a_j: da_j = sum_i dWm[i][j] W[i][j]   (index i of this thread plays the role of j)
+                    float s = 0.f;
+                    for (int r = 0; r < C; ++r) s += dWk[r * C + i] * Wk[r * C + i];
+                    va = s + g * p.hw / a[i];
+                }
+            }
+            if (b && dbk) {
+                if (p.reverse) vb = -dbk[i] / (a ? a[i] : 1.f);
+                else {
+                    for (int r = 0; r < C; ++r) vb += Wk[r * C + i] * dbk[r];   // db = W^T dbm
+                }
+            }
+            da[(size_t)k * C + i] = va;
+            db[(size_t)k * C + i] = vb;
+        }
+    }
+#undef TMG_LU_DW
+}
+
+// dims = {K, C, reverse}; fl = {sgn (+1 / -1: sign of the log_s term of the log-det), hw}.  tab: device int64 [K][5]; sign_s [K][C];
+// perm / iperm: device int32 [K][C].  Outputs W, Wm [K,C,C], bm [K,C], ld [1].
+extern "C" int tmg_lu_fold_fwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, void* W, void* Wm, void* bm, void* ld,
+                               const int64_t* dims, const float* fl, hipStream_t st) {
+    LuFoldP p;
+    p.tab = (const long long*)tab; p.sign_s = (const float*)sign_s; p.perm = (const int*)perm; p.iperm = (const int*)iperm;
+    p.K = (int)dims[0]; p.C = (int)dims[1]; p.reverse = (int)dims[2]; p.sgn = fl[0]; p.hw = fl[1];
+    if (p.K < 1 || p.C < 1) return -1;
+    const int gx = (p.C * p.C + 255) / 256 < 64 ? (p.C * p.C + 255) / 256 : 64;
+    hipLaunchKernelGGL(lu_fold_fwd_kernel, dim3(gx, p.K), dim3(256), 0, st, p, (float*)W, (float*)Wm, (float*)bm, (float*)ld);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tmg_lu_fold_bwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W, const void* dWm,
+                               const void* dbm, const void* dld, void* dl, void* du, void* dlogs, void* da, void* db, const int64_t* dims,
+                               const float* fl, hipStream_t st) {
+    LuFoldP p;
+    p.tab = (const long long*)tab; p.sign_s = (const float*)sign_s; p.perm = (const int*)perm; p.iperm = (const int*)iperm;
+    p.K = (int)dims[0]; p.C = (int)dims[1]; p.reverse = (int)dims[2]; p.sgn = fl[0]; p.hw = fl[1];
+    if (p.K < 1 || p.C < 1) return -1;
+    const int gx = (p.C * p.C + 255) / 256 < 64 ? (p.C * p.C + 255) / 256 : 64;
+    hipLaunchKernelGGL(lu_fold_bwd_kernel, dim3(gx, p.K), dim3(256), 0, st, p, (const float*)W, (const float*)dWm, (const float*)dbm,
+                       (const float*)dld, (float*)dl, (float*)du, (float*)dlogs, (float*)da, (float*)db);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

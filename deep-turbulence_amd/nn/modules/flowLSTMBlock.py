@@ -194,6 +194,10 @@ class LSTMFLowBlock(nn.Module):
         convs = [l.conv for l in layers]
         if not all(isinstance(c, InvertibleConv1x1LU) and c.train_sampling == convs[0].train_sampling for c in convs):
             return None
+        ts = convs[0].train_sampling
+        if ((reverse if ts else not reverse) and convs[0].l.is_cuda and all(hasattr(l, 'norm') for l in layers)
+                and os.environ.get("TMG_NO_LU_FOLD_KERNEL") is None):
+            return self._level_mix_hip(layers, convs, reverse, hw)
         st = lambda name: torch.stack([getattr(c, name) for c in convs])  # noqa: E731
         eye = convs[0].eye
         logs = st('log_s')
@@ -221,6 +225,32 @@ class LSTMFLowBlock(nn.Module):
         ld = logs.sum() * hw
         ld = (-ld if ts else ld) + a.abs().log().sum() * hw
         return Wm, bm, ld
+
+    def _level_mix_hip(self, layers, convs, reverse, hw):
+        """The W = P L U direction of _level_mix through tmg_lu_fold_fwd / _bwd (two launches; the parameters are read in place
+        through a cached device pointer table, P as a cached row permutation)."""
+        params = []
+        for l, c in zip(layers, convs):
+            params += [c.l, c.u, c.log_s, l.norm.weight, l.norm.bias]
+        key = tuple(t.data_ptr() for t in params) + tuple(c.p.data_ptr() for c in convs)
+        cache = getattr(self, '_lu_fold_cache', None)
+        if cache is None or cache[0] != key:
+            dev = convs[0].l.device
+            tab = torch.tensor([[t.data_ptr() for t in params[5 * k:5 * k + 5]] for k in range(len(convs))], dtype=torch.int64).to(dev)
+            P = torch.stack([c.p for c in convs])
+            perm = P.argmax(dim=2).to(torch.int32).contiguous()            # P[i, perm[i]] = 1
+            iperm = P.argmax(dim=1).to(torch.int32).contiguous()           # P[iperm[r], r] = 1
+            sign_s = torch.stack([c.sign_s for c in convs]).contiguous()
+            cache = (key, tab, sign_s, perm, iperm)
+            self._lu_fold_cache = cache
+        _, tab, sign_s, perm, iperm = cache
+        ts = convs[0].train_sampling
+        with torch.no_grad():  # the reference's W-cache key (glowConv.py:157,209-212), all layers in one launch
+            torch._foreach_copy_([c.log_s_old for c in convs], [c.log_s for c in convs])
+        K, C = sign_s.shape
+        meta = (tab, sign_s, perm, iperm, 1 if reverse else 0, -1.0 if ts else 1.0, float(hw), K, C)
+        Wm, bm, ld = ops.LevelMixFoldFn.apply(meta, *params)
+        return Wm, bm, ld.view(())
 
     def _fusable(self, lm, xn):
         """The level-fused node needs LU blocks throughout (lm) and >= 1 non-LSTM layer.  Halves that are not 16-byte aligned

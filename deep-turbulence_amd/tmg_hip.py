@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd",
 ]
 
 
@@ -509,6 +509,18 @@ def mix_f16(x, W, bias, y, transposed=False):
     assert W.is_contiguous() and W.shape == (C, C) and y.shape == x.shape
     _chk(lib().tmg_mix_f16(_ptr(x), _d2(x), _ptr(W), _ptr(bias), _ptr(y), _d2(y), _i64(B * Hh * Ww, C, 1 if transposed else 0), _stream()),
          "tmg_mix_f16")
+
+
+def lu_fold_fwd(tab, sign_s, perm, iperm, W, Wm, bm, ld, reverse, sgn, hw):
+    K, C = sign_s.shape
+    _chk(lib().tmg_lu_fold_fwd(_ptr(tab), _ptr(sign_s), _ptr(perm), _ptr(iperm), _ptr(W), _ptr(Wm), _ptr(bm), _ptr(ld), _i64(K, C, reverse),
+                               _flts([sgn, hw]), _stream()), "tmg_lu_fold_fwd")
+
+
+def lu_fold_bwd(tab, sign_s, perm, iperm, W, dWm, dbm, dld, dl, du, dlogs, da, db, reverse, sgn, hw):
+    K, C = sign_s.shape
+    _chk(lib().tmg_lu_fold_bwd(_ptr(tab), _ptr(sign_s), _ptr(perm), _ptr(iperm), _ptr(W), _ptr(dWm), _ptr(dbm), _ptr(dld), _ptr(dl), _ptr(du),
+                               _ptr(dlogs), _ptr(da), _ptr(db), _i64(K, C, reverse), _flts([sgn, hw]), _stream()), "tmg_lu_fold_bwd")
 
 
 def mix_f32(x, W, bias, y, transposed=False):

@@ -780,3 +780,42 @@ class LevelCouplingFn(torch.autograd.Function):
         for k in range(NL):
             grads += [dW1[k], dW2[k], dWz[k], dBz[k], dK[k].reshape(kps[k].shape)]
         return (dcur, Gc, dWm, dbm, None) + tuple(grads)
+
+
+class LevelMixFoldFn(torch.autograd.Function):
+    """ActNorm + PLU folding of all K layers of a level (W = P L U, then the ActNorm scale / shift) as one node: two launches per
+    level (tmg_lu_fold_fwd / _bwd) instead of ~70 tiny torch launches.  Inputs after the meta tuple: per layer l, u, log_s, ActNorm
+    weight, ActNorm bias (the module's own tensors, read through a device pointer table).  Outputs Wm [K,C,C], bm [K,C], ld [1]."""
+
+    @staticmethod
+    def forward(ctx, meta, *params):
+        tab, sign_s, perm, iperm, reverse, sgn, hw, K, C = meta
+        dev = sign_s.device
+        W = torch.empty((K, C, C), device=dev, dtype=torch.float32)
+        Wm = torch.empty((K, C, C), device=dev, dtype=torch.float32)
+        bm = torch.empty((K, C), device=dev, dtype=torch.float32)
+        ld = torch.empty(1, device=dev, dtype=torch.float32)
+        H.lu_fold_fwd(tab, sign_s, perm, iperm, W, Wm, bm, ld, reverse, sgn, hw)
+        ctx.meta = meta
+        ctx.shapes = [t.shape for t in params]
+        ctx.save_for_backward(W, *params)      # params: kept alive (and version-checked) for the pointer table
+        return Wm, bm, ld
+
+    @staticmethod
+    def backward(ctx, dWm, dbm, dld):
+        tab, sign_s, perm, iperm, reverse, sgn, hw, K, C = ctx.meta
+        W = ctx.saved_tensors[0]
+        dev = W.device
+        dl = torch.empty((K, C, C), device=dev, dtype=torch.float32)
+        du = torch.empty((K, C, C), device=dev, dtype=torch.float32)
+        dlogs = torch.empty((K, C), device=dev, dtype=torch.float32)
+        da = torch.empty((K, C), device=dev, dtype=torch.float32)
+        db = torch.empty((K, C), device=dev, dtype=torch.float32)
+        dWm = dWm.contiguous() if dWm is not None else torch.zeros((K, C, C), device=dev, dtype=torch.float32)
+        H.lu_fold_bwd(tab, sign_s, perm, iperm, W, dWm, dbm.contiguous() if dbm is not None else None,
+                      dld.contiguous() if dld is not None else None, dl, du, dlogs, da, db, reverse, sgn, hw)
+        grads = []
+        for k in range(K):
+            sh = ctx.shapes[5 * k:5 * k + 5]
+            grads += [dl[k], du[k], dlogs[k].view(sh[2]), da[k].view(sh[3]), db[k].view(sh[4])]
+        return (None,) + tuple(grads)

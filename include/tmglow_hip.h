@@ -265,6 +265,16 @@ int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void*
  * W^T (the input gradient of the same mix).  C % 4 == 0, C <= 256. */
 int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d, const int64_t* dims,
                 tmg_stream_t st);
+/* Parameter-side folding of one flow level: ActNorm (actNorm.py:66-83) + PLU-parameterised invertible 1x1 conv (glowConv.py:151-161) of all
+ * K layers -> mix matrices Wm [K,C,C], biases bm [K,C], the unfolded W [K,C,C] (kept for the backward) and the scalar log-det ld of all K
+ * mixes; and the backward of that map (dl, du zero outside their triangular masks).  tab: device int64 [K][5] = pointers to the layers'
+ * own l, u, log_s, ActNorm weight, ActNorm bias tensors (the last two null: no ActNorm); sign_s [K][C]; perm / iperm: int32 [K][C], the row
+ * permutation of P and its inverse.  dims = {K, C, reverse}; fl = {sign of the log_s term of the log-det, pixels per image}. */
+int tmg_lu_fold_fwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, void* W, void* Wm, void* bm, void* ld,
+                    const int64_t* dims, const float* fl, tmg_stream_t st);
+int tmg_lu_fold_bwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W, const void* dWm, const void* dbm,
+                    const void* dld, void* dl, void* du, void* dlogs, void* da, void* db, const int64_t* dims, const float* fl, tmg_stream_t st);
+
 /* The same mix in full fp32 (v_mfma_f32_16x16x4_f32) for C <= 128: the stand-alone 1x1 mixes (wide flow levels, ConvLSTM blocks)
  * without the general conv kernel's patch staging and operand-packing launch.  Arguments as tmg_mix_f16. */
 int tmg_mix_f32(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d,

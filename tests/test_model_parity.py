@@ -818,3 +818,43 @@ def test_encoder_dropout_option():
     y, ld, _ = m1.sample(x, st)
     C.loss_reverse(y, ld).backward()
     assert torch.isfinite(y).all() and all(p.grad is None or torch.isfinite(p.grad).all() for p in m1.parameters())
+
+
+@pytest.mark.parametrize("reverse,ts", [(True, True), (False, False), (False, True)])
+def test_lu_fold_kernels_match_torch_folding(reverse, ts):
+    """tmg_lu_fold_fwd / _bwd (ActNorm + PLU folding of a whole level in two launches) against the same folding written with
+    differentiable torch ops in fp64 (the reference's arithmetic: glowConv.py:151-161, actNorm.py:66-83): mix matrices, biases,
+    log-det and every parameter gradient, for the direction that applies W (reverse with train_sampling, the one training uses)
+    and - through the torch path the module keeps for it - the inverse direction."""
+    import os
+    from nn.tmGlow import TMGlow
+    cfg = C.CFG_TINY3
+    C.seed_all(21)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 11, 0.03, 0.2, 0.05)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(8)
+    for blk in m.glow.flow_blocks:
+        for layer in blk.revlayers._modules.values():
+            layer.conv.train_sampling = ts      # (False, False): W is applied in the density direction -> the kernels' forward fold
+        names = [n for n, _ in blk.named_parameters() if n.endswith((".l", ".u", ".log_s", "norm.weight", "norm.bias"))]
+        res = {}
+        for mode in ("hip", "torch"):
+            os.environ.pop("TMG_NO_LU_FOLD_KERNEL", None)
+            if mode == "torch":
+                os.environ["TMG_NO_LU_FOLD_KERNEL"] = "1"
+            blk.zero_grad()
+            Wm, bm, ld = blk._level_mix(reverse, 37)
+            if mode == "hip":
+                gW = torch.randn(Wm.shape, generator=g).to(DEV)
+                gb = torch.randn(bm.shape, generator=g).to(DEV)
+            ((Wm * gW).sum() + (bm * gb).sum() + 0.3 * ld).backward()
+            res[mode] = (Wm.detach().clone(), bm.detach().clone(), ld.detach().clone(), {n: p.grad.detach().clone() for n, p in blk.named_parameters() if n in names})
+        os.environ.pop("TMG_NO_LU_FOLD_KERNEL", None)
+        a, b = res["hip"], res["torch"]
+        for x, y, what in ((a[0], b[0], "Wm"), (a[1], b[1], "bm"), (a[2], b[2], "ld")):
+            assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-6), what
+        assert set(a[3]) == set(b[3]) and len(a[3]) >= 5
+        for n in a[3]:
+            sc = max(float(b[3][n].abs().max()), 1e-6)
+            assert float((a[3][n] - b[3][n]).abs().max()) <= 5e-5 * sc, (n, float((a[3][n] - b[3][n]).abs().max()), sc)
