@@ -712,6 +712,11 @@ struct WinoWP {
     const float* dy; int dy_stride, dy_off;
     float* ws;        // [gx][gy][gz][8 waves][2][CIT][NCO][64 lanes][4] partial sums, then [gx][gy][64] bias partials
     int want_bias;
+    // grouped launch (the per-layer zero-conv weight gradients of a wide flow level): group g = blockIdx.y / bpg reads its own input
+    // segments from gtab[g] ([ngroups][4][4] int64, rows 0-2 = {pointer, pixel stride, channel offset, channels}) and dy channels
+    // [g * dy_goff, + Cout) of the shared tensor; null: one group
+    const long long* gtab;
+    int bpg, dy_goff;
     int tiles_x, tiles_y, ntiles;
 };
 
@@ -731,7 +736,8 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
     const int xi = wave >> 1, par = wave & 1;
-    const int ci0 = (int)blockIdx.z * CIT * 16, co0 = (int)blockIdx.y * NCO * 16;
+    const int grp = p.gtab ? (int)blockIdx.y / p.bpg : 0;
+    const int ci0 = (int)blockIdx.z * CIT * 16, co0 = ((int)blockIdx.y - grp * p.bpg) * NCO * 16;
     // row combination of xi for the input transform: u = x[ra] + sg x[rb]; G' row of xi for dy: e = g0 dy[0] + g1 dy[1]
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sg = xi == 1 ? 1.f : -1.f;
@@ -759,14 +765,23 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
     {
         int cl = ci0 + 4 * xc4;
         if (xc4 < CIT * 4 && cl < p.Cin) {
-            const float* sp = p.in[0].p;
-            int ss = p.in[0].stride, so = p.in[0].off;
-            if (cl >= p.in[0].n) {
-                cl -= p.in[0].n;
-                sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
-                if (cl >= p.in[1].n) {
-                    cl -= p.in[1].n;
-                    sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+            const float* sp0 = p.in[0].p; int ss0 = p.in[0].stride, so0 = p.in[0].off, sn0 = p.in[0].n;
+            const float* sp1 = p.in[1].p; int ss1 = p.in[1].stride, so1 = p.in[1].off, sn1 = p.in[1].n;
+            const float* sp2 = p.in[2].p; int ss2 = p.in[2].stride, so2 = p.in[2].off;
+            if (p.gtab) {
+                const long long* gt = p.gtab + (size_t)grp * 16;
+                sp0 = reinterpret_cast<const float*>(gt[0]); ss0 = (int)gt[1]; so0 = (int)gt[2]; sn0 = (int)gt[3];
+                sp1 = reinterpret_cast<const float*>(gt[4]); ss1 = (int)gt[5]; so1 = (int)gt[6]; sn1 = (int)gt[7];
+                sp2 = reinterpret_cast<const float*>(gt[8]); ss2 = (int)gt[9]; so2 = (int)gt[10];
+            }
+            const float* sp = sp0;
+            int ss = ss0, so = so0;
+            if (cl >= sn0) {
+                cl -= sn0;
+                sp = sp1; ss = ss1; so = so1;
+                if (cl >= sn1) {
+                    cl -= sn1;
+                    sp = sp2; ss = ss2; so = so2;
                 }
             }
             xptr = sp + so + cl;
@@ -783,7 +798,7 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
     const int dc4 = tid & (KD - 1), dpix0 = tid >> KDL;
     constexpr int dstep = NT >> KDL;
     const bool dcv = dc4 < NCO * 4 && co0 + 4 * dc4 < p.Cout;
-    const float* dptr = dcv ? p.dy + p.dy_off + co0 + 4 * dc4 : tmg_zero_page;
+    const float* dptr = dcv ? p.dy + p.dy_off + grp * p.dy_goff + co0 + 4 * dc4 : tmg_zero_page;
     const int dss = dcv ? p.dy_stride : 0;
     float4 xv[UX], dv[UD];
     float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -904,7 +919,8 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
 // 0 adds the result onto dW.  (A single serial walk over all gx slabs per thread left the chip idle for 120 us per launch.)
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
                                                                 int gx, int gy, int gz, int CIT, int NCO, int Cin, int Cout, int cin_dst,
-                                                                int cin_valid, int ci_split, int ci_off0, int ci_off1) {
+                                                                int cin_valid, int ci_split, int ci_off0, int ci_off1, int bpg,
+                                                                long long dw_gstride, int db_gstride) {
     __shared__ float red[3][64][37];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     int r_ = blockIdx.x;
@@ -957,8 +973,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
             for (int k = 0; k < 9; ++k) red[grp - 1][lane][r * 9 + k] = tap[r][k];
     }
     __syncthreads();
+    const int group = by / bpg, cb = by - group * bpg;   // grouped launch: block row by = (group, output-channel block)
+    dW += (size_t)group * dw_gstride;
     if (grp == 0) {
-        const int co = (by * NCO + n) * 16 + li;
+        const int co = (cb * NCO + n) * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = (bz * CIT + i) * 16 + 4 * q + r;
@@ -969,7 +987,8 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
         }
     }
     if (dbias && bz == 0 && i == 0 && n == 0 && threadIdx.x < NCO * 16) {
-        const int c = threadIdx.x, co = by * NCO * 16 + c;
+        dbias += (size_t)group * db_gstride;
+        const int c = threadIdx.x, co = cb * NCO * 16 + c;
         if (co < Cout) {
             const float* wsb = ws + (size_t)gx * gy * gz * 8 * (2 * CIT * NCO) * 256;
             float s_ = 0.f;
@@ -981,7 +1000,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 
 struct WinoWPlan { int CIT, NCO, gx, gy, gz; size_t ws_floats; };
 
-static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, WinoWPlan* pl) {
+static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, int ngroups, WinoWPlan* pl) {
     const int cit = (Cin + 15) >> 4, cot = (Cout + 15) >> 4;
     if (cit < 2 || cot < 2) return -100;
     pl->gz = (cit + 3) / 4;
@@ -990,6 +1009,7 @@ static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, WinoWPlan* pl
     pl->gy = (cot + 3) / 4;
     const int cotg = (cot + pl->gy - 1) / pl->gy;
     pl->NCO = cotg <= 2 ? 2 : (cotg == 3 ? 3 : 4);
+    pl->gy *= ngroups;     // block row = (group, output-channel block)
     const int ntiles = B * ((W + 15) / 16) * ((H + 7) / 8);
     int gx = 256 / (pl->gy * pl->gz);
     if (gx > ntiles / 2) gx = ntiles / 2;
@@ -1002,7 +1022,7 @@ static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, WinoWPlan* pl
 // scratch floats tmg_conv_wino_wgrad wants for dims = {B,H,W,Cin,Cout,...} (0: shape not eligible)
 extern "C" int64_t tmg_conv_wino_wgrad_ws_floats(const int64_t* dims) {
     WinoWPlan pl;
-    if (plan_wino_wgrad((int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], &pl) != 0) return 0;
+    if (plan_wino_wgrad((int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], 1, &pl) != 0) return 0;
     return (int64_t)pl.ws_floats;
 }
 
@@ -1016,12 +1036,9 @@ static int launch_wino_wgrad(const WinoWP& p, const WinoWPlan& pl, hipStream_t s
     return 0;
 }
 
-// dW[Cout][cin_dst][3][3] += sum_pixels act(in)(p + tap) (x) dy(p)  and  dbias += sum dy, for 3x3 / stride-1 / padding-1 convs with
-// >= 32 input and output channels, as Winograd F(3x3, 2x2).  dims = {B,H,W,Cin,Cout,relu_in,pad_replicate,cin_dst,cin_valid,ci_split,
-// ci_off0,ci_off1} (destination mapping as tmg_conv_wgrad); dy_desc = {stride, off}; ws: >= tmg_conv_wino_wgrad_ws_floats(dims) floats.
-// Returns -100 outside the envelope (nothing launched).
-extern "C" int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* dy, const int64_t* dy_desc,
-                                   void* dW, void* dbias, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st) {
+static int wino_wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* dy, const int64_t* dy_desc,
+                           void* dW, void* dbias, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st, const long long* gtab,
+                           int ngroups, int dy_goff, long long dw_gstride, int db_gstride) {
     WinoWP p;
     p.nseg = (int)nseg;
     if (p.nseg < 1 || p.nseg > TMG_MAX_IN_SEG) return -3;
@@ -1041,12 +1058,13 @@ extern "C" int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in
     const int ci_off0 = (int)dims[10], ci_off1 = (int)dims[11];
     if (csum != p.Cin) return -3;
     p.dy = (const float*)dy; p.dy_stride = (int)dy_desc[0]; p.dy_off = (int)dy_desc[1];
-    if (((p.dy_stride | p.dy_off) & 3) || (((uintptr_t)dy) & 15) || (p.Cin & 3) || (p.Cout & 3)) ok = false;
+    if (((p.dy_stride | p.dy_off | dy_goff) & 3) || (((uintptr_t)dy) & 15) || (p.Cin & 3) || (p.Cout & 3)) ok = false;
     WinoWPlan pl;
-    if (!ok || plan_wino_wgrad(p.B, p.Hin, p.Win, p.Cin, p.Cout, &pl) != 0) return -100;
+    if (!ok || plan_wino_wgrad(p.B, p.Hin, p.Win, p.Cin, p.Cout, ngroups, &pl) != 0) return -100;
     if (!ws || (size_t)ws_floats < pl.ws_floats || (((uintptr_t)ws) & 15)) return -100;
     p.ws = (float*)ws;
     p.want_bias = dbias ? 1 : 0;
+    p.gtab = gtab; p.bpg = pl.gy / ngroups; p.dy_goff = dy_goff;
     p.tiles_x = (p.Win + 15) / 16; p.tiles_y = (p.Hin + 7) / 8;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.ntiles <= 0) return 0;
@@ -1056,7 +1074,34 @@ extern "C" int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in
 #undef TMG_WW_CASE
     if (rc != 0) return rc;
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(256), 0, st, (const float*)p.ws, (float*)dW,
-                       (float*)dbias, pl.gx, pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid, ci_split, ci_off0, ci_off1);
+                       (float*)dbias, pl.gx, pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid, ci_split, ci_off0, ci_off1,
+                       p.bpg, dw_gstride, db_gstride);
     TMG_CHECK_LAUNCH();
     return 0;
+}
+
+// dW[Cout][cin_dst][3][3] += sum_pixels act(in)(p + tap) (x) dy(p)  and  dbias += sum dy, for 3x3 / stride-1 / padding-1 convs with
+// >= 32 input and output channels, as Winograd F(3x3, 2x2).  dims = {B,H,W,Cin,Cout,relu_in,pad_replicate,cin_dst,cin_valid,ci_split,
+// ci_off0,ci_off1} (destination mapping as tmg_conv_wgrad); dy_desc = {stride, off}; ws: >= tmg_conv_wino_wgrad_ws_floats(dims) floats.
+// Returns -100 outside the envelope (nothing launched).
+extern "C" int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* dy, const int64_t* dy_desc,
+                                   void* dW, void* dbias, void* ws, int64_t ws_floats, const int64_t* dims, hipStream_t st) {
+    return wino_wgrad_impl(in_ptrs, in_desc, nseg, dy, dy_desc, dW, dbias, ws, ws_floats, dims, st, nullptr, 1, 0, 0, 0);
+}
+
+// `ngroups` identically shaped weight gradients in one launch (the per-layer zero-conv weight gradients of a wide flow level): arguments
+// as tmg_conv_wgrad_grouped without per-group dy tensors - gtab = device table [ngroups][4][4] int64 (rows 0-2: the group's input
+// segments), gdims = {dy channels per group, dW floats per group, dbias floats per group}.  ws: tmg_conv_wino_wgrad_grouped_ws_floats.
+extern "C" int tmg_conv_wino_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* gtab, int64_t ngroups,
+                                           const int64_t* gdims, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, void* ws,
+                                           int64_t ws_floats, const int64_t* dims, hipStream_t st) {
+    if (ngroups < 1 || !gtab) return -3;
+    return wino_wgrad_impl(in_ptrs, in_desc, nseg, dy, dy_desc, dW, dbias, ws, ws_floats, dims, st, (const long long*)gtab, (int)ngroups,
+                           (int)gdims[0], (long long)gdims[1], (int)gdims[2]);
+}
+
+extern "C" int64_t tmg_conv_wino_wgrad_grouped_ws_floats(const int64_t* dims, int64_t ngroups) {
+    WinoWPlan pl;
+    if (plan_wino_wgrad((int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)ngroups, &pl) != 0) return 0;
+    return (int64_t)pl.ws_floats;
 }

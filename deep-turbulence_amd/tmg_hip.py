@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats",
 ]
 
 
@@ -460,6 +460,19 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
         row += ([seg(group_dy[len(rows)])[0], seg(group_dy[len(rows)])[1], 0, 0] if group_dy is not None else [0, 0, 0, 0])
         rows.append(row)
     gtab = _segment_table(rows, dy.device)
+    if (group_dy is None and ksize == 3 and stride == 1 and Cin >= 32 and Cg >= 32 and os.environ.get("TMG_NO_WINOGRAD") is None
+            and os.environ.get("TMG_NO_WINOGRAD_WGRAD") is None):
+        # the wide levels' per-layer zero-conv weight gradients: Winograd F(3x3, 2x2), all layers of the level in one launch
+        wd = _i64(B, Hin, Win, Cin, Cg, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
+        need = lib().tmg_conv_wino_wgrad_grouped_ws_floats(wd, c_i64(G))
+        if need > 0:
+            ws = workspace(need, dy.device)
+            gd = _i64(Cg, dW[0].numel(), dbias[0].numel() if dbias is not None else 0)
+            rc = lib().tmg_conv_wino_wgrad_grouped(ip, idesc, c_i64(n_in), _ptr(gtab), c_i64(G), gd, _ptr(dy), _d2(dy), _ptr(dW), _ptr(dbias),
+                                                   _ptr(ws), c_i64(ws.numel()), wd, _stream())
+            if rc != -100:
+                _chk(rc, "tmg_conv_wino_wgrad_grouped")
+                return True
     dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cg, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
     ws = workspace(lib().tmg_conv_wgrad_grouped_ws_floats(dims, c_i64(G)), dy.device)
     gd = _i64(Cg, dW[0].numel(), dbias[0].numel() if dbias is not None else 0)

@@ -87,6 +87,13 @@ int tmg_conv_wino_narrow(const void* const* in_ptrs, const int64_t* in_desc, int
 int64_t tmg_conv_wino_wgrad_ws_floats(const int64_t* dims);
 int tmg_conv_wino_wgrad(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* dy, const int64_t* dy_desc,
                         void* dW, void* dbias, void* ws, int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
+/* `ngroups` identically shaped Winograd weight gradients in one launch (the per-layer zero-conv weight gradients of a wide flow level):
+ * gtab = device int64 table [ngroups][4][4], rows 0-2 = {pointer, pixel stride, channel offset, channels} of the group's input segments;
+ * group g reads dy channels [g * gdims[0], + Cout), accumulates into dW + g * gdims[1] floats and dbias + g * gdims[2] floats. */
+int64_t tmg_conv_wino_wgrad_grouped_ws_floats(const int64_t* dims, int64_t ngroups);
+int tmg_conv_wino_wgrad_grouped(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* gtab, int64_t ngroups,
+                                const int64_t* gdims, const void* dy, const int64_t* dy_desc, void* dW, void* dbias, void* ws,
+                                int64_t ws_floats, const int64_t* dims, tmg_stream_t st);
 
 /* dW[Cout][Cin][k][k] += scale * sum_pixels act(in)(p*s+tap) (x) dy(p) ; dbias += scale * sum dy.
  * (accumulating: caller zero-fills; per-block partial sums go through the scratch `ws` and a reduce kernel.)  Replaces the autograd weight-gradient of the convs above.
