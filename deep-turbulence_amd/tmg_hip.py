@@ -460,7 +460,7 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
         row += ([seg(group_dy[len(rows)])[0], seg(group_dy[len(rows)])[1], 0, 0] if group_dy is not None else [0, 0, 0, 0])
         rows.append(row)
     gtab = _segment_table(rows, dy.device)
-    if (group_dy is None and ksize == 3 and stride == 1 and Cin >= 32 and Cg >= 32 and os.environ.get("TMG_NO_WINOGRAD") is None
+    if (group_dy is None and ksize == 3 and stride == 1 and Cin >= 20 and Cg >= 32 and os.environ.get("TMG_NO_WINOGRAD") is None
             and os.environ.get("TMG_NO_WINOGRAD_WGRAD") is None):
         # the wide levels' per-layer zero-conv weight gradients: Winograd F(3x3, 2x2), all layers of the level in one launch
         wd = _i64(B, Hin, Win, Cin, Cg, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
