@@ -195,8 +195,7 @@ class LSTMFLowBlock(nn.Module):
         if not all(isinstance(c, InvertibleConv1x1LU) and c.train_sampling == convs[0].train_sampling for c in convs):
             return None
         ts = convs[0].train_sampling
-        if ((reverse if ts else not reverse) and convs[0].l.is_cuda and all(hasattr(l, 'norm') for l in layers)
-                and os.environ.get("TMG_NO_LU_FOLD_KERNEL") is None):
+        if (reverse if ts else not reverse) and convs[0].l.is_cuda and os.environ.get("TMG_NO_LU_FOLD_KERNEL") is None:
             return self._level_mix_hip(layers, convs, reverse, hw)
         st = lambda name: torch.stack([getattr(c, name) for c in convs])  # noqa: E731
         eye = convs[0].eye
@@ -231,12 +230,14 @@ class LSTMFLowBlock(nn.Module):
         through a cached device pointer table, P as a cached row permutation)."""
         params = []
         for l, c in zip(layers, convs):
-            params += [c.l, c.u, c.log_s, l.norm.weight, l.norm.bias]
-        key = tuple(t.data_ptr() for t in params) + tuple(c.p.data_ptr() for c in convs)
+            nm = getattr(l, 'norm', None)       # a block without ActNorm: null pointers (scale 1, shift 0)
+            params += [c.l, c.u, c.log_s, nm.weight if nm is not None else None, nm.bias if nm is not None else None]
+        key = tuple(t.data_ptr() if t is not None else 0 for t in params) + tuple(c.p.data_ptr() for c in convs)
         cache = getattr(self, '_lu_fold_cache', None)
         if cache is None or cache[0] != key:
             dev = convs[0].l.device
-            tab = torch.tensor([[t.data_ptr() for t in params[5 * k:5 * k + 5]] for k in range(len(convs))], dtype=torch.int64).to(dev)
+            tab = torch.tensor([[t.data_ptr() if t is not None else 0 for t in params[5 * k:5 * k + 5]] for k in range(len(convs))],
+                               dtype=torch.int64).to(dev)
             P = torch.stack([c.p for c in convs])
             perm = P.argmax(dim=2).to(torch.int32).contiguous()            # P[i, perm[i]] = 1
             iperm = P.argmax(dim=1).to(torch.int32).contiguous()           # P[iperm[r], r] = 1

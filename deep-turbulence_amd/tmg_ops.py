@@ -797,8 +797,8 @@ class LevelMixFoldFn(torch.autograd.Function):
         ld = torch.empty(1, device=dev, dtype=torch.float32)
         H.lu_fold_fwd(tab, sign_s, perm, iperm, W, Wm, bm, ld, reverse, sgn, hw)
         ctx.meta = meta
-        ctx.shapes = [t.shape for t in params]
-        ctx.save_for_backward(W, *params)      # params: kept alive (and version-checked) for the pointer table
+        ctx.shapes = [t.shape if t is not None else None for t in params]
+        ctx.save_for_backward(W, *[t for t in params if t is not None])      # params: kept alive (and version-checked) for the pointer table
         return Wm, bm, ld
 
     @staticmethod
@@ -817,5 +817,6 @@ class LevelMixFoldFn(torch.autograd.Function):
         grads = []
         for k in range(K):
             sh = ctx.shapes[5 * k:5 * k + 5]
-            grads += [dl[k], du[k], dlogs[k].view(sh[2]), da[k].view(sh[3]), db[k].view(sh[4])]
+            grads += [dl[k], du[k], dlogs[k].view(sh[2]), da[k].view(sh[3]) if sh[3] is not None else None,
+                      db[k].view(sh[4]) if sh[4] is not None else None]
         return (None,) + tuple(grads)
