@@ -278,15 +278,24 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                             const int ax = ox == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : (nu == 1 ? 1 : -1));
                             const int cf = ay * ax;
                             if (cf != 0) {
+                                // packed fp32 adds (v_pk_add_f32: two lanes per instruction); the compiler packs the additions by itself
+                                // but issues the subtractions as scalar v_sub_f32, hence the explicit form with negated second operand
+                                typedef float f2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
                                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                                        for (int r = 0; r < 4; ++r) {
-                                            if (cf > 0) Y[oy * 2 + ox][m][n][r] += acc[m][n][r];
-                                            else Y[oy * 2 + ox][m][n][r] -= acc[m][n][r];
+                                    for (int n = 0; n < 2; ++n) {
+                                        f32x4& y_ = Y[oy * 2 + ox][m][n];
+                                        if (cf > 0) {
+                                            y_ += acc[m][n];
+                                        } else {
+                                            f2_t ylo = __builtin_shufflevector(y_, y_, 0, 1), yhi = __builtin_shufflevector(y_, y_, 2, 3);
+                                            const f2_t alo = __builtin_shufflevector(acc[m][n], acc[m][n], 0, 1), ahi = __builtin_shufflevector(acc[m][n], acc[m][n], 2, 3);
+                                            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ylo) : "v"(ylo), "v"(alo));
+                                            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(yhi) : "v"(yhi), "v"(ahi));
+                                            y_ = __builtin_shufflevector(ylo, yhi, 0, 1, 2, 3);
                                         }
+                                    }
                                 // pin the update HERE: left alone the compiler sinks all 16 positions' additions below the last
                                 // position and keeps 16 x 16 accumulator registers alive (300 spilled registers)
                                 asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][0][1]), "+v"(Y[oy * 2 + ox][1][0]), "+v"(Y[oy * 2 + ox][1][1]));
