@@ -48,7 +48,7 @@ struct CplFP {
 
 // CT: 16-channel output tiles (C <= 16 CT); K4: input-channel quads of the zero conv = ch/4 + 1 (the last quad is d1, d2, 0, 0)
 template <int CT, int K4>
-__global__ __launch_bounds__(256, CT == 1 ? 3 : 1) void cpl_fwd_kernel(CplFP p) {
+__global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) {
     constexpr int CH4 = K4 - 1, CHP = 2 * CH4;        // x1 channel quads / pairs
     constexpr int PW = 18, PP = PW * PW;              // staged patch (tile + halo 1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -362,7 +362,7 @@ struct CplBP {
 
 // CT = 16-channel tiles of C; MT = 16-channel tiles of the dgrad output (ch + 2 channels); KS = C / 4 channel quads of dhh
 template <int CT, int MT, int KS>
-__global__ __launch_bounds__(256, CT == 1 ? 2 : 1) void cpl_bwd_kernel(CplBP p) {
+__global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) {
     constexpr int PW = 18, PP = PW * PW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int C = p.C, ch = C >> 1;
