@@ -144,7 +144,8 @@ def main():
     ap.add_argument("--direction", default="sample", choices=["sample", "forward"],
                     help="sample: the generative direction the reference trains through (the metric); forward: density direction "
                          "forward(x, y) with loss -mean(logp)/(noc*H*W), reported beside it (SURVEY 8-D)")
-    ap.add_argument("--adam", default="foreach", choices=["fused", "foreach"], help="torch implementation of the Adam update")
+    ap.add_argument("--adam", default="hip", choices=["fused", "foreach", "hip"],
+                    help="implementation of the Adam update: torch foreach (what main.py constructs), torch fused, or tmg_optim.HipAdam (one launch)")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in one hipGraph and replay it (N=1 only)")
     ap.add_argument("--mix", default=None, choices=["f32", "f16"],
                     help="arithmetic of the 1x1 channel mixes: f32 MFMA (default) or fp16 operands / fp32 accumulation (default for "
@@ -172,8 +173,12 @@ def main():
     use_graph = args.graph and world == 1
     # the reference's optimizer (main.py:78: Adam, weight decay 1e-8, amsgrad); `fused` = torch's single-kernel multi-tensor
     # implementation of the same update (about 100 launches per step fewer than the default foreach one)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True, capturable=use_graph,
-                           fused=(args.adam == "fused") or None)
+    if args.adam == "hip" and not use_graph:
+        from tmg_optim import HipAdam       # the same update, one launch for all ~1 000 parameter tensors
+        opt = HipAdam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True, capturable=use_graph,
+                               fused=(args.adam == "fused") or None)
     Hin, Win = cfg["_in_hw"]
     up = cfg["_up"]
     g = torch.Generator().manual_seed(12345 + rank)
@@ -316,7 +321,7 @@ def main():
                args.config, "sample()" if args.direction == "sample" else "forward(x,y)", Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
                "global_batch": B * world, "parallelism": "dp%d" % world, "world_size_observed": world,
                "backend": (torch.distributed.get_backend() if world > 1 else None), "rank0_device": torch.cuda.get_device_name(dev) + " cuda:%d" % local,
-               "mix_precision": mix, "optimizer": "Adam(amsgrad, wd 1e-8, %s)" % args.adam, "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
+               "mix_precision": mix, "optimizer": "Adam(amsgrad, wd 1e-8): %s" % {"hip": "tmg_optim.HipAdam, one launch for all parameters (same update as torch.optim.Adam)", "foreach": "torch.optim.Adam (foreach)", "fused": "torch.optim.Adam (fused)"}[args.adam if not use_graph else "foreach"], "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
            "peak_mem_gb": round(peak_gb, 2), "roofline": roof}
     if hbm:
         # bandwidth-bound kernel classes: algorithmic HBM bytes / HIP-event time on the launch stream, against the 8 TB/s HBM3E peak

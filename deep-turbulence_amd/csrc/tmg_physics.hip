@@ -308,3 +308,53 @@ extern "C" int tmg_phys_bwd_dev(const void* y, const void* target, const void* m
     TMG_CHECK_LAUNCH();
     return 0;
 }
+
+// =================================================================================================================================
+// Adam / AMSGrad update of ALL parameters in one launch (the trainer's optimizer step, reference main.py:78: Adam, weight decay 1e-8,
+// amsgrad): torch's multi-tensor implementations walk ~1 000 small tensors in ~100 launches (1.4 ms per step at config M); the update
+// itself moves 36 bytes per parameter (190 MB: ~40 us).  tab: device int64 [n][5] = pointers (param, grad, exp_avg, exp_avg_sq,
+// max_exp_avg_sq); chunks: device int32 [nchunks][3] = (tensor, first element, elements) covering every tensor in pieces of <= 4096.
+// Same arithmetic and operation order as torch.optim.Adam (single-tensor form):
+//   g += wd p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  vmax = max(vmax, v);  p -= (lr / bc1) m / (sqrt(vmax) / sqrt(bc2) + eps)
+// =================================================================================================================================
+__global__ __launch_bounds__(256) void adam_step_kernel(const long long* __restrict__ tab, const int* __restrict__ chunks, int nchunks,
+                                                        float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, float omb1,
+                                                        float omb2, int amsgrad) {
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int t = chunks[3 * c], e0 = chunks[3 * c + 1], n = chunks[3 * c + 2];
+        float* p = reinterpret_cast<float*>(tab[5 * t]) + e0;
+        const float* g = reinterpret_cast<const float*>(tab[5 * t + 1]) + e0;
+        float* m = reinterpret_cast<float*>(tab[5 * t + 2]) + e0;
+        float* v = reinterpret_cast<float*>(tab[5 * t + 3]) + e0;
+        float* vm = reinterpret_cast<float*>(tab[5 * t + 4]) + e0;
+        const float step_size = lr / bc1;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float gi = g[i];
+            const float pi = p[i];
+            if (wd != 0.f) gi = fmaf(wd, pi, gi);
+            const float mi = m[i] + (gi - m[i]) * omb1;                // torch: exp_avg.lerp_(grad, 1 - beta1); 1 - beta formed in double on the host
+            const float vi = b2 * v[i] + omb2 * (gi * gi);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+            m[i] = mi; v[i] = vi;
+            float den;
+            if (amsgrad) {
+                const float vx = fmaxf(vm[i], vi);
+                vm[i] = vx;
+                den = sqrtf(vx) / bc2s + eps;
+            } else {
+                den = sqrtf(vi) / bc2s + eps;
+            }
+            p[i] = pi - step_size * (mi / den);
+        }
+    }
+}
+
+// fl = {lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrt(bias_correction2), 1 - beta1, 1 - beta2}; dims = {nchunks, amsgrad}
+extern "C" int tmg_adam_step(const void* tab, const void* chunks, const int64_t* dims, const float* fl, hipStream_t st) {
+    const int nchunks = (int)dims[0];
+    if (nchunks <= 0) return 0;
+    const int grid = nchunks < 4096 ? nchunks : 4096;
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, st, (const long long*)tab, (const int*)chunks, nchunks, fl[0], fl[1], fl[2],
+                       fl[3], fl[4], fl[5], fl[6], fl[7], fl[8], (int)dims[1]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
 ]
 
 
@@ -534,6 +534,12 @@ def lu_fold_bwd(tab, sign_s, perm, iperm, W, dWm, dbm, dld, dl, du, dlogs, da, d
     K, C = sign_s.shape
     _chk(lib().tmg_lu_fold_bwd(_ptr(tab), _ptr(sign_s), _ptr(perm), _ptr(iperm), _ptr(W), _ptr(dWm), _ptr(dbm), _ptr(dld), _ptr(dl), _ptr(du),
                                _ptr(dlogs), _ptr(da), _ptr(db), _i64(K, C, reverse), _flts([sgn, hw]), _stream()), "tmg_lu_fold_bwd")
+
+
+def adam_step(tab, chunks, nchunks, lr, b1, b2, eps, wd, bc1, bc2s, amsgrad):
+    """One launch for the Adam / AMSGrad update of every parameter (tmg_adam_step): tab int64 [n][5] pointers, chunks int32 [nchunks][3]."""
+    _chk(lib().tmg_adam_step(_ptr(tab), _ptr(chunks), _i64(nchunks, 1 if amsgrad else 0), _flts([lr, b1, b2, eps, wd, bc1, bc2s, 1.0 - b1, 1.0 - b2]), _stream()),
+         "tmg_adam_step")
 
 
 def mix_f32(x, W, bias, y, transposed=False):

@@ -272,6 +272,12 @@ int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void*
  * W^T (the input gradient of the same mix).  C % 4 == 0, C <= 256. */
 int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d, const int64_t* dims,
                 tmg_stream_t st);
+/* The trainer's optimizer step (main.py:78: Adam, weight decay 1e-8, amsgrad) for all parameters in one launch.  tab: device int64 [n][5] =
+ * pointers (param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq); chunks: device int32 [nchunks][3] = (tensor, first element, elements <= 4096);
+ * dims = {nchunks, amsgrad}; fl = {lr, beta1, beta2, eps, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t), 1 - beta1, 1 - beta2}.  Arithmetic and order of
+ * torch.optim.Adam's single-tensor form. */
+int tmg_adam_step(const void* tab, const void* chunks, const int64_t* dims, const float* fl, tmg_stream_t st);
+
 /* Parameter-side folding of one flow level: ActNorm (actNorm.py:66-83) + PLU-parameterised invertible 1x1 conv (glowConv.py:151-161) of all
  * K layers -> mix matrices Wm [K,C,C], biases bm [K,C], the unfolded W [K,C,C] (kept for the backward) and the scalar log-det ld of all K
  * mixes; and the backward of that map (dl, du zero outside their triangular masks).  tab: device int64 [K][5] = pointers to the layers'

@@ -542,3 +542,29 @@ def test_mix_f32_kernel(C_, npix, slice_of):
         _close(y, ref, tol=2e-6, what="mix_f32 C=%d transposed=%d" % (C_, transposed))
         if slice_of:
             assert bool((obuf[..., C_:] == 7.0).all()), "wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("amsgrad,wd", [(True, 1e-8), (False, 0.0), (True, 0.05)])
+def test_hip_adam_matches_torch_adam(amsgrad, wd):
+    """tmg_optim.HipAdam (one launch for all parameters) against torch.optim.Adam over four steps on tensors of assorted sizes
+    (scalar, odd lengths, several 4096-element chunks): parameters and all three state tensors; the state dict loads across."""
+    from tmg_optim import HipAdam
+    g = torch.Generator().manual_seed(17)
+    shapes = [(1,), (7,), (33, 5), (4096,), (3, 4097), (16, 16, 3, 3), (1, 1, 1, 1), (20000,)]
+    pa = [torch.randn(s_, generator=g).to(DEV).requires_grad_(True) for s_ in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = HipAdam(pa, lr=3e-3, weight_decay=wd, amsgrad=amsgrad)
+    ob = torch.optim.Adam(pb, lr=3e-3, weight_decay=wd, amsgrad=amsgrad, foreach=False)
+    for it in range(4):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (10.0 ** (it - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        _close(a, b.detach().double(), tol=2e-6, what="parameter")
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 4
+        for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
+            _close(sa[k], sb[k].double(), tol=2e-6, what=k)
+    ob.load_state_dict(oa.state_dict())     # same schema
