@@ -1420,8 +1420,9 @@ struct LuFoldP {
 };
 
 __device__ __forceinline__ float lu_lower(const float* l, int C, int r, int k) { return k < r ? l[r * C + k] : (k == r ? 1.f : 0.f); }
-__device__ __forceinline__ float lu_upper(const float* u, const float* ls, const float* sg, int C, int k, int j) {
-    return k < j ? u[k * C + j] : (k == j ? expf(ls[k]) * sg[k] + 0.01f : 0.f);
+// diag: exp(log_s) sign_s + 0.01 per channel, staged in LDS once per block (an expf per inner-loop term made the kernels 3x slower)
+__device__ __forceinline__ float lu_upper(const float* u, const float* diag, int C, int k, int j) {
+    return k < j ? u[k * C + j] : (k == j ? diag[k] : 0.f);
 }
 
 __global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __restrict__ W, float* __restrict__ Wm, float* __restrict__ bm,
@@ -1435,13 +1436,20 @@ __global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __re
     const float* b = reinterpret_cast<const float*>(t[4]);
     const float* sg = p.sign_s + (size_t)k * C;
     const int* perm = p.perm + (size_t)k * C;
+    __shared__ float diag[256], sa[256];
+    for (int i = threadIdx.x; i < C; i += 256) {
+        diag[i] = expf(ls[i]) * sg[i] + 0.01f;
+        sa[i] = a ? (p.reverse ? 1.f / a[i] : a[i]) : 1.f;
+    }
+    __syncthreads();
     for (int e = blockIdx.x * 256 + threadIdx.x; e < C * C; e += gridDim.x * 256) {
         const int i = e / C, j = e - i * C, r = perm[i];
-        float acc = 0.f;
-        const int kmax = min(r, j);
-        for (int q = 0; q <= kmax; ++q) acc += lu_lower(l, C, r, q) * lu_upper(u, ls, sg, C, q, j);
+        // row r of lower times column j of upper: terms q < min(r, j) are plain products, the last one involves a unit / diagonal entry
+        const int kmin = min(r, j);
+        float acc = r < j ? u[r * C + j] : (r == j ? diag[j] : l[r * C + j] * diag[j]);
+        for (int q = 0; q < kmin; ++q) acc = fmaf(l[r * C + q], u[q * C + j], acc);
         W[((size_t)k * C + i) * C + j] = acc;
-        Wm[((size_t)k * C + i) * C + j] = p.reverse ? acc / (a ? a[i] : 1.f) : acc * (a ? a[j] : 1.f);
+        Wm[((size_t)k * C + i) * C + j] = acc * (p.reverse ? sa[i] : sa[j]);
     }
     if (blockIdx.x == 0) {
         // biases need whole rows of W: recomputed here from the factors (C <= 256: a few thousand flops per thread)
@@ -1455,7 +1463,7 @@ __global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __re
                     for (int j = 0; j < C; ++j) {
                         float acc = 0.f;
                         const int kmax = min(r, j);
-                        for (int q = 0; q <= kmax; ++q) acc += lu_lower(l, C, r, q) * lu_upper(u, ls, sg, C, q, j);
+                        for (int q = 0; q <= kmax; ++q) acc += lu_lower(l, C, r, q) * lu_upper(u, diag, C, q, j);
                         v += acc * b[j];
                     }
                 }
@@ -1495,22 +1503,32 @@ __global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const float
     const float* dWk = dWm + (size_t)k * C * C;
     const float* dbk = dbm ? dbm + (size_t)k * C : nullptr;
     const float g = dld ? dld[0] : 0.f;
+    __shared__ float diag[256], sa[256], sb[256], sdb[256];
+    for (int i = threadIdx.x; i < C; i += 256) {
+        diag[i] = expf(ls[i]) * sg[i] + 0.01f;
+        sa[i] = a ? (p.reverse ? 1.f / a[i] : a[i]) : 1.f;
+        sb[i] = (!p.reverse && b && dbk) ? b[i] : 0.f;
+        sdb[i] = (!p.reverse && b && dbk) ? dbk[i] : 0.f;
+    }
+    __syncthreads();
     // gradient w.r.t. W (before the ActNorm fold) at row i, column j
-#define TMG_LU_DW(I, J) (p.reverse ? dWk[(I) * C + (J)] / (a ? a[I] : 1.f) : dWk[(I) * C + (J)] * (a ? a[J] : 1.f) + ((dbk && b) ? dbk[I] * b[J] : 0.f))
+#define TMG_LU_DW(I, J) (p.reverse ? dWk[(I) * C + (J)] * sa[I] : fmaf(dWk[(I) * C + (J)], sa[J], sdb[I] * sb[J]))
     for (int e = blockIdx.x * 256 + threadIdx.x; e < C * C; e += gridDim.x * 256) {
         const int x = e / C, y = e - x * C;
         float vl = 0.f, vu = 0.f;
         if (x > y) {
             // dlower[x][y] = sum_j M[x][j] upper[y][j], M = P^T dW: M[x][j] = dW[iperm[x]][j]; upper[y][j] = 0 for j < y
             const int i = iperm[x];
-            for (int j = y; j < C; ++j) vl += TMG_LU_DW(i, j) * lu_upper(u, ls, sg, C, y, j);
+            vl = TMG_LU_DW(i, y) * diag[y];
+            for (int j = y + 1; j < C; ++j) vl = fmaf(TMG_LU_DW(i, j), u[y * C + j], vl);
         } else {
             // dupper[x][y] = sum_r lower[r][x] M[r][y]; lower[r][x] = 0 for r < x
-            for (int r = x; r < C; ++r) vu += lu_lower(l, C, r, x) * TMG_LU_DW(iperm[r], y);
+            vu = TMG_LU_DW(iperm[x], y);
+            for (int r = x + 1; r < C; ++r) vu = fmaf(l[r * C + x], TMG_LU_DW(iperm[r], y), vu);
         }
         dl[((size_t)k * C + x) * C + y] = vl;
         du[((size_t)k * C + x) * C + y] = x < y ? vu : 0.f;
-        if (x == y) dlogs[(size_t)k * C + x] = vu * expf(ls[x]) * sg[x] + p.sgn * p.hw * g;
+        if (x == y) dlogs[(size_t)k * C + x] = vu * (diag[x] - 0.01f) + p.sgn * p.hw * g;
     }
     if (blockIdx.x == 0) {
         const float* Wk = W + (size_t)k * C * C;
