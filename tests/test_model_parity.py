@@ -805,7 +805,8 @@ def test_encoder_dropout_option():
     y0, ld0, _ = m0.sample(x, st)
     torch.manual_seed(3)
     y1, ld1, _ = m1.sample(x, st)
-    assert torch.equal(y0, y1) and torch.equal(ld0, ld1)
+    # (the per-sample log-det is accumulated with float atomics: equal up to the order of the additions)
+    assert torch.equal(y0, y1) and torch.allclose(ld0, ld1, rtol=2e-6, atol=0)
     m1.train()
     # the mask semantics on one dense layer: each sample's new channels are either zero or 2x the rate-0 values
     layer1 = m1.encoder.encoding_blocks[0][-1].denselayer1
