@@ -6,6 +6,7 @@ three steps against torch's).  torch's multi-tensor implementations walk the mod
 (1.4 ms per step at the metric configuration); the update itself moves 36 bytes per parameter (~40 us).  Optional: the trainer takes
 whatever optimizer main.py constructs."""
 import torch
+from torch.optim.adam import adam as _torch_adam
 
 import tmg_hip as H
 
@@ -44,7 +45,7 @@ class HipAdam(torch.optim.Adam):
                   and not group.get("maximize", False) and not group.get("capturable", False) and not group.get("differentiable", False)
                   and len({float(s) for s in steps[:1] + steps[-1:]}) == 1)
             if not ok:   # anything unusual: torch's own single-tensor path on this group (same state)
-                torch.optim.adam.adam(params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps, amsgrad=group["amsgrad"], has_complex=False,
+                _torch_adam(params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps, amsgrad=group["amsgrad"], has_complex=False,
                                       beta1=beta1, beta2=beta2, lr=group["lr"], weight_decay=group["weight_decay"], eps=group["eps"],
                                       maximize=group.get("maximize", False), foreach=False, capturable=False, differentiable=False,
                                       fused=False, grad_scale=None, found_inf=None, decoupled_weight_decay=False)

@@ -97,3 +97,28 @@ def test_zero_padded_channel_layout_is_exact():
             y = x @ W[k].t() + b[k]
             assert torch.allclose(B._unpad_x(yp, ch, pad), y, atol=1e-6)
             assert float(yp[..., ch:ch + pad].abs().max()) == 0.0 and float(yp[..., 2 * ch + pad:].abs().max()) == 0.0
+
+
+def test_hip_adam_falls_back_to_torch_off_device():
+    """tmg_optim.HipAdam on tensors the one-launch kernel does not take (here: CPU tensors) runs torch's own single-tensor Adam on
+    the same state - same numbers as torch.optim.Adam, same state-dict schema."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deep-turbulence_amd"))
+    from tmg_optim import HipAdam
+    g = torch.Generator().manual_seed(3)
+    pa = [torch.randn(s, generator=g).requires_grad_(True) for s in [(5,), (3, 4), (2, 2, 3, 3)]]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = HipAdam(pa, lr=1e-2, weight_decay=1e-8, amsgrad=True)
+    ob = torch.optim.Adam(pb, lr=1e-2, weight_decay=1e-8, amsgrad=True, foreach=False)
+    for _ in range(3):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+        assert set(oa.state[a]) == set(ob.state[b]) and float(oa.state[a]["step"]) == 3
+    ob.load_state_dict(oa.state_dict())
