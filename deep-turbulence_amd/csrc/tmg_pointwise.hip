@@ -1487,8 +1487,11 @@ __global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __re
 }
 
 // Backward: dWm [K,C,C], dbm [K,C], dld (device scalar) -> dl, du [K,C,C] (zero outside the masks), dlog_s, da, db [K,C].
+// dWt / dbt (optional): the last layer's upstream gradients live in tensors of their own ([C,C] / [C]); dWm / dbm then hold the
+// first K - 1 layers (the level-fused node consumes layers 0..K-2 as one slice, the ConvLSTM layer takes the last one).
 __global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const float* __restrict__ W, const float* __restrict__ dWm,
-                                                          const float* __restrict__ dbm, const float* __restrict__ dld, float* __restrict__ dl,
+                                                          const float* __restrict__ dbm, const float* __restrict__ dWt,
+                                                          const float* __restrict__ dbt, const float* __restrict__ dld, float* __restrict__ dl,
                                                           float* __restrict__ du, float* __restrict__ dlogs, float* __restrict__ da,
                                                           float* __restrict__ db) {
     const int C = p.C, k = blockIdx.y;
@@ -1500,8 +1503,9 @@ __global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const float
     const float* b = reinterpret_cast<const float*>(t[4]);
     const float* sg = p.sign_s + (size_t)k * C;
     const int* iperm = p.iperm + (size_t)k * C;
-    const float* dWk = dWm + (size_t)k * C * C;
-    const float* dbk = dbm ? dbm + (size_t)k * C : nullptr;
+    const bool tail = dWt != nullptr && k == p.K - 1;
+    const float* dWk = tail ? dWt : dWm + (size_t)k * C * C;
+    const float* dbk = tail ? dbt : (dbm ? dbm + (size_t)k * C : nullptr);
     const float g = dld ? dld[0] : 0.f;
     __shared__ float diag[256], sa[256], sb[256], sdb[256];
     for (int i = threadIdx.x; i < C; i += 256) {
@@ -1574,16 +1578,117 @@ extern "C" int tmg_lu_fold_fwd(const void* tab, const void* sign_s, const void* 
     return 0;
 }
 
-extern "C" int tmg_lu_fold_bwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W, const void* dWm,
-                               const void* dbm, const void* dld, void* dl, void* du, void* dlogs, void* da, void* db, const int64_t* dims,
-                               const float* fl, hipStream_t st) {
+extern "C" int tmg_lu_fold_bwd_split(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W,
+                                     const void* dWm, const void* dbm, const void* dWm_tail, const void* dbm_tail, const void* dld, void* dl,
+                                     void* du, void* dlogs, void* da, void* db, const int64_t* dims, const float* fl, hipStream_t st) {
     LuFoldP p;
     p.tab = (const long long*)tab; p.sign_s = (const float*)sign_s; p.perm = (const int*)perm; p.iperm = (const int*)iperm;
     p.K = (int)dims[0]; p.C = (int)dims[1]; p.reverse = (int)dims[2]; p.sgn = fl[0]; p.hw = fl[1];
     if (p.K < 1 || p.C < 1) return -1;
     const int gx = (p.C * p.C + 255) / 256 < 64 ? (p.C * p.C + 255) / 256 : 64;
+    if (!dWm && !(dWm_tail && p.K == 1)) return -1;
     hipLaunchKernelGGL(lu_fold_bwd_kernel, dim3(gx, p.K), dim3(256), 0, st, p, (const float*)W, (const float*)dWm, (const float*)dbm,
-                       (const float*)dld, (float*)dl, (float*)du, (float*)dlogs, (float*)da, (float*)db);
+                       (const float*)dWm_tail, (const float*)dbm_tail, (const float*)dld, (float*)dl, (float*)du, (float*)dlogs, (float*)da,
+                       (float*)db);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tmg_lu_fold_bwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W, const void* dWm,
+                               const void* dbm, const void* dld, void* dl, void* du, void* dlogs, void* da, void* db, const int64_t* dims,
+                               const float* fl, hipStream_t st) {
+    return tmg_lu_fold_bwd_split(tab, sign_s, perm, iperm, W, dWm, dbm, nullptr, nullptr, dld, dl, du, dlogs, da, db, dims, fl, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Parameter-gradient epilogue of a level's fused coupling node (LevelCouplingFn.backward), one launch for all NL layers:
+//   dK_k   = (<Wz_k, dWz_k> + <bz_k, dBz_k>) [-4 <= kappa_k <= ln 4]      (homogeneity of the zero conv in (W, b); flowUtils.py:104-106;
+//            the two inner products nearly cancel for small gradients, hence fp64 accumulation)
+//   dW1_k[0, j]   += tmpX_k[0, j] (j < ch),  tmpC_k[0, j - ch] (ch <= j < cin)
+//   dW2_k[0, j]   += tmpX_k[1, j] (j < ch),  tmpC_k[1, j - ch] (ch <= j < cin),  tmpX_k[1, ch] (j = cin: the d1 input row)
+// tmpX [NL,4,ch+4,3,3] / tmpC [NL,4,Cc,3,3]: the grouped weight-gradient launches' 4-row results (rows 0 / 1 = growth layers 1 / 2).
+// acc / cnt: zero-initialised fp64 sums and arrival counters per layer (the last of the S blocks of a layer writes dK).
+struct LevelFinP {
+    const float *Wz, *dWz, *Bz, *dBz, *Kp, *tmpX, *tmpC;
+    float *dW1, *dW2, *dK;
+    double* acc;
+    unsigned* cnt;
+    int NL, C, ch, Cc, S;
+};
+
+__global__ __launch_bounds__(256) void level_finish_kernel(LevelFinP p) {
+    const int k = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int cin = p.ch + p.Cc;
+    const size_t nz = (size_t)p.C * (cin + 2) * 9;
+    const float* w = p.Wz + (size_t)k * nz;
+    const float* g = p.dWz + (size_t)k * nz;
+    double a = 0.0;
+    if ((nz & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g)) & 15) == 0) {
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        for (size_t i = (size_t)s * 256 + tid; i < nz / 4; i += (size_t)p.S * 256) {
+            const float4 x = w4[i], y = g4[i];
+            a += (double)x.x * (double)y.x + (double)x.y * (double)y.y + (double)x.z * (double)y.z + (double)x.w * (double)y.w;
+        }
+    } else {
+        for (size_t i = (size_t)s * 256 + tid; i < nz; i += (size_t)p.S * 256) a += (double)w[i] * (double)g[i];
+    }
+    if (s == 0) {
+        for (int i = tid; i < p.C; i += 256) a += (double)p.Bz[(size_t)k * p.C + i] * (double)p.dBz[(size_t)k * p.C + i];
+    }
+    if (s == p.S - 1) {
+        // scatter of the grouped launches' rows into the native weight-gradient layout
+        const float* tx = p.tmpX ? p.tmpX + (size_t)k * 4 * (p.ch + 4) * 9 : nullptr;
+        const float* tc = p.tmpC ? p.tmpC + (size_t)k * 4 * p.Cc * 9 : nullptr;
+        float* d1 = p.dW1 + (size_t)k * cin * 9;
+        float* d2 = p.dW2 + (size_t)k * (cin + 1) * 9;
+        for (int e = tid; e < (cin + 1) * 9; e += 256) {
+            const int j = e / 9, t = e - j * 9;
+            float v1 = 0.f, v2 = 0.f;
+            if (j < p.ch) {
+                if (tx) { v1 = tx[j * 9 + t]; v2 = tx[((p.ch + 4) + j) * 9 + t]; }
+            } else if (j < cin) {
+                if (tc) { v1 = tc[(j - p.ch) * 9 + t]; v2 = tc[(p.Cc + (j - p.ch)) * 9 + t]; }
+            } else if (tx) {
+                v2 = tx[((p.ch + 4) + p.ch) * 9 + t];
+            }
+            if (j < cin) d1[e] += v1;
+            d2[e] += v2;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    __shared__ double part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = part[0] + part[1] + part[2] + part[3];
+        unsafeAtomicAdd(p.acc + k, tot);
+        __threadfence();
+        if (atomicAdd(p.cnt + k, 1u) == (unsigned)p.S - 1) {
+            __threadfence();
+            const double sum = unsafeAtomicAdd(p.acc + k, 0.0);
+            const float kp = p.Kp[k];
+            p.dK[k] = (kp >= -4.0f && kp <= 1.3862943611198906f) ? (float)sum : 0.f;
+        }
+    }
+}
+
+// dims = {NL, C, ch, Cc}.  tmpX / tmpC may be null (nothing to scatter from that source).  ws: >= 4 * NL zero-initialised floats,
+// 8-byte aligned.
+extern "C" int tmg_level_finish(const void* Wz, const void* dWz, const void* Bz, const void* dBz, const void* Kp, const void* tmpX,
+                                const void* tmpC, void* dW1, void* dW2, void* dK, void* ws, const int64_t* dims, hipStream_t st) {
+    LevelFinP p;
+    p.Wz = (const float*)Wz; p.dWz = (const float*)dWz; p.Bz = (const float*)Bz; p.dBz = (const float*)dBz; p.Kp = (const float*)Kp;
+    p.tmpX = (const float*)tmpX; p.tmpC = (const float*)tmpC; p.dW1 = (float*)dW1; p.dW2 = (float*)dW2; p.dK = (float*)dK;
+    p.NL = (int)dims[0]; p.C = (int)dims[1]; p.ch = (int)dims[2]; p.Cc = (int)dims[3];
+    if (p.NL < 1 || p.C < 1 || !ws || ((uintptr_t)ws & 7)) return -1;
+    p.acc = (double*)ws;
+    p.cnt = (unsigned*)((float*)ws + 2 * (size_t)p.NL);
+    const size_t nz = (size_t)p.C * (p.ch + p.Cc + 2) * 9;
+    int S = (int)((nz / 4 + 256 * 8 - 1) / (256 * 8));
+    p.S = S < 1 ? 1 : (S > 32 ? 32 : S);
+    hipLaunchKernelGGL(level_finish_kernel, dim3(p.S, p.NL), dim3(256), 0, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -69,8 +69,12 @@ class LSTMAffineCouplingLayer(nn.Module):
         float4-addressable segments and the padding channels of the result stay exactly zero."""
         chp = xn.shape[3] // 2
         db, zc = self.dense_nn.dense_block, self.out_conv.zero_conv
+        if xn.requires_grad and torch.is_grad_enabled():
+            xn, x1 = ops.LeadingChannelsFn.apply(xn, chp)     # the slice's gradient joins the whole tensor's in place
+        else:
+            x1 = xn[..., :chp]
         if pad == 0:
-            out, h_next, c_next = self.resid_lstm.run([xn[..., :chp], condn], state)
+            out, h_next, c_next = self.resid_lstm.run([x1, condn], state)
             y, ld = ops.CouplingTailFn.apply(xn, out, db.denselayer1.conv1.weight, db.denselayer2.conv1.weight, zc.conv.weight,
                                              zc.conv.bias, zc.scale, reverse, 1)
             return y, ld, (h_next, c_next)
@@ -79,7 +83,6 @@ class LSTMAffineCouplingLayer(nn.Module):
         ins = lambda w, at: torch.cat([w[:, :at], z(w.shape[0], pad, 3, 3), w[:, at:]], 1)  # noqa: E731  zero input rows at `at`
         cell, oc = self.resid_lstm.convLSTM, self.resid_lstm.out_seq.LSTM_out_conv
         cin = oc.weight.shape[0]                       # ch + cond channels: width of the block's feature map
-        x1 = xn[..., :chp]
         if state is None:
             h_cur, c_cur = z(*xn.shape[:3], cell.hidden_dim), None
         else:

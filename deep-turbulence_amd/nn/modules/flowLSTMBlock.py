@@ -250,8 +250,8 @@ class LSTMFLowBlock(nn.Module):
             torch._foreach_copy_([c.log_s_old for c in convs], [c.log_s for c in convs])
         K, C = sign_s.shape
         meta = (tab, sign_s, perm, iperm, 1 if reverse else 0, -1.0 if ts else 1.0, float(hw), K, C)
-        Wm, bm, ld = ops.LevelMixFoldFn.apply(meta, *params)
-        return Wm, bm, ld.view(())
+        Wm, bm, ld, Wh, bh, Wt, bt = ops.LevelMixFoldFn.apply(meta, *params)
+        return Wm, bm, ld.view(()), (Wh, bh, Wt, bt)
 
     def _fusable(self, lm, xn):
         """The level-fused node needs LU blocks throughout (lm) and >= 1 non-LSTM layer.  Halves that are not 16-byte aligned
@@ -336,13 +336,15 @@ class LSTMFLowBlock(nn.Module):
         Wm, bm = (None, None) if lm is None else (self._pad_mix(lm[0], lm[1], ch, pad) if pad else (lm[0], lm[1]))
         if pad:
             xn = self._pad_x(xn, ch, pad)
+        sp = lm[3] if (fused and not pad and len(lm) > 3) else None      # (head, tail) views of the fold node: no autograd slicing
         if fused:
-            xn, dld = self._level_call(xn, condn, Wm[:-1], bm[:-1], layers[:-1], False, ch, pad)
+            Wh, bh = (sp[0], sp[1]) if sp else (Wm[:-1], bm[:-1])
+            xn, dld = self._level_call(xn, condn, Wh, bh, layers[:-1], False, ch, pad)
             logdet = logdet + dld
         for i, layer in enumerate(layers):
             if fused and i < self.n_layers - 1:
                 continue
-            mix = None if lm is None else (Wm[i], bm[i])
+            mix = None if lm is None else ((sp[2], sp[3]) if sp else (Wm[i], bm[i]))
             if i == self.n_layers - 1:
                 xn, dld, so = layer.run(xn, condn, st, False, mix, pad=pad)
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
@@ -374,13 +376,15 @@ class LSTMFLowBlock(nn.Module):
         Wm, bm = (None, None) if lm is None else (self._pad_mix(lm[0], lm[1], ch, pad) if pad else (lm[0], lm[1]))
         if pad:
             yn = self._pad_x(yn, ch, pad)
+        sp = lm[3] if (fused and not pad and len(lm) > 3) else None      # (head, tail) views of the fold node: no autograd slicing
         for i in range(len(layers) - 1, -1, -1):
-            mix = None if lm is None else (Wm[i], bm[i])
+            mix = None if lm is None else ((sp[2], sp[3]) if (sp and i == self.n_layers - 1) else (Wm[i], bm[i]))
             if i == self.n_layers - 1:
                 yn, dld, so = layers[i].run(yn, condn, st, True, mix, pad=pad)
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
             elif fused:
-                yn, dld = self._level_call(yn, condn, Wm[:-1], bm[:-1], layers[:-1], True, ch, pad)
+                Wh, bh = (sp[0], sp[1]) if sp else (Wm[:-1], bm[:-1])
+                yn, dld = self._level_call(yn, condn, Wh, bh, layers[:-1], True, ch, pad)
                 logdet = logdet + dld
                 break
             else:

@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
 ]
 
 
@@ -530,10 +530,23 @@ def lu_fold_fwd(tab, sign_s, perm, iperm, W, Wm, bm, ld, reverse, sgn, hw):
                                _flts([sgn, hw]), _stream()), "tmg_lu_fold_fwd")
 
 
-def lu_fold_bwd(tab, sign_s, perm, iperm, W, dWm, dbm, dld, dl, du, dlogs, da, db, reverse, sgn, hw):
+def lu_fold_bwd(tab, sign_s, perm, iperm, W, dWm, dbm, dld, dl, du, dlogs, da, db, reverse, sgn, hw, dWm_tail=None, dbm_tail=None):
+    """dWm_tail / dbm_tail: upstream gradients of the LAST layer in tensors of their own (dWm / dbm then cover layers 0..K-2)."""
     K, C = sign_s.shape
-    _chk(lib().tmg_lu_fold_bwd(_ptr(tab), _ptr(sign_s), _ptr(perm), _ptr(iperm), _ptr(W), _ptr(dWm), _ptr(dbm), _ptr(dld), _ptr(dl), _ptr(du),
-                               _ptr(dlogs), _ptr(da), _ptr(db), _i64(K, C, reverse), _flts([sgn, hw]), _stream()), "tmg_lu_fold_bwd")
+    _chk(lib().tmg_lu_fold_bwd_split(_ptr(tab), _ptr(sign_s), _ptr(perm), _ptr(iperm), _ptr(W), _ptr(dWm), _ptr(dbm), _ptr(dWm_tail),
+                                     _ptr(dbm_tail), _ptr(dld), _ptr(dl), _ptr(du), _ptr(dlogs), _ptr(da), _ptr(db), _i64(K, C, reverse),
+                                     _flts([sgn, hw]), _stream()), "tmg_lu_fold_bwd_split")
+
+
+def level_finish(Wz, dWz, Bz, dBz, Kp, tmpX, tmpC, dW1, dW2, dK, ws, ch, Cc):
+    """Parameter-gradient epilogue of a level's fused coupling node in one launch (tmg_level_finish): d(kappa) of all NL zero convs
+    (fp64 inner products) and the scatter of the grouped weight-gradient rows tmpX / tmpC into dW1 / dW2.  ws: 4 * NL zeroed floats."""
+    NL, C = dBz.shape
+    for t in (Wz, dWz, Bz, dBz, Kp, tmpX, tmpC, dW1, dW2, dK, ws):
+        assert t is None or t.is_contiguous()
+    assert ws.numel() >= 4 * NL
+    _chk(lib().tmg_level_finish(_ptr(Wz), _ptr(dWz), _ptr(Bz), _ptr(dBz), _ptr(Kp), _ptr(tmpX), _ptr(tmpC), _ptr(dW1), _ptr(dW2), _ptr(dK),
+                                _ptr(ws), _i64(NL, C, ch, Cc), _stream()), "tmg_level_finish")
 
 
 def adam_step(tab, chunks, nchunks, lr, b1, b2, eps, wd, bc1, bc2s, amsgrad):

@@ -9,6 +9,7 @@ All activations are NHWC ([B,H,W,C] contiguous, or channel-slice views of such t
 import math
 
 import os
+import threading
 
 import torch
 
@@ -18,6 +19,53 @@ LOG5 = math.log(5.0)
 LOG4 = math.log(4.0)
 SPLIT_LIMITS = (-2.0, LOG5, -2.0, LOG5)      # hardtanh(-2, ln5) on both halves (flowUtils.py:262,274)
 TOP_LIMITS = (0.0, 0.0, -10.0, LOG5)         # only the log-std is clamped (flowUtils.py:163)
+
+
+class _ZeroPool:
+    """Zero-initialised scratch for the many parameter-sized gradient / statistics buffers of a step (~170 `torch.zeros` launches
+    of a few microseconds each): buffers of up to LIMIT floats are carved, 256-byte aligned, from ONE zero-filled chunk per
+    (device, stream), so a step pays one or two fill launches instead.  A carved buffer is an ordinary tensor on the chunk's storage:
+    it keeps the chunk alive and is never handed out twice; chunks are freed by the caching allocator once every buffer is gone (for
+    parameter gradients: at the next zero_grad).  Bypassed during hipGraph capture - a replay would not re-zero a chunk filled before the
+    capture - and with TMG_NO_ZERO_POOL."""
+    CHUNK = 8 << 20
+    LIMIT = 2 << 20
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.cur = {}
+        self.off = os.environ.get("TMG_NO_ZERO_POOL") is not None
+
+    def zeros(self, shape, device):
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        n = math.prod(shape)
+        device = torch.device(device)
+        if self.off or n == 0 or n > self.LIMIT or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        need = (n + 63) & ~63
+        with self.lock:
+            buf, off = self.cur.get(key, (None, 0))
+            if buf is None or off + need > buf.numel():
+                buf, off = torch.zeros(self.CHUNK, device=device, dtype=torch.float32), 0
+            self.cur[key] = (buf, off + need)
+        # not a view: a tensor of its own on the chunk's storage - views of one base share a version counter, and an in-place torch
+        # op on one carved buffer would invalidate every other one that some autograd node has saved
+        return torch.empty(0, device=device, dtype=torch.float32).set_(buf.untyped_storage(), off, shape)
+
+
+_pool = _ZeroPool()
+
+
+def zeros(shape, device):
+    """fp32 zeros on `device` (pooled when small, see _ZeroPool)."""
+    return _pool.zeros(shape, device)
+
+
+def zeros_like(t):
+    return _pool.zeros(t.shape, t.device)
 
 
 def _out_hw(h, w, stride):
@@ -61,10 +109,10 @@ class ConvFn(torch.autograd.Function):
         dW = db = dk = None
         ss = None
         if ctx.needs_input_grad[0] or ctx.has_kappa:
-            dW = torch.zeros_like(weight)
-            db = torch.zeros_like(bias) if ctx.has_bias else None
+            dW = zeros_like(weight)
+            db = zeros_like(bias) if ctx.has_bias else None
             if ctx.has_kappa:
-                dk = torch.zeros_like(kappa)
+                dk = zeros_like(kappa)
             # weight gradients run on the side stream, concurrently with the input-gradient kernels below
             ss = H.side_stream(dy.device, keep=(dy, dW, db, dk, weight, bias, kappa) + tuple(inputs))
             with ss:
@@ -91,7 +139,7 @@ class ConvFn(torch.autograd.Function):
                     # = a stride-1 correlation with the flipped taps over dy spread onto the even positions of a zero grid
                     # (4x the minimal MFMA work, but these encoder convs have 8-32 channels: the scalar direct kernel spent
                     # 260 us per call at 0.12 TB/s on them)
-                    up = torch.zeros((dy.shape[0], Hin_, Win_, dy.shape[3]), device=dy.device, dtype=torch.float32)
+                    up = zeros((dy.shape[0], Hin_, Win_, dy.shape[3]), dy.device)
                     up[:, ::2, ::2] = dy
                     H.conv_fwd([up], H.conv_pack(weight, 1), inputs[0].shape[3], ksize, 1, dins)
                 else:
@@ -132,12 +180,12 @@ class BNReLUConvFn(torch.autograd.Function):
         dy = dout.contiguous()
         B, Hh, Ww, C = x.shape
         n = B * Hh * Ww
-        dW = torch.zeros_like(weight)
+        dW = zeros_like(weight)
         H.conv_wgrad([x], dy, dW, None, 3, 1, in_scale=a, in_shift=bsh, relu_in=True)
         wpk_t = H.conv_pack(weight, 1)
         G = torch.empty((B, Hh, Ww, C), device=x.device, dtype=torch.float32)
         H.conv_fwd([dy], wpk_t, C, 3, 1, [G])
-        s = torch.zeros((3, C), device=x.device)  # sums of du, du*xhat, and a zero row for the eval-mode call
+        s = zeros((3, C), x.device)  # sums of du, du*xhat, and a zero row for the eval-mode call
         s0, s1 = s[0], s[1]
         H.chan_reduce(x, G, a, bsh, mean, rstd, s0, s1, 1)
         dgamma, dbeta = s1, s0
@@ -156,7 +204,7 @@ def bn_batch_stats(x, bn):
     -> (mean, rstd, a, bsh), each [C]."""
     B, Hh, Ww, C = x.shape
     n = B * Hh * Ww
-    acc = torch.zeros((4, C), device=x.device)
+    acc = zeros((4, C), x.device)
     H.chan_reduce(x, None, None, None, None, None, acc[0], acc[1], 0)
     H.chan_reduce(x, None, acc[0], None, None, None, acc[2], acc[3], 0, divisor=n)
     out = torch.empty((5, C), device=x.device)
@@ -173,12 +221,12 @@ def batch_moments(x):
     """Two-pass per-channel mean / biased variance over (B,H,W) of an NHWC tensor or channel-slice view."""
     B, Hh, Ww, C = x.shape
     n = B * Hh * Ww
-    s0 = torch.zeros(C, device=x.device)
-    s1 = torch.zeros(C, device=x.device)
+    s0 = zeros(C, x.device)
+    s1 = zeros(C, x.device)
     H.chan_reduce(x, None, None, None, None, None, s0, s1, 0)
     mean = s0 / n
-    s0b = torch.zeros(C, device=x.device)
-    s1b = torch.zeros(C, device=x.device)
+    s0b = zeros(C, x.device)
+    s1b = zeros(C, x.device)
     H.chan_reduce(x, None, mean, None, None, None, s0b, s1b, 0)
     return mean, s1b / n, n
 
@@ -195,7 +243,7 @@ class AffineFn(torch.autograd.Function):
         y = torch.empty((B, Hh, Ww, C), device=x.device, dtype=torch.float32)
         H.masked_add(y[..., :ch], src=x[..., :ch])
         r = torch.empty((B, Hh, Ww, ch), device=x.device, dtype=torch.float32)
-        logdet = torch.zeros(B, device=x.device, dtype=torch.float32)
+        logdet = zeros(B, x.device)
         H.affine_apply(hh, x[..., ch:], y[..., ch:], r, logdet, reverse)
         ctx.reverse = reverse
         ctx.save_for_backward(r, x if reverse else y)
@@ -283,8 +331,8 @@ class ConvLSTMCellFn(torch.autograd.Function):
                              dc.contiguous() if dc is not None else None, dc_prev)
         dg = acts  # now the pre-activation gate gradients
         segs = list(inputs) + [h_cur]
-        dW = torch.zeros_like(weight)
-        db = torch.zeros_like(bias)
+        dW = zeros_like(weight)
+        db = zeros_like(bias)
         H.conv_wgrad(segs, dg, dW, db, 3, 1)
         # input gradients only for the channel prefix that needs them: the recurrent state of the first time-step of a
         # window (and any constant input) carries no gradient, which removes R of the Cin+R gradient channels
@@ -306,7 +354,7 @@ class GaussLogpFn(torch.autograd.Function):
         hz = hz.contiguous()
         z2 = z2 if z2.stride(3) == 1 else z2.contiguous()
         B = z2.shape[0]
-        logp = torch.zeros(B, device=z2.device, dtype=torch.float32)
+        logp = zeros(B, z2.device)
         eps = torch.empty(z2.shape, device=z2.device, dtype=torch.float32) if want_eps else None
         H.gauss_fwd(hz, z2, eps, logp, 0, clip_mean, limits)
         ctx.cfg = (clip_mean, limits)
@@ -332,7 +380,7 @@ class GaussSampleFn(torch.autograd.Function):
         hz = hz.contiguous()
         eps = eps.contiguous()
         B = eps.shape[0]
-        logp = torch.zeros(B, device=eps.device, dtype=torch.float32)
+        logp = zeros(B, eps.device)
         z2 = torch.empty(eps.shape, device=eps.device, dtype=torch.float32)
         H.gauss_fwd(hz, eps, z2, logp, 1, clip_mean, limits)
         ctx.cfg = (clip_mean, limits)
@@ -430,7 +478,7 @@ class CouplingTailFn(torch.autograd.Function):
         y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
         H.masked_add(y[..., :ch], src=x[..., :ch])
         r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
-        logdet = torch.zeros(B, device=dev, dtype=torch.float32)
+        logdet = zeros(B, dev)
         H.affine_apply(hh, x[..., ch:], y[..., ch:], r, logdet, reverse)
         ctx.reverse, ctx.mode, ctx.cin = reverse, mode, cin
         ctx.save_for_backward(x, aux, D, r, y, w1, w2, wz, bz, kappa)
@@ -452,7 +500,7 @@ class CouplingTailFn(torch.autograd.Function):
         H.affine_bwd(dy[..., ch:], (x if reverse else y)[..., ch:], r, g, dx[..., ch:], dhh, reverse)
         # one zero-filled buffer for every parameter gradient of this node
         n1, n2, nz = cin * 9, (cin + 1) * 9, C * (cin + 2) * 9
-        flat = torch.zeros(n1 + n2 + nz + C + 1, device=dev, dtype=torch.float32)
+        flat = zeros(n1 + n2 + nz + C + 1, dev)
         dw1 = flat[:n1].view(1, cin, 3, 3)
         dw2 = flat[n1:n1 + n2].view(1, cin + 1, 3, 3)
         dwz = flat[n1 + n2:n1 + n2 + nz].view(C, cin + 2, 3, 3)
@@ -531,8 +579,8 @@ class MixFn(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         C = W.shape[0]
-        dW = torch.zeros_like(W)
-        db = torch.zeros(C, device=W.device, dtype=torch.float32)
+        dW = zeros_like(W)
+        db = zeros(C, W.device)
         dx = _mix_bwd(x, dy, W, dW, db)
         return dx, dW, (db if ctx.has_b else None)
 
@@ -588,14 +636,14 @@ class LevelCouplingFn(torch.autograd.Function):
         # cond-side operands of the whole level (parameter-sized copies, no autograd inside a Function)
         Wz = torch.stack(wzs)                                              # [NL, C, cin+2, 3, 3]
         Wzc = Wz[:, :, ch:cin].reshape(NL * C, Cc, 3, 3).contiguous()
-        Wdc = torch.zeros((2 * NLp, Cc, 3, 3), device=dev, dtype=torch.float32)
+        Wdc = zeros((2 * NLp, Cc, 3, 3), dev)
         Wdc[:NL] = torch.stack(w1s)[:, 0, ch:cin]
         Wdc[NLp:NLp + NL] = torch.stack(w2s)[:, 0, ch:cin]
         Hc = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)
         H.conv3x3_auto([cond], Wzc, NL * C, [Hc], relu_in=True, pad_rep=True)
         Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
         H.conv_fwd([cond], H.conv_pack(Wdc, 0), 2 * NLp, 3, 1, [Dc], relu_in=True)
-        logdet = torch.zeros(B, device=dev, dtype=torch.float32)
+        logdet = zeros(B, dev)
         # operand packing of every layer's weights in two launches per level instead of two per layer
         PZ = H.conv_pack_batched(Wz, 0, ch + 4, (ch + 2, ch, Cc))
         PM = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 0)
@@ -665,18 +713,18 @@ class LevelCouplingFn(torch.autograd.Function):
         g = dld.contiguous() if dld is not None else None
         # stacked native-layout parameter gradients of the whole level, one zero fill
         n1, n2, nz = cin * 9, (cin + 1) * 9, C * (cin + 2) * 9
-        flat = torch.zeros(NL * (n1 + n2 + nz + C) + NL * C * C + NL * C, device=dev, dtype=torch.float32)
+        flat = zeros(NL * (n1 + n2 + nz + C) + NL * C * C + NL * C, dev)
         o = 0
+        dWz = flat[o:o + NL * nz].view(NL, C, cin + 2, 3, 3); o += NL * nz      # first: 16-byte aligned slices (tmg_level_finish)
         dW1 = flat[o:o + NL * n1].view(NL, 1, cin, 3, 3); o += NL * n1
         dW2 = flat[o:o + NL * n2].view(NL, 1, cin + 1, 3, 3); o += NL * n2
-        dWz = flat[o:o + NL * nz].view(NL, C, cin + 2, 3, 3); o += NL * nz
         dBz = flat[o:o + NL * C].view(NL, C); o += NL * C
         dWm = flat[o:o + NL * C * C].view(NL, C, C); o += NL * C * C
         dbm = flat[o:o + NL * C].view(NL, C)
         DH = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)     # exp(kappa_k) * dhh_k, all layers
         # masked gradients w.r.t. the growth channels, 4 channels per layer (dd1_k, dd2_k, 0, 0): float4-addressable slices for
         # the grouped weight-gradient launch below
-        DD = torch.zeros((B, Hh, Ww, 4 * NL), device=dev, dtype=torch.float32)
+        DD = zeros((B, Hh, Ww, 4 * NL), dev)
         dcur = dy
         # The NL zero-conv weight gradients (x1 | D part) are independent of each other once DH holds every layer's
         # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
@@ -736,6 +784,7 @@ class LevelCouplingFn(torch.autograd.Function):
             if grouped:
                 mix_wg[k] = mdef[0]
             del xin, tin, D, r, y
+        tmpX = None
         if grouped:
             if not H.conv_wgrad_grouped(wg_in, DH, C, dWz, dBz, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
                                         ci_split=ch, ci_off0=0, ci_off1=Cc):
@@ -744,13 +793,10 @@ class LevelCouplingFn(torch.autograd.Function):
                                  cin_valid=ch + 2, ci_split=ch, ci_off0=0, ci_off1=Cc)
             # x1 | d1 rows of the growth-layer weight gradients: same inputs, dy = this layer's (dd1, dd2, 0, 0) quad; row 0 of the
             # result belongs to w1, row 1 to w2 (its column ch is the d1 input)
-            tmpX = torch.zeros((NL, 4, ch + 4, 3, 3), device=dev, dtype=torch.float32)
+            tmpX = zeros((NL, 4, ch + 4, 3, 3), dev)
             if not H.conv_wgrad_grouped(wg_in, DD, 4, tmpX, None, 3, 1, relu_in=True):
                 for k in range(NL):
                     H.conv_wgrad(wg_in[k], DD[..., 4 * k:4 * k + 4], tmpX[k], None, 3, 1, relu_in=True)
-            dW1[:, 0, :ch] += tmpX[:, 0, :ch]
-            dW2[:, 0, :ch] += tmpX[:, 1, :ch]
-            dW2[:, 0, cin] += tmpX[:, 1, ch]
             wg_in = None
             # the 1x1 mix weight gradients of all layers: same trick, every group with its own upstream gradient tensor
             if not H.conv_wgrad_grouped([a for a, _ in mix_wg], None, C, dWm.view(NL, C, C, 1, 1), dbm, 1, 1, group_dy=[g_ for _, g_ in mix_wg]):
@@ -761,21 +807,19 @@ class LevelCouplingFn(torch.autograd.Function):
         Gc = torch.empty(cond.shape, device=dev, dtype=torch.float32)
         wzc_t = H.conv3x3_auto([DH], Wzc, Cc, [Gc], dgrad=True)
         H.conv_rep_border_fix(DH, wzc_t if wzc_t is not None else H.conv_pack(Wzc, 1), [Gc])
-        Wd4 = torch.zeros((4 * NL, Cc, 3, 3), device=dev, dtype=torch.float32)   # rows 4k / 4k+1: cond columns of w1_k / w2_k
+        Wd4 = zeros((4 * NL, Cc, 3, 3), dev)   # rows 4k / 4k+1: cond columns of w1_k / w2_k
         Wd4.view(NL, 4, Cc, 3, 3)[:, 0] = Wdc[:NL]
         Wd4.view(NL, 4, Cc, 3, 3)[:, 1] = Wdc[NLp:NLp + NL]
         H.conv_fwd([DD], H.conv_pack(Wd4, 1), Cc, 3, 1, [Gc], accumulate=True)
         H.masked_add(Gc, src=Gc, ref=cond)
         H.conv_wgrad([cond], DH, dWz, None, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=Cc, ci_off0=ch)
-        tmpC = torch.zeros((NL, 4, Cc, 3, 3), device=dev, dtype=torch.float32)   # one launch for both growth layers of all layers
+        tmpC = zeros((NL, 4, Cc, 3, 3), dev)   # one launch for both growth layers of all layers
         H.conv_wgrad([cond], DD, tmpC.view(4 * NL, Cc, 3, 3), None, 3, 1, relu_in=True)
-        dW1[:, 0, ch:cin] += tmpC[:, 0]
-        dW2[:, 0, ch:cin] += tmpC[:, 1]
-        # d(kappa_k) = <wz_k, dwz_k> + <bz_k, dbz_k> inside the clamp range (homogeneity of the zero conv in (W, b))
+        # one launch: rows of tmpX / tmpC -> dW1 / dW2, and d(kappa_k) = <wz_k, dwz_k> + <bz_k, dbz_k> inside the clamp range
+        # (homogeneity of the zero conv in (W, b); the two inner products nearly cancel for small kappa gradients: fp64 sums)
         Kp = torch.stack([kp.reshape(()) for kp in kps])
-        # (the two inner products nearly cancel for small kappa gradients: accumulate them in fp64, the operands are parameter-sized)
-        dK = ((Wz.double() * dWz.double()).flatten(1).sum(1) + (torch.stack(bzs).double() * dBz.double()).sum(1)).float() \
-            * ((Kp >= -4.0) & (Kp <= LOG4)).to(torch.float32)
+        dK = torch.empty(NL, device=dev, dtype=torch.float32)
+        H.level_finish(Wz, dWz, torch.stack(bzs), dBz, Kp, tmpX, tmpC, dW1, dW2, dK, zeros(4 * NL, dev), ch, Cc)
         grads = []
         for k in range(NL):
             grads += [dW1[k], dW2[k], dWz[k], dBz[k], dK[k].reshape(kps[k].shape)]
@@ -785,7 +829,10 @@ class LevelCouplingFn(torch.autograd.Function):
 class LevelMixFoldFn(torch.autograd.Function):
     """ActNorm + PLU folding of all K layers of a level (W = P L U, then the ActNorm scale / shift) as one node: two launches per
     level (tmg_lu_fold_fwd / _bwd) instead of ~70 tiny torch launches.  Inputs after the meta tuple: per layer l, u, log_s, ActNorm
-    weight, ActNorm bias (the module's own tensors, read through a device pointer table).  Outputs Wm [K,C,C], bm [K,C], ld [1]."""
+    weight, ActNorm bias (the module's own tensors, read through a device pointer table).  Outputs Wm [K,C,C], bm [K,C], ld [1] and
+    the same mixes once more as (first K-1 layers, last layer) views: a caller that consumes the head as one slice and the tail on its
+    own (LSTMFLowBlock) hands their gradients back as two tensors, read in place by the backward launch - slicing Wm under autograd
+    instead costs a zero fill, a copy and an add of a full-size gradient per slice.  Use either Wm / bm or the split views."""
 
     @staticmethod
     def forward(ctx, meta, *params):
@@ -799,10 +846,11 @@ class LevelMixFoldFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.shapes = [t.shape if t is not None else None for t in params]
         ctx.save_for_backward(W, *[t for t in params if t is not None])      # params: kept alive (and version-checked) for the pointer table
-        return Wm, bm, ld
+        ctx.set_materialize_grads(False)
+        return Wm, bm, ld, Wm[:K - 1], bm[:K - 1], Wm[K - 1], bm[K - 1]
 
     @staticmethod
-    def backward(ctx, dWm, dbm, dld):
+    def backward(ctx, dWm, dbm, dld, dWh, dbh, dWt, dbt):
         tab, sign_s, perm, iperm, reverse, sgn, hw, K, C = ctx.meta
         W = ctx.saved_tensors[0]
         dev = W.device
@@ -811,12 +859,49 @@ class LevelMixFoldFn(torch.autograd.Function):
         dlogs = torch.empty((K, C), device=dev, dtype=torch.float32)
         da = torch.empty((K, C), device=dev, dtype=torch.float32)
         db = torch.empty((K, C), device=dev, dtype=torch.float32)
-        dWm = dWm.contiguous() if dWm is not None else torch.zeros((K, C, C), device=dev, dtype=torch.float32)
-        H.lu_fold_bwd(tab, sign_s, perm, iperm, W, dWm, dbm.contiguous() if dbm is not None else None,
-                      dld.contiguous() if dld is not None else None, dl, du, dlogs, da, db, reverse, sgn, hw)
+        split = dWm is None and dbm is None and dWt is not None and (dWh is not None or K == 1) and (dbt is None) == (dbh is None or K == 1)
+        if split:
+            dWm, dbm, dWt, dbt = (None if t is None else t.contiguous() for t in (dWh, dbh, dWt, dbt))
+        else:
+            # general case (rare): assemble full-size gradients from whatever arrived
+            full = zeros((K, C, C), dev) if dWm is None else dWm.clone()
+            fb = zeros((K, C), dev) if dbm is None else dbm.clone()
+            if dWh is not None:
+                full[:K - 1] += dWh
+            if dWt is not None:
+                full[K - 1] += dWt
+            if dbh is not None:
+                fb[:K - 1] += dbh
+            if dbt is not None:
+                fb[K - 1] += dbt
+            dWm, dbm, dWt, dbt = full, fb, None, None
+        H.lu_fold_bwd(tab, sign_s, perm, iperm, W, dWm, dbm, dld.contiguous() if dld is not None else None, dl, du, dlogs, da, db,
+                      reverse, sgn, hw, dWm_tail=dWt, dbm_tail=dbt)
         grads = []
         for k in range(K):
             sh = ctx.shapes[5 * k:5 * k + 5]
             grads += [dl[k], du[k], dlogs[k].view(sh[2]), da[k].view(sh[3]) if sh[3] is not None else None,
                       db[k].view(sh[4]) if sh[4] is not None else None]
         return (None,) + tuple(grads)
+
+
+class LeadingChannelsFn(torch.autograd.Function):
+    """x -> (x, x[..., :n]) as two autograd outputs for a tensor whose leading channels feed one branch (the ConvLSTM block of the LSTM
+    coupling layer, flowAffine.py:199-205) while the whole tensor feeds another.  A plain slice makes autograd zero-fill a full-size
+    gradient, copy the branch gradient in and add the two full-size tensors; here the branch gradient is added in place into the
+    leading channels of the whole-tensor gradient (a fresh buffer owned by the producing node): one half-size launch."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.C = n, x.shape[3]
+        ctx.set_materialize_grads(False)
+        return x.view(x.shape), x[..., :n]
+
+    @staticmethod
+    def backward(ctx, dx, d1):
+        if d1 is None:
+            return dx, None
+        if dx is None:   # the whole-tensor output took no part in the loss
+            dx = torch.zeros(d1.shape[:3] + (ctx.C,), device=d1.device, dtype=d1.dtype)
+        dx[..., :ctx.n] += d1
+        return dx, None

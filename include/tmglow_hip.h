@@ -287,6 +287,20 @@ int tmg_lu_fold_fwd(const void* tab, const void* sign_s, const void* perm, const
                     const int64_t* dims, const float* fl, tmg_stream_t st);
 int tmg_lu_fold_bwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W, const void* dWm, const void* dbm,
                     const void* dld, void* dl, void* du, void* dlogs, void* da, void* db, const int64_t* dims, const float* fl, tmg_stream_t st);
+/* The same with the LAST layer's upstream gradients in tensors of their own (dWm_tail [C,C], dbm_tail [C]; dWm / dbm then hold layers
+ * 0..K-2): the level-fused coupling node consumes the first K-1 mixes as one slice, the ConvLSTM layer the last one
+ * (flowLSTMBlock.py:137-160), and autograd would otherwise zero-fill and add two full-size gradients per level. */
+int tmg_lu_fold_bwd_split(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W, const void* dWm,
+                          const void* dbm, const void* dWm_tail, const void* dbm_tail, const void* dld, void* dl, void* du, void* dlogs,
+                          void* da, void* db, const int64_t* dims, const float* fl, tmg_stream_t st);
+
+/* Parameter-gradient epilogue of a level's NL plain coupling layers, one launch: d(kappa_k) = (<Wz_k, dWz_k> + <bz_k, dBz_k>) inside the
+ * clamp range of the zero conv's log-scale (flowUtils.py:104-106; fp64 accumulation), and the scatter-add of the grouped 4-row
+ * weight-gradient results tmpX [NL,4,ch+4,3,3] (x1 | d1 columns) and tmpC [NL,4,Cc,3,3] (conditioning columns) into the native
+ * dW1 [NL,1,ch+Cc,3,3] / dW2 [NL,1,ch+Cc+1,3,3] of the two growth-1 convs (denseBlock.py:18-36).  Wz, dWz [NL,C,ch+Cc+2,3,3]; Bz, dBz [NL,C];
+ * Kp, dK [NL]; tmpX / tmpC may be null; ws: 4*NL zero-initialised floats (8-byte aligned).  dims = {NL, C, ch, Cc}. */
+int tmg_level_finish(const void* Wz, const void* dWz, const void* Bz, const void* dBz, const void* Kp, const void* tmpX, const void* tmpC,
+                     void* dW1, void* dW2, void* dK, void* ws, const int64_t* dims, tmg_stream_t st);
 
 /* The same mix in full fp32 (v_mfma_f32_16x16x4_f32) for C <= 128: the stand-alone 1x1 mixes (wide flow levels, ConvLSTM blocks)
  * without the general conv kernel's patch staging and operand-packing launch.  Arguments as tmg_mix_f16. */

@@ -122,3 +122,29 @@ def test_hip_adam_falls_back_to_torch_off_device():
         assert torch.equal(a, b)
         assert set(oa.state[a]) == set(ob.state[b]) and float(oa.state[a]["step"]) == 3
     ob.load_state_dict(oa.state_dict())
+
+
+def test_leading_channels_node_matches_plain_slicing():
+    """tmg_ops.LeadingChannelsFn (x -> (x, x[..., :n]) with the slice's gradient added in place into the whole tensor's) gives the
+    gradients of plain slicing - pure tensor bookkeeping, no kernel involved."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deep-turbulence_amd"))
+    import tmg_ops
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(2, 3, 4, 6, generator=g)
+    w_all, w_lead = torch.randn(2, 3, 4, 6, generator=g), torch.randn(2, 3, 4, 2, generator=g)
+    res = []
+    for mode in range(2):
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.5
+        xa, x1 = tmg_ops.LeadingChannelsFn.apply(h, 2) if mode else (h, h[..., :2])
+        ((xa.tanh() * w_all).sum() + (x1 * x1 * w_lead).sum()).backward()
+        res.append(x.grad)
+    assert torch.allclose(res[0], res[1], rtol=1e-6, atol=1e-7)
+    # only the slice takes part in the loss
+    x = x0.clone().requires_grad_(True)
+    _, x1 = tmg_ops.LeadingChannelsFn.apply(x * 1.0, 2)
+    (x1 * w_lead).sum().backward()
+    assert torch.equal(x.grad[..., :2], w_lead) and not bool(x.grad[..., 2:].any())

@@ -568,3 +568,57 @@ def test_hip_adam_matches_torch_adam(amsgrad, wd):
         for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
             _close(sa[k], sb[k].double(), tol=2e-6, what=k)
     ob.load_state_dict(oa.state_dict())     # same schema
+
+
+@pytest.mark.parametrize("NL,C_,Cc,with_x", [(3, 16, 8, True), (15, 32, 32, True), (2, 128, 32, False), (1, 12, 4, True)])
+def test_level_finish_kernel(NL, C_, Cc, with_x):
+    """tmg_level_finish (parameter-gradient epilogue of a level's fused coupling node, one launch) against the torch formulation
+    it replaces: d(kappa) = (<Wz, dWz> + <bz, dBz>) inside the clamp range in fp64, and the scatter-add of the grouped
+    weight-gradient rows into dW1 / dW2."""
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(5 + NL)
+    ch = C_ // 2
+    cin = ch + Cc
+    rnd = lambda *s_: torch.randn(s_, generator=g).to(DEV)  # noqa: E731
+    Wz, dWz, Bz, dBz = rnd(NL, C_, cin + 2, 3, 3), rnd(NL, C_, cin + 2, 3, 3), rnd(NL, C_), rnd(NL, C_)
+    Kp = torch.tensor([(-4.5, -4.0, 0.3, 1.38, 1.3862944, 1.5)[k % 6] for k in range(NL)], device=DEV)
+    tmpX = rnd(NL, 4, ch + 4, 3, 3) if with_x else None
+    tmpC = rnd(NL, 4, Cc, 3, 3)
+    dW1, dW2 = rnd(NL, 1, cin, 3, 3), rnd(NL, 1, cin + 1, 3, 3)
+    r1, r2 = dW1.clone(), dW2.clone()
+    if with_x:
+        r1[:, 0, :ch] += tmpX[:, 0, :ch]
+        r2[:, 0, :ch] += tmpX[:, 1, :ch]
+        r2[:, 0, cin] += tmpX[:, 1, ch]
+    r1[:, 0, ch:cin] += tmpC[:, 0]
+    r2[:, 0, ch:cin] += tmpC[:, 1]
+    rK = ((Wz.double() * dWz.double()).flatten(1).sum(1) + (Bz.double() * dBz.double()).sum(1)).float() \
+        * ((Kp >= -4.0) & (Kp <= math.log(4.0))).to(torch.float32)
+    dK = torch.full((NL,), 7.0, device=DEV)
+    # a misaligned dWz view exercises the scalar path of the inner product
+    dWz_mis = torch.cat([torch.zeros(1, device=DEV), dWz.flatten()])[1:].view(dWz.shape)
+    for gz in (dWz, dWz_mis):
+        a1, a2 = dW1.clone(), dW2.clone()
+        H.level_finish(Wz, gz, Bz, dBz, Kp, tmpX, tmpC, a1, a2, dK, torch.zeros(4 * NL, device=DEV), ch, Cc)
+        assert torch.equal(a1, r1) and torch.equal(a2, r2)
+        assert float((dK - rK).abs().max()) <= 1e-6 * max(float(rK.abs().max()), 1.0), (dK, rK)
+        assert bool(((dK == 0) == (rK == 0)).all())
+
+
+def test_zero_pool_hands_out_disjoint_zeroed_buffers():
+    """tmg_ops.zeros: small buffers are carved from a shared zero-filled chunk (one fill launch for many buffers) - zero content,
+    256-byte aligned, pairwise disjoint, unaffected by writes to their neighbours; large requests get a tensor of their own."""
+    import tmg_ops
+    bufs = [tmg_ops.zeros(s_, DEV) for s_ in [(3,), (5, 7), (1,), (64, 64, 3, 3), (2, 2)] * 8]
+    for b in bufs:
+        assert b.dtype == torch.float32 and b.is_contiguous() and b.data_ptr() % 256 == 0 and not bool(b.any())
+    for i, b in enumerate(bufs):
+        b.fill_(float(i + 1))
+    for i, b in enumerate(bufs):
+        assert bool((b == float(i + 1)).all())
+    spans = sorted((b.data_ptr(), b.data_ptr() + 4 * b.numel()) for b in bufs)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+    big = tmg_ops.zeros((tmg_ops._ZeroPool.LIMIT + 1,), DEV)
+    assert big.untyped_storage().nbytes() == 4 * big.numel() and not bool(big.any())
+    assert bufs[0].untyped_storage().nbytes() > 4 * bufs[0].numel() and bufs[0]._base is None      # pooled, but not an autograd view
+    assert tmg_ops.zeros_like(bufs[1]).shape == bufs[1].shape

@@ -840,18 +840,29 @@ def test_lu_fold_kernels_match_torch_folding(reverse, ts):
             layer.conv.train_sampling = ts      # (False, False): W is applied in the density direction -> the kernels' forward fold
         names = [n for n, _ in blk.named_parameters() if n.endswith((".l", ".u", ".log_s", "norm.weight", "norm.bias"))]
         res = {}
-        for mode in ("hip", "torch"):
+        for mode in ("hip", "split", "torch"):
             os.environ.pop("TMG_NO_LU_FOLD_KERNEL", None)
             if mode == "torch":
                 os.environ["TMG_NO_LU_FOLD_KERNEL"] = "1"
             blk.zero_grad()
-            Wm, bm, ld = blk._level_mix(reverse, 37)
+            lm = blk._level_mix(reverse, 37)
+            Wm, bm, ld = lm[:3]
             if mode == "hip":
                 gW = torch.randn(Wm.shape, generator=g).to(DEV)
                 gb = torch.randn(bm.shape, generator=g).to(DEV)
-            ((Wm * gW).sum() + (bm * gb).sum() + 0.3 * ld).backward()
+            if mode == "split":
+                # the (first K-1 layers, last layer) views of the same node, whose gradients the backward launch reads in place
+                if len(lm) < 4:
+                    continue
+                Wh, bh, Wt, bt = lm[3]
+                ((Wh * gW[:-1]).sum() + (Wt * gW[-1]).sum() + (bh * gb[:-1]).sum() + (bt * gb[-1]).sum() + 0.3 * ld).backward()
+            else:
+                ((Wm * gW).sum() + (bm * gb).sum() + 0.3 * ld).backward()
             res[mode] = (Wm.detach().clone(), bm.detach().clone(), ld.detach().clone(), {n: p.grad.detach().clone() for n, p in blk.named_parameters() if n in names})
         os.environ.pop("TMG_NO_LU_FOLD_KERNEL", None)
+        if "split" in res:
+            for n in res["hip"][3]:
+                assert torch.equal(res["hip"][3][n], res["split"][3][n]), n
         a, b = res["hip"], res["torch"]
         for x, y, what in ((a[0], b[0], "Wm"), (a[1], b[1], "bm"), (a[2], b[2], "ld")):
             assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-6), what

@@ -18,7 +18,7 @@ blocks = list(model.glow.flow_blocks)
 def run():
     tot = 0
     for i, b in enumerate(blocks):
-        Wm, bm, ld = b._level_mix(True, 100)
+        Wm, bm, ld = b._level_mix(True, 100)[:3]
         tot = tot + (Wm * Wm).sum() + (bm * bm).sum() + ld
     tot.backward()
 
