@@ -1,0 +1,172 @@
+// Grouped 3x3 weight gradient for FOUR output channels per group: the growth-1 layers of the coupling networks
+// (denseBlock.py:18-36 under autograd), all NL layers of a flow level in one launch.
+//
+//   dW[g][co][ci][ky][kx] += sum_{b,y,x} dy[b,y,x, 4 g + co] * act(X_g[b, y + ky - 1, x + kx - 1, ci]),   zero padding, co < 4
+//
+// With 4 output channels a 16x16x4 MFMA tile is 2/16 (the two real growth channels) to 4/16 used: the general grouped kernel
+// (conv_wgrad_kernel<9,1>) spends 72 matrix-pipe cycles per pixel and 16 input channels there.  v_mfma_f32_4x4x1_16B_f32 is sixteen
+// independent 4x4 outer products per instruction at the same flop rate (lane l: block l / 4; A = row l % 4, B = column l % 4;
+// D[l][r] = A[4 (l / 4) + r] * B[l], measured with tools/micro/mfma4x4.hip) - a block here is a (tap, input-channel quad)
+// pair, its 4 columns are the group's 4 dy channels, and one instruction consumes ONE pixel: 8 cycles per pixel and 16 blocks, i.e.
+// 9 Cin / 64 instructions per pixel instead of 9 Cin / 16 / 4 four times as long ones (4.5x fewer pipe cycles).
+//
+// Layout: a block of 4 waves stages the ReLU'd input patch (TH + 2) x 18 pixels x Cin channels of one 16-wide tile in LDS (NHWC, pixel
+// stride Cin words - Cin / 4 is odd for every supported width - and a row pitch of 19 pixels: with these the 16 blocks' 4-word reads of
+// one ds_read_b32 fall on distinct banks, checked exhaustively on the host when the table below was chosen) plus the tile's dy quads.
+// A wave walks the rows r = wave, wave + 4, ..; per pixel one broadcast read of dy[l % 4] and, per slot (16 blocks), one read of
+// x[tap, quad, l % 4] and one MFMA.  A block keeps its SL x 4 accumulator registers over all its tiles (grid = partitions x groups)
+// and adds them to dW once at the end (the four waves meet in LDS first).
+#include "tmg_common.h"
+
+struct ThinP {
+    const long long* gtab;   // [G][16]: 3 input segments {pointer, pixel stride, 0, channels} + {dy pointer or 0, ...}   (tmg_conv_wgrad_grouped)
+    const float* dy;         // shared upstream gradient: group g at channels [4 g, 4 g + 4)
+    int dys;
+    float* dW;               // [G][4][Cin][3][3], accumulated into
+    int B, H, W, relu_in;
+    int tiles_x, tiles_y, ntiles;   // per group
+};
+
+// SL slots of 16 blocks cover the 9 * Cin / 4 (tap, channel quad) blocks; CS = Cin; TH tile rows
+template <int SL, int CS, int TH>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinP p) {
+    constexpr int Q = CS / 4, NB = 9 * Q;
+    constexpr int PWp = 19, PH = TH + 2, PW = 18;
+    constexpr int XW = PH * PWp * CS;                  // words of the input patch
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* X = lds;
+    float* DY = lds + XW;                              // [TH * 16][4]
+    static_assert(SL * 16 >= NB, "slots");
+    static_assert(SL * 256 * 4 <= XW + TH * 64, "the cross-wave reduction reuses the staging area");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.y;
+    const long long* gt = p.gtab + (size_t)g * 16;
+    const float* sp0 = reinterpret_cast<const float*>(gt[0]);
+    const float* sp1 = reinterpret_cast<const float*>(gt[4]);
+    const float* sp2 = reinterpret_cast<const float*>(gt[8]);
+    const int ss0 = (int)gt[1], ss1 = (int)gt[5], ss2 = (int)gt[9];
+    const int n0 = (int)gt[3], n1 = (int)gt[7];
+    const float* dyb = p.dy + 4 * g;
+
+    // lane offsets of the A operand inside the patch, per slot: block beta = 16 t + lane / 4 = tap * Q + quad (blocks past NB repeat
+    // the last one; their results are dropped)
+    int aoff[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int beta = min(16 * t + (lane >> 2), NB - 1);
+        const int u = beta / Q, s = beta - u * Q;
+        const int ky = u / 3, kx = u - ky * 3;
+        aoff[t] = (ky * PWp + kx) * CS + 4 * s + (lane & 3);
+    }
+    f32x4 acc[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t_ = tile;
+        const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
+        const int ty = t_ % p.tiles_y;
+        const int b = t_ / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * 16;
+        const size_t img = (size_t)b * p.H * p.W;
+        __syncthreads();   // the previous tile's readers are done
+        for (int it = tid; it < PH * PW * Q; it += 256) {
+            const int pp = it / Q, qd = it - pp * Q;
+            const int row = pp / PW, col = pp - row * PW;
+            const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                const size_t pix = img + (size_t)iy * p.W + ix;
+                int c = 4 * qd;
+                const float* a_;
+                if (c < n0) a_ = sp0 + pix * ss0 + c;
+                else if (c < n0 + n1) a_ = sp1 + pix * ss1 + (c - n0);
+                else a_ = sp2 + pix * ss2 + (c - n0 - n1);
+                v = *reinterpret_cast<const float4*>(a_);
+                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4*>(X + (row * PWp + col) * CS + 4 * qd) = v;
+        }
+        for (int it = tid; it < TH * 16; it += 256) {
+            const int r = it >> 4, c = it & 15;
+            const int oy = oy0 + r, ox = ox0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < p.H && ox < p.W) v = *reinterpret_cast<const float4*>(dyb + (img + (size_t)oy * p.W + ox) * p.dys);
+            *reinterpret_cast<float4*>(DY + it * 4) = v;
+        }
+        __syncthreads();
+        for (int r = wave; r < TH; r += 4) {
+            const float* xr = X + r * PWp * CS;
+            const float* dr = DY + r * 64 + (lane & 3);
+#pragma unroll
+            for (int px = 0; px < 16; ++px) {
+                const float bv = dr[px * 4];
+#pragma unroll
+                for (int t = 0; t < SL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[aoff[t] + px * CS], bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the four waves' partial sums meet in LDS, then one atomic per (block, element) ------------------------------------------
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < SL; ++t) *reinterpret_cast<f32x4*>(lds + ((wave * SL + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    float* dWg = p.dW + (size_t)g * 4 * CS * 9;
+    for (int e = tid; e < SL * 256; e += 256) {
+        const int t = e >> 8, l = (e >> 2) & 63, r = e & 3;
+        const int beta = 16 * t + (l >> 2);
+        if (beta < NB) {
+            const int idx = (t * 64 + l) * 4 + r;
+            const float v = lds[idx] + lds[idx + SL * 256] + lds[idx + 2 * SL * 256] + lds[idx + 3 * SL * 256];
+            const int u = beta / Q, s = beta - u * Q;
+            unsafeAtomicAdd(dWg + ((size_t)(l & 3) * CS + 4 * s + r) * 9 + u, v);
+        }
+    }
+}
+
+template <int SL, int CS, int TH>
+static int launch_thin(ThinP p, int G, hipStream_t st) {
+    constexpr int lds_bytes = ((TH + 2) * 19 * CS + TH * 64) * 4;
+    p.tiles_x = (p.W + 15) / 16;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    // enough blocks to fill every CU to its LDS-limited occupancy, few enough that the final atomics stay negligible
+    int per_cu = 160 * 1024 / lds_bytes;
+    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    int P = (per_cu * 256 + G - 1) / G;
+    P = P > p.ntiles ? p.ntiles : (P < 1 ? 1 : P);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_thin_kernel<SL, CS, TH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_thin_kernel<SL, CS, TH>), dim3(P, G), dim3(256), lds_bytes, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// gtab: device int64 [G][16] as for tmg_conv_wgrad_grouped (input segments of every group; the dy entries are not used: dy is the
+// shared tensor, group g at channels [4 g, 4 g + 4)).  dims = {B, H, W, Cin, relu_in}.  dW [G][4][Cin][3][3] is ACCUMULATED into
+// (float atomics: zero it first).  Supported: Cin in {12, 20, 36, 68} (channel halves 8 / 16 / 32 / 64 plus the 4 growth channels),
+// every segment a multiple of 4 channels with 16-byte aligned pixels; otherwise -100 (nothing launched; use tmg_conv_wgrad_grouped).
+extern "C" int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const int64_t* seg_channels, int64_t nseg, const void* dy,
+                                           int64_t dy_stride, void* dW, const int64_t* dims, hipStream_t st) {
+    ThinP p;
+    p.gtab = (const long long*)gtab; p.dy = (const float*)dy; p.dys = (int)dy_stride; p.dW = (float*)dW;
+    p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.relu_in = (int)dims[4];
+    const int Cin = (int)dims[3];
+    if (G < 1 || !gtab || nseg < 1 || nseg > 3 || (dy_stride & 3) || ((uintptr_t)dy & 15)) return -100;
+    for (int i = 0; i < nseg; ++i)
+        if (seg_channels[i] & 3) return -100;
+    if (G > 65535) return -100;
+    switch (Cin) {
+        case 12: return launch_thin<2, 12, 16>(p, (int)G, st);
+        case 20: return launch_thin<3, 20, 16>(p, (int)G, st);
+        case 36: return launch_thin<6, 36, 16>(p, (int)G, st);
+        case 68: return launch_thin<10, 68, 8>(p, (int)G, st);
+        default: return -100;
+    }
+}

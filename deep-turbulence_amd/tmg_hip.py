@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtmglow_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip", "tmg_coupling.hip", "tmg_wino.hip"]
+SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip", "tmg_coupling.hip", "tmg_wino.hip", "tmg_thin.hip"]
 _lib = None
 
 c_i64 = ctypes.c_int64
@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
 ]
 
 
@@ -473,6 +473,15 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
             if rc != -100:
                 _chk(rc, "tmg_conv_wino_wgrad_grouped")
                 return True
+    if (group_dy is None and ksize == 3 and stride == 1 and Cg == 4 and not pad_rep and dbias is None and cin_dst in (0, Cin)
+            and cin_valid in (0, Cin) and ci_split == 0 and Cin in (12, 20, 36, 68) and os.environ.get("TMG_NO_THIN_WGRAD") is None
+            and all(t.stride(2) % 4 == 0 and t.data_ptr() % 16 == 0 for segs in group_inputs for t in segs)):
+        # four output channels per group (the growth-1 layers): 4x4x1 MFMA blocks instead of 16x16 tiles that would be 2/16 used
+        rc = lib().tmg_conv_wgrad_thin_grouped(_ptr(gtab), c_i64(G), _i64(*[t.shape[3] for t in first]), c_i64(n_in), _ptr(dy),
+                                               c_i64(dy.stride(2)), _ptr(dW), _i64(B, Hin, Win, Cin, relu_in), _stream())
+        if rc != -100:
+            _chk(rc, "tmg_conv_wgrad_thin_grouped")
+            return True
     dims = _i64(B, Hin, Win, Hout, Wout, ksize, stride, Cin, Cg, relu_in, pad_rep, cin_dst, cin_valid, ci_split, ci_off0, ci_off1)
     ws = workspace(lib().tmg_conv_wgrad_grouped_ws_floats(dims, c_i64(G)), dy.device)
     gd = _i64(Cg, dW[0].numel(), dbias[0].numel() if dbias is not None else 0)

@@ -15,7 +15,7 @@ class HipAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, foreach=False, fused=False)
         self._chunks = {}
-        self._stage = {}
+        self._fast = {}
 
     def _chunk_table(self, numels, device):
         key = (tuple(numels), device.index)
@@ -35,7 +35,9 @@ class HipAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
+            if self._fast_step(gi, group):
+                continue
             params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
             beta1, beta2 = group["betas"]
             self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)
@@ -43,39 +45,70 @@ class HipAdam(torch.optim.Adam):
                 continue
             ok = (all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params)
                   and not group.get("maximize", False) and not group.get("capturable", False) and not group.get("differentiable", False)
-                  and len({float(s) for s in steps[:1] + steps[-1:]}) == 1)
+                  and len({float(s) for s in steps}) == 1 and len({p.device for p in params}) == 1)
             if not ok:   # anything unusual: torch's own single-tensor path on this group (same state)
                 _torch_adam(params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps, amsgrad=group["amsgrad"], has_complex=False,
                                       beta1=beta1, beta2=beta2, lr=group["lr"], weight_decay=group["weight_decay"], eps=group["eps"],
                                       maximize=group.get("maximize", False), foreach=False, capturable=False, differentiable=False,
                                       fused=False, grad_scale=None, found_inf=None, decoupled_weight_decay=False)
                 continue
-            torch._foreach_add_(steps, 1)
-            step = float(steps[0])
-            grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+            # first step with this set of tensors: build the launch state once.  The pointer table goes through a persistent PINNED
+            # staging buffer and an asynchronous copy: a pageable host-to-device copy would make the host wait for everything enqueued
+            # before it, i.e. a host-device synchronisation per step.  Parameter and state pointers are written once; only the
+            # gradient column changes from step to step.
             dev = params[0].device
             amsgrad = bool(group["amsgrad"])
-            # pointer table through a persistent PINNED staging buffer and an asynchronous copy: a pageable host-to-device copy would
-            # make the host wait for everything enqueued before it, i.e. a host-device synchronisation per step
             n = len(params)
-            stage = self._stage.get(dev.index)
-            if stage is None or stage[0].numel() < 5 * n:
-                stage = (torch.empty(5 * n, dtype=torch.int64).pin_memory(), torch.empty(5 * n, dtype=torch.int64, device=dev),
-                         torch.cuda.Event())
-                self._stage[dev.index] = stage
-            host, tab, done = stage
-            done.synchronize()          # the previous step's copy has left the staging buffer (it has, long ago)
+            host = torch.empty(5 * n, dtype=torch.int64).pin_memory()
             hv = host.numpy()
             hv[0:5 * n:5] = [p.data_ptr() for p in params]
-            hv[1:5 * n:5] = [g.data_ptr() for g in grads]
             hv[2:5 * n:5] = [m.data_ptr() for m in exp_avgs]
             hv[3:5 * n:5] = [v.data_ptr() for v in exp_avg_sqs]
             hv[4:5 * n:5] = [m.data_ptr() for m in max_sqs] if amsgrad else 0
-            tab.copy_(host, non_blocking=True)
-            done.record()
             chunks, nchunks = self._chunk_table([p.numel() for p in params], dev)
-            bc1 = 1.0 - beta1 ** step
-            bc2s = (1.0 - beta2 ** step) ** 0.5
-            H.adam_step(tab, chunks, nchunks, group["lr"], beta1, beta2, group["eps"], group["weight_decay"], bc1, bc2s, amsgrad)
-            del grads   # (kept alive until the launch is enqueued)
+            self._fast[gi] = dict(params=params, states=[self.state[p] for p in params], steps=steps, host=host, hv=hv,
+                                  tab=torch.empty(5 * n, dtype=torch.int64, device=dev), done=torch.cuda.Event(), chunks=chunks,
+                                  nchunks=nchunks, amsgrad=amsgrad, keep=(exp_avgs, exp_avg_sqs, max_sqs), step=int(float(steps[0])))
+            ok = self._fast_step(gi, group)
+            assert ok
         return loss
+
+    def _fast_step(self, gi, group):
+        """The steady-state step: everything that does not change between steps (parameter / state pointers, chunk table, pinned
+        staging buffer) is cached, so the host side is one pass over the gradients (~0.3 ms for ~600 tensors instead of ~3 ms of
+        list building, during which the GPU - done with backward - would sit idle).  False: not applicable, take the general path."""
+        c = self._fast.get(gi)
+        if c is None:
+            return False
+        params = c["params"]
+        gp = [p for p in group["params"] if p.grad is not None]
+        if (len(gp) != len(params) or any(a is not b for a, b in zip(gp, params)) or bool(group["amsgrad"]) != c["amsgrad"]
+                or group.get("maximize", False) or group.get("capturable", False) or group.get("differentiable", False)):
+            self._fast.pop(gi)
+            return False
+        grads = [p.grad for p in params]
+        if any(g is None or not g.is_contiguous() or g.is_sparse for g in grads):
+            self._fast.pop(gi)
+            return False
+        st = c["states"]
+        if any(self.state.get(p) is not s for p, s in zip(params[:1] + params[-1:], st[:1] + st[-1:])):   # load_state_dict replaced the state
+            self._fast.pop(gi)
+            return False
+        if int(float(c["steps"][0])) != c["step"] or c["steps"][0] is not st[0]["step"]:
+            self._fast.pop(gi)
+            return False
+        torch._foreach_add_(c["steps"], 1)
+        c["step"] += 1
+        step = float(c["step"])
+        beta1, beta2 = group["betas"]
+        n = len(params)
+        c["done"].synchronize()          # the previous step's copy has left the staging buffer (it has, long ago)
+        c["hv"][1:5 * n:5] = [g.data_ptr() for g in grads]
+        c["tab"].copy_(c["host"], non_blocking=True)
+        c["done"].record()
+        bc1 = 1.0 - beta1 ** step
+        bc2s = (1.0 - beta2 ** step) ** 0.5
+        H.adam_step(c["tab"], c["chunks"], c["nchunks"], group["lr"], beta1, beta2, group["eps"], group["weight_decay"], bc1, bc2s,
+                    c["amsgrad"])
+        del grads   # (kept alive until the launch is enqueued)
+        return True

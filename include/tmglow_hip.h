@@ -294,6 +294,15 @@ int tmg_lu_fold_bwd_split(const void* tab, const void* sign_s, const void* perm,
                           const void* dbm, const void* dWm_tail, const void* dbm_tail, const void* dld, void* dl, void* du, void* dlogs,
                           void* da, void* db, const int64_t* dims, const float* fl, tmg_stream_t st);
 
+/* Grouped 3x3 weight gradient with FOUR output channels per group (the growth-1 convs of the coupling networks, denseBlock.py:18-36, all
+ * layers of a level in one launch) on v_mfma_f32_4x4x1 blocks - a (tap, input-channel quad) pair per block, one pixel per instruction -
+ * instead of 16x16 tiles that would be 2/16 used.  gtab: device int64 [G][16] as for tmg_conv_wgrad_grouped; seg_channels[nseg]: channels of
+ * the input segments; dy: shared upstream gradient, group g at channels [4g, 4g+4), pixel stride dy_stride; dW [G][4][Cin][3][3] is
+ * accumulated into (atomics).  dims = {B, H, W, Cin, relu_in}; zero padding, stride 1.  -100: shape outside the envelope (Cin not in
+ * {12, 20, 36, 68} or unaligned segments), nothing launched. */
+int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const int64_t* seg_channels, int64_t nseg, const void* dy, int64_t dy_stride,
+                                void* dW, const int64_t* dims, tmg_stream_t st);
+
 /* Parameter-gradient epilogue of a level's NL plain coupling layers, one launch: d(kappa_k) = (<Wz_k, dWz_k> + <bz_k, dBz_k>) inside the
  * clamp range of the zero conv's log-scale (flowUtils.py:104-106; fp64 accumulation), and the scatter-add of the grouped 4-row
  * weight-gradient results tmpX [NL,4,ch+4,3,3] (x1 | d1 columns) and tmpC [NL,4,Cc,3,3] (conditioning columns) into the native

@@ -622,3 +622,67 @@ def test_zero_pool_hands_out_disjoint_zeroed_buffers():
     assert big.untyped_storage().nbytes() == 4 * big.numel() and not bool(big.any())
     assert bufs[0].untyped_storage().nbytes() > 4 * bufs[0].numel() and bufs[0]._base is None      # pooled, but not an autograd view
     assert tmg_ops.zeros_like(bufs[1]).shape == bufs[1].shape
+
+
+def test_hip_adam_cached_path_follows_changes():
+    """HipAdam's cached steady-state path (parameter / state pointers kept between steps) against torch.optim.Adam when things change
+    under it: a parameter without a gradient in one step, a changed learning rate, and a state dict loaded half-way."""
+    import copy
+    from tmg_optim import HipAdam
+    g = torch.Generator().manual_seed(23)
+    shapes = [(5,), (4100,), (8, 3, 3, 3), (1,)]
+    pa = [torch.randn(s_, generator=g).to(DEV).requires_grad_(True) for s_ in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = HipAdam(pa, lr=2e-3, weight_decay=1e-8, amsgrad=True)
+    ob = torch.optim.Adam(pb, lr=2e-3, weight_decay=1e-8, amsgrad=True, foreach=False)
+    for it in range(9):
+        skip = 2 if it == 3 else -1                   # parameter 2 takes no part in step 3
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad, b.grad = (None, None) if i == skip else (gr.clone(), gr.clone())
+        if it == 5:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 5e-4
+        if it == 7:                                   # round trip through the state dict (a workspace reload)
+            oa.load_state_dict(copy.deepcopy(ob.state_dict()))     # (deep copy: load_state_dict keeps the tensors it is given)
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            _close(a, b.detach().double(), tol=3e-6, what="parameter after step %d" % it)
+    for a, b in zip(pa, pb):
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])
+        for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            _close(oa.state[a][k], ob.state[b][k].double(), tol=3e-6, what=k)
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 16, 16, 8), (15, 1, 20, 35, 8), (4, 2, 33, 17, 16), (5, 1, 16, 32, 32), (3, 2, 9, 16, 64)])
+def test_thin_grouped_weight_gradient(shape):
+    """tmg_conv_wgrad_thin_grouped (growth-layer weight gradients, four output channels per group, 4x4x1 MFMA blocks) against the
+    general grouped kernel it replaces and against fp64 autograd: ragged tiles, every supported channel half, ReLU'd inputs, zero
+    padding, channel-slice views as inputs, a shared dy tensor with the groups side by side."""
+    import os
+    import tmg_hip as H
+    G, B, Hh, Ww, ch = shape
+    g = torch.Generator().manual_seed(G * 10 + ch)
+    xs = [torch.randn(B, Hh, Ww, 2 * ch, generator=g).to(DEV) for _ in range(G)]
+    Ds = [torch.randn(B, Hh, Ww, 4, generator=g).to(DEV) for _ in range(G)]
+    DD = torch.randn(B, Hh, Ww, 4 * G, generator=g).to(DEV)
+    groups = [[x[..., :ch], d] for x, d in zip(xs, Ds)]
+    res = {}
+    for mode in ("thin", "general"):
+        os.environ.pop("TMG_NO_THIN_WGRAD", None)
+        if mode == "general":
+            os.environ["TMG_NO_THIN_WGRAD"] = "1"
+        dW = torch.zeros(G, 4, ch + 4, 3, 3, device=DEV)
+        try:
+            assert H.conv_wgrad_grouped(groups, DD, 4, dW, None, 3, 1, relu_in=True)
+        finally:
+            os.environ.pop("TMG_NO_THIN_WGRAD", None)
+        res[mode] = dW
+    _close(res["thin"], res["general"], tol=2e-5, what="thin vs general grouped kernel")
+    for k in range(G):
+        xin = torch.cat([xs[k][..., :ch], Ds[k]], 3).permute(0, 3, 1, 2).double().relu()
+        w = torch.zeros(4, ch + 4, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+        y = F.conv2d(xin, w, padding=1)
+        (y * DD[..., 4 * k:4 * k + 4].permute(0, 3, 1, 2).double()).sum().backward()
+        _close(res["thin"][k], w.grad, tol=2e-5, what="group %d vs fp64" % k)
