@@ -25,6 +25,7 @@ struct ThinP {
     float* dW;               // [G][4][Cin][3][3], accumulated into
     int B, H, W, relu_in;
     int tiles_x, tiles_y, ntiles;   // per group
+    int G, P;                       // groups, tile partitions per group (grid = G * P blocks)
 };
 
 // SL slots of 16 blocks cover the 9 * Cin / 4 (tap, channel quad) blocks; CS = Cin; TH tile rows
@@ -40,7 +41,18 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinP p) {
     static_assert(SL * 256 * 4 <= XW + TH * 64, "the cross-wave reduction reuses the staging area");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.y;
+    // block -> (partition, group): the G blocks of a partition walk the same tiles at the same time and share the dy lines (a group
+    // uses 16 bytes of every pixel of the shared dy tensor) - keep them on ONE XCD (consecutive block ids go round the 8 XCDs), so the
+    // lines are fetched into one L2 once instead of G times into all of them
+    int g, part;
+    if ((p.P & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g = slot % p.G;
+        part = xcd + 8 * (slot / p.G);
+    } else {
+        g = blockIdx.x % p.G;
+        part = blockIdx.x / p.G;
+    }
     const long long* gt = p.gtab + (size_t)g * 16;
     const float* sp0 = reinterpret_cast<const float*>(gt[0]);
     const float* sp1 = reinterpret_cast<const float*>(gt[4]);
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinP p) {
 #pragma unroll
     for (int t = 0; t < SL; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int tile = part; tile < p.ntiles; tile += p.P) {
         int t_ = tile;
         const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
         const int ty = t_ % p.tiles_y;
@@ -136,6 +148,8 @@ static int launch_thin(ThinP p, int G, hipStream_t st) {
     per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     int P = (per_cu * 256 + G - 1) / G;
     P = P > p.ntiles ? p.ntiles : (P < 1 ? 1 : P);
+    if (P >= 8) P &= ~7;
+    p.G = G; p.P = P;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_thin_kernel<SL, CS, TH>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -143,7 +157,7 @@ static int launch_thin(ThinP p, int G, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_thin_kernel<SL, CS, TH>), dim3(P, G), dim3(256), lds_bytes, st, p);
+    hipLaunchKernelGGL((wgrad_thin_kernel<SL, CS, TH>), dim3(P * G), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
 }
@@ -161,7 +175,6 @@ extern "C" int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const in
     if (G < 1 || !gtab || nseg < 1 || nseg > 3 || (dy_stride & 3) || ((uintptr_t)dy & 15)) return -100;
     for (int i = 0; i < nseg; ++i)
         if (seg_channels[i] & 3) return -100;
-    if (G > 65535) return -100;
     switch (Cin) {
         case 12: return launch_thin<2, 12, 16>(p, (int)G, st);
         case 20: return launch_thin<3, 20, 16>(p, (int)G, st);
