@@ -636,9 +636,10 @@ class LevelCouplingFn(torch.autograd.Function):
         # cond-side operands of the whole level (parameter-sized copies, no autograd inside a Function)
         Wz = torch.stack(wzs)                                              # [NL, C, cin+2, 3, 3]
         Wzc = Wz[:, :, ch:cin].reshape(NL * C, Cc, 3, 3).contiguous()
+        # output channel 2k / 2k+1 = growth layer 1 / 2 of coupling layer k: a layer's two addends share one cache line of Dc
         Wdc = zeros((2 * NLp, Cc, 3, 3), dev)
-        Wdc[:NL] = torch.stack(w1s)[:, 0, ch:cin]
-        Wdc[NLp:NLp + NL] = torch.stack(w2s)[:, 0, ch:cin]
+        Wdc.view(NLp, 2, Cc, 3, 3)[:NL, 0] = torch.stack(w1s)[:, 0, ch:cin]
+        Wdc.view(NLp, 2, Cc, 3, 3)[:NL, 1] = torch.stack(w2s)[:, 0, ch:cin]
         Hc = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)
         H.conv3x3_auto([cond], Wzc, NL * C, [Hc], relu_in=True, pad_rep=True)
         Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
@@ -658,7 +659,7 @@ class LevelCouplingFn(torch.autograd.Function):
             if fuse:
                 tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
                 D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-                H.c1x2_fwd([tin[..., :ch]], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., k:k + 1], add2=Dc[..., NLp + k:NLp + k + 1])
+                H.c1x2_fwd([tin[..., :ch]], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., 2 * k:2 * k + 1], add2=Dc[..., 2 * k + 1:2 * k + 2])
                 out = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
                 r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
                 y2 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32) if reverse else None
@@ -674,10 +675,10 @@ class LevelCouplingFn(torch.autograd.Function):
             D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
             if ch % 4 == 0:
                 # both growth-1 layers in one launch (the conditioning parts arrive as add operands)
-                H.c1x2_fwd([x1], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., k:k + 1], add2=Dc[..., NLp + k:NLp + k + 1])
+                H.c1x2_fwd([x1], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., 2 * k:2 * k + 1], add2=Dc[..., 2 * k + 1:2 * k + 2])
             else:
-                H.c1_fwd([x1], w1s[k], D[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=Dc[..., k:k + 1])
-                H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=Dc[..., NLp + k:NLp + k + 1])
+                H.c1_fwd([x1], w1s[k], D[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=Dc[..., 2 * k:2 * k + 1])
+                H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=Dc[..., 2 * k + 1:2 * k + 2])
             hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             H.conv_fwd([x1, D], PZ[k], C, 3, 1, [hh], bias=bzs[k], kappa=kps[k], relu_in=True, pad_rep=True, add=Hc[..., k * C:(k + 1) * C])
             y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
@@ -808,8 +809,7 @@ class LevelCouplingFn(torch.autograd.Function):
         wzc_t = H.conv3x3_auto([DH], Wzc, Cc, [Gc], dgrad=True)
         H.conv_rep_border_fix(DH, wzc_t if wzc_t is not None else H.conv_pack(Wzc, 1), [Gc])
         Wd4 = zeros((4 * NL, Cc, 3, 3), dev)   # rows 4k / 4k+1: cond columns of w1_k / w2_k
-        Wd4.view(NL, 4, Cc, 3, 3)[:, 0] = Wdc[:NL]
-        Wd4.view(NL, 4, Cc, 3, 3)[:, 1] = Wdc[NLp:NLp + NL]
+        Wd4.view(NL, 4, Cc, 3, 3)[:, :2] = Wdc.view(NLp, 2, Cc, 3, 3)[:NL]
         H.conv_fwd([DD], H.conv_pack(Wd4, 1), Cc, 3, 1, [Gc], accumulate=True)
         H.masked_add(Gc, src=Gc, ref=cond)
         H.conv_wgrad([cond], DH, dWz, None, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=Cc, ci_off0=ch)
