@@ -183,3 +183,122 @@ extern "C" int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const in
         default: return -100;
     }
 }
+
+// =================================================================================================================================
+// Grouped weight gradient of the 1x1 channel mixes (ActNorm folded into the invertible 1x1 conv, glowConv.py:193-222 under autograd),
+// all layers of a level in one launch:   dW[g][o][i] += sum_px dout_g[px][o] * y_g[px][i],   db[g][o] += sum_px dout_g[px][o].
+// A streaming GEMM with the pixels as the contraction index: both operands are read straight from global memory in MFMA fragment
+// order - lane (c = l % 16, k = l / 16) loads channel c of pixel p + k, a load instruction covers four whole 64-byte pixels - no LDS
+// staging, no packing; one v_mfma_f32_16x16x4_f32 per 16x16 channel tile and 4 pixels.  The general grouped kernel ran this shape
+// through its 3x3 machinery (patch staging, tap pairs) at 2.2-2.9 TB/s of the 128 B per pixel and layer it has to read.
+struct MixWgP {
+    const long long* gtab;   // [G][16]: input segments (the mix input y = (x1 | y2) as <= 3 channel segments) + {dout pointer, pixel stride}
+    float* dW;               // [G][C][C]
+    float* db;               // [G][C] or null
+    long long npix;
+    int C, G, P;
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void mix_wgrad_kernel(MixWgP p) {
+    constexpr int U = CT == 2 ? 4 : 8;     // pixel groups (of 4) in flight per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int g = blockIdx.x % p.G, part = blockIdx.x / p.G;
+    const long long* gt = p.gtab + (size_t)g * 16;
+    const int n0 = (int)gt[3], n1 = (int)gt[7];
+    const float* dyp = reinterpret_cast<const float*>(gt[12]);
+    const long long dys = gt[13];
+    // per-lane source of the B operand (mix input channel 16 nt + li): segment pointer and pixel stride
+    const float* bp[CT];
+    long long bs[CT];
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+        const int c = 16 * nt + li;
+        const int s = c < n0 ? 0 : (c < n0 + n1 ? 1 : 2);
+        const int cl = c - (s == 0 ? 0 : (s == 1 ? n0 : n0 + n1));
+        bp[nt] = reinterpret_cast<const float*>(gt[4 * s]) + cl;
+        bs[nt] = gt[4 * s + 1];
+    }
+    f32x4 acc[CT][CT];
+#pragma unroll
+    for (int mt = 0; mt < CT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dbs[CT];
+#pragma unroll
+    for (int mt = 0; mt < CT; ++mt) dbs[mt] = 0.f;
+
+    // partition `part` owns a contiguous pixel range (a multiple of 16 U pixels); its 4 waves interleave units of 4 U pixels
+    const long long per = ((p.npix + p.P - 1) / p.P + 16 * U - 1) / (16 * U) * (16 * U);
+    const long long p0 = (long long)part * per, p1 = min(p0 + per, p.npix);
+    for (long long pb = p0 + (long long)wave * 4 * U; pb < p1; pb += 16 * U) {
+        float a[U][CT], b[U][CT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long px = pb + 4 * u + q;
+            const bool ok = px < p1;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                a[u][t] = *(ok ? dyp + px * dys + 16 * t + li : tmg_zero_page);
+                b[u][t] = *(ok ? bp[t] + px * bs[t] : tmg_zero_page);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < CT; ++mt) {
+                dbs[mt] += a[u][mt];
+#pragma unroll
+                for (int nt = 0; nt < CT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt], b[u][nt], acc[mt][nt], 0, 0, 0);
+            }
+    }
+    // ---- four waves meet in LDS; D rows = dout channel 16 mt + 4 q + r, column = input channel 16 nt + li -------------------------
+    __shared__ float red[4][CT * CT * 256 + CT * 64];
+    float* mine = red[wave];
+#pragma unroll
+    for (int mt = 0; mt < CT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) *reinterpret_cast<f32x4*>(mine + ((mt * CT + nt) * 64 + lane) * 4) = acc[mt][nt];
+#pragma unroll
+    for (int mt = 0; mt < CT; ++mt) mine[CT * CT * 256 + mt * 64 + lane] = dbs[mt];
+    __syncthreads();
+    float* dWg = p.dW + (size_t)g * p.C * p.C;
+    for (int e = tid; e < CT * CT * 256; e += 256) {
+        const int t = e >> 8, l = (e >> 2) & 63, r = e & 3;
+        const int mt = t / CT, nt = t - mt * CT;
+        const float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        unsafeAtomicAdd(dWg + (size_t)(16 * mt + 4 * (l >> 4) + r) * p.C + 16 * nt + (l & 15), v);
+    }
+    if (p.db) {
+        for (int e = tid; e < CT * 16; e += 256) {
+            const int mt = e >> 4, c = e & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v += red[w][CT * CT * 256 + mt * 64 + 16 * k + c];
+            unsafeAtomicAdd(p.db + (size_t)g * p.C + 16 * mt + c, v);
+        }
+    }
+}
+
+// gtab as for tmg_conv_wgrad_grouped with every group's own upstream gradient (row entries 12 / 13: pointer, pixel stride); all
+// tensors pixel-linear NHWC (address = pointer + pixel * stride + channel).  dims = {npix, C}.  dW [G][C][C] and db [G][C] (nullable) are
+// ACCUMULATED into (zero them first).  C in {16, 32} (the levels whose mixes are bandwidth kernels); otherwise -100 (nothing launched).
+extern "C" int tmg_mix_wgrad_grouped(const void* gtab, int64_t G, void* dW, void* db, const int64_t* dims, hipStream_t st) {
+    MixWgP p;
+    p.gtab = (const long long*)gtab; p.dW = (float*)dW; p.db = (float*)db; p.npix = dims[0]; p.C = (int)dims[1]; p.G = (int)G;
+    if (G < 1 || !gtab || p.npix < 1) return -100;
+    if (p.C != 16 && p.C != 32) return -100;
+    // ~8 blocks per CU in total, each with at least a few hundred pixels
+    long long P = (2048 + G - 1) / G;
+    const long long maxp = (p.npix + 511) / 512;
+    if (P > maxp) P = maxp;
+    if (P < 1) P = 1;
+    p.P = (int)P;
+    if (p.C == 16) hipLaunchKernelGGL(mix_wgrad_kernel<1>, dim3((unsigned)(P * G)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(mix_wgrad_kernel<2>, dim3((unsigned)(P * G)), dim3(256), 0, st, p);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

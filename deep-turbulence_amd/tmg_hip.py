@@ -29,7 +29,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
 ]
 
 
@@ -432,6 +432,12 @@ def _segment_table(rows, device):
     return t
 
 
+def _pixel_linear(t):
+    """[B,H,W,c] view whose pixels are equally spaced in memory (address = base + pixel index * stride(2) + channel)."""
+    B, Hh, Ww, _ = t.shape
+    return t.stride(3) == 1 and (Hh == 1 or t.stride(1) == t.stride(2) * Ww) and (B == 1 or t.stride(0) == t.stride(2) * Ww * Hh)
+
+
 def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, stride, relu_in=False, pad_rep=False, cin_dst=0,
                        cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0, group_dy=None):
     """One launch for len(group_inputs) identically shaped weight gradients.  group_inputs[g]: list of <= 3 NHWC segments;
@@ -473,6 +479,14 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
             if rc != -100:
                 _chk(rc, "tmg_conv_wino_wgrad_grouped")
                 return True
+    if (group_dy is not None and ksize == 1 and stride == 1 and Cg == Cin and Cin in (16, 32) and cin_dst in (0, Cin)
+            and cin_valid in (0, Cin) and ci_split == 0 and os.environ.get("TMG_NO_MIX_WGRAD_KERNEL") is None
+            and all(_pixel_linear(t) for segs in group_inputs for t in segs) and all(_pixel_linear(t) for t in group_dy)):
+        # the 1x1 mixes' weight gradients: streaming GEMM over the pixels, operands straight from global memory
+        rc = lib().tmg_mix_wgrad_grouped(_ptr(gtab), c_i64(G), _ptr(dW), _ptr(dbias), _i64(B * Hin * Win, Cin), _stream())
+        if rc != -100:
+            _chk(rc, "tmg_mix_wgrad_grouped")
+            return True
     if (group_dy is None and ksize == 3 and stride == 1 and Cg == 4 and not pad_rep and dbias is None and cin_dst in (0, Cin)
             and cin_valid in (0, Cin) and ci_split == 0 and Cin in (12, 20, 36, 68) and os.environ.get("TMG_NO_THIN_WGRAD") is None
             and all(t.stride(2) % 4 == 0 and t.data_ptr() % 16 == 0 for segs in group_inputs for t in segs)):

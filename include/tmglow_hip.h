@@ -303,6 +303,13 @@ int tmg_lu_fold_bwd_split(const void* tab, const void* sign_s, const void* perm,
 int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const int64_t* seg_channels, int64_t nseg, const void* dy, int64_t dy_stride,
                                 void* dW, const int64_t* dims, tmg_stream_t st);
 
+/* Grouped weight gradient of the 1x1 channel mixes (glowConv.py:193-222 + actNorm.py:71-85 under autograd), all layers of a level in
+ * one launch: dW[g][o][i] += sum_px dout_g[px][o] y_g[px][i], db[g][o] += sum_px dout_g[px][o] - a streaming GEMM over the pixels with
+ * both operands read from global memory in MFMA fragment order.  gtab: device int64 [G][16] as for tmg_conv_wgrad_grouped, every
+ * group with its own dout (entries 12 / 13: pointer, pixel stride); tensors pixel-linear NHWC.  dims = {npix, C}; C in {16, 32},
+ * otherwise -100.  dW [G][C][C], db [G][C] (nullable) are accumulated into. */
+int tmg_mix_wgrad_grouped(const void* gtab, int64_t G, void* dW, void* db, const int64_t* dims, tmg_stream_t st);
+
 /* Parameter-gradient epilogue of a level's NL plain coupling layers, one launch: d(kappa_k) = (<Wz_k, dWz_k> + <bz_k, dBz_k>) inside the
  * clamp range of the zero conv's log-scale (flowUtils.py:104-106; fp64 accumulation), and the scatter-add of the grouped 4-row
  * weight-gradient results tmpX [NL,4,ch+4,3,3] (x1 | d1 columns) and tmpC [NL,4,Cc,3,3] (conditioning columns) into the native

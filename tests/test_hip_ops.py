@@ -686,3 +686,38 @@ def test_thin_grouped_weight_gradient(shape):
         y = F.conv2d(xin, w, padding=1)
         (y * DD[..., 4 * k:4 * k + 4].permute(0, 3, 1, 2).double()).sum().backward()
         _close(res["thin"][k], w.grad, tol=2e-5, what="group %d vs fp64" % k)
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 16, 16, 16), (15, 1, 20, 35, 16), (4, 3, 17, 9, 32), (2, 1, 64, 64, 32)])
+def test_mix_weight_gradient_grouped_kernel(shape):
+    """tmg_mix_wgrad_grouped (weight / bias gradients of the 1x1 mixes of all layers of a level, streaming GEMM over the pixels)
+    against the general grouped kernel and fp64: two-segment mix inputs (x1 as a channel-slice view | y2), every group with its own
+    upstream gradient, pixel counts that are not a multiple of the unroll."""
+    import os
+    import tmg_hip as H
+    G, B, Hh, Ww, C_ = shape
+    ch = C_ // 2
+    g = torch.Generator().manual_seed(G + C_)
+    tins = [torch.randn(B, Hh, Ww, C_, generator=g).to(DEV) for _ in range(G)]
+    y2s = [torch.randn(B, Hh, Ww, ch, generator=g).to(DEV) for _ in range(G)]
+    douts = [torch.randn(B, Hh, Ww, C_, generator=g).to(DEV) for _ in range(G)]
+    ins = [[t[..., :ch], y2] for t, y2 in zip(tins, y2s)]
+    res = {}
+    for mode in ("stream", "general"):
+        os.environ.pop("TMG_NO_MIX_WGRAD_KERNEL", None)
+        if mode == "general":
+            os.environ["TMG_NO_MIX_WGRAD_KERNEL"] = "1"
+        dW = torch.zeros(G, C_, C_, device=DEV)
+        db = torch.zeros(G, C_, device=DEV)
+        try:
+            assert H.conv_wgrad_grouped(ins, None, C_, dW.view(G, C_, C_, 1, 1), db, 1, 1, group_dy=douts)
+        finally:
+            os.environ.pop("TMG_NO_MIX_WGRAD_KERNEL", None)
+        res[mode] = (dW, db)
+    _close(res["stream"][0], res["general"][0], tol=2e-5, what="dW: streaming vs general grouped kernel")
+    _close(res["stream"][1], res["general"][1], tol=2e-5, what="db: streaming vs general grouped kernel")
+    for k in range(G):
+        y = torch.cat([tins[k][..., :ch], y2s[k]], 3).reshape(-1, C_).double()
+        d = douts[k].reshape(-1, C_).double()
+        _close(res["stream"][0][k], d.t() @ y, tol=2e-5, what="dW group %d vs fp64" % k)
+        _close(res["stream"][1][k], d.sum(0), tol=2e-5, what="db group %d vs fp64" % k)
