@@ -302,3 +302,41 @@ extern "C" int tmg_mix_wgrad_grouped(const void* gtab, int64_t G, void* dW, void
     TMG_CHECK_LAUNCH();
     return 0;
 }
+
+// =================================================================================================================================
+// [npix][2 K] -> [K][npix][2]: the level-wide conditioning addends of the growth-1 convs (one conv over cond for all layers of a level,
+// channel 2k / 2k+1 = layer k) re-laid as one pixel-contiguous float2 plane per layer.  Every layer's c1x2_fwd launch reads its two
+// addends for every pixel: out of the [npix][2K] tensor that is a full 128-byte line per pixel for 8 useful bytes (134 MB per launch at
+// 128 x 128 x 64, more than the kernel's real input), out of its plane 8 bytes.  64 pixels per block through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void layer_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, long long npix, int CP) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int RS = CP + 2;                      // row stride (words): float2 reads of one layer from consecutive pixels stay 2-way at worst
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int q4 = CP >> 2;
+    for (int it = threadIdx.x; it < 64 * q4; it += 256) {
+        const int px = it / q4, c4 = it - px * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + px < npix) v = *reinterpret_cast<const float4*>(src + (p0 + px) * CP + 4 * c4);
+        float* d = lds + px * RS + 4 * c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int K = CP >> 1;
+    for (int it = threadIdx.x; it < 64 * K; it += 256) {
+        const int k = it >> 6, px = it & 63;
+        if (p0 + px < npix) {
+            const float2 v = *reinterpret_cast<const float2*>(lds + px * RS + 2 * k);
+            *reinterpret_cast<float2*>(dst + ((size_t)k * npix + p0 + px) * 2) = v;
+        }
+    }
+}
+
+// src [npix][CP] contiguous (CP a multiple of 4), dst [CP / 2][npix][2].
+extern "C" int tmg_layer_planes(const void* src, void* dst, int64_t npix, int64_t CP, hipStream_t st) {
+    if (npix < 1 || CP < 4 || (CP & 3) || CP > 512) return -1;
+    const long long blocks = (npix + 63) / 64;
+    hipLaunchKernelGGL(layer_planes_kernel, dim3((unsigned)blocks), dim3(256), (size_t)64 * (CP + 2) * 4, st, (const float*)src, (float*)dst,
+                       (long long)npix, (int)CP);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

@@ -644,6 +644,13 @@ class LevelCouplingFn(torch.autograd.Function):
         H.conv3x3_auto([cond], Wzc, NL * C, [Hc], relu_in=True, pad_rep=True)
         Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
         H.conv_fwd([cond], H.conv_pack(Wdc, 0), 2 * NLp, 3, 1, [Dc], relu_in=True)
+        if B * Hh * Ww >= int(os.environ.get("TMG_LAYER_PLANES_MIN", 1 << 17)):
+            # large images: one float2 plane per layer (every layer reads its addends for every pixel - out of the interleaved
+            # tensor that is a full cache line per pixel, more than the growth kernels' real input)
+            Dc = H.layer_planes(Dc)
+            dc_of = lambda k: (Dc[k][..., 0:1], Dc[k][..., 1:2])  # noqa: E731
+        else:
+            dc_of = lambda k: (Dc[..., 2 * k:2 * k + 1], Dc[..., 2 * k + 1:2 * k + 2])  # noqa: E731
         logdet = zeros(B, dev)
         # operand packing of every layer's weights in two launches per level instead of two per layer
         PZ = H.conv_pack_batched(Wz, 0, ch + 4, (ch + 2, ch, Cc))
@@ -659,7 +666,7 @@ class LevelCouplingFn(torch.autograd.Function):
             if fuse:
                 tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
                 D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-                H.c1x2_fwd([tin[..., :ch]], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., 2 * k:2 * k + 1], add2=Dc[..., 2 * k + 1:2 * k + 2])
+                H.c1x2_fwd([tin[..., :ch]], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=dc_of(k)[0], add2=dc_of(k)[1])
                 out = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
                 r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
                 y2 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32) if reverse else None
@@ -675,10 +682,10 @@ class LevelCouplingFn(torch.autograd.Function):
             D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
             if ch % 4 == 0:
                 # both growth-1 layers in one launch (the conditioning parts arrive as add operands)
-                H.c1x2_fwd([x1], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=Dc[..., 2 * k:2 * k + 1], add2=Dc[..., 2 * k + 1:2 * k + 2])
+                H.c1x2_fwd([x1], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=dc_of(k)[0], add2=dc_of(k)[1])
             else:
-                H.c1_fwd([x1], w1s[k], D[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=Dc[..., 2 * k:2 * k + 1])
-                H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=Dc[..., 2 * k + 1:2 * k + 2])
+                H.c1_fwd([x1], w1s[k], D[..., 0:1], relu_in=True, w_rows=ch, fill4=True, add=dc_of(k)[0])
+                H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=dc_of(k)[1])
             hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             H.conv_fwd([x1, D], PZ[k], C, 3, 1, [hh], bias=bzs[k], kappa=kps[k], relu_in=True, pad_rep=True, add=Hc[..., k * C:(k + 1) * C])
             y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)

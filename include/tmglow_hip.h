@@ -310,6 +310,11 @@ int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const int64_t* seg_
  * otherwise -100.  dW [G][C][C], db [G][C] (nullable) are accumulated into. */
 int tmg_mix_wgrad_grouped(const void* gtab, int64_t G, void* dW, void* db, const int64_t* dims, tmg_stream_t st);
 
+/* [npix][CP] -> [CP/2][npix][2]: the level-wide conditioning addends of the growth-1 convs (channel 2k / 2k+1 = coupling layer k,
+ * flowAffine.py:73-75 with the conditioning part of the dense block's input split off) as one pixel-contiguous float2 plane per layer, so
+ * that each layer's launch reads 8 bytes per pixel instead of a whole line of the interleaved tensor.  CP a multiple of 4. */
+int tmg_layer_planes(const void* src, void* dst, int64_t npix, int64_t CP, tmg_stream_t st);
+
 /* Parameter-gradient epilogue of a level's NL plain coupling layers, one launch: d(kappa_k) = (<Wz_k, dWz_k> + <bz_k, dBz_k>) inside the
  * clamp range of the zero conv's log-scale (flowUtils.py:104-106; fp64 accumulation), and the scatter-add of the grouped 4-row
  * weight-gradient results tmpX [NL,4,ch+4,3,3] (x1 | d1 columns) and tmpC [NL,4,Cc,3,3] (conditioning columns) into the native

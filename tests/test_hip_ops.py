@@ -721,3 +721,13 @@ def test_mix_weight_gradient_grouped_kernel(shape):
         d = douts[k].reshape(-1, C_).double()
         _close(res["stream"][0][k], d.t() @ y, tol=2e-5, what="dW group %d vs fp64" % k)
         _close(res["stream"][1][k], d.sum(0), tol=2e-5, what="db group %d vs fp64" % k)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 8), (1, 16, 16, 32), (3, 9, 33, 4)])
+def test_layer_planes_kernel(shape):
+    """tmg_layer_planes: [B,H,W,2K] -> [K,B,H,W,2] (pixel counts that are not a multiple of the 64-pixel block)."""
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(sum(shape))
+    src = torch.randn(*shape, generator=g).to(DEV)
+    B, Hh, Ww, CP = shape
+    assert torch.equal(H.layer_planes(src), src.view(B, Hh, Ww, CP // 2, 2).permute(3, 0, 1, 2, 4).contiguous())

@@ -533,6 +533,38 @@ def test_level_fused_node_matches_per_layer_path():
     C.assert_grads(ga, gb, "fused vs per-layer grads", global_tol=1e-4, tensor_tol=2e-3)
 
 
+def test_layer_plane_addends_give_identical_results():
+    """The growth convs' conditioning addends as one float2 plane per layer (tmg_layer_planes, used on large images) against the
+    interleaved [B,H,W,2K] tensor: same numbers in another layout, so outputs and gradients are identical bit for bit."""
+    import os
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+    C.seed_all(78)
+    blk = LSTMFLowBlock(4, 32, 16, 5, LUdecompose=True, train_sampling=True, do_split=False, squeeze_type=0)   # (no split: no fresh latents per call)
+    C.perturb_(blk, 6, 0.05, 0.1, 0.05)
+    blk.to(DEV)
+    g = torch.Generator().manual_seed(10)
+    z = torch.randn(3, 16, 12, 20, generator=g).to(DEV)
+    cond = torch.randn(3, 32, 12, 20, generator=g).to(DEV)
+    res = {}
+    for tag, env in (("planes", "1"), ("interleaved", str(1 << 40))):
+        os.environ["TMG_LAYER_PLANES_MIN"] = env
+        try:
+            blk.zero_grad()
+            ci = cond.clone().requires_grad_(True)
+            zi = z.clone().requires_grad_(True)
+            xr, ldr, _ = blk.reverse(zi, ci, None)
+            ((xr ** 2).sum() * 0.5 + ldr.sum() * 0.02).backward()
+        finally:
+            os.environ.pop("TMG_LAYER_PLANES_MIN", None)
+        res[tag] = (xr.detach(), ci.grad.clone(), zi.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+    a, b = res["planes"], res["interleaved"]
+    assert torch.equal(a[0], b[0])
+    # (log-det sums and weight gradients meet in float atomics: equal up to summation order)
+    assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-6) and torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-6)
+    for k in a[3]:
+        assert torch.allclose(a[3][k], b[3][k], rtol=1e-4, atol=1e-5), k
+
+
 def test_training_window_capture_matches_reference():
     """A16 on the HIP path: three optimizer steps of the trainer's inner loop (3-step BPTT windows with LSTM-state
     gradients flowing across time-steps, clip, Adam(amsgrad), state re-anchoring) against the capture recorded from
