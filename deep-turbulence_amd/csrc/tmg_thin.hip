@@ -150,13 +150,7 @@ static int launch_thin(ThinP p, int G, hipStream_t st) {
     P = P > p.ntiles ? p.ntiles : (P < 1 ? 1 : P);
     if (P >= 8) P &= ~7;
     p.G = G; p.P = P;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_thin_kernel<SL, CS, TH>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static_assert(lds_bytes <= 64 * 1024, "above 64 KB the kernel would need the per-device LDS opt-in (TMG_LDS_OPTIN)");
     hipLaunchKernelGGL((wgrad_thin_kernel<SL, CS, TH>), dim3(P * G), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
