@@ -800,6 +800,7 @@ struct D2BP {
     TmgOSeg out[2];
     const float* add0; int add0_stride;
     float* dd1_out; float* dd2_out; int dd_stride;  // optional: masked gradients w.r.t. d1 / d2 per pixel (null: not written)
+    int dd_quad;                                    // the two are channels 0, 1 of a float4 slot whose channels 2, 3 are to be zero: one 16-byte store
     int TW_log2, tiles_x, tiles_y, ntiles, KCH;
 };
 
@@ -915,7 +916,9 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
         if (p.dd1_out && blockIdx.y == 0 && own) {
             const size_t px_ = ((size_t)b * p.Hin + oy) * p.Win + ox;
             const float d1v = A1[(row + 1) * PW + col + 1], d2v = A2[(row + 2) * QW + col + 2];
-            if (p.dd2_out == p.dd1_out + 1 && !(p.dd_stride & 1) && !(((uintptr_t)p.dd1_out) & 7)) {
+            if (p.dd_quad) {
+                *reinterpret_cast<float4*>(p.dd1_out + px_ * p.dd_stride) = make_float4(d1v, d2v, 0.f, 0.f);   // no zero fill of the stash needed
+            } else if (p.dd2_out == p.dd1_out + 1 && !(p.dd_stride & 1) && !(((uintptr_t)p.dd1_out) & 7)) {
                 *reinterpret_cast<float2*>(p.dd1_out + px_ * p.dd_stride) = make_float2(d1v, d2v);  // adjacent channels: one store
             } else {
                 p.dd1_out[px_ * p.dd_stride] = d1v;
@@ -1338,7 +1341,8 @@ extern "C" int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, in
 }
 
 // Fused backward of both growth-1 layers (see dense2_bwd_kernel).
-// in segments: nn inputs followed by D (4 channels); dims = {B,H,W,Cin_total (incl. D's 4),cin_nn,rows1,rows2,dd1_out ptr,dd2_out ptr,dd stride,split2,gap2}
+// in segments: nn inputs followed by D (4 channels); dims = {B,H,W,Cin_total (incl. D's 4),cin_nn,rows1,rows2,dd1_out ptr,dd2_out ptr,dd stride,split2,gap2,dd_quad}
+// (dd_quad: dd1 / dd2 are channels 0, 1 of a 16-byte aligned float4 slot per pixel; the kernel writes (dd1, dd2, 0, 0) in one store)
 // g0/out: up to two segments each (same channel split as the nn inputs); add0 optional (null) added to out segment 0.
 extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2,
                               void* dW1, void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride,
@@ -1363,6 +1367,8 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     }
     p.add0 = (const float*)add0; p.add0_stride = (int)add0_stride;
     p.dd1_out = (float*)dims[7]; p.dd2_out = (float*)dims[8]; p.dd_stride = (int)dims[9];
+    p.dd_quad = dims[12] && p.dd1_out && p.dd2_out == p.dd1_out + 1 && !(p.dd_stride & 3) && !(((uintptr_t)p.dd1_out) & 15);
+    if (dims[12] && !p.dd_quad) return -4;   // the caller relies on the zero channels
     p.split2 = dims[10] > 0 ? (int)dims[10] : 0x7fffffff; p.gap2 = (int)dims[11];
     if (add0 && ((add0_stride & 3) || (((uintptr_t)add0) & 15))) p.vec4 = 0;
     c1_tile(p.Win, p.Hin, &p.TW_log2);

@@ -758,7 +758,8 @@ def dkappa(w, dw, b, db, kappa, dk):
          "tmg_dkappa")
 
 
-def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None, rows1=0, rows2=0, dd1=None, dd2=None, split2=0, gap2=0):
+def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None, rows1=0, rows2=0, dd1=None, dd2=None, split2=0, gap2=0,
+               dd_quad=False):
     """Fused backward of the two growth-1 layers; `inputs` = nn inputs + [D]; g0 / outs: lists (<= 2) of NHWC tensors."""
     B, H, W, _ = inputs[0].shape
     ip, idesc, n_in = _segs(inputs)
@@ -769,7 +770,7 @@ def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None,
     _chk(lib().tmg_dense2_bwd(ip, idesc, c_i64(n_in), _ptr(w1p), _ptr(w2p), _ptr(dW1p), _ptr(dW2p), _ptr(GD), c_i64(seg(GD)[1]), _ptr(D),
                               c_i64(seg(D)[1]), gp, gdesc, op, odesc, c_i64(ng), _ptr(add0), c_i64(a_stride),
                               _i64(B, H, W, Cin, cin_nn, rows1 or Cin, rows2 or Cin, dd1.data_ptr() if dd1 is not None else 0,
-                                   dd2.data_ptr() if dd2 is not None else 0, seg(dd1)[1] if dd1 is not None else 0, split2, gap2),
+                                   dd2.data_ptr() if dd2 is not None else 0, seg(dd1)[1] if dd1 is not None else 0, split2, gap2, 1 if dd_quad else 0),
                               _stream()),
          "tmg_dense2_bwd")
 

@@ -317,6 +317,7 @@ class ConvLSTMCellFn(torch.autograd.Function):
         ctx.has_c = c_cur is not None
         ctx.consumed = False
         ctx.save_for_backward(weight, bias, h_cur, c_cur, gates, c_next, *inputs)
+        ctx.set_materialize_grads(False)     # an unused output (the cell state of the last time-step) sends None, not a zero tensor
         return h_next, c_next
 
     @staticmethod
@@ -732,7 +733,8 @@ class LevelCouplingFn(torch.autograd.Function):
         DH = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)     # exp(kappa_k) * dhh_k, all layers
         # masked gradients w.r.t. the growth channels, 4 channels per layer (dd1_k, dd2_k, 0, 0): float4-addressable slices for
         # the grouped weight-gradient launch below
-        DD = zeros((B, Hh, Ww, 4 * NL), dev)
+        # (written whole by the per-layer backward kernels, 16 bytes per pixel and layer: no zero fill)
+        DD = torch.empty((B, Hh, Ww, 4 * NL), device=dev, dtype=torch.float32)
         dcur = dy
         # The NL zero-conv weight gradients (x1 | D part) are independent of each other once DH holds every layer's
         # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
@@ -765,7 +767,7 @@ class LevelCouplingFn(torch.autograd.Function):
                     H.conv_wgrad(y, dcur, dWm[k], dbm[k], 1, 1)
                 H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
                              add0=dtin[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
-                             split2=ch, gap2=Cc)
+                             split2=ch, gap2=Cc, dd_quad=True)
                 dcur = dtin
                 del xin, tin, D, r, y
                 continue
@@ -787,7 +789,7 @@ class LevelCouplingFn(torch.autograd.Function):
             H.conv_rep_border_fix(dhh, wt, [G0, GD])
             H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
                          add0=dto[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2], split2=ch,
-                         gap2=Cc)
+                         gap2=Cc, dd_quad=True)
             dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k], mdef)
             if grouped:
                 mix_wg[k] = mdef[0]

@@ -40,6 +40,7 @@ class HipAdam(torch.optim.Adam):
                 continue
             params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
             beta1, beta2 = group["betas"]
+            self._prealloc_state(group)
             self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)
             if not params:
                 continue
@@ -72,6 +73,28 @@ class HipAdam(torch.optim.Adam):
             ok = self._fast_step(gi, group)
             assert ok
         return loss
+
+    def _prealloc_state(self, group):
+        """First step: the moment tensors of all parameters out of ONE zero-filled allocation (torch's lazy init is a `zeros_like`
+        launch per tensor: ~1 800 fills for this model).  Same keys, shapes and values as torch.optim.Adam's own state; every tensor is
+        a tensor of its own on the shared storage, 256-byte aligned."""
+        new = [p for p in group["params"] if p.grad is not None and len(self.state[p]) == 0]
+        if len(new) < 8 or not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == new[0].device for p in new):
+            return
+        if group.get("capturable", False) or group.get("fused", False) or group.get("differentiable", False):
+            return
+        kinds = ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if group["amsgrad"] else ())
+        offs, total = [], 0
+        for p in new:
+            offs.append(total)
+            total += (p.numel() + 63) & ~63
+        flat = torch.zeros(len(kinds) * total, dtype=torch.float32, device=new[0].device)
+        store = flat.untyped_storage()
+        for p, o in zip(new, offs):
+            st = self.state[p]
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)
+            for ki, kind in enumerate(kinds):
+                st[kind] = torch.empty(0, dtype=torch.float32, device=p.device).set_(store, ki * total + o, p.shape, p.stride())
 
     def _fast_step(self, gi, group):
         """The steady-state step: everything that does not change between steps (parameter / state pointers, chunk table, pinned

@@ -208,8 +208,9 @@ int tmg_c1_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg,
 
 /* Fused backward of both growth-1 layers of a coupling network (denseBlock.py:135-152 x2) incl. the ReLU masks
  * and the concat adjoint: one pass over the network input.  in segments = nn inputs followed by the 4-channel D
- * buffer; dims = {B,H,W,Cin_total(incl. D),cin_nn,rows1,rows2,dd1_out,dd2_out,dd_stride,split2,gap2} (dd*_out: optional device
- * pointers, passed as integers, receiving the masked gradients w.r.t. d1 / d2). */
+ * buffer; dims = {B,H,W,Cin_total(incl. D),cin_nn,rows1,rows2,dd1_out,dd2_out,dd_stride,split2,gap2,dd_quad} (dd*_out: optional device
+ * pointers, passed as integers, receiving the masked gradients w.r.t. d1 / d2; dd_quad = 1: they are channels 0, 1 of a 16-byte aligned
+ * float4 slot per pixel and the kernel stores (dd1, dd2, 0, 0) whole - the level-wide stash then needs no zero fill). */
 int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* w1, const void* w2, void* dW1,
                    void* dW2, const void* GD, int64_t gd_stride, const void* Dp, int64_t d_stride, const void* const* g0_ptrs,
                    const int64_t* g0_desc, void* const* out_ptrs, const int64_t* out_desc, int64_t ng, const void* add0,
