@@ -289,8 +289,11 @@ static int launch_cpl_fwd(const CplFP& p, hipStream_t st) {
     constexpr int CH4 = K4 - 1, CHP = 2 * CH4;
     const size_t lds = (2 * ((size_t)(CHP + 1) * 324 * 2 + (size_t)CHP * 256 * 2) + (5 * 18 + 4) * 2) * sizeof(float);
     if (lds > 64 * 1024) TMG_LDS_OPTIN((&cpl_fwd_kernel<CT, K4>));
-    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : 768;
-    const int grid = p.ntiles < gcap ? p.ntiles : gcap;
+    // blocks: one resident wave (3 per CU at C <= 16, 2 above), every block with the same number of tiles (measured at 64 x 128 x 128 and
+    // 64 x 64 x 64: 768 / 512; an uneven 5-or-6 split or a second wave of blocks costs 10-20 %)
+    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : (CT == 1 ? 768 : 512);
+    const int per_blk = (p.ntiles + gcap - 1) / gcap;
+    const int grid = (p.ntiles + per_blk - 1) / per_blk;
     // algorithmic HBM bytes: x (C), D (4), hc (C) read; out (C), r (C/2), y2 (C/2) written
     TmgProf prof(TMG_PROF_CPL, 4.0 * p.B * (double)p.H * p.W * (3.0 * p.C + 4 + (p.y2save ? 1.0 : 0.5) * p.C), st);
     hipLaunchKernelGGL((cpl_fwd_kernel<CT, K4>), dim3(grid), dim3(256), lds, st, p);
@@ -544,8 +547,11 @@ template <int CT, int MT, int KS>
 static int launch_cpl_bwd(const CplBP& p, hipStream_t st) {
     const size_t lds = (size_t)(p.C / 2) * 324 * 2 * sizeof(float);
     if (lds > 64 * 1024) TMG_LDS_OPTIN((&cpl_bwd_kernel<CT, MT, KS>));
-    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : 768;
-    const int grid = p.ntiles < gcap ? p.ntiles : gcap;
+    // blocks: measured at 64 x 128 x 128 (C = 16: 4 096 tiles) 256: 193 us, 512: 140, 768: 139, 1 024: 119, 2 048: 124, 4 096: 136 - two
+    // resident blocks per CU, twice as many blocks as that with an even tile count each; at C = 32 (1 024 tiles) 512: 87, 768: 90, 1 024: 100
+    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : (CT == 1 ? 1024 : 512);
+    const int per_blk = (p.ntiles + gcap - 1) / gcap;
+    const int grid = (p.ntiles + per_blk - 1) / per_blk;
     // algorithmic HBM bytes: dout (C), r (C/2), tin2 (C/2) read; DH (C), dtin (C), G0 (C/2), GD (4) written
     TmgProf prof(TMG_PROF_CPLB, 4.0 * p.B * (double)p.H * p.W * (4.5 * p.C + 4), st);
     hipLaunchKernelGGL((cpl_bwd_kernel<CT, MT, KS>), dim3(grid), dim3(256), lds, st, p);
