@@ -1432,13 +1432,26 @@ struct LuFoldP {
     float sgn, hw;
 };
 
-__device__ __forceinline__ float lu_lower(const float* l, int C, int r, int k) { return k < r ? l[r * C + k] : (k == r ? 1.f : 0.f); }
-// diag: exp(log_s) sign_s + 0.01 per channel, staged in LDS once per block (an expf per inner-loop term made the kernels 3x slower)
-__device__ __forceinline__ float lu_upper(const float* u, const float* diag, int C, int k, int j) {
-    return k < j ? u[k * C + j] : (k == j ? diag[k] : 0.f);
+// Arithmetic: fp64 throughout, rounded once to fp32 on store.  The mixes are applied to every pixel of every sample, so a rounding
+// error in W is COHERENT over the whole field and - unlike per-pixel rounding noise - does not average out in the weight-gradient
+// sums: with fp32 dot products and a rounded reciprocal 1 / a shared by a whole row (and inconsistent with the exactly divided bias),
+// the generative direction's gradients sat at 4.1e-4 global rel-L2 from the fp64 oracle on config M against 3.7e-5 with torch's fp32
+// fold (profiles/r3_parity_report_*.json); in fp64 the fold is exact to the last fp32 bit and costs nothing (K C^3 flops).
+__device__ __forceinline__ double lu_lower(const float* l, int C, int r, int k) { return k < r ? (double)l[r * C + k] : (k == r ? 1.0 : 0.0); }
+// diag: exp(log_s) sign_s + 0.01 per channel, staged in LDS once per block (an exp per inner-loop term made the kernels 3x slower)
+__device__ __forceinline__ double lu_upper(const float* u, const double* diag, int C, int k, int j) {
+    return k < j ? (double)u[k * C + j] : (k == j ? diag[k] : 0.0);
 }
 
-__global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __restrict__ W, float* __restrict__ Wm, float* __restrict__ bm,
+__device__ __forceinline__ double block_sum_256_f64(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, double* __restrict__ W, float* __restrict__ Wm, float* __restrict__ bm,
                                                           float* __restrict__ ld) {
     const int C = p.C, k = blockIdx.y;
     const long long* t = p.tab + (size_t)k * 5;
@@ -1449,52 +1462,52 @@ __global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __re
     const float* b = reinterpret_cast<const float*>(t[4]);
     const float* sg = p.sign_s + (size_t)k * C;
     const int* perm = p.perm + (size_t)k * C;
-    __shared__ float diag[256], sa[256];
+    __shared__ double diag[256], sa[256];
     for (int i = threadIdx.x; i < C; i += 256) {
-        diag[i] = expf(ls[i]) * sg[i] + 0.01f;
-        sa[i] = a ? (p.reverse ? 1.f / a[i] : a[i]) : 1.f;
+        diag[i] = exp((double)ls[i]) * (double)sg[i] + 0.01;
+        sa[i] = a ? (p.reverse ? 1.0 / (double)a[i] : (double)a[i]) : 1.0;
     }
     __syncthreads();
     for (int e = blockIdx.x * 256 + threadIdx.x; e < C * C; e += gridDim.x * 256) {
         const int i = e / C, j = e - i * C, r = perm[i];
         // row r of lower times column j of upper: terms q < min(r, j) are plain products, the last one involves a unit / diagonal entry
         const int kmin = min(r, j);
-        float acc = r < j ? u[r * C + j] : (r == j ? diag[j] : l[r * C + j] * diag[j]);
-        for (int q = 0; q < kmin; ++q) acc = fmaf(l[r * C + q], u[q * C + j], acc);
-        W[((size_t)k * C + i) * C + j] = acc;
-        Wm[((size_t)k * C + i) * C + j] = acc * (p.reverse ? sa[i] : sa[j]);
+        double acc = r < j ? (double)u[r * C + j] : (r == j ? diag[j] : (double)l[r * C + j] * diag[j]);
+        for (int q = 0; q < kmin; ++q) acc = fma((double)l[r * C + q], (double)u[q * C + j], acc);
+        W[((size_t)k * C + i) * C + j] = acc;       // fp64 copy of W = P L U for the backward launch
+        Wm[((size_t)k * C + i) * C + j] = (float)(acc * (p.reverse ? sa[i] : sa[j]));
     }
     if (blockIdx.x == 0) {
         // biases need whole rows of W: recomputed here from the factors (C <= 256: a few thousand flops per thread)
         for (int i = threadIdx.x; i < C; i += 256) {
-            float v;
-            if (p.reverse) v = b ? -b[i] / (a ? a[i] : 1.f) : 0.f;
+            double v;
+            if (p.reverse) v = b ? -(double)b[i] / (a ? (double)a[i] : 1.0) : 0.0;
             else {
-                v = 0.f;
+                v = 0.0;
                 if (b) {
                     const int r = perm[i];
                     for (int j = 0; j < C; ++j) {
-                        float acc = 0.f;
+                        double acc = 0.0;
                         const int kmax = min(r, j);
-                        for (int q = 0; q <= kmax; ++q) acc += lu_lower(l, C, r, q) * lu_upper(u, diag, C, q, j);
-                        v += acc * b[j];
+                        for (int q = 0; q <= kmax; ++q) acc = fma(lu_lower(l, C, r, q), lu_upper(u, diag, C, q, j), acc);
+                        v = fma(acc, (double)b[j], v);
                     }
                 }
             }
-            bm[(size_t)k * C + i] = v;
+            bm[(size_t)k * C + i] = (float)v;
         }
         if (k == 0) {
             // scalar log-det of all K mixes (one block: K C <= 4096 terms)
-            __shared__ float red[4];
-            float s = 0.f;
+            __shared__ double red[4];
+            double s = 0.0;
             for (int e = threadIdx.x; e < p.K * C; e += 256) {
                 const int kk = e / C, i = e - kk * C;
                 const long long* tt = p.tab + (size_t)kk * 5;
                 const float* aa = reinterpret_cast<const float*>(tt[3]);
-                s += p.sgn * reinterpret_cast<const float*>(tt[2])[i] + (aa ? logf(fabsf(aa[i])) : 0.f);
+                s += (double)p.sgn * (double)reinterpret_cast<const float*>(tt[2])[i] + (aa ? log(fabs((double)aa[i])) : 0.0);
             }
-            const float tot = block_sum_256(s, red);
-            if (threadIdx.x == 0) ld[0] = tot * p.hw;
+            const double tot = block_sum_256_f64(s, red);
+            if (threadIdx.x == 0) ld[0] = (float)(tot * (double)p.hw);
         }
     }
 }
@@ -1502,7 +1515,7 @@ __global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, float* __re
 // Backward: dWm [K,C,C], dbm [K,C], dld (device scalar) -> dl, du [K,C,C] (zero outside the masks), dlog_s, da, db [K,C].
 // dWt / dbt (optional): the last layer's upstream gradients live in tensors of their own ([C,C] / [C]); dWm / dbm then hold the
 // first K - 1 layers (the level-fused node consumes layers 0..K-2 as one slice, the ConvLSTM layer takes the last one).
-__global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const float* __restrict__ W, const float* __restrict__ dWm,
+__global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const double* __restrict__ W, const float* __restrict__ dWm,
                                                           const float* __restrict__ dbm, const float* __restrict__ dWt,
                                                           const float* __restrict__ dbt, const float* __restrict__ dld, float* __restrict__ dl,
                                                           float* __restrict__ du, float* __restrict__ dlogs, float* __restrict__ da,
@@ -1519,74 +1532,75 @@ __global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const float
     const bool tail = dWt != nullptr && k == p.K - 1;
     const float* dWk = tail ? dWt : dWm + (size_t)k * C * C;
     const float* dbk = tail ? dbt : (dbm ? dbm + (size_t)k * C : nullptr);
-    const float g = dld ? dld[0] : 0.f;
-    __shared__ float diag[256], sa[256], sb[256], sdb[256];
+    const double g = dld ? (double)dld[0] : 0.0;
+    __shared__ double diag[256], sa[256], sb[256], sdb[256];
     for (int i = threadIdx.x; i < C; i += 256) {
-        diag[i] = expf(ls[i]) * sg[i] + 0.01f;
-        sa[i] = a ? (p.reverse ? 1.f / a[i] : a[i]) : 1.f;
-        sb[i] = (!p.reverse && b && dbk) ? b[i] : 0.f;
-        sdb[i] = (!p.reverse && b && dbk) ? dbk[i] : 0.f;
+        diag[i] = exp((double)ls[i]) * (double)sg[i] + 0.01;
+        sa[i] = a ? (p.reverse ? 1.0 / (double)a[i] : (double)a[i]) : 1.0;
+        sb[i] = (!p.reverse && b && dbk) ? (double)b[i] : 0.0;
+        sdb[i] = (!p.reverse && b && dbk) ? (double)dbk[i] : 0.0;
     }
     __syncthreads();
     // gradient w.r.t. W (before the ActNorm fold) at row i, column j
-#define TMG_LU_DW(I, J) (p.reverse ? dWk[(I) * C + (J)] * sa[I] : fmaf(dWk[(I) * C + (J)], sa[J], sdb[I] * sb[J]))
+#define TMG_LU_DW(I, J) (p.reverse ? (double)dWk[(I) * C + (J)] * sa[I] : fma((double)dWk[(I) * C + (J)], sa[J], sdb[I] * sb[J]))
     for (int e = blockIdx.x * 256 + threadIdx.x; e < C * C; e += gridDim.x * 256) {
         const int x = e / C, y = e - x * C;
-        float vl = 0.f, vu = 0.f;
+        double vl = 0.0, vu = 0.0;
         if (x > y) {
             // dlower[x][y] = sum_j M[x][j] upper[y][j], M = P^T dW: M[x][j] = dW[iperm[x]][j]; upper[y][j] = 0 for j < y
             const int i = iperm[x];
             vl = TMG_LU_DW(i, y) * diag[y];
-            for (int j = y + 1; j < C; ++j) vl = fmaf(TMG_LU_DW(i, j), u[y * C + j], vl);
+            for (int j = y + 1; j < C; ++j) vl = fma(TMG_LU_DW(i, j), (double)u[y * C + j], vl);
         } else {
             // dupper[x][y] = sum_r lower[r][x] M[r][y]; lower[r][x] = 0 for r < x
             vu = TMG_LU_DW(iperm[x], y);
-            for (int r = x + 1; r < C; ++r) vu = fmaf(l[r * C + x], TMG_LU_DW(iperm[r], y), vu);
+            for (int r = x + 1; r < C; ++r) vu = fma((double)l[r * C + x], TMG_LU_DW(iperm[r], y), vu);
         }
-        dl[((size_t)k * C + x) * C + y] = vl;
-        du[((size_t)k * C + x) * C + y] = x < y ? vu : 0.f;
-        if (x == y) dlogs[(size_t)k * C + x] = vu * (diag[x] - 0.01f) + p.sgn * p.hw * g;
+        dl[((size_t)k * C + x) * C + y] = (float)vl;
+        du[((size_t)k * C + x) * C + y] = x < y ? (float)vu : 0.f;
+        if (x == y) dlogs[(size_t)k * C + x] = (float)(vu * (diag[x] - 0.01) + (double)p.sgn * (double)p.hw * g);
     }
     if (blockIdx.x == 0) {
-        const float* Wk = W + (size_t)k * C * C;
+        const double* Wk = W + (size_t)k * C * C;
         for (int i = threadIdx.x; i < C; i += 256) {
-            float va = 0.f, vb = 0.f;
+            double va = 0.0, vb = 0.0;
+            const double ai = a ? (double)a[i] : 1.0;
             if (a) {
                 if (p.reverse) {
                     // Wm = W / a_i, bm = -b_i / a_i
-                    float s = 0.f;
-                    for (int j = 0; j < C; ++j) s += dWk[i * C + j] * Wk[i * C + j];
-                    va = -s / (a[i] * a[i]) + ((dbk && b) ? dbk[i] * b[i] / (a[i] * a[i]) : 0.f) + g * p.hw / a[i];
+                    double s = 0.0;
+                    for (int j = 0; j < C; ++j) s = fma((double)dWk[i * C + j], Wk[i * C + j], s);
+                    va = -s / (ai * ai) + ((dbk && b) ? (double)dbk[i] * (double)b[i] / (ai * ai) : 0.0) + g * (double)p.hw / ai;
                 } else {
                     // Wm = W a_j: da_j = sum_i dWm[i][j] W[i][j]   (index i of this thread plays the role of j)
-                    float s = 0.f;
-                    for (int r = 0; r < C; ++r) s += dWk[r * C + i] * Wk[r * C + i];
-                    va = s + g * p.hw / a[i];
+                    double s = 0.0;
+                    for (int r = 0; r < C; ++r) s = fma((double)dWk[r * C + i], Wk[r * C + i], s);
+                    va = s + g * (double)p.hw / ai;
                 }
             }
             if (b && dbk) {
-                if (p.reverse) vb = -dbk[i] / (a ? a[i] : 1.f);
+                if (p.reverse) vb = -(double)dbk[i] / ai;
                 else {
-                    for (int r = 0; r < C; ++r) vb += Wk[r * C + i] * dbk[r];   // db = W^T dbm
+                    for (int r = 0; r < C; ++r) vb = fma(Wk[r * C + i], (double)dbk[r], vb);   // db = W^T dbm
                 }
             }
-            da[(size_t)k * C + i] = va;
-            db[(size_t)k * C + i] = vb;
+            da[(size_t)k * C + i] = (float)va;
+            db[(size_t)k * C + i] = (float)vb;
         }
     }
 #undef TMG_LU_DW
 }
 
 // dims = {K, C, reverse}; fl = {sgn (+1 / -1: sign of the log_s term of the log-det), hw}.  tab: device int64 [K][5]; sign_s [K][C];
-// perm / iperm: device int32 [K][C].  Outputs W, Wm [K,C,C], bm [K,C], ld [1].
+// perm / iperm: device int32 [K][C].  Outputs W [K,C,C] FP64 (scratch for the backward launch), Wm [K,C,C], bm [K,C], ld [1] fp32.
 extern "C" int tmg_lu_fold_fwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, void* W, void* Wm, void* bm, void* ld,
                                const int64_t* dims, const float* fl, hipStream_t st) {
     LuFoldP p;
     p.tab = (const long long*)tab; p.sign_s = (const float*)sign_s; p.perm = (const int*)perm; p.iperm = (const int*)iperm;
     p.K = (int)dims[0]; p.C = (int)dims[1]; p.reverse = (int)dims[2]; p.sgn = fl[0]; p.hw = fl[1];
-    if (p.K < 1 || p.C < 1) return -1;
+    if (p.K < 1 || p.C < 1 || p.C > 256) return -1;     // per-channel vectors live in 256-entry LDS arrays
     const int gx = (p.C * p.C + 255) / 256 < 64 ? (p.C * p.C + 255) / 256 : 64;
-    hipLaunchKernelGGL(lu_fold_fwd_kernel, dim3(gx, p.K), dim3(256), 0, st, p, (float*)W, (float*)Wm, (float*)bm, (float*)ld);
+    hipLaunchKernelGGL(lu_fold_fwd_kernel, dim3(gx, p.K), dim3(256), 0, st, p, (double*)W, (float*)Wm, (float*)bm, (float*)ld);
     TMG_CHECK_LAUNCH();
     return 0;
 }
@@ -1597,10 +1611,10 @@ extern "C" int tmg_lu_fold_bwd_split(const void* tab, const void* sign_s, const 
     LuFoldP p;
     p.tab = (const long long*)tab; p.sign_s = (const float*)sign_s; p.perm = (const int*)perm; p.iperm = (const int*)iperm;
     p.K = (int)dims[0]; p.C = (int)dims[1]; p.reverse = (int)dims[2]; p.sgn = fl[0]; p.hw = fl[1];
-    if (p.K < 1 || p.C < 1) return -1;
+    if (p.K < 1 || p.C < 1 || p.C > 256) return -1;     // per-channel vectors live in 256-entry LDS arrays
     const int gx = (p.C * p.C + 255) / 256 < 64 ? (p.C * p.C + 255) / 256 : 64;
     if (!dWm && !(dWm_tail && p.K == 1)) return -1;
-    hipLaunchKernelGGL(lu_fold_bwd_kernel, dim3(gx, p.K), dim3(256), 0, st, p, (const float*)W, (const float*)dWm, (const float*)dbm,
+    hipLaunchKernelGGL(lu_fold_bwd_kernel, dim3(gx, p.K), dim3(256), 0, st, p, (const double*)W, (const float*)dWm, (const float*)dbm,
                        (const float*)dWm_tail, (const float*)dbm_tail, (const float*)dld, (float*)dl, (float*)du, (float*)dlogs, (float*)da,
                        (float*)db);
     TMG_CHECK_LAUNCH();

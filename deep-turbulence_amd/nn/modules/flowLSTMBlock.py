@@ -195,7 +195,9 @@ class LSTMFLowBlock(nn.Module):
         if not all(isinstance(c, InvertibleConv1x1LU) and c.train_sampling == convs[0].train_sampling for c in convs):
             return None
         ts = convs[0].train_sampling
-        if (reverse if ts else not reverse) and convs[0].l.is_cuda and os.environ.get("TMG_NO_LU_FOLD_KERNEL") is None:
+        # (tmg_lu_fold_* keep per-channel vectors in fixed 256-entry LDS arrays: wider levels take the batched torch fold below)
+        if ((reverse if ts else not reverse) and convs[0].l.is_cuda and convs[0].l.shape[0] <= 256
+                and os.environ.get("TMG_NO_LU_FOLD_KERNEL") is None):
             return self._level_mix_hip(layers, convs, reverse, hw)
         st = lambda name: torch.stack([getattr(c, name) for c in convs])  # noqa: E731
         eye = convs[0].eye
@@ -232,7 +234,10 @@ class LSTMFLowBlock(nn.Module):
         for l, c in zip(layers, convs):
             nm = getattr(l, 'norm', None)       # a block without ActNorm: null pointers (scale 1, shift 0)
             params += [c.l, c.u, c.log_s, nm.weight if nm is not None else None, nm.bias if nm is not None else None]
-        key = tuple(t.data_ptr() if t is not None else 0 for t in params) + tuple(c.p.data_ptr() for c in convs)
+        # the cache holds VALUES derived from the buffers p / sign_s (row permutations, the sign stack): load_state_dict copies into
+        # them in place, so the key carries their version counters beside the addresses
+        key = (tuple(t.data_ptr() if t is not None else 0 for t in params)
+               + tuple(v for c in convs for v in (c.p.data_ptr(), c.p._version, c.sign_s.data_ptr(), c.sign_s._version)))
         cache = getattr(self, '_lu_fold_cache', None)
         if cache is None or cache[0] != key:
             dev = convs[0].l.device

@@ -6,6 +6,8 @@ reference's `nn` (put `deep-turbulence_amd/` on sys.path instead of `tmglow/`).
 Tensors cross this API as logical NCHW fp32 (any strides); internally everything is NHWC and every
 numerical operation is a kernel of libtmglow_hip.so -- there is no eager / CPU fallback.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -177,14 +179,16 @@ class TMGlow(nn.Module):
     def _num_parameters(self):
         return sum(p.numel() for p in self.parameters())
 
-    def initLSTMStates(self, seeds, input_dim):
-        """Per (level, sample) a fresh CPU generator with the sample's seed: hidden ~ U[-1,1], cell ~ N(0,1)
-        (reference :481-509).  Host RNG by construction (the streams are part of the reference's semantics), then one copy per
-        level to the model's device.  The (level, sample) draws are independent, so they run on a small thread pool (torch
-        releases the GIL inside rand / randn): at the metric shape and 64 samples this is 180 M numbers, 2 s single-threaded."""
+    # ---- seed states ---------------------------------------------------------------------------------------------------------
+    # The trainer asks for the seed states of every mini-batch (trainFlowParallel.py:225) and the reference draws them on the host,
+    # one generator per (level, sample): 180 M numbers at the metric shape and 64 samples, 1.3 s - twice a 10-step BPTT window on
+    # this device.  But the loaders draw the seeds from random_(0, 1000) (dataLoader.py:284, :422): at most 1 000 distinct states
+    # exist, 11 MB each at the metric shape, so they live in HBM after their first use and a mini-batch is a device gather.
+    SEED_CACHE_GB = float(os.environ.get("TMG_SEED_CACHE_GB", "48"))
+
+    def _draw_seed_states(self, seed_list, input_dim):
+        """The reference's host draw (tmGlow.py:494-509) for the given seeds -> per seed a list over levels of (h, c), [1,R,h,w]."""
         from concurrent.futures import ThreadPoolExecutor
-        device = next(self.parameters()).device
-        seed_list = [int(s) for s in seeds.tolist()]
         L = len(self.glow_blocks)
 
         def draw(job):
@@ -194,14 +198,47 @@ class TMGlow(nn.Module):
             h = 2 * torch.rand(dims, generator=gen) - 1
             return h, torch.randn(dims, generator=gen)
 
-        jobs = [(i, seed) for i in range(L) for seed in seed_list]
+        jobs = [(i, seed) for seed in seed_list for i in range(L)]
         if len(jobs) > 8:
             with ThreadPoolExecutor(max_workers=min(16, len(jobs))) as ex:
                 res = list(ex.map(draw, jobs))
         else:
             res = [draw(j) for j in jobs]
-        states, n = [], len(seed_list)
+        return [res[k * L:(k + 1) * L] for k in range(len(seed_list))]
+
+    def initLSTMStates(self, seeds, input_dim):
+        """Per (level, sample) a fresh CPU generator with the sample's seed: hidden ~ U[-1,1], cell ~ N(0,1)
+        (reference :481-509).  Host RNG by construction (the streams are part of the reference's semantics): every DISTINCT seed is
+        drawn once on the host - the (level, sample) draws are independent and run on a small thread pool, torch releases the GIL
+        inside rand / randn - and kept on the model's device in the channels-last layout the flow works in; a call is then one
+        gather per level.  Returns the reference's structure: a list over levels of (h, c), [B,R,h,w] (values bit-identical to the
+        reference's, strides channels-last).  The cache is keyed by (seed, field size), dropped when the model changes device, and
+        bounded by TMG_SEED_CACHE_GB (seeds beyond it are drawn per call, as before)."""
+        device = next(self.parameters()).device
+        seed_list = [int(s) for s in torch.as_tensor(seeds).tolist()]
+        L = len(self.glow_blocks)
+        key = (str(device), self.rec_features, int(input_dim[0]), int(input_dim[1]), L)
+        cache = self.__dict__.get("_seed_states")
+        if cache is None or cache["key"] != key:
+            cache = {"key": key, "rows": {}, "bytes": 0}
+            self.__dict__["_seed_states"] = cache          # (plain attribute: not a buffer, never part of the state_dict)
+        rows = cache["rows"]
+        missing = [s for s in dict.fromkeys(seed_list) if s not in rows]
+        extra = {}
+        if missing:
+            per_seed = 8 * self.rec_features * sum((input_dim[0] // 2 ** (i + 1)) * (input_dim[1] // 2 ** (i + 1)) for i in range(L))
+            for s, lv in zip(missing, self._draw_seed_states(missing, input_dim)):
+                # [1,R,h,w] -> [h,w,R] contiguous on the device: stacking such rows gives the flow's NHWC layout directly
+                dev_lv = [(h[0].permute(1, 2, 0).contiguous().to(device), c[0].permute(1, 2, 0).contiguous().to(device)) for h, c in lv]
+                if cache["bytes"] + per_seed <= self.SEED_CACHE_GB * 2 ** 30:
+                    rows[s] = dev_lv
+                    cache["bytes"] += per_seed
+                else:
+                    extra[s] = dev_lv
+        get = lambda s: rows[s] if s in rows else extra[s]  # noqa: E731
+        states = []
         for i in range(L):
-            part = res[i * n:(i + 1) * n]
-            states.append((torch.cat([p[0] for p in part], dim=0).to(device), torch.cat([p[1] for p in part], dim=0).to(device)))
+            h = torch.stack([get(s)[i][0] for s in seed_list]).permute(0, 3, 1, 2)
+            c = torch.stack([get(s)[i][1] for s in seed_list]).permute(0, 3, 1, 2)
+            states.append((h, c))
         return states

@@ -42,23 +42,41 @@ class GradBucket:
     The first call of `allreduce_mean()` runs synchronously after backward and learns which parameters receive gradients at
     all (the reference's dead `norm2`, SURVEY fact 8, never does: no find_unused_parameters pass, no hang).  From then on
     every live parameter carries a post-accumulate-grad hook; a bucket (parameters in reverse registration order, <=
-    `bucket_mb`) is flattened with ONE multi-tensor launch and its all-reduce (RCCL over xGMI with backend "nccl", async) is
-    issued the moment its last gradient has been produced, i.e. while backward is still running on the earlier layers.
-    `allreduce_mean()` then only waits for the handles, divides each flat bucket by the world size (one launch) and re-binds
-    every `p.grad` to its slice of the reduced bucket - no copy back.  Works unchanged with gloo on CPU tensors."""
+    `bucket_mb`) owns ONE persistent flat buffer: its gradients are copied into it with one multi-tensor launch and the
+    all-reduce (RCCL over xGMI with backend "nccl", async) is issued the moment its last gradient has been produced, i.e. while
+    backward is still running on the earlier layers.  `allreduce_mean()` then only waits for the handles, divides each flat
+    bucket by the world size (one launch) and re-binds every `p.grad` to its slice of the reduced bucket - no copy back, no
+    allocation per step.  Works unchanged with gloo on CPU tensors.
 
-    def __init__(self, params, bucket_mb=32):
+    Contract: ONE backward per `allreduce_mean()` (no gradient accumulation, no retain_graph second pass) - a second gradient
+    for a parameter whose bucket has already been handed to the collective raises.  The live set may change between steps: a
+    parameter that first receives a gradient later triggers a rebuild of the buckets (all ranks run the same graph, so they
+    rebuild together); a bucketed parameter without a gradient in some step contributes zeros.
+
+    `measure=True`: event pairs around the exchange (see `overlap_report`)."""
+
+    def __init__(self, params, bucket_mb=32, measure=False):
         self.params = [p for p in params if p.requires_grad]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self.buckets = None        # list of parameter lists once the live set is known
+        self._flat = []            # persistent flat buffer per bucket
+        self._views = []           # per bucket: views of the flat buffer, one per parameter
         self._where = {}           # id(p) -> bucket index
         self._pending = []         # gradients still missing per bucket in this backward
-        self._work = []            # (bucket index, flat tensor, async handle)
+        self._work = []            # (bucket index, async handle)
+        self._launched = set()
         self._hooks = []
         self.launched_during_backward = 0   # diagnostics: buckets whose all-reduce was issued from a hook
+        self.rebuilds = 0
+        self.measure = bool(measure)
+        self._ev = []              # per step: (first bucket ready, backward done, last all-reduce done) events
+        self._ev_first = None
 
-    # ---- bucket construction (after the first backward) ------------------------------------------------------------
+    # ---- bucket construction (after the first backward, or when the live set grew) ----------------------------------
     def _build(self, live):
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._where = [], {}
         order = list(reversed(live))   # backward produces the last-registered parameters' gradients first (roughly)
         self.buckets, cur, n = [], [], 0
         for p in order:
@@ -69,24 +87,45 @@ class GradBucket:
             n += p.numel()
         if cur:
             self.buckets.append(cur)
+        self._flat, self._views = [], []
         for bi, bk in enumerate(self.buckets):
+            flat = torch.empty(sum(p.numel() for p in bk), device=bk[0].device, dtype=bk[0].dtype)
+            views, o = [], 0
             for p in bk:
+                views.append(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
                 self._where[id(p)] = bi
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            self._flat.append(flat)
+            self._views.append(views)
         self._reset()
 
     def _reset(self):
         self._pending = [len(bk) for bk in self.buckets]
         self._work = []
+        self._launched = set()
+        self._ev_first = None
 
     def _launch(self, bi):
-        bk = self.buckets[bi]
-        flat = torch.cat([p.grad.reshape(-1) for p in bk])
-        self._work.append((bi, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)))
+        bk, views = self.buckets[bi], self._views[bi]
+        have = [(v, p.grad) for v, p in zip(views, bk) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(views, bk):
+            if p.grad is None:      # no gradient this step: this rank contributes zeros (the other ranks run the same graph)
+                v.zero_()
+        if self.measure and self._ev_first is None and self._flat[bi].is_cuda:
+            self._ev_first = torch.cuda.Event(enable_timing=True)
+            self._ev_first.record()
+        self._launched.add(bi)
+        self._work.append((bi, dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)))
 
     def _on_grad(self, p):
         bi = self._where[id(p)]
         self._pending[bi] -= 1
+        if self._pending[bi] < 0 or (bi in self._launched and self._pending[bi] != 0):
+            raise RuntimeError("GradBucket: a second gradient arrived for a parameter of bucket %d before allreduce_mean() - one "
+                               "backward per all-reduce (no gradient accumulation / retain_graph passes)" % bi)
         if self._pending[bi] == 0:
             self._launch(bi)
             self.launched_during_backward += 1
@@ -96,26 +135,59 @@ class GradBucket:
         if not (dist.is_initialized() and dist.get_world_size() > 1):
             return 0
         world = dist.get_world_size()
-        if self.buckets is None:
-            # every rank runs the same graph, hence has the same live set
-            self._build([p for p in self.params if p.grad is not None])
+        live = [p for p in self.params if p.grad is not None]
+        ev_done = None
+        if self.measure and live and live[0].is_cuda:
+            ev_done = torch.cuda.Event(enable_timing=True)
+            ev_done.record()                       # backward has been issued up to here on the compute stream
+        if self.buckets is None or any(id(p) not in self._where for p in live):
+            # first step, or a parameter outside the bucket layout received a gradient: (re)build from the union - every rank runs
+            # the same graph, hence sees the same live set and rebuilds in the same step
+            for bi, work in self._work:            # buckets already in flight from hooks: finish them, their values are re-reduced below
+                work.wait()
+                # p.grad still holds this rank's OWN gradient (re-binding to the reduced buffer has not happened), so a fresh pass
+                # over the new layout is exact - unless the gradients were accumulated in place into the old buffers
+                if any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for v, p in zip(self._views[bi], self.buckets[bi])):
+                    raise RuntimeError("GradBucket: the set of parameters with gradients changed while gradients alias the reduced "
+                                       "buckets (zero_grad(set_to_none=False)); use set_to_none=True")
+            if self.buckets is not None:
+                self.rebuilds += 1
+            known = set(self._where)
+            self._build([p for p in self.params if p.grad is not None or id(p) in known])
             for bi in range(len(self.buckets)):
                 self._launch(bi)
         else:
-            for bi, left in enumerate(self._pending):   # buckets a hook did not complete (a parameter without gradient this time)
-                if left > 0 and all(p.grad is not None for p in self.buckets[bi]):
+            for bi in range(len(self.buckets)):    # buckets a hook did not complete (a parameter without gradient this time)
+                if bi not in self._launched:
                     self._launch(bi)
-        for bi, flat, work in self._work:
+        for bi, work in self._work:
             work.wait()
-            flat.div_(world)
-            o = 0
-            for p in self.buckets[bi]:
-                k = p.numel()
-                p.grad = flat[o:o + k].view_as(p)
-                o += k
+            self._flat[bi].div_(world)
+            for v, p in zip(self._views[bi], self.buckets[bi]):
+                p.grad = v
+        if ev_done is not None and self._ev_first is not None:
+            ev_last = torch.cuda.Event(enable_timing=True)
+            ev_last.record()
+            self._ev.append((self._ev_first, ev_done, ev_last))
         nb = len(self._work)
         self._reset()
         return nb
+
+    def overlap_report(self):
+        """Event-pair measurement of the exchange (measure=True, CUDA tensors): per step, `exchange_ms` = first bucket ready ->
+        last all-reduce complete on the compute stream, `exposed_ms` = end of backward -> last all-reduce complete (what the
+        step actually waits for), `overlap` = 1 - exposed / exchange.  Means over the recorded steps; clears the record."""
+        if not self._ev:
+            return None
+        torch.cuda.synchronize()
+        ex = [a.elapsed_time(c) for a, _, c in self._ev]
+        xp = [max(b.elapsed_time(c), 0.0) for _, b, c in self._ev]
+        n = len(self._ev)
+        self._ev = []
+        exch, expo = sum(ex) / n, sum(xp) / n
+        return {"steps": n, "exchange_ms": round(exch, 3), "exposed_ms": round(expo, 3),
+                "overlap": round(1.0 - expo / exch, 4) if exch > 0 else None, "buckets": len(self.buckets),
+                "bytes": int(sum(f.numel() * f.element_size() for f in self._flat))}
 
 
 def shard(t, rank, world):

@@ -558,6 +558,7 @@ def mix_f16(x, W, bias, y, transposed=False):
 
 def lu_fold_fwd(tab, sign_s, perm, iperm, W, Wm, bm, ld, reverse, sgn, hw):
     K, C = sign_s.shape
+    assert W.dtype == torch.float64 and C <= 256
     _chk(lib().tmg_lu_fold_fwd(_ptr(tab), _ptr(sign_s), _ptr(perm), _ptr(iperm), _ptr(W), _ptr(Wm), _ptr(bm), _ptr(ld), _i64(K, C, reverse),
                                _flts([sgn, hw]), _stream()), "tmg_lu_fold_fwd")
 

@@ -847,7 +847,7 @@ class LevelMixFoldFn(torch.autograd.Function):
     def forward(ctx, meta, *params):
         tab, sign_s, perm, iperm, reverse, sgn, hw, K, C = meta
         dev = sign_s.device
-        W = torch.empty((K, C, C), device=dev, dtype=torch.float32)
+        W = torch.empty((K, C, C), device=dev, dtype=torch.float64)     # P L U in fp64, kept for the backward launch
         Wm = torch.empty((K, C, C), device=dev, dtype=torch.float32)
         bm = torch.empty((K, C), device=dev, dtype=torch.float32)
         ld = torch.empty(1, device=dev, dtype=torch.float32)

@@ -11,6 +11,21 @@ from torch.optim.adam import adam as _torch_adam
 import tmg_hip as H
 
 
+def _torch_adam_signature_ok():
+    """`torch.optim.adam.adam` is a private functional API: the general (non-HIP) path below calls it only if it still accepts the
+    keywords this file passes."""
+    import inspect
+    try:
+        names = set(inspect.signature(_torch_adam).parameters)
+    except (TypeError, ValueError):
+        return False
+    return {"amsgrad", "has_complex", "beta1", "beta2", "lr", "weight_decay", "eps", "maximize", "foreach", "capturable", "differentiable",
+            "fused", "grad_scale", "found_inf", "decoupled_weight_decay"} <= names
+
+
+_TORCH_ADAM_OK = _torch_adam_signature_ok()
+
+
 class HipAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, foreach=False, fused=False)
@@ -45,9 +60,13 @@ class HipAdam(torch.optim.Adam):
             if not params:
                 continue
             ok = (all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params)
+                  and all(g.dtype == torch.float32 and g.device == params[0].device and not g.is_sparse for g in grads)
                   and not group.get("maximize", False) and not group.get("capturable", False) and not group.get("differentiable", False)
                   and len({float(s) for s in steps}) == 1 and len({p.device for p in params}) == 1)
             if not ok:   # anything unusual: torch's own single-tensor path on this group (same state)
+                if not _TORCH_ADAM_OK:
+                    raise RuntimeError("HipAdam: this parameter group needs torch's own Adam path, whose functional signature differs in "
+                                       "this torch version; construct torch.optim.Adam for it instead")
                 _torch_adam(params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps, amsgrad=group["amsgrad"], has_complex=False,
                                       beta1=beta1, beta2=beta2, lr=group["lr"], weight_decay=group["weight_decay"], eps=group["eps"],
                                       maximize=group.get("maximize", False), foreach=False, capturable=False, differentiable=False,
@@ -69,7 +88,9 @@ class HipAdam(torch.optim.Adam):
             chunks, nchunks = self._chunk_table([p.numel() for p in params], dev)
             self._fast[gi] = dict(params=params, states=[self.state[p] for p in params], steps=steps, host=host, hv=hv,
                                   tab=torch.empty(5 * n, dtype=torch.int64, device=dev), done=torch.cuda.Event(), chunks=chunks,
-                                  nchunks=nchunks, amsgrad=amsgrad, keep=(exp_avgs, exp_avg_sqs, max_sqs), step=int(float(steps[0])))
+                                  nchunks=nchunks, amsgrad=amsgrad, keep=(exp_avgs, exp_avg_sqs, max_sqs), step=int(float(steps[0])),
+                                  ptrs=[p.data_ptr() for p in params] + [t.data_ptr() for ts in ((exp_avgs, exp_avg_sqs, max_sqs) if amsgrad
+                                                                                                else (exp_avgs, exp_avg_sqs)) for t in ts])
             ok = self._fast_step(gi, group)
             assert ok
         return loss
@@ -110,11 +131,19 @@ class HipAdam(torch.optim.Adam):
             self._fast.pop(gi)
             return False
         grads = [p.grad for p in params]
-        if any(g is None or not g.is_contiguous() or g.is_sparse for g in grads):
+        dev = c["tab"].device
+        if any(g is None or g.is_sparse or g.dtype != torch.float32 or g.device != dev or not g.is_contiguous() for g in grads):
             self._fast.pop(gi)
             return False
         st = c["states"]
-        if any(self.state.get(p) is not s for p, s in zip(params[:1] + params[-1:], st[:1] + st[-1:])):   # load_state_dict replaced the state
+        if any(self.state.get(p) is not s for p, s in zip(params, st)):   # load_state_dict replaced the state
+            self._fast.pop(gi)
+            return False
+        # the cached pointer table must still describe the live storage: model.to(...), `p.data = ...` or a state tensor swapped by hand
+        # re-materialise storage under the same Parameter / dict objects (one cheap pass, like the gradient pointer pass below)
+        kinds = ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if c["amsgrad"] else ())
+        ptrs = [p.data_ptr() for p in params] + [s[k].data_ptr() for k in kinds for s in st]
+        if ptrs != c["ptrs"]:
             self._fast.pop(gi)
             return False
         if int(float(c["steps"][0])) != c["step"] or c["steps"][0] is not st[0]["step"]:

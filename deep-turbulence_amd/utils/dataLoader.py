@@ -43,9 +43,16 @@ class DeviceLoader(object):
             dist.broadcast_object_list(seed, src=0)   # one permutation stream for all ranks even if their RNGs were seeded apart
         self._seed = seed[0]
 
+    def _tail(self):
+        """Rows of the last, partial global batch that are handed out (0 = there is none).  Sharded: truncated to a multiple of the
+        world size, so that every rank gets the same number of rows (the gradient mean over ranks stays the mean over the rows)
+        and no rank ever sees an empty batch; the reference's scatter simply uses fewer replicas for a short batch
+        (parallel.py:118), which one-process-per-GPU data parallelism cannot do without idling ranks inside a collective."""
+        r = 0 if self.drop_last else self.inputs.size(0) % self.batch_size
+        return r - r % self.world
+
     def __len__(self):
-        n = self.inputs.size(0)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return self.inputs.size(0) // self.batch_size + (1 if self._tail() else 0)
 
     def __iter__(self):
         n = self.inputs.size(0)
@@ -55,8 +62,10 @@ class DeviceLoader(object):
             order = (torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)).to(self.inputs.device)
         else:
             order = torch.randperm(n, device=self.inputs.device) if self.shuffle else torch.arange(n, device=self.inputs.device)
+        full = n // self.batch_size
         for i in range(len(self)):
-            idx = order[i * self.batch_size:(i + 1) * self.batch_size][self.rank::self.world]
+            rows = self.batch_size if i < full else self._tail()
+            idx = order[i * self.batch_size:i * self.batch_size + rows][self.rank::self.world]
             x, y = self.inputs[idx], self.targets[idx]
             if self.input_noise_std:
                 x = x + self.input_noise_std * torch.randn_like(x)

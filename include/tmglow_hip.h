@@ -280,8 +280,9 @@ int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, const void* bi
 int tmg_adam_step(const void* tab, const void* chunks, const int64_t* dims, const float* fl, tmg_stream_t st);
 
 /* Parameter-side folding of one flow level: ActNorm (actNorm.py:66-83) + PLU-parameterised invertible 1x1 conv (glowConv.py:151-161) of all
- * K layers -> mix matrices Wm [K,C,C], biases bm [K,C], the unfolded W [K,C,C] (kept for the backward) and the scalar log-det ld of all K
- * mixes; and the backward of that map (dl, du zero outside their triangular masks).  tab: device int64 [K][5] = pointers to the layers'
+ * K layers -> mix matrices Wm [K,C,C], biases bm [K,C], the unfolded W [K,C,C] as FP64 scratch (kept for the backward) and the scalar
+ * log-det ld of all K mixes; and the backward of that map (dl, du zero outside their triangular masks).  C <= 256.  The fold is evaluated in
+ * fp64 and rounded once on store: a rounding error in a mix matrix is coherent over every pixel it is applied to.  tab: device int64 [K][5] = pointers to the layers'
  * own l, u, log_s, ActNorm weight, ActNorm bias tensors (the last two null: no ActNorm); sign_s [K][C]; perm / iperm: int32 [K][C], the row
  * permutation of P and its inverse.  dims = {K, C, reverse}; fl = {sign of the log_s term of the log-det, pixels per image}. */
 int tmg_lu_fold_fwd(const void* tab, const void* sign_s, const void* perm, const void* iperm, void* W, void* Wm, void* bm, void* ld,

@@ -48,6 +48,39 @@ def test_reference_state_dict_loads_strictly(name, cfg):
         assert np.array_equal(h.numpy(), d["h_in.%d.h" % i]) and np.array_equal(c.numpy(), d["h_in.%d.c" % i])
 
 
+def test_seed_state_cache_is_bit_identical_and_draws_each_seed_once():
+    """`initLSTMStates` keeps every distinct seed's states resident after the first host draw (the loaders draw seeds from
+    random_(0, 1000), reference dataLoader.py:284, :422): later mini-batches - any order, repeated seeds - are gathers of the same
+    bits the reference's per-call host draw (tmGlow.py:494-509, fixture `h_in.*` recorded from the reference) produces."""
+    from nn.tmGlow import TMGlow
+    d = C.load_npz("tiny_model.npz")
+    cfg = C.CFG_TINY
+    m = TMGlow(**C.build_kwargs(cfg))
+    hw = list(d["y"].shape[2:])
+    calls = []
+    real = m._draw_seed_states
+    m._draw_seed_states = lambda seeds, dim: (calls.append(list(seeds)), real(seeds, dim))[1]
+    a = m.initLSTMStates(torch.tensor([0, 1]), hw)
+    for i, (h, c) in enumerate(a):                     # the fixture's seeds are arange(B)
+        assert np.array_equal(h.numpy(), d["h_in.%d.h" % i]) and np.array_equal(c.numpy(), d["h_in.%d.c" % i])
+    b = m.initLSTMStates(torch.tensor([1, 7, 1, 0]), hw)
+    assert calls == [[0, 1], [7]]                        # each distinct seed drawn once
+    fresh = TMGlow(**C.build_kwargs(cfg))
+    want = fresh.initLSTMStates(torch.tensor([1, 7, 1, 0]), hw)
+    for (h, c), (h2, c2), (h0, c0) in zip(b, want, a):
+        assert torch.equal(h, h2) and torch.equal(c, c2) and h.shape == h2.shape
+        assert torch.equal(h[0], h0[1]) and torch.equal(h[2], h0[1]) and torch.equal(c[3], c0[0])
+        assert h.permute(0, 2, 3, 1).is_contiguous()     # channels-last: the layout the flow works in
+    # another field size is another cache; returned tensors are fresh (mutating them does not touch the cache)
+    b[0][0].zero_()
+    again = m.initLSTMStates(torch.tensor([1]), hw)
+    assert torch.equal(again[0][0][0], want[0][0][0])
+    other = m.initLSTMStates(torch.tensor([1]), [2 * hw[0], 2 * hw[1]])
+    assert other[0][0].shape[2] == hw[0] and calls[-1] == [1]
+    # the cache never enters the state_dict
+    assert not any("seed" in k for k in m.state_dict())
+
+
 def test_public_api_surface():
     import nn.tmGlow as T
     from nn.modules import actNorm, glowConv, flowAffine, flowLSTMBlock, flowUtils, denseBlock, convLSTM, misc

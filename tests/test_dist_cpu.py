@@ -137,3 +137,69 @@ def test_two_rank_window_matches_two_replica_emulation():
             assert abs(ret[r]["gn"][a] - gn[a]) < 2e-4 * gn[a] * (1 + a)        # clip norm of the AVERAGED gradient on every rank
         # the second window's buckets were all-reduced from the gradient hooks, while backward was still running
         assert ret[r]["nbuckets"] > 1 and ret[r]["hooked"] >= ret[r]["nbuckets"] - 1, (ret[r]["hooked"], ret[r]["nbuckets"])
+
+
+def _run_bucket_edges(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, C.PKG)
+    import tmg_dist
+    torch.set_num_threads(1)
+    tmg_dist.init_from_env("gloo")
+    torch.manual_seed(5)
+    a, b, c = (torch.nn.Parameter(torch.randn(7, 3)) for _ in range(3))
+    x = torch.randn(4, 3) + rank
+    bucket = tmg_dist.GradBucket([a, b, c], bucket_mb=1e-4)      # one parameter per bucket
+    out = {}
+
+    def step(use):
+        for p in (a, b, c):
+            p.grad = None
+        sum(((p @ x.t()) ** 2).sum() * (i + 1) for i, p in enumerate((a, b, c)) if i in use).backward()
+        own = {i: p.grad.clone() for i, p in enumerate((a, b, c)) if p.grad is not None}
+        bucket.allreduce_mean()
+        return own
+
+    flat_ptrs = None
+    for name, use in (("first", (0, 1)), ("hooked", (0, 1)), ("late", (0, 1, 2)), ("missing", (0, 2)), ("steady", (0, 1, 2))):
+        own = step(use)
+        out[name] = {"own": own, "mean": {i: p.grad.clone() for i, p in enumerate((a, b, c)) if p.grad is not None}}
+        if name == "late":
+            flat_ptrs = [f.data_ptr() for f in bucket._flat]
+    out["persistent"] = flat_ptrs == [f.data_ptr() for f in bucket._flat]      # no new flat buffers after the layout settled
+    out["rebuilds"], out["nbuckets"] = bucket.rebuilds, len(bucket.buckets)
+    # a second backward before the exchange must raise instead of silently reducing partial gradients
+    for p in (a, b, c):
+        p.grad = None
+    loss = sum(((p @ x.t()) ** 2).sum() for p in (a, b, c))
+    loss.backward(retain_graph=True)
+    try:
+        loss.backward()
+        out["second_backward"] = "accepted"
+    except RuntimeError as e:
+        out["second_backward"] = "raised" if "GradBucket" in str(e) else str(e)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_live_set_changes_and_misuse():
+    """GradBucket hygiene: a parameter that first receives a gradient in a later step is picked up (bucket rebuild, on all ranks
+    together), a bucketed parameter without a gradient contributes zeros instead of silently skipping the bucket, the flat
+    buffers persist across steps, and a second backward before the exchange raises."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_bucket_edges, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    for name in ("first", "hooked", "late", "missing", "steady"):
+        keys = set(r0[name]["own"]) | set(r1[name]["own"])
+        for i in sorted(set(r0[name]["mean"]) | keys):
+            want = 0.5 * (r0[name]["own"].get(i, 0.0) + r1[name]["own"].get(i, 0.0))
+            if i in keys:
+                assert torch.allclose(r0[name]["mean"][i], want, rtol=1e-6, atol=1e-6), (name, i)
+                assert torch.equal(r0[name]["mean"][i], r1[name]["mean"][i]), (name, i)
+            else:                                     # bucketed, no gradient this step: the reduced value is exactly zero
+                assert float(r0[name]["mean"][i].abs().max()) == 0.0, (name, i)
+    assert r0["rebuilds"] == 1 and r0["nbuckets"] == 3 and r0["persistent"]
+    assert r0["second_backward"] == "raised" and r1["second_backward"] == "raised"

@@ -635,7 +635,7 @@ def test_hip_adam_cached_path_follows_changes():
     pb = [p.detach().clone().requires_grad_(True) for p in pa]
     oa = HipAdam(pa, lr=2e-3, weight_decay=1e-8, amsgrad=True)
     ob = torch.optim.Adam(pb, lr=2e-3, weight_decay=1e-8, amsgrad=True, foreach=False)
-    for it in range(9):
+    for it in range(11):
         skip = 2 if it == 3 else -1                   # parameter 2 takes no part in step 3
         for i, (a, b) in enumerate(zip(pa, pb)):
             gr = torch.randn(a.shape, generator=g).to(DEV)
@@ -645,6 +645,11 @@ def test_hip_adam_cached_path_follows_changes():
                 o.param_groups[0]["lr"] = 5e-4
         if it == 7:                                   # round trip through the state dict (a workspace reload)
             oa.load_state_dict(copy.deepcopy(ob.state_dict()))     # (deep copy: load_state_dict keeps the tensors it is given)
+        if it == 8:
+            # storage re-materialised under the SAME Parameter / state-dict objects (model.to(...), `p.data = ...`, a state tensor
+            # swapped by hand for a middle parameter): the cached pointer table must not be used
+            pa[1].data = pa[1].data.clone()
+            oa.state[pa[2]]["exp_avg"] = oa.state[pa[2]]["exp_avg"].clone()
         oa.step()
         ob.step()
         for a, b in zip(pa, pb):

@@ -102,7 +102,15 @@ def test_seeded_models_match_reference(name, cfg):
 # cfg5 at a reduced field: the widths and the five levels of BASELINE configs[4] on a 64x64 output (level 5 works on 2x2 maps
 # with 256 channels); the full 512x512 field is covered by test_cfg5_full_size_properties
 CFG5_REDUCED = dict(C.CFG5, _in_hw=(32, 32))
-YARDSTICK = 3.0   # a quantity may deviate from the fp64 oracle by 3x what the reference's own fp32 arithmetic does
+YARDSTICK = 3.0        # fields / log-dets / states may deviate from the fp64 oracle by 3x what the reference's own fp32 arithmetic does
+GRAD_YARDSTICK = 1.5   # gradients: bound = max(stated tolerance, 1.5 x the fp32 oracle's own error against fp64)
+# Why gradients need a yardstick at all (profiles/r3_kink_scan_M.json, tools/kink_scan.py): at the metric configuration, batch 1, the
+# generative pass evaluates 48 M ReLUs, and for EVERY input seed 14-63 of them have an fp64 pre-activation within 1e-5 of zero that the
+# reference's own fp32 arithmetic puts on the other side; whether a given fp32 evaluation flips a given one depends on the last bit of
+# the encoder's BatchNorm sums.  One flipped element of a deep 16x16 map moves the deepest level's weight gradients by 1e-3 of their
+# scale: the SAME HIP build lands at 6.5e-5 or at 2.9e-4 global rel-L2 from fp64 on config M (profiles/r3_parity_report_M.json, the
+# variant run twice), the second value within 4e-5 of the fp32 oracle, which sits at 2.9e-4 itself.  The arithmetic noise proper of
+# the HIP path is the smaller number; the flips are a property of the case, shared with the reference.
 
 
 def _maxabs(a, b):
@@ -133,7 +141,8 @@ def _oracle_pass(O, sd, cfg, x, y, seeds, dtype, eps=None):
     C.loss_forward(lp, yy).backward()
     gf = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
     P = O.params_from_state_dict(sd, dtype=dtype)
-    e_in = [t.detach().to(dtype) for t in (eps if eps is not None else eo)]
+    # identical inputs for every evaluation: the latents are ROUNDED to fp32 (what the fp32 paths can be given) before the fp64 pass too
+    e_in = [t.detach().float().to(dtype) for t in (eps if eps is not None else eo)]
     yr, ld, ho2 = O.tmglow_reconstruct(P, cfg, xx, st, e_in, training=True)
     C.loss_reverse(yr, ld).backward()
     gr = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
@@ -211,9 +220,10 @@ def test_baseline_configs_match_fp64_oracle(name, cfg, B):
     def grads(tag, got, key):
         fl = _grad_err(r32[key], r64[key])
         er = _grad_err(got, r64[key])
-        rep[tag] = {"hip_vs_fp64": er, "oracle_fp32_vs_fp64": fl, "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX)}
-        C.assert_grads(got, r64[key], "%s %s" % (name, tag), global_tol=max(C.GRAD_GLOBAL_REL_L2, YARDSTICK * fl[0]),
-                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, YARDSTICK * fl[1]))
+        rep[tag] = {"hip_vs_fp64": er, "oracle_fp32_vs_fp64": fl, "hip_vs_oracle_fp32": _grad_err(got, r32[key]),
+                    "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK}
+        C.assert_grads(got, r64[key], "%s %s" % (name, tag), global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
+                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]))
 
     try:
         field("z", z, "z", C.FIELD_ATOL)
@@ -237,47 +247,103 @@ def test_baseline_configs_match_fp64_oracle(name, cfg, B):
                 json.dump({"config": name, "batch": B, "yardstick": YARDSTICK, "quantities": rep}, f, indent=1, default=float)
 
 
-@pytest.mark.parametrize("name,cfg,B", [("cfg2", C.CFG2, 32), ("cfg3", C.CFG3, 64)])
-def test_stated_batches_match_oracle_on_a_subset(name, cfg, B):
-    """BASELINE configs[1] / configs[2] at their STATED batch sizes (32 / 64).  Samples are independent through the flow and
-    coupled only by the encoder's BatchNorm batch statistics, so the CPU oracle runs its encoder on the full batch (< 1 % of
-    the work) and the flow on the first two samples; the HIP path runs the whole batch."""
+def _stated_batch_case(name, cfg, B, n=2):
+    """One BASELINE configuration at its STATED batch size on the HIP path - generative direction, loss on the first `n` samples,
+    backward - against the CPU oracle with gradients.  Samples are independent through the flow and coupled only by the encoder's
+    BatchNorm batch statistics, so the oracle runs its encoder on the FULL batch (< 1 % of the work; its gradient flows through the
+    batch statistics of all B samples) and the flow on the `n` samples the loss sees, in fp64 (truth) and in fp32 (the reference's
+    arithmetic: the yardstick).  Compared: y, log-det, the recurrent states and ALL parameter gradients.  The same step is then
+    repeated with the batch rolled by `n` (the loss samples now sit at the END of every tensor - the last tiles of the persistent
+    kernels, the highest addresses of the 1 GB activations) and must give the same gradients."""
+    import json
     import os
     import sys
     sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
     import tmglow_oracle as O
     from nn.tmGlow import TMGlow
+    import contextlib
+    import io
     C.seed_all(12345)
-    m = TMGlow(**C.build_kwargs(cfg))
-    C.perturb_(m, 7, 0.004, 0.02, 0.004)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, *C.perturb_scales(cfg))
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m.to(DEV).train()
+    L = len(cfg["glow_blocks"])
     h, w = cfg["_in_hw"]
     H_, W_ = h * cfg["_up"], w * cfg["_up"]
     g = torch.Generator().manual_seed(77)
     x = torch.randn(B, cfg["in_features"], h, w, generator=g)
     y = torch.randn(B, cfg["out_features"], H_, W_, generator=g)
     seeds = torch.arange(B) + 11
-    n = 2
-    with torch.no_grad():
-        st = m.initLSTMStates(seeds, [H_, W_])
-        z, lp, ho, e = m.forward(x.to(DEV), y.to(DEV), st, return_eps=True)
+    st = m.initLSTMStates(seeds, [H_, W_])
+    with torch.no_grad():    # latents of realistic size and shape: the density direction's own, whole batch
+        _, _, _, eps = m.forward(x.to(DEV), y.to(DEV), st, return_eps=True)
+        m.load_state_dict(sd)    # (BatchNorm running statistics back to their initial values)
+    eps = [e.detach() for e in eps]
+
+    def hip_step(xx, states, ee, sl):
         m.load_state_dict(sd)
-        yr, ld, _ = m.reconstruct(x.to(DEV), st, e)
-        res = {}
-        for dt in (torch.float64, torch.float32):
-            P = O.params_from_state_dict(sd, dtype=dt, requires_grad=False)
-            z_out, c_out = O.encoder(P, cfg, x.to(dt), True)
-            cmean, clsd = z_out[:n].chunk(2, 1)
-            clsd = clsd.clamp(-10.0, O.LOG5)
-            sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
-            zo, ldo, _, eo = O.decoder_forward(P, cfg, y[:n].to(dt), [c[:n] for c in c_out], sto, True)
-            res[dt] = (zo, O.gauss_logp(cmean, clsd, zo) + ldo)
-    floor = _maxabs(res[torch.float32][0], res[torch.float64][0])
-    C.assert_field(z[:n], res[torch.float64][0], name + " z at the stated batch", atol=max(C.FIELD_ATOL, YARDSTICK * floor))
-    lfloor = float(((res[torch.float32][1].double() - res[torch.float64][1]).abs() / res[torch.float64][1].abs()).max())
-    C.assert_logdet(lp[:n], res[torch.float64][1], name + " logp at the stated batch", rtol=max(C.LOGDET_RTOL, YARDSTICK * lfloor))
-    assert float((yr - y.to(DEV)).abs().max()) < 2e-3   # forward -> reconstruct round trip over the whole batch
+        m.zero_grad()
+        yr, ld, ho = m.reconstruct(xx, states, ee)
+        C.loss_reverse(yr[sl], ld[sl]).backward()
+        return yr.detach(), ld.detach(), [(a.detach(), b.detach()) for a, b in ho], {k: v.detach().clone() for k, v in _grads(m).items()}
+
+    yr, ld, ho, gr = hip_step(x.to(DEV), st, eps, slice(0, n))
+    assert float((yr - y.to(DEV)).abs().max()) < 2e-3          # forward -> reconstruct round trip over the WHOLE batch
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        P = O.params_from_state_dict(sd, dtype=dt)
+        z_out, c_out = O.encoder(P, cfg, x.to(dt), True)
+        cmean, clsd = z_out[:n].chunk(2, 1)
+        clsd = clsd.clamp(-10.0, O.LOG5)
+        z = cmean + torch.exp(clsd) * eps[-1][:n].cpu().to(dt)
+        sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
+        yo, ldo, hoo = O.decoder_reverse(P, cfg, z, [c[:n] for c in c_out], sto, [e[:n].cpu().to(dt) for e in eps[:-1]])
+        C.loss_reverse(yo, ldo).backward()
+        res[dt] = dict(y=yo.detach(), ld=ldo.detach(), h=[(a.detach(), b.detach()) for a, b in hoo],
+                       g={k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None})
+    r64, r32 = res[torch.float64], res[torch.float32]
+    rep = {"config": name, "batch": B, "loss_samples": n}
+    try:
+        floor = _maxabs(r32["y"], r64["y"])
+        rep["y"] = {"hip_vs_fp64": _maxabs(yr[:n], r64["y"]), "oracle_fp32_vs_fp64": floor}
+        C.assert_field(yr[:n], r64["y"], name + " y at the stated batch", atol=max(C.FIELD_ATOL, YARDSTICK * floor))
+        lfloor = float(((r32["ld"].double() - r64["ld"]).abs() / r64["ld"].abs().clamp_min(1.0)).max())
+        C.assert_logdet(ld[:n], r64["ld"], name + " logdet at the stated batch", rtol=max(C.LOGDET_RTOL, YARDSTICK * lfloor))
+        for i in range(L):
+            for j in range(2):
+                fl = _maxabs(r32["h"][i][j], r64["h"][i][j])
+                C.assert_field(ho[i][j][:n], r64["h"][i][j], "%s state %d.%d" % (name, i, j), atol=max(C.STATE_ATOL, YARDSTICK * fl))
+        fl = _grad_err(r32["g"], r64["g"])
+        er = _grad_err(gr, r64["g"])
+        rep["reverse grads"] = {"hip_vs_fp64": er, "oracle_fp32_vs_fp64": fl, "hip_vs_oracle_fp32": _grad_err(gr, r32["g"]),
+                                "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK}
+        assert set(gr) == set(r64["g"]), sorted(set(gr) ^ set(r64["g"]))[:5]
+        C.assert_grads(gr, r64["g"], name + " reverse grads at the stated batch", global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
+                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]))
+        # the same samples at the END of the batch
+        roll = lambda t: torch.roll(t, -n, 0)  # noqa: E731
+        yr2, ld2, _, gr2 = hip_step(roll(x).to(DEV), [(roll(a), roll(b)) for a, b in st], [roll(e) for e in eps], slice(B - n, B))
+        C.assert_field(yr2[B - n:], yr[:n], name + " y, loss samples last", atol=2e-5, rtol=1e-5)
+        C.assert_logdet(ld2[B - n:], ld[:n], name + " logdet, loss samples last", rtol=2e-6, atol=1e-3)
+        rep["rolled batch grads vs first"] = _grad_err(gr2, gr)
+        # (equal up to the order of the atomics and of the BatchNorm sums; the reference's fp32 noise floor is the scale)
+        C.assert_grads(gr2, gr, name + " grads with the loss samples at the end of the batch", global_tol=max(1e-4, fl[0]),
+                       tensor_tol=max(2e-3, fl[1]))
+    finally:
+        print("\nparity %s at batch %d: %s" % (name, B, json.dumps(rep, default=float)))
+        out = os.path.join(C.ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "parity_%s_batch%d.json" % (name, B)), "w") as f:
+                json.dump(rep, f, indent=1, default=float)
+
+
+@pytest.mark.parametrize("name,cfg,B", [("cfg2", C.CFG2, 32), ("cfg3", C.CFG3, 64), ("M", C.CFG_M, 64)])
+def test_stated_batches_match_oracle_with_gradients(name, cfg, B):
+    """BASELINE configs[1] / configs[2] / the metric configuration at their STATED batch sizes (32 / 64 / 64: the benchmarked
+    shapes), with gradients - see _stated_batch_case."""
+    _stated_batch_case(name, cfg, B)
 
 
 def test_cfg5_full_size_properties():

@@ -99,6 +99,28 @@ def test_sharded_loader_partitions_every_global_batch():
     assert sorted(v for p in parts for b in p for v in b) == list(range(24))
 
 
+def test_sharded_loader_tail_batch_is_truncated_to_equal_shards():
+    """Rank sharding with a partial last batch (drop_last=False, the backward-step training loader): the tail is truncated to a
+    multiple of the world size, so every rank gets the same number of rows in every batch (the gradient mean over ranks stays the mean
+    over rows) and no rank ever sees an empty batch - a remainder smaller than the world drops the tail batch on all ranks."""
+    from utils.dataLoader import DeviceLoader
+    torch.manual_seed(4)
+    for n, bs, world, want in ((23, 8, 2, [4, 4, 3]), (17, 8, 2, [4, 4]), (25, 8, 4, [2, 2, 2]), (27, 8, 4, [2, 2, 2]), (30, 8, 4, [2, 2, 2, 1])):
+        t = torch.arange(float(n)).view(n, 1)
+        parts = []
+        for r in range(world):
+            ld = DeviceLoader(t, t, t, bs, True, False)
+            ld.set_shard(r, world)
+            rows = [b[0].flatten().tolist() for b in ld]
+            assert len(ld) == len(rows) == len(want), (n, bs, world, len(ld), len(rows))
+            parts.append(rows)
+        for i, k in enumerate(want):
+            assert all(len(p[i]) == k for p in parts), (n, bs, world, i)                       # equal, non-empty shards
+            assert len({v for p in parts for v in p[i]}) == k * world                           # disjoint
+    t = torch.arange(10.).view(10, 1)
+    assert [len(b[0]) for b in DeviceLoader(t, t, t, 4, False, False)] == [4, 4, 2]             # unsharded: the reference's tail batch
+
+
 def test_loader_noise_and_batching(tmp_path):
     """tar_noise_std lands on the INPUT (the reference's positional-argument quirk), drawn per batch; drop_last rules."""
     from utils.dataLoader import BackwardStepLoader, DeviceLoader
