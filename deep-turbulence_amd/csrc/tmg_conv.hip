@@ -698,7 +698,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
     // ---- lean staging (p.fstage): VALU cycles add to MFMA cycles on a SIMD, so the per-item address math is kept to
     // ~a dozen full-rate instructions.  A thread owns one channel quad (its segment is resolved once) and every
     // (NT / k4p)-th patch pixel; the patch coordinates of its items are tile-invariant and live in registers.
-    const int k4l = citn <= 1 ? 2 : (citn <= 2 ? 3 : 4), k4p = 1 << k4l;  // float4 slots per pixel, padded to 2^n
+    // (up to 8 channel tiles per group: the 1x1 contractions of the 128-channel level stage 8; plan_wgrad's fits() mirrors this)
+    const int k4l = citn <= 1 ? 2 : (citn <= 2 ? 3 : (citn <= 4 ? 4 : 5)), k4p = 1 << k4l;  // float4 slots per pixel, padded to 2^n
     const int pc4 = tid & (k4p - 1), ppix0 = tid >> k4l, pstep = NT >> k4l;
     const float* tptr = g_tmg_zero_page;  // this thread's segment base (+ channel); padding channels read zeros
     int tss = 0;
@@ -1727,7 +1728,8 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     const int PW = stride * (TW - 1) + 1 + 2 * halo, PH = stride * (pl->TH - 1) + 1 + 2 * halo;
     // kernel limits: the patch of one tile fits the register window (7 float4 x 512 threads) and two LDS buffers fit
     auto fits = [&](int cg, int nc) {
-        const int k4p = cg <= 1 ? 4 : (cg <= 2 ? 8 : 16);  // float4 slots per pixel as the lean staging path pads them
+        if (cg > 8) return false;                          // the lean staging path addresses at most 32 float4 slots per pixel
+        const int k4p = cg <= 1 ? 4 : (cg <= 2 ? 8 : (cg <= 4 ? 16 : 32));  // float4 slots per pixel as the lean staging path pads them
         return PH * PW * k4p <= 7 * 512 && 2 * ((size_t)(PH * PW * 16 + 16) * cg + (size_t)(pl->MPIX * 16 + 16) * nc) * 4 <= 160 * 1024;
     };
     int CITG = 1, NCO = 1, bestg = -1;
@@ -1776,7 +1778,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
         // Narrow layers do little MFMA work per pixel: with 128-pixel tiles every wave walks ONE 16-pixel unit per tile and
         // the read/MFMA pipeline never fills.  Larger tiles (as far as registers, LDS and the tile count allow) give each
         // wave 2-4 units per tile and less halo per staged pixel.
-        const int k4p = pl->CITG <= 1 ? 4 : (pl->CITG <= 2 ? 8 : 16);
+        const int k4p = pl->CITG <= 1 ? 4 : (pl->CITG <= 2 ? 8 : (pl->CITG <= 4 ? 16 : 32));
         for (int mp = 512; mp > 128; mp >>= 1) {
             const int th = mp >> twl, ph = th + 2 * halo;
             const int tiles = B * ((Wout + TW - 1) / TW) * ((Hout + th - 1) / th);

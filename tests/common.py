@@ -138,10 +138,17 @@ def assert_logdet(a, b, what="logdet", rtol=LOGDET_RTOL, atol=1e-4):
     assert bool((err <= atol + rtol * b.abs()).all()), "%s: %s vs %s" % (what, a.flatten()[:4].tolist(), b.flatten()[:4].tolist())
 
 
-def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_tol=GRAD_TENSOR_REL_MAX, skip=()):
-    """got/ref: name -> tensor.  Global relative L2 and worst per-tensor relative max."""
+def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_tol=GRAD_TENSOR_REL_MAX, skip=(), outliers=(0, 1.0)):
+    """got/ref: name -> tensor.  Global relative L2 and worst per-tensor relative max.
+    outliers = (count, factor): at most `count` tensors may exceed tensor_tol, by at most `factor` - for the large-configuration
+    comparisons against an fp64 evaluation, where single ReLU pre-activations within 1e-6 of zero land on the other side in ANY
+    fp32 evaluation (tools/kink_scan.py: 14-63 of 48 M per case) and one such element of a deep, small map moves one or two
+    small weight-gradient tensors by a few per cent of their scale; which elements flip differs between two fp32 evaluations
+    (the reference's own and this one), so the reference's measured floor bounds the typical tensor, not the worst one.  A kernel
+    fault is not confused with this: it moves a tensor by tens of per cent (the round-3 staging bug: 126 %) and fails the factor
+    and the global bound."""
     num = den = 0.0
-    worst, worst_k = 0.0, None
+    rels = []
     for k, r in ref.items():
         if any(s in k for s in skip):
             continue
@@ -153,12 +160,14 @@ def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_t
         den += float((r ** 2).sum())
         scale = float(r.abs().max())
         if scale > 0:
-            rel = float((g - r).abs().max()) / scale
-            if rel > worst:
-                worst, worst_k = rel, k
+            rels.append((float((g - r).abs().max()) / scale, k))
+    rels.sort(reverse=True)
+    worst, worst_k = rels[0] if rels else (0.0, None)
     glob = (num / max(den, 1e-300)) ** 0.5
     assert glob <= global_tol, "%s: global rel-L2 %.3e > %.1e (worst tensor %s %.3e)" % (what, glob, global_tol, worst_k, worst)
-    assert worst <= tensor_tol, "%s: tensor %s rel-max %.3e > %.1e" % (what, worst_k, worst, tensor_tol)
+    over = [(v, k) for v, k in rels if v > tensor_tol]
+    assert len(over) <= outliers[0], "%s: %d tensors beyond rel-max %.1e (allowed %d): %s" % (what, len(over), tensor_tol, outliers[0], over[:4])
+    assert worst <= tensor_tol * outliers[1], "%s: tensor %s rel-max %.3e > %.1e x %.1f" % (what, worst_k, worst, tensor_tol, outliers[1])
     return glob, worst
 
 

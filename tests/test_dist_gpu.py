@@ -75,3 +75,28 @@ def test_two_ranks_on_one_device_match_single_process(tmp_path):
             assert abs(res[k]["loss"][a] - losses[a][k]) < 2e-5 * (1 + a)
             assert abs(res[k]["gn"][a] - gns[a]) < 5e-4 * gns[a] * (1 + a)
         assert res[k]["nbuckets"] > 1 and res[k]["hooked"] >= res[k]["nbuckets"] - 1
+
+
+def test_bench_two_rank_path_on_one_device():
+    """`bench.py --gpus 2 --config cfg4` (BASELINE configs[3]: back-step 256x256x4 sharded over the ranks) through the launcher the
+    driver uses, both ranks on this one GPU (TMG_SINGLE_DEVICE=1, gloo - RCCL cannot put two ranks on one device): the N>1 bench
+    path - init from the environment, parameter broadcast, persistent gradient buckets all-reduced from the hooks, barrier + MAX
+    timing, the one JSON line from rank 0 with the event-pair measurement of the exchange - cannot rot unnoticed."""
+    import json
+    env = dict(os.environ, TMG_SINGLE_DEVICE="1", TMG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 31200 + (os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(C.ROOT, "bench.py"), "--gpus", "2", "--config", "cfg4", "--batch", "4", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline", "--no-events"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                          # rank 0 prints exactly one JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["global_batch"] == 8 and cfg["world_size_observed"] == 2 and cfg["backend"] == "gloo" and cfg["parallelism"] == "dp2"
+    assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-2 * out["value"]          # whole-job samples / max-over-ranks time
+    ar = cfg["allreduce"]
+    assert ar is not None and ar["buckets"] >= 1 and ar["bytes"] > 20e6 and ar["exchange_ms"] > 0 and ar["exposed_ms"] >= 0
+    assert cfg["loss_last"] == cfg["loss_last"]            # not NaN

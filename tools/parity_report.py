@@ -69,6 +69,20 @@ def inputs(cfg, B, seed):
     return x, y, torch.arange(B) + 3, (H_, W_)
 
 
+def oracle_subset_pass(cfg, sd, x, seeds, hw, dtype, eps, n):
+    """Generative direction with the loss on the first n samples: encoder on the whole batch (BatchNorm statistics), flow on n."""
+    import tmglow_oracle as O
+    P = O.params_from_state_dict(sd, dtype=dtype)
+    z_out, c_out = O.encoder(P, cfg, x.to(dtype), True)
+    cmean, clsd = z_out[:n].chunk(2, 1)
+    clsd = clsd.clamp(-10.0, O.LOG5)
+    z = cmean + torch.exp(clsd) * eps[-1][:n].float().to(dtype)
+    st = [(a[:n].to(dtype), b[:n].to(dtype)) for a, b in O.init_lstm_states(cfg, seeds[:n], list(hw))]
+    yo, ldo, _ = O.decoder_reverse(P, cfg, z, [c[:n] for c in c_out], st, [e[:n].float().to(dtype) for e in eps[:-1]])
+    C.loss_reverse(yo, ldo).backward()
+    return {"gr": {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}, "y": yo.detach(), "ld": ldo.detach()}
+
+
 def oracle_pass(cfg, sd, x, y, seeds, dtype, eps=None, want_forward=True):
     import tmglow_oracle as O
     H_, W_ = y.shape[2], y.shape[3]
@@ -108,9 +122,10 @@ def hip_child(path):
         m.load_state_dict(sd)
         m.zero_grad()
     yr, ld, _ = m.reconstruct(x.cuda(), st, [t.float().cuda() for t in d["eps"]])
-    C.loss_reverse(yr, ld).backward()
+    n = d.get("loss_samples") or x.shape[0]
+    C.loss_reverse(yr[:n], ld[:n]).backward()
     out["gr"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
-    out["y"], out["ld"] = yr.detach().cpu(), ld.detach().cpu()
+    out["y"], out["ld"] = yr.detach().cpu()[:n], ld.detach().cpu()[:n]
     torch.save(out, path + ".out")
 
 
@@ -163,6 +178,8 @@ def main():
     ap.add_argument("--seed", type=int, default=31)
     ap.add_argument("--variants", default="default,no_wino,no_wino_wgrad,no_fused_bwd")
     ap.add_argument("--forward", action="store_true", help="also the density direction")
+    ap.add_argument("--loss-samples", type=int, default=0, help="loss on the first n samples of the batch only (oracle: encoder on the "
+                                                                "whole batch, flow on n samples): stated-batch parity")
     ap.add_argument("--out", default=None)
     ap.add_argument("--child", default=None)
     args = ap.parse_args()
@@ -174,8 +191,21 @@ def main():
     del m
     x, y, seeds, hw = inputs(cfg, args.batch, args.seed)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    r64 = oracle_pass(cfg, sd, x, y, seeds, torch.float64, want_forward=True)
-    r32 = oracle_pass(cfg, sd, x, y, seeds, torch.float32, eps=r64["eps"], want_forward=args.forward)
+    if args.loss_samples:
+        # latents: seeded normal draws of the right shapes (taken from a batch-1 fp32 oracle forward)
+        import tmglow_oracle as O
+        with torch.no_grad():
+            P = O.params_from_state_dict(sd, requires_grad=False)
+            st1 = O.init_lstm_states(cfg, seeds[:1], list(hw))
+            _, _, _, e1 = O.tmglow_forward(P, cfg, x[:1], y[:1], st1, return_eps=True, training=True)
+        g = torch.Generator().manual_seed(args.seed + 1000)
+        eps = [torch.randn((args.batch,) + tuple(e.shape[1:]), generator=g) for e in e1]
+        r64 = oracle_subset_pass(cfg, sd, x, seeds, hw, torch.float64, eps, args.loss_samples)
+        r32 = oracle_subset_pass(cfg, sd, x, seeds, hw, torch.float32, eps, args.loss_samples)
+        r64["eps"] = eps
+    else:
+        r64 = oracle_pass(cfg, sd, x, y, seeds, torch.float64, want_forward=True)
+        r32 = oracle_pass(cfg, sd, x, y, seeds, torch.float32, eps=r64["eps"], want_forward=args.forward)
     rep = {"config": args.config, "batch": args.batch, "input_seed": args.seed, "variants": {}}
     yard = {}
     for key in (("gf", "gr") if args.forward else ("gr",)):
@@ -186,7 +216,8 @@ def main():
     tmp = tempfile.mkdtemp(prefix="tmg_parity_")
     for name in args.variants.split(","):
         path = os.path.join(tmp, name + ".pt")
-        torch.save({"config": args.config, "x": x, "y": y, "seeds": seeds, "hw": hw, "eps": r64["eps"], "forward": args.forward}, path)
+        torch.save({"config": args.config, "x": x, "y": y, "seeds": seeds, "hw": hw, "eps": r64["eps"], "forward": args.forward,
+                    "loss_samples": args.loss_samples}, path)
         env = dict(os.environ, **VARIANTS[name])
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path], env=env, capture_output=True, text=True)
         if r.returncode != 0:
@@ -203,7 +234,7 @@ def main():
         print("%-18s reverse grads: global rel-L2 %.3e  worst rel-max %.3e   (fp32 oracle %.3e / %.3e; hip vs fp32 oracle %.3e)  y %.2e" % (
             name, g["global_rel_l2"], g["worst_rel_max"], rep["oracle_fp32"]["gr"]["global_rel_l2"], rep["oracle_fp32"]["gr"]["worst_rel_max"],
             g["global_rel_l2_vs_oracle_fp32"], v["y_maxabs"]))
-        for w in g["worst_by_share"][:3]:
+        for w in g["worst_by_share"][:int(os.environ.get("TMG_REPORT_TOP", 3))]:
             print("     share %.2f  rel_l2 %.2e rel_max %.2e (fp32 oracle %.2e)  %s" % (w["share_of_global_err2"], w["rel_l2"], w["rel_max"], w["oracle_fp32_rel_max"], w["name"]))
         sys.stdout.flush()
     if args.out:
