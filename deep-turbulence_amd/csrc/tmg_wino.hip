@@ -89,6 +89,23 @@ extern "C" int tmg_conv_wino_pack(const void* w, void* U, int64_t Cout, int64_t 
     return 0;
 }
 
+// Diagnostic build only (-DTMG_WINO_STAMP, tools/scratch/wino_stamps.py): s_memtime stamps at the phase boundaries of wino_fwd_kernel,
+// cycles per phase summed over waves into g_wino_stamps (never read by the kernel; the product build contains no stamp).
+#ifdef TMG_WINO_STAMP
+__device__ unsigned long long g_wino_stamps[16];
+#define TMG_STAMP(I) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[I] += (unsigned)(t_ - st_last); st_last = t_; }
+extern "C" int tmg_wino_stamps(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_stamps), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_stamps), 16 * sizeof(unsigned long long));
+}
+#else
+#define TMG_STAMP(I)
+#endif
+
+// NPW: 16-channel output tiles per wave.  2: a block covers up to 256 output channels (wave w: n-tiles 2w, 2w+1).  1: up to 128 -
+// the contractions with 64..128 output channels (the ConvLSTM block's out-conv input gradient, 40 -> 104 at the first level) would leave
+// waves 4-7 of the 2-tile form multiplying repeated tiles; with one tile per wave all eight waves carry live work.
+template <int NPW>
 __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = 512;
@@ -104,10 +121,12 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
     const int li = lane & 15, q = lane >> 4;
     const int KB = p.Cin_pad >> 4;
     const int ntt = p.Npad >> 4;
-    const int ntile0 = (int)blockIdx.y * 16 + 2 * wave;
+    const int ntile0 = (int)blockIdx.y * (8 * NPW) + NPW * wave;
     const size_t kb_stride = (size_t)p.Npad * 16, pos_stride = (size_t)KB * p.Npad * 16;
     // B-operand (U) lane offsets of this wave's two n-tiles (tiles past the end repeat the last: dropped in the epilogue)
-    const int boff[2] = {li * 16 + 4 * q + min(ntile0, ntt - 1) * 256, li * 16 + 4 * q + min(ntile0 + 1, ntt - 1) * 256};
+    int boff[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) boff[n] = li * 16 + 4 * q + min(ntile0 + n, ntt - 1) * 256;
 
     // ---- lean staging state: a thread owns channel quad pc4 of every 64th patch pixel -------------------------------------
     const int pc4 = tid & 7, ppix0 = tid >> 3;
@@ -134,16 +153,21 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
     int ci = 0, cc = 0, cm = 0;
     int ti = blockIdx.x, tm = blockIdx.x;
 
-    f32x4 Y[4][2][2];   // [output pixel of the 2x2 tile][m-tile][n-tile]
+    f32x4 Y[4][2][NPW];   // [output pixel of the 2x2 tile][m-tile][n-tile]
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 bfr[4][2][2];   // U fragments [ring][16-channel group][n-tile], three positions ahead of the MFMAs
+    float4 bfr[4][2][NPW];   // U fragments [ring][16-channel group][n-tile], three positions ahead of the MFMAs
+#ifdef TMG_WINO_STAMP
+    unsigned st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = -2; k < nst; ++k) {
+        TMG_STAMP(7)   // loop overhead / previous barrier exit
         // ---- commit stage k+1 --------------------------------------------------------------------------------------------------
         if (k >= -1 && k + 1 < nst) {
             float* rb = lds + ((k + 1) & 1) * RAWW;
@@ -157,6 +181,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
             }
             if (++cc == nchunks) cc = 0;
         }
+        TMG_STAMP(0)   // commit
         // ---- issue the loads of stage k+2 -------------------------------------------------------------------------------------
         if (k + 2 < nst) {
             int t_ = ti;
@@ -194,6 +219,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
             }
             if (++ci == nchunks) { ci = 0; ti += G; }
         }
+        TMG_STAMP(1)   // issue
         if (k >= 0) {
             // ---- input transform of stage k: V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] ----------------------
             {
@@ -220,7 +246,9 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                 }
 #undef TMG_W4
             }
+            TMG_STAMP(2)   // transform
             __syncthreads();
+            TMG_STAMP(3)   // barrier 1
             // ---- 16 position GEMMs over this chunk, output transform folded in ---------------------------------------------------
             {
                 const int c0 = cm * KC;
@@ -230,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
 #define TMG_WN_LOADB(R, UB, KGN, POS)                                                                                 \
                 {                                                                                                     \
                     const float* up_ = (UB) + (size_t)(POS) * pos_stride;                                             \
-                    _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                   \
+                    _Pragma("unroll") for (int n = 0; n < NPW; ++n) {                                                 \
                         bfr[R][0][n] = *reinterpret_cast<const float4*>(up_ + boff[n]);                               \
                         bfr[R][1][n] = *reinterpret_cast<const float4*>(up_ + (size_t)((KGN) - 1) * kb_stride + boff[n]); \
                     }                                                                                                 \
@@ -257,13 +285,13 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                         af[1][m] = v4[(pos * VPL + m * 16 * VS + 16) / 4];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc[2][2];
+                    f32x4 acc[2][NPW];
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int n = 0; n < NPW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #define TMG_WN_STEP(KG, E)                                                                                            \
-                    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)         \
+                    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n)       \
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[R][KG][n].E, af[KG][m].E, acc[m][n], 0, 0, 0);
                     TMG_WN_STEP(0, x) TMG_WN_STEP(0, y) TMG_WN_STEP(0, z) TMG_WN_STEP(0, w)
                     if (kgn == 2) { TMG_WN_STEP(1, x) TMG_WN_STEP(1, y) TMG_WN_STEP(1, z) TMG_WN_STEP(1, w) }
@@ -284,19 +312,21 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
 #pragma unroll
                                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                                    for (int n = 0; n < 2; ++n) {
+                                    for (int n = 0; n < NPW; ++n) {
                                         f32x4& y_ = Y[oy * 2 + ox][m][n];
                                         if (cf > 0) y_ += acc[m][n];
                                         else y_ -= acc[m][n];
                                     }
                                 // pin the update HERE: left alone the compiler sinks all 16 positions' additions below the last
                                 // position and keeps 16 x 16 accumulator registers alive (300 spilled registers)
-                                asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][0][1]), "+v"(Y[oy * 2 + ox][1][0]), "+v"(Y[oy * 2 + ox][1][1]));
+                                if constexpr (NPW == 2) asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][0][1]), "+v"(Y[oy * 2 + ox][1][0]), "+v"(Y[oy * 2 + ox][1][1]));
+                                else asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][1][0]));
                             }
                         }
                 }
 #undef TMG_WN_LOADB
             }
+            TMG_STAMP(4)   // MFMA loop
             if (cm + 1 == nchunks) {
                 // ---- epilogue: lane (li, q) holds channels 4 q .. 4 q + 3 (of each n-tile) of Winograd tile 16 m + li -------------
                 int t_ = tm;
@@ -308,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                     const int wt = 16 * m + li;
                     const int oyb = ty_ * TH + 2 * (wt >> 3), oxb = tx_ * TW + 2 * (wt & 7);
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
+                    for (int n = 0; n < NPW; ++n) {
                         const int n0 = (ntile0 + n) * 16 + 4 * q;
                         if (ntile0 + n < ntt && n0 < p.Cout) {
                             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -332,14 +362,21 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 cm = 0; tm += G;
             } else {
                 ++cm;
             }
         }
+        TMG_STAMP(5)   // epilogue
         __syncthreads();   // V and the raw buffer just read are rewritten next round; the raw buffer just written is complete
+        TMG_STAMP(6)   // barrier 2
     }
+#ifdef TMG_WINO_STAMP
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_wino_stamps[i], (unsigned long long)st_acc[i]);
+    if (tid == 0) atomicAdd(&g_wino_stamps[8], 1ull);
+#endif
 }
 
 // out = conv3x3_stride1(pad(act(in))) + bias with the Winograd operand of tmg_conv_wino_pack.
@@ -378,14 +415,21 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     p.nchunks = (p.Cin_pad + 31) / 32;
     if (p.ntiles <= 0) return 0;
-    const int gy = (p.Npad / 16 + 15) / 16;
+    const int ntt = p.Npad / 16;
+    const int npw = ntt <= 8 ? 1 : 2;           // output-channel tiles per wave (see the kernel)
+    const int gy = (ntt + 8 * npw - 1) / (8 * npw);
     int G = 256 / gy;
     if (G < 1) G = 1;
     if (G > p.ntiles) G = p.ntiles;
     const size_t lds_bytes = (size_t)(2 * 180 * 40 + 16 * 32 * 40) * sizeof(float);
-    TMG_LDS_OPTIN((&wino_fwd_kernel));
     TmgProf prof(TMG_PROF_WINO, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);   // algorithmic (direct) flops
-    hipLaunchKernelGGL(wino_fwd_kernel, dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
+    if (npw == 1) {
+        TMG_LDS_OPTIN((&wino_fwd_kernel<1>));
+        hipLaunchKernelGGL(wino_fwd_kernel<1>, dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
+    } else {
+        TMG_LDS_OPTIN((&wino_fwd_kernel<2>));
+        hipLaunchKernelGGL(wino_fwd_kernel<2>, dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
+    }
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -58,6 +58,7 @@ def build(force=False, verbose=False):
         objs.append(ob)
         if force or not os.path.exists(ob) or os.path.getmtime(ob) < max(os.path.getmtime(sp), hmt):
             extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if src in nopk else []
+            extra += os.environ.get("TMG_EXTRA_DEFS", "").split()      # diagnostic builds (e.g. -DTMG_WINO_STAMP), never the product's
             jobs.append([hipcc] + flags + extra + ["-c", sp, "-o", ob])
     if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH

@@ -425,6 +425,9 @@ def test_mix_f16_kernel(C_, npix, slice_of):
     (2, 8, 8, [32], 1920, True, True, False),              # several output-channel blocks
     (3, 5, 3, [16], 64, False, True, True),                # image smaller than a tile
     (1, 32, 48, [64, 64], 128, True, False, True),         # several tiles per image, two full chunks per tile
+    (2, 16, 24, [40], 104, False, False, False),           # one output tile per wave (<= 128 channels), 7 of 8 waves live: the out-conv input gradient
+    (2, 12, 16, [48], 112, False, False, True),            # the same at the second level's widths
+    (1, 16, 16, [96], 144, False, True, True),             # 9 tiles: back on the two-tiles-per-wave instance
 ])
 def test_winograd_conv_matches_fp64(case):
     """tmg_conv_wino_fwd (Winograd F(2x2,3x3) on the fp32 matrix cores) against fp64 F.conv2d, at the direct kernel's tolerance,

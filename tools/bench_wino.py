@@ -11,7 +11,9 @@ import tmg_hip as H  # noqa: E402
 dev = torch.device("cuda")
 CASES = [(64, 128, 128, [8, 32, 64], 256, False, False, True), (64, 128, 128, [32], 240, True, True, False),
          (64, 64, 64, [16, 32, 64], 256, False, False, True), (64, 64, 64, [32], 480, True, True, False),
-         (64, 32, 32, [32], 960, True, True, False), (64, 16, 16, [32], 1920, True, True, False)]
+         (64, 32, 32, [32], 960, True, True, False), (64, 16, 16, [32], 1920, True, True, False),
+         # 64..128 output channels (one tile per wave): the ConvLSTM block's out-conv input gradients
+         (64, 128, 128, [40], 104, False, False, False), (64, 64, 64, [48], 112, False, False, False), (64, 32, 32, [64], 128, False, False, False)]
 for B, Hh, Ww, segs, Cout, relu, rep, hb in CASES:
     xs = [torch.randn(B, Hh, Ww, c, device=dev) for c in segs]
     w = 0.1 * torch.randn(Cout, sum(segs), 3, 3, device=dev)
