@@ -168,11 +168,12 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float* __restrict_
     __shared__ float red[4];
     const int b = blockIdx.y;
     const size_t base = (size_t)b * pix_per_img;
-    const size_t total = (size_t)pix_per_img * Ch;
+    const unsigned total = (unsigned)pix_per_img * (unsigned)Ch;   // per image: < 2^31 (checked by the launcher); 32-bit div / mod
     float lp = 0.f;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t pix = base + i / Ch;
-        const int j = i % Ch;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned pl = i / (unsigned)Ch;
+        const size_t pix = base + pl;
+        const int j = (int)(i - pl * (unsigned)Ch);
         float mean = hz[pix * hs + ho + j];
         float lsd = hz[pix * hs + ho + Ch + j];
         if (clip_mean) mean = fminf(fmaxf(mean, mlo), mhi);
@@ -327,6 +328,86 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __res
             }
         }
         din[i] = acc;
+    }
+}
+
+// The same two maps for C % 4 == 0 (every conditioning map of the path: 32 channels): one float4 of channels per thread, 32-bit index
+// arithmetic (the scalar kernels above spend most of their time in 64-bit div / mod per element: 122 us for the 134 MB first-level map,
+// a quarter of the achievable bandwidth), and - backward - the 1-D hat weights of the <= 6 candidate rows / columns evaluated once
+// per thread instead of inside the 2-D loop.
+__global__ __launch_bounds__(256) void upsample_fwd4_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int hi, int wi,
+                                                            int ho, int wo, int C4) {
+    const float ry = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.f;
+    const float rx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.f;
+    const unsigned total = (unsigned)B * ho * wo * C4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned c4 = i % (unsigned)C4;
+        unsigned r = i / (unsigned)C4;
+        const int ox = r % (unsigned)wo;
+        r /= (unsigned)wo;
+        const int oy = r % (unsigned)ho;
+        const int b = r / (unsigned)ho;
+        const float sy = ry * oy, sx = rx * ox;
+        const int y0 = min((int)sy, hi - 1), x0 = min((int)sx, wi - 1);
+        const int y1 = min(y0 + 1, hi - 1), x1 = min(x0 + 1, wi - 1);
+        const float fy = sy - y0, fx = sx - x0;
+        const float4* sb = reinterpret_cast<const float4*>(src) + (size_t)b * hi * wi * C4 + c4;
+        const float4 v00 = sb[(size_t)(y0 * wi + x0) * C4], v01 = sb[(size_t)(y0 * wi + x1) * C4];
+        const float4 v10 = sb[(size_t)(y1 * wi + x0) * C4], v11 = sb[(size_t)(y1 * wi + x1) * C4];
+        // (same expression, evaluated per component in the same order as the scalar kernel: bit-identical results)
+        float4 o;
+        o.x = (1.f - fy) * ((1.f - fx) * v00.x + fx * v01.x) + fy * ((1.f - fx) * v10.x + fx * v11.x);
+        o.y = (1.f - fy) * ((1.f - fx) * v00.y + fx * v01.y) + fy * ((1.f - fx) * v10.y + fx * v11.y);
+        o.z = (1.f - fy) * ((1.f - fx) * v00.z + fx * v01.z) + fy * ((1.f - fx) * v10.z + fx * v11.z);
+        o.w = (1.f - fy) * ((1.f - fx) * v00.w + fx * v01.w) + fy * ((1.f - fx) * v10.w + fx * v11.w);
+        reinterpret_cast<float4*>(dst)[i] = o;
+    }
+}
+
+// hat weight of output coordinate o (source coordinate r * o) on input index idx, as the forward kernel rounds it
+__device__ __forceinline__ float upsample_hat(float r, int o, int idx, int n_in) {
+    const float sv = r * o;
+    const int i0 = min((int)sv, n_in - 1), i1 = min(i0 + 1, n_in - 1);
+    const float f = sv - i0;
+    return (i0 == idx ? 1.f - f : 0.f) + (i1 == idx ? f : 0.f);
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd4_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int hi, int wi,
+                                                            int ho, int wo, int C4) {
+    constexpr int NW = 8;   // candidate outputs per axis: (2 / r) + 3 <= 8 for up-scaling factors >= 0.4 (the launcher checks)
+    const float ry = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.f;
+    const float rx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.f;
+    const unsigned total = (unsigned)B * hi * wi * C4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned c4 = i % (unsigned)C4;
+        unsigned r = i / (unsigned)C4;
+        const int ix = r % (unsigned)wi;
+        r /= (unsigned)wi;
+        const int iy = r % (unsigned)hi;
+        const int b = r / (unsigned)hi;
+        int oy_lo = 0, ox_lo = 0;
+        if (ry > 0.f) oy_lo = max(0, (int)floorf((iy - 1) / ry) - 1);
+        if (rx > 0.f) ox_lo = max(0, (int)floorf((ix - 1) / rx) - 1);
+        float wy[NW], wx[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            wy[k] = oy_lo + k < ho ? upsample_hat(ry, oy_lo + k, iy, hi) : 0.f;
+            wx[k] = ox_lo + k < wo ? upsample_hat(rx, ox_lo + k, ix, wi) : 0.f;
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* db = reinterpret_cast<const float4*>(dout) + (size_t)b * ho * wo * C4 + c4;
+#pragma unroll
+        for (int ky = 0; ky < NW; ++ky) {
+            if (wy[ky] == 0.f) continue;
+#pragma unroll
+            for (int kx = 0; kx < NW; ++kx) {
+                if (wx[kx] == 0.f) continue;
+                const float4 v = db[(size_t)((oy_lo + ky) * wo + ox_lo + kx) * C4];
+                const float wgt = wy[ky] * wx[kx];
+                acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+            }
+        }
+        reinterpret_cast<float4*>(din)[i] = acc;
     }
 }
 
@@ -1114,8 +1195,14 @@ extern "C" int tmg_gauss_fwd(const void* hz, const int64_t* hz_d, const void* zi
                              const int64_t* zo_d, void* logp, const int64_t* dims, const float* fl, hipStream_t st) {
     const int B = (int)dims[0], ppi = (int)dims[1], Ch = (int)dims[2];
     const size_t per = (size_t)ppi * Ch;
+    if (per >= (1ull << 31)) return -2;
+    // blocks per image: every block ends with ONE atomic on its image's log-prob, so few blocks per image (<= 32 per address) as long
+    // as the grid still fills the chip (256 blocks per image at 64 images were 16 384 atomics on 64 addresses: 135 us for a 30-us map)
     int gx = (int)((per + 255) / 256);
-    if (gx > 256) gx = 256;
+    int cap = (2048 + B - 1) / B;
+    if (cap < 4) cap = 4;
+    if (cap > 256) cap = 256;
+    if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(gauss_fwd_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)hz, (int)hz_d[0], (int)hz_d[1], (const float*)zin,
                        (int)zi_d[0], (int)zi_d[1], (float*)zout, (int)zo_d[0], (int)zo_d[1], (float*)logp, ppi, Ch, (int)dims[3],
@@ -1149,6 +1236,12 @@ extern "C" int tmg_checker(const void* src, const int64_t* s_d, void* dst, const
 // dims: [B, hi, wi, ho, wo, C]; dense NHWC tensors
 extern "C" int tmg_upsample_fwd(const void* src, void* dst, const int64_t* dims, hipStream_t st) {
     const size_t total = (size_t)dims[0] * dims[3] * dims[4] * dims[5];
+    if (dims[5] % 4 == 0 && total / 4 < (1ull << 31) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+        hipLaunchKernelGGL(upsample_fwd4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, (const float*)src, (float*)dst, (int)dims[0],
+                           (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)(dims[5] / 4));
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)src, (float*)dst, (int)dims[0],
                        (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5]);
     TMG_CHECK_LAUNCH();
@@ -1157,6 +1250,14 @@ extern "C" int tmg_upsample_fwd(const void* src, void* dst, const int64_t* dims,
 
 extern "C" int tmg_upsample_bwd(const void* dout, void* din, const int64_t* dims, hipStream_t st) {
     const size_t total = (size_t)dims[0] * dims[1] * dims[2] * dims[5];
+    // window of 8 candidate outputs per axis: enough while an input step spans <= 2.5 output steps (integer up-scaling by 2: 2.02)
+    const bool win_ok = (dims[3] - 1) * 2 <= (dims[1] - 1) * 5 + 2 && (dims[4] - 1) * 2 <= (dims[2] - 1) * 5 + 2 && dims[1] > 1 && dims[2] > 1;
+    if (dims[5] % 4 == 0 && win_ok && (size_t)dims[0] * dims[3] * dims[4] * dims[5] / 4 < (1ull << 31) && ((((uintptr_t)dout) | ((uintptr_t)din)) & 15) == 0) {
+        hipLaunchKernelGGL(upsample_bwd4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, (const float*)dout, (float*)din, (int)dims[0],
+                           (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)(dims[5] / 4));
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)dout, (float*)din, (int)dims[0],
                        (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5]);
     TMG_CHECK_LAUNCH();

@@ -252,8 +252,10 @@ def test_checker_and_upsample():
     assert torch.equal(_back(xd.grad), O.checker_unsqueeze(gy))
     back = ops.CheckerFn.apply(y.detach(), False)
     assert torch.equal(_back(back), x)
-    for (h, w, sc) in [(5, 7, 2), (8, 8, 2), (3, 4, 4), (1, 6, 2)]:
-        x = torch.randn(2, 4, h, w, generator=g)
+    # (channels % 4 == 0: the float4 kernels; scale 4 and one-row maps exceed their candidate window and take the scalar kernels, as do
+    # the odd channel counts)
+    for (h, w, sc, ch) in [(5, 7, 2, 4), (8, 8, 2, 4), (3, 4, 4, 4), (1, 6, 2, 4), (6, 5, 2, 3), (16, 24, 2, 32), (2, 2, 2, 8), (9, 4, 3, 8)]:
+        x = torch.randn(2, ch, h, w, generator=g)
         xr = x.double().requires_grad_(True)
         yr = F.interpolate(xr, scale_factor=sc, mode="bilinear", align_corners=True)
         gy = torch.randn(yr.shape, generator=g).double()
