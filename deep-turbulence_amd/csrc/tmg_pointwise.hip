@@ -625,41 +625,49 @@ struct C1X2P {
     int TW_log2, tiles_x, tiles_y, KCH;
 };
 
+// CG: threads per pixel.  The kernel is a chain of LDS-read latencies with one pixel per thread, so a 256-pixel tile per block leaves the
+// small levels on a fraction of the chip (64 tiles at 16 x 16 x 64 samples) with one wave per SIMD and nothing to hide the chain behind;
+// with CG = 2 / 4 adjacent lanes splitting a pixel's channel quads, a tile is 128 / 64 pixels: 2 - 4 x the blocks and a 2 - 4 x shorter
+// chain per thread, the partial sums meeting in two xor-shuffles.
+template <int CG>
 __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NPX = 256 / CG;
     const int tid = threadIdx.x;
+    const int pid = tid / CG, cg = tid % CG;   // the CG lanes of a pixel are adjacent lanes of one wave
+    const bool lead = cg == 0;
     int t = blockIdx.x;
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
     const int ty = t % p.tiles_y;
     const int b = t / p.tiles_y;
-    const int TWl = p.TW_log2, TW = 1 << TWl, TH = 256 >> TWl;
+    const int TWl = p.TW_log2, TW = 1 << TWl, TH = NPX >> TWl;
     const int PW = TW + 4, PH = TH + 4;   // staged patch (halo 2)
     const int RW = TW + 2, RH = TH + 2;   // d1 region (halo 1)
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int row = tid >> TWl, col = tid & (TW - 1);
+    const int row = pid >> TWl, col = pid & (TW - 1);
     const int Cpad = (p.Cin + 3) & ~3;
-    // this thread's d1-region pixels: [0] its OWN pixel (region coordinates (row + 1, col + 1): the conv-1 and conv-2 sums then read the
+    // this pixel's d1-region pixels: [0] its OWN pixel (region coordinates (row + 1, col + 1): the conv-1 and conv-2 sums then read the
     // same patch values - the kernel is bound by LDS reads, a third of them were this duplicate), [1] one pixel of the one-pixel ring
-    // around the tile for the first 2 (RW + RH) - 4 threads (top row, bottom row, left column, right column)
+    // around the tile for the first 2 (RW + RH) - 4 pixels' threads (top row, bottom row, left column, right column)
     int ry[2], rx[2];
     bool rok[2];
     ry[0] = row + 1; rx[0] = col + 1; rok[0] = true;
+    const int nring = 2 * RW + 2 * (RH - 2);   // <= NPX (the launcher's tile shapes)
     {
-        const int nring = 2 * RW + 2 * (RH - 2);
-        rok[1] = tid < nring;
-        int i = rok[1] ? tid : 0;
+        rok[1] = pid < nring;
+        int i = rok[1] ? pid : 0;
         if (i < RW) { ry[1] = 0; rx[1] = i; }
         else if (i < 2 * RW) { ry[1] = RH - 1; rx[1] = i - RW; }
         else if (i < 2 * RW + RH - 2) { ry[1] = 1 + i - 2 * RW; rx[1] = 0; }
         else { ry[1] = 1 + i - (2 * RW + RH - 2); rx[1] = RW - 1; }
     }
-    const bool ring_wave = (tid & ~63) < 2 * RW + 2 * (RH - 2);   // wave-uniform: does any lane of this wave own a ring pixel
+    const bool ring_wave = (tid & ~63) / CG < nring;   // wave-uniform: does any lane of this wave own a ring pixel
     // all global operands of the epilogue up front (latency hides under the staging + compute)
     const int oy = oy0 + row, ox = ox0 + col;
     const bool own = oy < p.Hin && ox < p.Win;
     const size_t opx = ((size_t)b * p.Hin + min(oy, p.Hin - 1)) * p.Win + min(ox, p.Win - 1);
-    const float a2v = *((p.add2 && own) ? p.add2 + opx * p.a2_stride + p.a2_off : tmg_zero_page);
+    const float a2v = *((p.add2 && own && lead) ? p.add2 + opx * p.a2_stride + p.a2_off : tmg_zero_page);
     float a1v[2];
     bool rin[2];
 #pragma unroll
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
         const int y = oy0 - 1 + ry[u], x = ox0 - 1 + rx[u];
         rin[u] = rok[u] && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
         const size_t px = ((size_t)b * p.Hin + min(max(y, 0), p.Hin - 1)) * p.Win + min(max(x, 0), p.Win - 1);
-        a1v[u] = *((p.add1 && rin[u]) ? p.add1 + px * p.a1_stride + p.a1_off : tmg_zero_page);
+        a1v[u] = *((p.add1 && rin[u] && lead) ? p.add1 + px * p.a1_stride + p.a1_off : tmg_zero_page);
     }
     float acc1[2] = {0.f, 0.f}, acc2 = 0.f;
     for (int c0 = 0; c0 < Cpad; c0 += p.KCH) {
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
             const float* w2p = lw2 + tap * kch;
             const float* p0 = lds + ((ry[0] + tyy) * PW + rx[0] + txx) * CS;          // own pixel + tap (region pixel + tap; patch = region - 1)
             const float* p1 = lds + ((ry[1] + tyy) * PW + rx[1] + txx) * CS;          // ring pixel + tap
-            for (int c = 0; c < kch; c += 4) {
+            for (int c = 4 * cg; c < kch; c += 4 * CG) {
                 const float4 wa = *reinterpret_cast<const float4*>(w1p + c);
                 const float4 wb = *reinterpret_cast<const float4*>(w2p + c);
                 const float4 x0 = *reinterpret_cast<const float4*>(p0 + c);
@@ -706,14 +714,24 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
             }
         }
     }
+    // the CG partial sums of a pixel meet in its lanes (every lane ends up with the total)
+#pragma unroll
+    for (int o = 1; o < CG; o <<= 1) {
+        acc1[0] += __shfl_xor(acc1[0], o);
+        acc1[1] += __shfl_xor(acc1[1], o);
+        acc2 += __shfl_xor(acc2, o);
+    }
     // d1 on the ring-extended region: raw value at this thread's own pixel is needed for the output, relu(d1) for conv 2
     __syncthreads();
     float* ld1 = lds;  // [RH*RW] relu(d1), zero outside the image
+    if (lead) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-        if (rok[u]) ld1[ry[u] * RW + rx[u]] = rin[u] ? fmaxf(acc1[u] + a1v[u], 0.f) : 0.f;
+        for (int u = 0; u < 2; ++u)
+            if (rok[u]) ld1[ry[u] * RW + rx[u]] = rin[u] ? fmaxf(acc1[u] + a1v[u], 0.f) : 0.f;
+    }
     const float d1own = acc1[0] + a1v[0];   // raw d1 of the own pixel
     __syncthreads();
+    if (!lead) return;
     float w2d[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) w2d[tap] = p.w2[(size_t)p.w2_d1 * 9 + tap];
@@ -1359,7 +1377,23 @@ extern "C" int tmg_c1x2_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
     if ((out_d[0] & 3) || out_d[1] != 0 || (((uintptr_t)out) & 15)) return -2;
     p.out = (float*)out; p.out_stride = (int)out_d[0];
     c1_tile(p.Win, p.Hin, &p.TW_log2);
-    const int TW = 1 << p.TW_log2, TH = 256 >> p.TW_log2;
+    // threads per pixel (see the kernel): by the number of 256-pixel tiles the image offers
+    int CG = 1;
+    {
+        const int tw = 1 << p.TW_log2, th = 256 >> p.TW_log2;
+        const long t256 = (long)p.B * ((p.Win + tw - 1) / tw) * ((p.Hin + th - 1) / th);
+        const int Cq = (p.Cin + 3) / 4;
+        // (measured at config M: 4 threads per pixel take the 64- and 128-channel levels from 19 / 32 us to 15; 2 per pixel on the
+        // 1 024 tiles of the 32-channel level lose 5 us against one)
+        if (t256 < 512 && Cq >= 4) CG = 4;
+        else if (t256 < 1024 && Cq >= 2) CG = 2;
+        static const int force = getenv("TMG_C1X2_CG") ? atoi(getenv("TMG_C1X2_CG")) : 0;
+        if (force == 1 || force == 2 || force == 4) CG = force;
+    }
+    const int NPX = 256 / CG;
+    while ((NPX >> p.TW_log2) < 4 && p.TW_log2 > 3) --p.TW_log2;   // tiles at least 4 rows high: the ring fits the tile's pixels
+    const int TW = 1 << p.TW_log2, TH = NPX >> p.TW_log2;
+    if (2 * (TW + 2) + 2 * TH > NPX) return -2;
     p.tiles_x = (p.Win + TW - 1) / TW;
     p.tiles_y = (p.Hin + TH - 1) / TH;
     const int Cpad = (p.Cin + 3) & ~3;
@@ -1367,9 +1401,18 @@ extern "C" int tmg_c1x2_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
     size_t lds_floats = (size_t)(TH + 4) * (TW + 4) * (p.KCH + 4) + 18 * p.KCH;
     const size_t d1_floats = 2 * (size_t)(((TH + 2) * (TW + 2) + 3) & ~3);
     if (lds_floats < d1_floats) lds_floats = d1_floats;
-    TMG_LDS_OPTIN((&c1x2_fwd_kernel));
     TmgProf prof(TMG_PROF_C1X2, 4.0 * p.B * (double)p.Hin * p.Win * (p.Cin + 4 + (p.add1 ? 1 : 0) + (p.add2 ? 1 : 0)), st);   // input once, D written
-    hipLaunchKernelGGL(c1x2_fwd_kernel, dim3(p.B * p.tiles_x * p.tiles_y), dim3(256), lds_floats * 4, st, p);
+    const dim3 grid(p.B * p.tiles_x * p.tiles_y);
+    if (CG == 1) {
+        TMG_LDS_OPTIN((&c1x2_fwd_kernel<1>));
+        hipLaunchKernelGGL(c1x2_fwd_kernel<1>, grid, dim3(256), lds_floats * 4, st, p);
+    } else if (CG == 2) {
+        TMG_LDS_OPTIN((&c1x2_fwd_kernel<2>));
+        hipLaunchKernelGGL(c1x2_fwd_kernel<2>, grid, dim3(256), lds_floats * 4, st, p);
+    } else {
+        TMG_LDS_OPTIN((&c1x2_fwd_kernel<4>));
+        hipLaunchKernelGGL(c1x2_fwd_kernel<4>, grid, dim3(256), lds_floats * 4, st, p);
+    }
     TMG_CHECK_LAUNCH();
     return 0;
 }

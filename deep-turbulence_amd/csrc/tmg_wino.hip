@@ -1051,7 +1051,7 @@ static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, int ngroups, 
     if (cit < 2 || cot < 2) return -100;
     pl->gz = (cit + 3) / 4;
     const int citg = (cit + pl->gz - 1) / pl->gz;
-    pl->CIT = citg <= 2 ? 2 : 4;
+    pl->CIT = citg <= 2 ? 2 : (citg == 3 ? 3 : 4);
     pl->gy = (cot + 3) / 4;
     const int cotg = (cot + pl->gy - 1) / pl->gy;
     pl->NCO = cotg <= 2 ? 2 : (cotg == 3 ? 3 : 4);
@@ -1116,7 +1116,8 @@ static int wino_wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, i
     if (p.ntiles <= 0) return 0;
     int rc = -7;
 #define TMG_WW_CASE(C_, N_) if (pl.CIT == C_ && pl.NCO == N_) rc = launch_wino_wgrad<C_, N_>(p, pl, st);
-    TMG_WW_CASE(2, 2) TMG_WW_CASE(2, 3) TMG_WW_CASE(2, 4) TMG_WW_CASE(4, 2) TMG_WW_CASE(4, 3) TMG_WW_CASE(4, 4)
+    TMG_WW_CASE(2, 2) TMG_WW_CASE(2, 3) TMG_WW_CASE(2, 4) TMG_WW_CASE(3, 2) TMG_WW_CASE(3, 3) TMG_WW_CASE(3, 4) TMG_WW_CASE(4, 2) TMG_WW_CASE(4, 3)
+    TMG_WW_CASE(4, 4)
 #undef TMG_WW_CASE
     if (rc != 0) return rc;
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(256), 0, st, (const float*)p.ws, (float*)dW,

@@ -407,6 +407,11 @@ def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, 
                               _ptr(kappa), _ptr(ws), c_i64(ws.numel() if ws is not None else 0), dims, _stream()), "tmg_conv_wgrad")
 
 
+def wino_wgrad_eligible(Cin, Cout):
+    """conv_wgrad's routing rule for the Winograd weight-gradient kernel at large pixel counts (see conv_wgrad)."""
+    return (Cin >= 32 and Cout >= 128 and os.environ.get("TMG_NO_WINOGRAD") is None and os.environ.get("TMG_NO_WINOGRAD_WGRAD") is None)
+
+
 def conv_wino_wgrad(inputs, dy, dW, dbias, relu_in=False, pad_rep=False, cin_dst=0, cin_valid=0, ci_split=0, ci_off0=0, ci_off1=0):
     """3x3 / stride-1 weight gradient as Winograd F(3x3, 2x2) (tmg_conv_wino_wgrad); False when the shape is outside the kernel's
     envelope (nothing was launched).  conv_wgrad routes the large contractions here."""

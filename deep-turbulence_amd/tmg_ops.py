@@ -334,7 +334,16 @@ class ConvLSTMCellFn(torch.autograd.Function):
         segs = list(inputs) + [h_cur]
         dW = zeros_like(weight)
         db = zeros_like(bias)
-        H.conv_wgrad(segs, dg, dW, db, 3, 1)
+        nrest = sum(t.shape[3] for t in segs[:-1])
+        if h_cur.shape[3] == 64 and 32 < nrest <= 48 and nrest % 4 == 0 and H.wino_wgrad_eligible(nrest, weight.shape[0]):
+            # The Winograd weight-gradient kernel works on blocks of 64 (or 48) input channels: the 104 channels of the first level
+            # as 64 + 64 carry 24 padding channels through the matrix cores.  Two launches - the recurrent state's 64 channels, and
+            # (x1 | cond) as one 48-channel block - write disjoint column ranges of dW: 112 channels of work instead of 128.
+            Cin = nrest + 64
+            H.conv_wgrad(segs[:-1], dg, dW, db, 3, 1, cin_dst=Cin, cin_valid=nrest, ci_off0=0)
+            H.conv_wgrad([h_cur], dg, dW, None, 3, 1, cin_dst=Cin, cin_valid=64, ci_off0=nrest)
+        else:
+            H.conv_wgrad(segs, dg, dW, db, 3, 1)
         # input gradients only for the channel prefix that needs them: the recurrent state of the first time-step of a
         # window (and any constant input) carries no gradient, which removes R of the Cin+R gradient channels
         need = [ctx.needs_input_grad[4 + i] for i in range(ctx.n_in)] + [ctx.needs_input_grad[2]]

@@ -776,3 +776,51 @@ def test_weight_gradient_plans_at_stated_batch_sizes(shape):
             for i in range(G):
                 ref = torch.einsum("bhwo,bhwi->oi", ds[i].double(), xs[i].double())
                 _close(dWg[i].view(C_, C_), ref, tol=tol, what="grouped launch, group %d" % i)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, [8, 32], True), (1, 9, 20, [16, 32], True), (2, 8, 8, [32, 32], False), (2, 16, 8, [64, 32], True),
+                                  (1, 12, 12, [4, 32], True)])
+def test_conv_lstm_cell_node_matches_fp64(case):
+    """ConvLSTMCellFn (reference convLSTM.py:72-85: gates = conv3x3(cat(t0, h)) + b, i / f / o / g activations, c' = f c + i g,
+    h' = o tanh(c')) at the model's widths (64 recurrent features, 40 / 48 / 64 / 96 / 36 input channels): outputs and every gradient
+    against fp64 autograd.  Covers the Winograd gate conv, its narrow input gradient (only the channels that need one), and the
+    weight gradient as 48 + 64 input-channel blocks on the first two levels."""
+    import tmg_ops as ops
+    B, Hh, Ww, segs, h_grad = case
+    R = 64
+    g = torch.Generator().manual_seed(sum(segs) + Hh)
+    xs = [torch.randn(B, Hh, Ww, c, generator=g) for c in segs]
+    h0 = torch.randn(B, Hh, Ww, R, generator=g)
+    c0 = torch.randn(B, Hh, Ww, R, generator=g)
+    cin = sum(segs) + R
+    w = 0.15 * torch.randn(4 * R, cin, 3, 3, generator=g)
+    b = 0.2 * torch.randn(4 * R, generator=g)
+    gh, gc = torch.randn(B, Hh, Ww, R, generator=g), torch.randn(B, Hh, Ww, R, generator=g)
+    # fp64 reference
+    xr = [t.double().requires_grad_(True) for t in xs]
+    hr, cr = h0.double().requires_grad_(h_grad), c0.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    t = torch.cat(xr + [hr], 3).permute(0, 3, 1, 2)
+    gates = F.conv2d(t, wr, br, padding=1).permute(0, 2, 3, 1)
+    i_, f_, o_, g_ = torch.split(gates, R, 3)
+    cn = torch.sigmoid(f_) * cr + torch.sigmoid(i_) * torch.tanh(g_)
+    hn = torch.sigmoid(o_) * torch.tanh(cn)
+    ((hn * gh.double()).sum() + (cn * gc.double()).sum()).backward()
+    # HIP
+    xd = [t.to(DEV).requires_grad_(True) for t in xs]
+    hd, cd = h0.to(DEV).requires_grad_(h_grad), c0.to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    h2, c2 = ops.ConvLSTMCellFn.apply(wd, bd, hd, cd, *xd)
+    _close(h2, hn, what="h'")
+    _close(c2, cn, what="c'")
+    ((h2 * gh.to(DEV)).sum() + (c2 * gc.to(DEV)).sum()).backward()
+    tol = 3e-5
+    for a, r, what in zip(xd, xr, ["dx%d" % k for k in range(len(xs))]):
+        _close(a.grad, r.grad, tol=tol, what=what)
+    _close(cd.grad, cr.grad, tol=tol, what="dc")
+    if h_grad:
+        _close(hd.grad, hr.grad, tol=tol, what="dh")
+    else:
+        assert hd.grad is None
+    _close(wd.grad, wr.grad, tol=tol, what="dW")
+    _close(bd.grad, br.grad, tol=tol, what="db")
