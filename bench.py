@@ -101,11 +101,16 @@ def cpu_baseline(name, hard_timeout_s=300, max_steps=12, budget_s=25.0):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of the event class `kernel` from the committed rocprofv3 PMC passes (profiles/r2_traffic_per_launch.json:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, launch-weighted over the kernels / template instances the class groups)."""
-    path = os.path.join(ROOT, "profiles", "r2_traffic_per_launch.json")
-    if not os.path.exists(path):
+    """HBM bytes per launch of the event class `kernel` from the committed rocprofv3 PMC passes (profiles/r<N>_traffic_per_launch.json of
+    the latest round: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, launch-weighted over the kernels / template instances the class
+    groups)."""
+    import glob
+    import re
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_per_launch.json")),
+                   key=lambda f: (int(re.match(r"r(\d+)", os.path.basename(f)).group(1)), len(os.path.basename(f))))
+    if not cands:
         return None
+    path = [f for f in cands if re.match(r"r\d+_traffic", os.path.basename(f))][-1] if any(re.match(r"r\d+_traffic", os.path.basename(f)) for f in cands) else cands[-1]
     tab = json.load(open(path))
     if kernel.startswith("wino_fwd"):
         pats = [("wino_fwd_kernel", None), ("wino_nn_kernel", None)]
