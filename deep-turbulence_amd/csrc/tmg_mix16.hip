@@ -141,15 +141,38 @@ __global__ __launch_bounds__(256) void mix32_kernel(Mix16P p) {
     float4* Wl = reinterpret_cast<float4*>(smem_raw);   // [NT*4][CP]: (ci quad, co) -> 4 floats
     constexpr int CP = NT * 16;
     const int C = p.C;
-    for (int i = threadIdx.x; i < NT * 4 * CP; i += 256) {
-        const int kq = i / CP, co = i - kq * CP;
-        float f[4];
+    // Weight tile -> LDS.  On the 64- / 128-channel levels a block works on 64 pixels only, so this staging IS the kernel's time: the
+    // loads of UB items are issued together (a one-item loop is a chain of exposed L2 latencies: 64 iterations at 128 channels), the
+    // W[co][ci] orientation as one float4 per item, out-of-range items from the zero page (no divergent loads).
+    constexpr int TOT = NT * 4 * CP, UB = 8;
+    for (int i0 = threadIdx.x; i0 < TOT; i0 += 256 * UB) {
+        float4 v[UB];
+        if (!p.transposed && (C & 3) == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ci = 4 * kq + e;
-            f[e] = (co < C && ci < C) ? (p.transposed ? p.W[(size_t)ci * C + co] : p.W[(size_t)co * C + ci]) : 0.f;
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + u * 256;
+                const int kq = i / CP, co = i - kq * CP;
+                const bool ok = i < TOT && co < C && 4 * kq < C;
+                v[u] = *reinterpret_cast<const float4*>(ok ? p.W + (size_t)co * C + 4 * kq : tmg_zero_page);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + u * 256;
+                const int kq = i / CP, co = i - kq * CP;
+                float f[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = 4 * kq + e;
+                    const bool ok = i < TOT && co < C && ci < C;
+                    f[e] = *(ok ? (p.transposed ? p.W + (size_t)ci * C + co : p.W + (size_t)co * C + ci) : tmg_zero_page);
+                }
+                v[u] = make_float4(f[0], f[1], f[2], f[3]);
+            }
         }
-        Wl[i] = make_float4(f[0], f[1], f[2], f[3]);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (i0 + u * 256 < TOT) Wl[i0 + u * 256] = v[u];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
