@@ -362,8 +362,9 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
         C.assert_logdet(ld2[B - n:], ld[:n], name + " logdet, loss samples last", rtol=2e-6, atol=1e-3)
         rep["rolled batch grads vs first"] = _grad_err(gr2, gr)
         # (equal up to the order of the atomics and of the BatchNorm sums; the reference's fp32 noise floor is the scale)
+        # (two fp32 evaluations that differ in the order of the BatchNorm sums flip different near-zero ReLUs: same allowance)
         C.assert_grads(gr2, gr, name + " grads with the loss samples at the end of the batch", global_tol=max(1e-4, fl[0]),
-                       tensor_tol=max(2e-3, fl[1]))
+                       tensor_tol=max(2e-3, fl[1]), outliers=FLIP_OUTLIERS)
     finally:
         print("\nparity %s at batch %d: %s" % (name, B, json.dumps(rep, default=float)))
         out = os.path.join(C.ROOT, "gpurun_out")
