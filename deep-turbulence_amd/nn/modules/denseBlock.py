@@ -1,5 +1,7 @@
 """Dense blocks on the HIP path.  API mirror of the reference's nn/modules/denseBlock.py
 (_DenseLayer :15-67, DenseBlock :69-100, _DenseLayerNoNorm :102-152, NoNormDenseBlock :154-185)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -76,6 +78,10 @@ class DenseBlock(nn.Sequential):
                 buf[..., c:c + g] = l.grow(buf[..., :c])
                 c += g
             return buf
+        if all(getattr(l, 'dropout', None) is None for l in layers) and os.environ.get("TMG_NO_DENSE_BLOCK_NODE") is None:
+            # training path: the same pre-sized buffer, as one autograd node (tmg_ops.DenseBlockFn)
+            params = [t for l in layers for t in (l.norm1.weight, l.norm1.bias, l.conv1.weight)]
+            return ops.DenseBlockFn.apply(xn, [l.norm1 for l in layers], self.training, *params)
         out = xn
         for l in layers:
             out = torch.cat([out, l.grow(out)], 3)

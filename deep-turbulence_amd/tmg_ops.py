@@ -197,6 +197,75 @@ class BNReLUConvFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dW, None, None, None, None, None
 
 
+class DenseBlockFn(torch.autograd.Function):
+    """All layers of an encoder dense block (reference denseBlock.py:69-100: x <- cat(x, conv3x3(relu(bn(x)))) per layer) as ONE node on
+    ONE pre-sized buffer [B,H,W,c0 + sum(growth)]: every layer reads the channel prefix it sees and writes its new channels in place.
+    The reference (and the per-layer path) re-concatenates the whole map per layer - on this device a `cat` launch per layer forward
+    and a slice + add of a full-size gradient per layer backward; here the gradient of the buffer is accumulated in place
+    (bn_bwd_apply with `accumulate`).  Arithmetic per layer = BNReLUConvFn's.
+
+    inputs: x, the block's BatchNorm modules (running statistics are updated as nn.BatchNorm2d does), training flag, then per layer
+    (gamma, beta, conv weight)."""
+
+    @staticmethod
+    def forward(ctx, x, bns, training, *params):
+        L = len(bns)
+        x = x if x.stride(3) == 1 else x.contiguous()
+        B, Hh, Ww, c0 = x.shape
+        growth = [params[3 * i + 2].shape[0] for i in range(L)]
+        buf = torch.empty((B, Hh, Ww, c0 + sum(growth)), device=x.device, dtype=torch.float32)
+        H.masked_add(buf[..., :c0], src=x)
+        stats, c = [], c0
+        for i in range(L):
+            gamma, beta, weight = params[3 * i:3 * i + 3]
+            bn = bns[i]
+            xin = buf[..., :c]
+            if training or not bn.track_running_stats:
+                mean, rstd, a, bsh = bn_batch_stats(xin, bn)
+            else:
+                mean = bn.running_mean
+                rstd = torch.rsqrt(bn.running_var + bn.eps)
+                a = gamma.detach() * rstd
+                bsh = beta.detach() - mean * a
+            H.conv_fwd([xin], H.conv_pack(weight, 0), growth[i], 3, 1, [buf[..., c:c + growth[i]]], in_scale=a, in_shift=bsh, relu_in=True)
+            stats.append((mean, rstd, a, bsh))
+            c += growth[i]
+        ctx.meta = (L, c0, growth, bool(training) or any(not bn.track_running_stats for bn in bns))
+        ctx.stats = stats
+        ctx.save_for_backward(buf, *params)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, c0, growth, training = ctx.meta
+        buf = ctx.saved_tensors[0]
+        params = ctx.saved_tensors[1:]
+        B, Hh, Ww, Ct = buf.shape
+        n = B * Hh * Ww
+        dbuf = dout.contiguous().clone()     # accumulated into in place below: never the caller's tensor
+        grads = [None] * (3 * L)
+        c = Ct
+        for i in range(L - 1, -1, -1):
+            gamma, beta, weight = params[3 * i:3 * i + 3]
+            mean, rstd, a, bsh = ctx.stats[i]
+            g = growth[i]
+            c -= g
+            xin, dy = buf[..., :c], dbuf[..., c:c + g]
+            dW = zeros_like(weight)
+            H.conv_wgrad([xin], dy, dW, None, 3, 1, in_scale=a, in_shift=bsh, relu_in=True)
+            G = torch.empty((B, Hh, Ww, c), device=buf.device, dtype=torch.float32)
+            H.conv_fwd([dy], H.conv_pack(weight, 1), c, 3, 1, [G])
+            s = zeros((3, c), buf.device)   # sums of du, du*xhat, and a zero row for the eval-mode call
+            H.chan_reduce(xin, G, a, bsh, mean, rstd, s[0], s[1], 1)
+            if training:
+                H.bn_bwd_apply(xin, G, a, bsh, mean, rstd, gamma, s[0], s[1], dbuf[..., :c], True, divisor=n)
+            else:
+                H.bn_bwd_apply(xin, G, a, bsh, mean, rstd, gamma, s[2], s[2], dbuf[..., :c], True)
+            grads[3 * i:3 * i + 3] = [s[1], s[0], dW]
+        ctx.stats = None
+        return (dbuf[..., :c0], None, None) + tuple(grads)
+
+
 def bn_batch_stats(x, bn):
     """Training-mode statistics of nn.BatchNorm2d `bn` on an NHWC tensor / channel-slice view: two-pass moments (sums, then
     centred squares), then ONE kernel for mean, var, rstd, the folded affine and the momentum update of the running

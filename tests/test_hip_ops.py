@@ -824,3 +824,44 @@ def test_conv_lstm_cell_node_matches_fp64(case):
         assert hd.grad is None
     _close(wd.grad, wr.grad, tol=tol, what="dW")
     _close(bd.grad, br.grad, tol=tol, what="db")
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_dense_block_node_matches_per_layer_path(training):
+    """tmg_ops.DenseBlockFn (all layers of an encoder dense block on one pre-sized buffer, gradient accumulated in place) against
+    the per-layer path it replaces (BNReLUConvFn + torch.cat, reference denseBlock.py:49-67): outputs, input gradient, every
+    parameter gradient and the BatchNorm running statistics."""
+    import os
+    from nn.modules.denseBlock import DenseBlock
+    C.seed_all(31)
+    blk = DenseBlock(num_layers=4, in_features=16, growth_rate=4, drop_rate=0.)
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.add_(0.2 * torch.randn(p_.shape, generator=g))
+    blk.to(DEV).train(training)
+    sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(3, 10, 14, 16, generator=g).to(DEV)
+    gy = torch.randn(3, 10, 14, 32, generator=g).to(DEV)
+    res = {}
+    for tag, env in (("node", None), ("layers", "1")):
+        if env:
+            os.environ["TMG_NO_DENSE_BLOCK_NODE"] = env
+        try:
+            blk.load_state_dict(sd0)
+            blk.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = blk.run(xi)
+            (y * gy).sum().backward()
+            res[tag] = (y.detach().clone(), xi.grad.clone(), {k: p_.grad.clone() for k, p_ in blk.named_parameters()},
+                        {k: v.clone() for k, v in blk.state_dict().items() if "running" in k or "num_batches" in k})
+        finally:
+            os.environ.pop("TMG_NO_DENSE_BLOCK_NODE", None)
+    a, b = res["node"], res["layers"]
+    assert a[0].shape == (3, 10, 14, 32)
+    _close(a[0], b[0].double(), tol=1e-6, what="block output")
+    _close(a[1], b[1].double(), tol=2e-5, what="input gradient")
+    for k in b[2]:
+        _close(a[2][k], b[2][k].double(), tol=2e-5, what=k)
+    for k in b[3]:
+        assert torch.allclose(a[3][k].float(), b[3][k].float(), rtol=1e-6, atol=1e-7), k
