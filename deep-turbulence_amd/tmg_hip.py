@@ -35,7 +35,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64",
 ]
 
 
@@ -722,6 +722,19 @@ def bn_bwd_apply(x, g, a, bsh, mean, rstd, gamma, m0, m1, dx, accumulate, diviso
     B, H, W, C = x.shape
     _chk(lib().tmg_bn_bwd_apply(_ptr(x), _d2(x), _ptr(g), _d2(g), _ptr(a), _ptr(bsh), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(m0),
                                 _ptr(m1), _ptr(dx), _d2(dx), _i64(B * H * W, C, accumulate, divisor), _stream()), "tmg_bn_bwd_apply")
+
+
+def chan_moments(x, acc64):
+    """One-pass per-channel sum / sum of squares of an NHWC tensor or channel-slice view into acc64 (double [2, C], zeroed)."""
+    B, H, W, C = x.shape
+    assert acc64.dtype == torch.float64 and acc64.numel() == 2 * C
+    _chk(lib().tmg_chan_moments(_ptr(x), _d2(x), _ptr(acc64), _i64(B * H * W, C), _stream()), "tmg_chan_moments")
+
+
+def bn_finalize64(acc64, gamma, beta, running_mean, running_var, out, n, eps, momentum):
+    C = gamma.numel()
+    _chk(lib().tmg_bn_finalize64(_ptr(acc64), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(out), _i64(C, n),
+                                 _flts([eps, momentum]), _stream()), "tmg_bn_finalize64")
 
 
 def bn_finalize(sums, csq, gamma, beta, running_mean, running_var, out, n, eps, momentum):

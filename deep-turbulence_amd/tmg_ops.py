@@ -215,12 +215,13 @@ class DenseBlockFn(torch.autograd.Function):
         growth = [params[3 * i + 2].shape[0] for i in range(L)]
         buf = torch.empty((B, Hh, Ww, c0 + sum(growth)), device=x.device, dtype=torch.float32)
         H.masked_add(buf[..., :c0], src=x)
-        stats, c = [], c0
+        stats, use_batch, c = [], [], c0
         for i in range(L):
             gamma, beta, weight = params[3 * i:3 * i + 3]
             bn = bns[i]
             xin = buf[..., :c]
-            if training or not bn.track_running_stats:
+            use_batch.append(bool(training) or not bn.track_running_stats)
+            if use_batch[-1]:
                 mean, rstd, a, bsh = bn_batch_stats(xin, bn)
             else:
                 mean = bn.running_mean
@@ -230,14 +231,14 @@ class DenseBlockFn(torch.autograd.Function):
             H.conv_fwd([xin], H.conv_pack(weight, 0), growth[i], 3, 1, [buf[..., c:c + growth[i]]], in_scale=a, in_shift=bsh, relu_in=True)
             stats.append((mean, rstd, a, bsh))
             c += growth[i]
-        ctx.meta = (L, c0, growth, bool(training) or any(not bn.track_running_stats for bn in bns))
+        ctx.meta = (L, c0, growth, use_batch)
         ctx.stats = stats
         ctx.save_for_backward(buf, *params)
         return buf
 
     @staticmethod
     def backward(ctx, dout):
-        L, c0, growth, training = ctx.meta
+        L, c0, growth, use_batch = ctx.meta
         buf = ctx.saved_tensors[0]
         params = ctx.saved_tensors[1:]
         B, Hh, Ww, Ct = buf.shape
@@ -257,7 +258,7 @@ class DenseBlockFn(torch.autograd.Function):
             H.conv_fwd([dy], H.conv_pack(weight, 1), c, 3, 1, [G])
             s = zeros((3, c), buf.device)   # sums of du, du*xhat, and a zero row for the eval-mode call
             H.chan_reduce(xin, G, a, bsh, mean, rstd, s[0], s[1], 1)
-            if training:
+            if use_batch[i]:
                 H.bn_bwd_apply(xin, G, a, bsh, mean, rstd, gamma, s[0], s[1], dbuf[..., :c], True, divisor=n)
             else:
                 H.bn_bwd_apply(xin, G, a, bsh, mean, rstd, gamma, s[2], s[2], dbuf[..., :c], True)
@@ -267,20 +268,28 @@ class DenseBlockFn(torch.autograd.Function):
 
 
 def bn_batch_stats(x, bn):
-    """Training-mode statistics of nn.BatchNorm2d `bn` on an NHWC tensor / channel-slice view: two-pass moments (sums, then
-    centred squares), then ONE kernel for mean, var, rstd, the folded affine and the momentum update of the running
+    """Training-mode statistics of nn.BatchNorm2d `bn` on an NHWC tensor / channel-slice view: one-pass fp64 moments (round 3; the
+    centred two-pass form is kept behind TMG_BN_TWO_PASS), then ONE kernel for mean, var, rstd, the folded affine and the momentum update of the running
     statistics (the ~15 element-wise torch ops this replaces were ~40 % of the step's small launches).
     -> (mean, rstd, a, bsh), each [C]."""
     B, Hh, Ww, C = x.shape
     n = B * Hh * Ww
-    acc = zeros((4, C), x.device)
-    H.chan_reduce(x, None, None, None, None, None, acc[0], acc[1], 0)
-    H.chan_reduce(x, None, acc[0], None, None, None, acc[2], acc[3], 0, divisor=n)
     out = torch.empty((5, C), device=x.device)
     track = bn.track_running_stats
+    mom = bn.momentum if bn.momentum is not None else 0.1
     with torch.no_grad():
-        H.bn_finalize(acc[0], acc[3], bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
-                      bn.running_var if track else None, out, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+        if os.environ.get("TMG_BN_TWO_PASS") is None:
+            # one pass: sum and sum of squares in fp64 (no cancellation error in E[x^2] - E[x]^2), the activation is read once
+            acc64 = zeros((4 * C,), x.device).view(torch.float64)     # [2][C] doubles out of the pooled zero buffer (256-byte aligned)
+            H.chan_moments(x, acc64)
+            H.bn_finalize64(acc64, bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
+                            bn.running_var if track else None, out, n, bn.eps, mom)
+        else:
+            acc = zeros((4, C), x.device)
+            H.chan_reduce(x, None, None, None, None, None, acc[0], acc[1], 0)
+            H.chan_reduce(x, None, acc[0], None, None, None, acc[2], acc[3], 0, divisor=n)
+            H.bn_finalize(acc[0], acc[3], bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
+                          bn.running_var if track else None, out, n, bn.eps, mom)
         if track:
             bn.num_batches_tracked += 1
     return out[0], out[2], out[3], out[4]

@@ -182,6 +182,12 @@ int tmg_bn_bwd_apply(const void* x, const int64_t* x_d, const void* g, const int
  * running statistics (unbiased variance), one launch.  dims = {C, n}; fl = {eps, momentum}; rmean / rvar may be NULL. */
 int tmg_bn_finalize(const void* sum, const void* csq, const void* gamma, const void* beta, void* rmean, void* rvar, void* out,
                     const int64_t* dims, const float* fl, tmg_stream_t st);
+/* BatchNorm batch moments in one pass (denseBlock.py:49 in training mode): per-channel sum and sum of squares of an NHWC tensor /
+ * channel-slice view accumulated in fp64 into acc (double [2][C], zeroed by the caller; dims = {pixels, C}, x_d = {pixel stride, offset}),
+ * and the finalize step on those moments (arguments as tmg_bn_finalize). */
+int tmg_chan_moments(const void* x, const int64_t* x_d, void* acc, const int64_t* dims, tmg_stream_t st);
+int tmg_bn_finalize64(const void* acc, const void* gamma, const void* beta, void* rmean, void* rvar, void* out, const int64_t* dims,
+                      const float* fl, tmg_stream_t st);
 
 /* dst (+)= src * [ref > 0] + add  over n channels: ReLU-mask / concat adjoints. dims = {npix,n,accumulate} */
 int tmg_masked_add(const void* src, const int64_t* s_d, const void* ref, const int64_t* r_d, const void* add,
