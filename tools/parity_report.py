@@ -46,7 +46,7 @@ VARIANTS = {
     "plain": {"TMG_NO_WINOGRAD": "1", "TMG_NO_FUSED_COUPLING": "1", "TMG_NO_THIN_WGRAD": "1", "TMG_NO_MIX_WGRAD_KERNEL": "1",
               "TMG_NO_LU_FOLD_KERNEL": "1", "TMG_NO_MIX32": "1"},
 }
-CONFIGS = {"M": C.CFG_M, "cfg3": C.CFG3, "cfg2": C.CFG2, "cfg1": C.CFG1, "tiny": C.CFG_TINY}
+CONFIGS = {"M": C.CFG_M, "cfg3": C.CFG3, "cfg2": C.CFG2, "cfg1": C.CFG1, "tiny": C.CFG_TINY, "cfg5": C.CFG5}
 
 
 def build(cfg):
