@@ -19,6 +19,17 @@ struct Mix16P {
     const float* W; const float* bias;
     float* y; int ys;
     long npix; int C; int transposed;
+    // mix32_kernel with the affine coupling fused in (AFF = 1 / 2, the 64- and 128-channel levels' generative direction):
+    int ppi;                       // pixels per image (multiple of a wave's pixel group)
+    const float* hh; int hs;       // AFF 1: zero-conv output [npix][C], (shift, r) interleaved
+    float* r_out; float* y2_out;   // AFF 1: softsign argument and transformed half, [npix][C/2] each (saved for backward)
+    float* logdet;                 // AFF 1: [images] accumulators
+    const float* r_in;             // AFF 2: the saved r
+    const float* t2; int t2s;      // AFF 2: the coupling's input half x2 (pointer at its first channel), pixel stride
+    const float* g;                // AFF 2: upstream gradient on the per-image log-det, or null
+    const float* kappa;            // AFF 2: log-scale of the zero conv (dhh is written pre-multiplied by exp(clamp(kappa)))
+    float* dtin2; int dts;         // AFF 2: gradient w.r.t. x2 (pointer at its first channel), pixel stride
+    float* dhh; int dhs;           // AFF 2: exp(kappa) x gradient w.r.t. the zero-conv output [npix][C], (da, dr) interleaved
 };
 
 template <int NT, int NP>
@@ -135,7 +146,14 @@ extern "C" int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, con
 // from global memory (B fragment = one float4 per lane and 16 channels) against the weight held in LDS ([ci/4][co][4] floats, read
 // as float4 = four k-steps), no packing launch.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NT, int NP>
+// AFF (the per-op chain of the wide levels, generative direction: coupling -> mix, flowAffine.py:102-109 + glowConv.py:207-222):
+//   0: y = W x + b.
+//   1: the affine coupling evaluated on the way IN: the second channel half of the mix input is y2 = x2 exp(-2 softsign(r)) - shift
+//      with (shift, r) read from the zero-conv output; r and y2 are stored for backward, the log-det is summed per wave and image.
+//   2: (transposed mix = its input gradient) the coupling's backward on the way OUT: the second half of W^T dy is turned into the
+//      gradient w.r.t. x2 and exp(kappa) x the gradient w.r.t. the zero-conv output (tmg_affine_bwd_scaled's arithmetic); the first
+//      half is stored as is.  One launch and one [npix][C] round trip less per layer and direction.
+template <int NT, int NP, int AFF>
 __global__ __launch_bounds__(256) void mix32_kernel(Mix16P p) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4* Wl = reinterpret_cast<float4*>(smem_raw);   // [NT*4][CP]: (ci quad, co) -> 4 floats
@@ -184,8 +202,11 @@ __global__ __launch_bounds__(256) void mix32_kernel(Mix16P p) {
         bv[mt] = (p.bias && c < C) ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const long group = 16L * NP;
+    constexpr int HT = NT / 2;               // channel tiles per half (AFF != 0: C == NT * 16)
+    const float hsc = AFF == 2 ? out_scale_of(p.kappa) : 1.f;
     for (long g0 = ((long)blockIdx.x * 4 + wave) * group; g0 < p.npix; g0 += (long)gridDim.x * 4 * group) {
         float4 xv[NP][NT];
+        float ldsum = 0.f;
 #pragma unroll
         for (int np = 0; np < NP; ++np)
 #pragma unroll
@@ -194,7 +215,33 @@ __global__ __launch_bounds__(256) void mix32_kernel(Mix16P p) {
                 const int c = ks * 16 + 4 * lq;
                 const float* a = (px < p.npix && c < C) ? p.x + (size_t)px * p.xs + c : tmg_zero_page;
                 xv[np][ks] = *reinterpret_cast<const float4*>(a);
+                if (AFF == 1 && ks >= HT) {
+                    const int c2 = c - HT * 16;          // channel inside the second half
+                    const bool ok = px < p.npix;
+                    const float* hp = ok ? p.hh + (size_t)px * p.hs + 2 * c2 : tmg_zero_page;
+                    const float4 ha = *reinterpret_cast<const float4*>(hp), hb = *reinterpret_cast<const float4*>(hp + (ok ? 4 : 0));
+                    const float sh[4] = {ha.x, ha.z, hb.x, hb.z}, rr[4] = {ha.y, ha.w, hb.y, hb.w};
+                    const float xx[4] = {xv[np][ks].x, xv[np][ks].y, xv[np][ks].z, xv[np][ks].w};
+                    float oo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sg = 2.f * rr[e] / (1.f + fabsf(rr[e]));
+                        oo[e] = xx[e] * expf(-sg) - sh[e];
+                        ldsum += ok ? sg : 0.f;
+                    }
+                    xv[np][ks] = make_float4(oo[0], oo[1], oo[2], oo[3]);
+                    if (ok) {
+                        *reinterpret_cast<float4*>(p.r_out + (size_t)px * (HT * 16) + c2) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                        *reinterpret_cast<float4*>(p.y2_out + (size_t)px * (HT * 16) + c2) = xv[np][ks];
+                    }
+                }
             }
+        if (AFF == 1) {
+            // one atomic per wave and group: the group's pixels lie in one image (ppi is a multiple of the group, launcher)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ldsum += __shfl_xor(ldsum, o);
+            if (lane == 0) atomicAdd(p.logdet + g0 / p.ppi, ldsum);
+        }
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const long px = g0 + np * 16 + l16;
@@ -222,23 +269,91 @@ __global__ __launch_bounds__(256) void mix32_kernel(Mix16P p) {
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
                 const int c = mt * 16 + 4 * lq;
-                if (px < p.npix && c < C)
+                if (AFF == 2 && mt >= HT) {
+                    if (px < p.npix) {
+                        const int c2 = c - HT * 16;
+                        const float4 rq = *reinterpret_cast<const float4*>(p.r_in + (size_t)px * (HT * 16) + c2);
+                        const float4 yq = *reinterpret_cast<const float4*>(p.t2 + (size_t)px * p.t2s + c2);
+                        const float gb = p.g ? p.g[px / p.ppi] : 0.f;
+                        const float rr[4] = {rq.x, rq.y, rq.z, rq.w}, yy[4] = {yq.x, yq.y, yq.z, yq.w};
+                        float gi[4], da[4], dr[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float den = 1.f + fabsf(rr[e]);
+                            const float sg = 2.f * rr[e] / den;
+                            const float inv = expf(-sg);
+                            const float go_ = acc[mt][e];
+                            gi[e] = go_ * inv;
+                            da[e] = -go_ * hsc;
+                            dr[e] = hsc * (-2.f * go_ * (yy[e] * inv) + 2.f * gb) / (den * den);
+                        }
+                        *reinterpret_cast<float4*>(p.dtin2 + (size_t)px * p.dts + c2) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+                        float* dp = p.dhh + (size_t)px * p.dhs + 2 * c2;
+                        *reinterpret_cast<float4*>(dp) = make_float4(da[0], dr[0], da[1], dr[1]);
+                        *reinterpret_cast<float4*>(dp + 4) = make_float4(da[2], dr[2], da[3], dr[3]);
+                    }
+                } else if (px < p.npix && c < C) {
                     *reinterpret_cast<float4*>(p.y + (size_t)px * p.ys + c) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+                }
             }
         }
     }
 }
 
-template <int NT, int NP>
+template <int NT, int NP, int AFF = 0>
 static int launch_mix32(const Mix16P& p, hipStream_t st) {
     const size_t lds = (size_t)NT * 4 * NT * 16 * sizeof(float4);
-    if (lds > 64 * 1024) TMG_LDS_OPTIN((&mix32_kernel<NT, NP>));
+    if (lds > 64 * 1024) TMG_LDS_OPTIN((&mix32_kernel<NT, NP, AFF>));
     const long groups = (p.npix + 64L * NP - 1) / (64L * NP);
     const int grid = (int)(groups < 2048 ? (groups < 1 ? 1 : groups) : 2048);
     TmgProf prof(31, 2.0 * (double)p.npix * p.C * p.C, st);   // the "conv 1x1 (invertible channel mix, fp32 MFMA)" class: flops
-    hipLaunchKernelGGL((mix32_kernel<NT, NP>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mix32_kernel<NT, NP, AFF>), dim3(grid), dim3(256), lds, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
+}
+
+// The mix of a coupling layer's generative direction with the affine coupling fused in (see mix32_kernel, AFF = 1): C = 64 or 128.
+// x: the layer input [npix][C] (x1 | x2), hh: zero-conv output; y = W [x1 ; y2] + bias, r / y2: [npix][C/2] dense, logdet[image] +=.
+// dims = {npix, C, pixels per image}; x_d / hh_d / y_d = {pixel stride, channel offset}.  -100 outside the envelope.
+extern "C" int tmg_mix_f32_affine_fwd(const void* x, const int64_t* x_d, const void* hh, const int64_t* hh_d, const void* W, const void* bias,
+                                      void* y, const int64_t* y_d, void* r, void* y2, void* logdet, const int64_t* dims, hipStream_t st) {
+    Mix16P p = {};
+    p.x = static_cast<const float*>(x) + x_d[1]; p.xs = (int)x_d[0];
+    p.hh = static_cast<const float*>(hh) + hh_d[1]; p.hs = (int)hh_d[0];
+    p.y = static_cast<float*>(y) + y_d[1]; p.ys = (int)y_d[0];
+    p.W = static_cast<const float*>(W); p.bias = static_cast<const float*>(bias);
+    p.r_out = static_cast<float*>(r); p.y2_out = static_cast<float*>(y2); p.logdet = static_cast<float*>(logdet);
+    p.npix = (long)dims[0]; p.C = (int)dims[1]; p.ppi = (int)dims[2]; p.transposed = 0;
+    if ((p.C != 64 && p.C != 128) || p.xs % 4 || p.ys % 4 || p.hs % 4 || x_d[1] % 4 || y_d[1] % 4 || hh_d[1] % 4 || p.ppi <= 0 ||
+        p.npix % p.ppi || p.ppi % (p.C == 64 ? 32 : 16))
+        return -100;
+    if (((((uintptr_t)p.x) | ((uintptr_t)p.hh) | ((uintptr_t)p.y) | ((uintptr_t)p.r_out) | ((uintptr_t)p.y2_out)) & 15)) return -100;
+    if (p.npix <= 0) return 0;
+    return p.C == 64 ? launch_mix32<4, 2, 1>(p, st) : launch_mix32<8, 1, 1>(p, st);
+}
+
+// Its input gradient with the coupling's backward fused in (AFF = 2): dy [npix][C] -> dto1 = (W^T dy)[:C/2] ([npix][C/2] dense),
+// dtin2 = gradient w.r.t. x2 (pointer at the first x2 channel, stride dtin2_d[0]), dhh [npix][C] = exp(clamp(kappa)) x the gradient
+// w.r.t. the zero-conv output.  r: saved softsign argument, t2: the coupling's input half x2, g: per-image log-det gradient or null.
+extern "C" int tmg_mix_f32_affine_bwd(const void* dy, const int64_t* dy_d, const void* W, const void* r, const void* t2, const int64_t* t2_d,
+                                      const void* g, const void* kappa, void* dto1, void* dtin2, const int64_t* dtin2_d, void* dhh,
+                                      const int64_t* dhh_d, const int64_t* dims, hipStream_t st) {
+    Mix16P p = {};
+    p.x = static_cast<const float*>(dy) + dy_d[1]; p.xs = (int)dy_d[0];
+    p.W = static_cast<const float*>(W); p.bias = nullptr;
+    p.npix = (long)dims[0]; p.C = (int)dims[1]; p.ppi = (int)dims[2]; p.transposed = 1;
+    p.y = static_cast<float*>(dto1); p.ys = p.C / 2;
+    p.r_in = static_cast<const float*>(r);
+    p.t2 = static_cast<const float*>(t2) + t2_d[1]; p.t2s = (int)t2_d[0];
+    p.g = static_cast<const float*>(g); p.kappa = static_cast<const float*>(kappa);
+    p.dtin2 = static_cast<float*>(dtin2) + dtin2_d[1]; p.dts = (int)dtin2_d[0];
+    p.dhh = static_cast<float*>(dhh) + dhh_d[1]; p.dhs = (int)dhh_d[0];
+    if ((p.C != 64 && p.C != 128) || p.xs % 4 || p.t2s % 4 || p.dts % 4 || p.dhs % 4 || dy_d[1] % 4 || t2_d[1] % 4 || dtin2_d[1] % 4 ||
+        dhh_d[1] % 4 || p.ppi <= 0 || p.npix % p.ppi)
+        return -100;
+    if (((((uintptr_t)p.x) | ((uintptr_t)p.y) | ((uintptr_t)p.r_in) | ((uintptr_t)p.t2) | ((uintptr_t)p.dtin2) | ((uintptr_t)p.dhh)) & 15)) return -100;
+    if (p.npix <= 0) return 0;
+    return p.C == 64 ? launch_mix32<4, 2, 2>(p, st) : launch_mix32<8, 1, 2>(p, st);
 }
 
 // y = W x + bias per pixel in fp32 on the matrix cores; arguments as tmg_mix_f16.  C % 4 == 0, C <= 128 (the weight tile lives in LDS).

@@ -35,7 +35,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd",
 ]
 
 
@@ -611,6 +611,33 @@ def mix_f32(x, W, bias, y, transposed=False):
         return False
     _chk(lib().tmg_mix_f32(_ptr(x), _d2(x), _ptr(W), _ptr(bias), _ptr(y), _d2(y), _i64(B * Hh * Ww, C, 1 if transposed else 0), _stream()),
          "tmg_mix_f32")
+    return True
+
+
+def _d2o(t):
+    """{pixel stride, 0}: the channel offset of a slice view is already folded into its data pointer."""
+    return _d2(t)
+
+
+def mix_affine_fwd(x, hh, W, bias, y, r, y2, logdet):
+    """Coupling (generative direction) + trailing mix in one launch (tmg_mix_f32_affine_fwd).  False outside the envelope."""
+    B, Hh, Ww, C = x.shape
+    rc = lib().tmg_mix_f32_affine_fwd(_ptr(x), _d2o(x), _ptr(hh), _d2o(hh), _ptr(W), _ptr(bias), _ptr(y), _d2o(y), _ptr(r), _ptr(y2),
+                                      _ptr(logdet), _i64(B * Hh * Ww, C, Hh * Ww), _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_mix_f32_affine_fwd")
+    return True
+
+
+def mix_affine_bwd(dy, W, r, t2, g, kappa, dto1, dtin2, dhh):
+    """Input gradient of the mix + the coupling's backward in one launch (tmg_mix_f32_affine_bwd).  False outside the envelope."""
+    B, Hh, Ww, C = dy.shape
+    rc = lib().tmg_mix_f32_affine_bwd(_ptr(dy), _d2o(dy), _ptr(W), _ptr(r), _ptr(t2), _d2o(t2), _ptr(g), _ptr(kappa), _ptr(dto1), _ptr(dtin2),
+                                      _d2o(dtin2), _ptr(dhh), _d2o(dhh), _i64(B * Hh * Ww, C, Hh * Ww), _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_mix_f32_affine_bwd")
     return True
 
 

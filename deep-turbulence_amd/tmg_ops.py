@@ -749,6 +749,8 @@ class LevelCouplingFn(torch.autograd.Function):
         # (tmg_coupling_fwd) after the growth layers' launch; wide levels keep one launch per op
         fuse = (8 <= C <= 32 and ch % 4 == 0 and _MIX_PRECISION == "f32" and os.environ.get("TMG_NO_FUSED_COUPLING") is None
                 and all(w.is_contiguous() for w in wts))
+        mixaff = (reverse and C in (64, 128) and _MIX_PRECISION == "f32" and Wm.is_contiguous() and bm.is_contiguous()
+                  and os.environ.get("TMG_NO_MIX_AFFINE") is None)
         for k in (range(NL - 1, -1, -1) if reverse else range(NL)):
             xin = cur
             if fuse:
@@ -776,8 +778,17 @@ class LevelCouplingFn(torch.autograd.Function):
                 H.c1_fwd([x1, D], w2s[k], D[..., 1:2], relu_in=True, w_rows=ch + 1, w_split=ch, w_gap=Cc, add=dc_of(k)[1])
             hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             H.conv_fwd([x1, D], PZ[k], C, 3, 1, [hh], bias=bzs[k], kappa=kps[k], relu_in=True, pad_rep=True, add=Hc[..., k * C:(k + 1) * C])
-            y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+            if mixaff:
+                # 64- / 128-channel levels, generative direction: coupling + trailing mix in ONE launch (the coupling is evaluated on
+                # the mix kernel's way in); the coupling output is kept as (x1 of the input, y2), never as a [.., C] tensor
+                y2 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+                out = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+                if H.mix_affine_fwd(tin, hh, Wm[k], bm[k], out, r, y2, logdet):
+                    cur = out
+                    saved[k] = (xin, tin, D, r, [x1, y2])
+                    continue
+            y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
             H.affine_apply(hh, tin[..., ch:], y[..., ch:], r, logdet, reverse, x1=x1, y1=y[..., :ch])
             cur = _mix_fwd(y, Wm[k], bm[k], PM[k]) if reverse else y
             saved[k] = (xin, tin, D, r, y)
@@ -859,10 +870,23 @@ class LevelCouplingFn(torch.autograd.Function):
                 del xin, tin, D, r, y
                 continue
             mdef = [] if grouped else None
-            dto = _mix_bwd(y, dcur, Wm[k], dWm[k], dbm[k], PMt[k], mdef) if reverse else dcur   # grad w.r.t. the tail output y
             dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)        # grad w.r.t. the tail input
             dhh = DH[..., k * C:(k + 1) * C]
-            H.affine_bwd(dto[..., ch:], (tin if reverse else y)[..., ch:], r, g, dtin[..., ch:], dhh, reverse, kappa=kps[k])
+            add0 = None
+            if reverse and isinstance(y, list) and C in (64, 128) and _MIX_PRECISION == "f32":
+                # the forward pass took the fused coupling + mix launch: its backward in one launch too (mix input gradient with the
+                # coupling's backward on the way out); dto1 = the pass-through half of the gradient, completed by dense2_bwd below
+                dto1 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+                if H.mix_affine_bwd(dcur, Wm[k].contiguous(), r, tin[..., ch:], g, kps[k], dto1, dtin[..., ch:], dhh):
+                    add0 = dto1
+                    if mdef is not None:
+                        mdef.append((y, dcur))
+                    else:
+                        H.conv_wgrad(y, dcur, dWm[k], dbm[k], 1, 1)
+            if add0 is None:
+                dto = _mix_bwd(y, dcur, Wm[k], dWm[k], dbm[k], PMt[k], mdef) if reverse else dcur   # grad w.r.t. the tail output y
+                H.affine_bwd(dto[..., ch:], (tin if reverse else y)[..., ch:], r, g, dtin[..., ch:], dhh, reverse, kappa=kps[k])
+                add0 = dto[..., :ch]
             x1 = tin[..., :ch]
             if grouped:
                 wg_in[k] = [x1, D]  # weight gradient of this layer's zero conv: deferred, one grouped launch per level
@@ -875,7 +899,7 @@ class LevelCouplingFn(torch.autograd.Function):
             H.conv_fwd([dhh], wt, ch + 4, 3, 1, [G0, GD])
             H.conv_rep_border_fix(dhh, wt, [G0, GD])
             H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
-                         add0=dto[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2], split2=ch,
+                         add0=add0, rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2], split2=ch,
                          gap2=Cc, dd_quad=True)
             dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k], mdef)
             if grouped:

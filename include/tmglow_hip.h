@@ -335,6 +335,17 @@ int tmg_level_finish(const void* Wz, const void* dWz, const void* Bz, const void
  * without the general conv kernel's patch staging and operand-packing launch.  Arguments as tmg_mix_f16. */
 int tmg_mix_f32(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d,
                 const int64_t* dims, tmg_stream_t st);
+/* The same mix with the affine coupling of the generative direction fused in (the per-op chain of the 64- / 128-channel levels:
+ * coupling -> mix, flowAffine.py:102-109 + glowConv.py:207-222 + actNorm.py:71-85).  _fwd: x [npix][C] = (x1 | x2), hh = zero-conv output
+ * ((shift, r) interleaved): y2 = x2 exp(-2 softsign(r)) - shift, y = W [x1 ; y2] + bias; r and y2 ([npix][C/2] dense) are stored for
+ * backward, logdet[image] += sum 2 softsign(r).  _bwd: dy -> dto1 = (W^T dy)[: C/2] ([npix][C/2] dense), dtin2 = gradient w.r.t. x2,
+ * dhh = exp(clamp(kappa)) x gradient w.r.t. hh.  dims = {npix, C, pixels per image}; *_d = {pixel stride, channel offset}.  C = 64 or
+ * 128; -100 outside the envelope (nothing launched). */
+int tmg_mix_f32_affine_fwd(const void* x, const int64_t* x_d, const void* hh, const int64_t* hh_d, const void* W, const void* bias,
+                           void* y, const int64_t* y_d, void* r, void* y2, void* logdet, const int64_t* dims, tmg_stream_t st);
+int tmg_mix_f32_affine_bwd(const void* dy, const int64_t* dy_d, const void* W, const void* r, const void* t2, const int64_t* t2_d,
+                           const void* g, const void* kappa, void* dto1, void* dtin2, const int64_t* dtin2_d, void* dhh,
+                           const int64_t* dhh_d, const int64_t* dims, tmg_stream_t st);
 
 /* ---- physics-constrained reverse-KL loss (tmg_physics.hip) ------------------------------ */
 

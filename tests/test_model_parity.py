@@ -635,6 +635,44 @@ def test_level_fused_node_matches_per_layer_path():
     C.assert_grads(ga, gb, "fused vs per-layer grads", global_tol=1e-4, tensor_tol=2e-3)
 
 
+@pytest.mark.parametrize("cin,hw", [(16, (16, 32)), (32, (8, 16)), (16, (6, 10))])
+def test_fused_coupling_mix_launches_match_the_per_op_chain(cin, hw):
+    """tmg_mix_f32_affine_fwd / _bwd (64- / 128-channel levels, generative direction: coupling + trailing mix, and the mix input
+    gradient + coupling backward, one launch each) against the separate affine and mix launches they replace (TMG_NO_MIX_AFFINE=1):
+    level output, log-det and every gradient.  The last case has a pixel count per image the fused kernels do not take (15 pixels):
+    the level node must fall back to the per-op chain by itself."""
+    import os
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+    C.seed_all(79)
+    blk = LSTMFLowBlock(cin, 32, 16, 4, LUdecompose=True, train_sampling=True, do_split=False, squeeze_type=0)
+    C.perturb_(blk, 7, 0.05, 0.1, 0.05)
+    blk.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    hs, ws = hw[0] // 2, hw[1] // 2
+    z = torch.randn(3, 4 * cin, hs, ws, generator=g).to(DEV)
+    cond = torch.randn(3, 32, hs, ws, generator=g).to(DEV)
+    res = {}
+    for tag, env in (("fused", None), ("per-op", "1")):
+        if env:
+            os.environ["TMG_NO_MIX_AFFINE"] = env
+        try:
+            blk.zero_grad()
+            ci = cond.clone().requires_grad_(True)
+            zi = z.clone().requires_grad_(True)
+            xr, ldr, _ = blk.reverse(zi, ci, None)
+            ((xr ** 2).sum() * 0.5 + ldr.sum() * 0.02).backward()
+        finally:
+            os.environ.pop("TMG_NO_MIX_AFFINE", None)
+        res[tag] = (xr.detach(), ldr.detach(), ci.grad.clone(), zi.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+    a, b = res["fused"], res["per-op"]
+    C.assert_field(a[0], b[0], "x", atol=2e-5, rtol=1e-5)
+    C.assert_logdet(a[1], b[1], rtol=2e-6, atol=1e-3)
+    ga, gb = dict(a[4]), dict(b[4])
+    ga.update({"@dcond": a[2], "@dz": a[3]})
+    gb.update({"@dcond": b[2], "@dz": b[3]})
+    C.assert_grads(ga, gb, "fused coupling + mix vs per-op chain", global_tol=1e-5, tensor_tol=2e-4)
+
+
 def test_layer_plane_addends_give_identical_results():
     """The growth convs' conditioning addends as one float2 plane per layer (tmg_layer_planes, used on large images) against the
     interleaved [B,H,W,2K] tensor: same numbers in another layout, so outputs and gradients are identical bit for bit."""
