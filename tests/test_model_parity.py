@@ -1042,3 +1042,36 @@ def test_lu_fold_kernels_match_torch_folding(reverse, ts):
         for n in a[3]:
             sc = max(float(b[3][n].abs().max()), 1e-6)
             assert float((a[3][n] - b[3][n]).abs().max()) <= 5e-5 * sc, (n, float((a[3][n] - b[3][n]).abs().max()), sc)
+
+
+def test_lu_fold_cache_follows_reloaded_permutations():
+    """The level's cached row permutations / sign vectors (derived VALUES of the buffers `p` and `sign_s`) must follow a
+    `load_state_dict` that copies a different permutation and signs into those buffers IN PLACE (same addresses): forward with
+    the first weights, load a model initialised from another seed, and compare the level output with the torch folding
+    (TMG_NO_LU_FOLD_KERNEL=1), which reads the buffers on every call."""
+    import os
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+
+    def make(seed):
+        C.seed_all(seed)
+        b = LSTMFLowBlock(4, 8, 8, 4, LUdecompose=True, train_sampling=True, do_split=False, squeeze_type=0)
+        C.perturb_(b, seed, 0.05, 0.1, 0.05)
+        return b
+
+    blk, other = make(5).to(DEV), make(6)
+    sd_other = {k: v.clone() for k, v in other.state_dict().items()}
+    assert any(not torch.equal(sd_other[k], v.cpu()) for k, v in blk.state_dict().items() if k.endswith(".p"))   # another permutation
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, 16, 8, 8, generator=g).to(DEV)
+    cond = torch.randn(2, 8, 8, 8, generator=g).to(DEV)
+    with torch.no_grad():
+        blk.reverse(z, cond, None)                      # fills the cache with the first model's permutations
+        blk.load_state_dict(sd_other)                   # in-place copies: the buffers keep their addresses
+        x_hip, ld_hip, _ = blk.reverse(z, cond, None)
+        os.environ["TMG_NO_LU_FOLD_KERNEL"] = "1"
+        try:
+            x_ref, ld_ref, _ = blk.reverse(z, cond, None)
+        finally:
+            os.environ.pop("TMG_NO_LU_FOLD_KERNEL", None)
+    C.assert_field(x_hip, x_ref, "level output after reloading other permutations", atol=2e-5, rtol=1e-5)
+    C.assert_logdet(ld_hip, ld_ref, rtol=2e-6, atol=1e-3)
