@@ -323,6 +323,37 @@ def test_physics_loss_matches_reference_fixture(tag):
     _close(phys.calcDivergence(hat[:, :2]), t("ustar"), what="ustar")
 
 
+@pytest.mark.parametrize("shape", [(8, 10, 256, 256), (3, 4, 100, 70), (2, 10, 128, 256)])
+def test_physics_loss_at_field_sizes_of_the_trainer(shape):
+    """The fused loss kernels at the sizes the trainer runs them at (a 10-step window of 256x256x3 fields, several samples: thousands
+    of tiles; and a ragged field) against the physics oracle evaluated in FP64 - the reference fixtures pin the arithmetic on small
+    fields only.  Loss value and both gradients."""
+    import os
+    import sys
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
+    import physics_oracle as PO
+    from nn.trainFlowParallel import TMGLowLoss
+    B, T, Hh, Ww = shape
+    g = torch.Generator().manual_seed(Hh + T)
+    y = 0.6 * torch.randn(B, T, 3, Hh, Ww, generator=g)
+    tgt = 0.6 * torch.randn(B, T, 3, Hh, Ww, generator=g)
+    logp = torch.randn(B, T, generator=g) * 50.0
+    std, mu = torch.tensor([1.3, 0.7, 2.1]), torch.tensor([0.2, -0.1, 0.4])
+    beta, dx, dy = 200.0, 2.0 / 64, 2.0 / 64
+    tmean = tgt.mean(1)
+    trms = torch.sqrt(((tgt - tmean.unsqueeze(1)) ** 2).mean(1))
+    yr, lr = y.double().requires_grad_(True), logp.double().requires_grad_(True)
+    ref = PO.tmglow_loss(yr, lr, tgt.double(), tmean.double(), trms.double(), std.double(), mu.double(), beta, dx, dy)
+    ref.backward()
+    crit = TMGLowLoss(SimpleNamespace(beta=beta, dx=dx, dy=dy), SimpleNamespace(out_std=std, out_mu=mu)).to(DEV)
+    yd, ld = y.to(DEV).requires_grad_(True), logp.to(DEV).requires_grad_(True)
+    loss = crit(yd, ld, tgt.to(DEV), tmean.to(DEV), trms.to(DEV))
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()), (loss.item(), ref.item())
+    loss.backward()
+    C.assert_grads({"y": yd.grad, "logp": ld.grad}, {"y": yr.grad, "logp": lr.grad}, "loss grads", global_tol=2e-5, tensor_tol=2e-4)
+
+
 @pytest.mark.parametrize("shape", [(4, 2, 16, 16, 8, 16, 32), (3, 1, 20, 12, 16, 32, 5), (5, 2, 32, 32, 32, 64, 32), (3, 4, 16, 16, 64, 128, 32)])
 def test_grouped_weight_gradient_matches_per_group_launches(shape):
     """tmg_conv_wgrad_grouped (one launch, device segment table) against G separate tmg_conv_wgrad launches and against
