@@ -1075,3 +1075,68 @@ def test_lu_fold_cache_follows_reloaded_permutations():
             os.environ.pop("TMG_NO_LU_FOLD_KERNEL", None)
     C.assert_field(x_hip, x_ref, "level output after reloading other permutations", atol=2e-5, rtol=1e-5)
     C.assert_logdet(ld_hip, ld_ref, rtol=2e-6, atol=1e-3)
+
+
+def test_bptt_window_at_stated_batch_matches_oracle():
+    """Two time-steps of a BPTT window (trainFlowParallel.py:256-287: the recurrent states of step 0 feed step 1 and carry a
+    gradient back) at BASELINE configs[1]'s stated batch 32 - 3-channel fields, i.e. the zero-padded channel layout on the first
+    level - with the loss on two samples: the gate conv's input gradient then covers all Cin + 64 channels and the cell state's
+    gradient is live, paths the single-step cases never take.  Oracle as in _stated_batch_case (encoder on the whole batch per
+    step, flow on the two samples), fp64 truth and fp32 yardstick, all parameter gradients."""
+    import contextlib
+    import io
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(C.ROOT, "oracle"))
+    import tmglow_oracle as O
+    from nn.tmGlow import TMGlow
+    name, cfg, B, n, T = "cfg2", C.CFG2, 32, 2, 2
+    C.seed_all(12345)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, *C.perturb_scales(cfg))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(DEV).train()
+    h, w = cfg["_in_hw"]
+    H_, W_ = h * cfg["_up"], w * cfg["_up"]
+    g = torch.Generator().manual_seed(78)
+    xs = [torch.randn(B, cfg["in_features"], h, w, generator=g) for _ in range(T)]
+    y = torch.randn(B, cfg["out_features"], H_, W_, generator=g)
+    seeds = torch.arange(B) + 5
+    st0 = m.initLSTMStates(seeds, [H_, W_])
+    with torch.no_grad():
+        _, _, _, e_ = m.forward(xs[0].to(DEV), y.to(DEV), st0, return_eps=True)
+        m.load_state_dict(sd)
+    eps = [[torch.randn(e.shape, generator=g) for e in e_] for _ in range(T)]
+    # ---- HIP
+    m.zero_grad()
+    st, loss = st0, 0.0
+    for t in range(T):
+        yt, ldt, st = m.reconstruct(xs[t].to(DEV), st, [e.to(DEV) for e in eps[t]])
+        loss = loss + C.loss_reverse(yt[:n], ldt[:n])
+    loss.backward()
+    gr = {k: v.detach().clone() for k, v in _grads(m).items()}
+    # ---- oracle
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        P = O.params_from_state_dict(sd, dtype=dt)
+        sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
+        lo = 0.0
+        for t in range(T):
+            z_out, c_out = O.encoder(P, cfg, xs[t].to(dt), True)
+            cmean, clsd = z_out[:n].chunk(2, 1)
+            clsd = clsd.clamp(-10.0, O.LOG5)
+            z = cmean + torch.exp(clsd) * eps[t][-1][:n].to(dt)
+            yo, ldo, sto = O.decoder_reverse(P, cfg, z, [c[:n] for c in c_out], sto, [e[:n].to(dt) for e in eps[t][:-1]])
+            lo = lo + C.loss_reverse(yo, ldo)
+        lo.backward()
+        res[dt] = dict(y=yo.detach(), loss=float(lo.detach()), g={k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None})
+    r64, r32 = res[torch.float64], res[torch.float32]
+    C.assert_field(yt[:n], r64["y"], "y of the second step", atol=max(C.FIELD_ATOL, YARDSTICK * _maxabs(r32["y"], r64["y"])))
+    assert abs(float(loss) - r64["loss"]) <= 1e-5 * abs(r64["loss"]) + 1e-6
+    fl = _grad_err(r32["g"], r64["g"])
+    er = _grad_err(gr, r64["g"])
+    print("\nBPTT window %s at batch %d: hip vs fp64 %s, fp32 oracle vs fp64 %s" % (name, B, er, fl))
+    assert set(gr) == set(r64["g"])
+    C.assert_grads(gr, r64["g"], "two-step window grads at the stated batch", global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
+                   tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), outliers=FLIP_OUTLIERS)
