@@ -1140,3 +1140,41 @@ def test_bptt_window_at_stated_batch_matches_oracle():
     assert set(gr) == set(r64["g"])
     C.assert_grads(gr, r64["g"], "two-step window grads at the stated batch", global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
                    tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), outliers=FLIP_OUTLIERS)
+
+
+@pytest.mark.parametrize("cin,hw,B", [(4, (64, 64), 64), (8, (17, 33), 32), (16, (16, 16), 128), (16, (9, 23), 64), (32, (8, 16), 64), (3, (30, 30), 64)])
+def test_level_kernels_across_field_and_batch_sizes(cin, hw, B):
+    """One flow level (generative direction + backward, recurrent states with gradients, loss on two samples) through the level-fused
+    node and its fused / grouped kernels against the per-layer path on the general kernels (TMG_NO_LEVEL_FUSION=1), over the model's
+    channel widths (16 .. 128, and the padded 12), ragged fields and batch sizes up to 128: the launch plans of the persistent, grouped
+    and fused kernels depend on the pixel count (tools/scratch/level_sweep.py is the long form)."""
+    import os
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+    hs, ws = hw
+    C.seed_all(cin * 7 + B)
+    blk = LSTMFLowBlock(cin, 32, 64, 6, LUdecompose=True, train_sampling=True, do_split=True, squeeze_type=0)
+    C.perturb_(blk, 5, 0.02, 0.05, 0.02)
+    blk.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    z, eps = (torch.randn(B, 2 * cin, hs, ws, generator=g).to(DEV) for _ in range(2))
+    cond = torch.randn(B, 32, hs, ws, generator=g).to(DEV)
+    hst, cst = (torch.randn(B, 64, hs, ws, generator=g).to(DEV) for _ in range(2))
+    res = {}
+    for tag, env in (("fused", None), ("plain", "1")):
+        if env:
+            os.environ["TMG_NO_LEVEL_FUSION"] = env
+        try:
+            blk.zero_grad()
+            zi, ci, hi, cc = (t.clone().requires_grad_(True) for t in (z, cond, hst, cst))
+            xr, ldr, st = blk.reverse(zi, ci, (hi, cc), eps=eps)
+            ((xr[:2] ** 2).sum() * 0.5 + ldr[:2].sum() * 0.02 + (st[0][:2] ** 2).sum() * 0.1).backward()
+        finally:
+            os.environ.pop("TMG_NO_LEVEL_FUSION", None)
+        gr = {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None}
+        gr.update({"@dz": zi.grad.clone(), "@dcond": ci.grad.clone(), "@dh": hi.grad.clone(), "@dc": cc.grad.clone()})
+        res[tag] = (xr.detach(), ldr.detach(), gr)
+    a, b = res["fused"], res["plain"]
+    C.assert_field(a[0], b[0], "level output", atol=1e-4 * float(b[0].abs().max()), rtol=1e-5)
+    C.assert_logdet(a[1], b[1], rtol=5e-6, atol=1e-3)
+    # (two fp32 evaluation orders flip different near-zero ReLUs: a local difference in @dz of a per cent of its scale, nothing global)
+    C.assert_grads(a[2], b[2], "level-fused vs per-layer path", global_tol=2e-4, tensor_tol=5e-3, outliers=FLIP_OUTLIERS)
