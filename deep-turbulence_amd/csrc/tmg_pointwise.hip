@@ -112,28 +112,28 @@ __global__ void affine_bwd_kernel(const float* gout, int gs, int go, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// ConvLSTM pointwise.  gates: [npix][4R] pre-activation in the order i,f,o,g; overwritten with the
-// activated gates (kept for backward).
+// ConvLSTM pointwise.  gates: [npix][4R] pre-activation in the order i,f,o,g; left as they are (kept for
+// backward, which evaluates the same activation functions on them again: the activated gates are never
+// written - 4R floats per pixel less HBM traffic in the forward pass, bit-identical values in backward).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ void lstm_pointwise_fwd_kernel(float* __restrict__ gates, const float* __restrict__ c_prev, int cps, int cpo,
+__global__ void lstm_pointwise_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev, int cps, int cpo,
                                           float* __restrict__ c_next, float* __restrict__ h_next, int R, size_t npix) {
     const size_t total = npix * R;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i / R;
         const int j = i % R;
-        float* gp = gates + pix * 4 * R + j;
+        const float* gp = gates + pix * 4 * R + j;
         const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[R]), go = sigmoidf_(gp[2 * R]), gg = tanhf(gp[3 * R]);
         const float cp = c_prev ? c_prev[pix * cps + cpo + j] : 0.f;
         const float cn = gf * cp + gi * gg;
-        gp[0] = gi; gp[R] = gf; gp[2 * R] = go; gp[3 * R] = gg;
         c_next[pix * R + j] = cn;
         h_next[pix * R + j] = go * tanhf(cn);
     }
 }
 
-// acts (activated gates) are overwritten in place by the pre-activation gradients.
+// acts: the pre-activation gates of the forward pass, overwritten in place by the pre-activation gradients.
 __global__ void lstm_pointwise_bwd_kernel(float* __restrict__ acts, const float* __restrict__ c_prev, int cps, int cpo,
                                           const float* __restrict__ c_next, const float* __restrict__ dh,
                                           const float* __restrict__ dc_in, float* __restrict__ dc_prev, int R, size_t npix) {
@@ -142,7 +142,7 @@ __global__ void lstm_pointwise_bwd_kernel(float* __restrict__ acts, const float*
         const size_t pix = i / R;
         const int j = i % R;
         float* gp = acts + pix * 4 * R + j;
-        const float gi = gp[0], gf = gp[R], go = gp[2 * R], gg = gp[3 * R];
+        const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[R]), go = sigmoidf_(gp[2 * R]), gg = tanhf(gp[3 * R]);
         const float cp = c_prev ? c_prev[pix * cps + cpo + j] : 0.f;
         const float tc = tanhf(c_next[pix * R + j]);
         const float dhv = dh ? dh[pix * R + j] : 0.f;
@@ -1256,8 +1256,8 @@ extern "C" int tmg_lstm_pointwise_fwd(void* gates, const void* c_prev, const int
                                       const int64_t* dims, hipStream_t st) {
     const size_t npix = (size_t)dims[0];
     const int R = (int)dims[1];
-    TmgProf prof(TMG_PROF_LSTMF, 4.0 * (double)npix * R * (c_prev ? 11 : 10), st);   // gates 4R read + 4R written, c_prev, c_next, h_next
-    hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (float*)gates, (const float*)c_prev,
+    TmgProf prof(TMG_PROF_LSTMF, 4.0 * (double)npix * R * (c_prev ? 7 : 6), st);   // gates 4R read, c_prev, c_next, h_next
+    hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (const float*)gates, (const float*)c_prev,
                        (int)cprev_d[0], (int)cprev_d[1], (float*)c_next, (float*)h_next, R, npix);
     TMG_CHECK_LAUNCH();
     return 0;

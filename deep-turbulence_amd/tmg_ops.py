@@ -346,7 +346,7 @@ class LSTMPointwiseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gates, c_prev):
-        acts = gates.contiguous().clone()
+        acts = gates.contiguous()       # read only; backward works on a copy
         B, Hh, Ww, R4 = acts.shape
         R = R4 // 4
         if c_prev is not None and c_prev.stride(3) != 1:
@@ -370,9 +370,10 @@ class LSTMPointwiseFn(torch.autograd.Function):
 
 class ConvLSTMCellFn(torch.autograd.Function):
     """ConvLSTM cell as one node: gates = conv3x3(cat(inputs, h)) + b; i,f,o,g activations; c' = f c + i g; h' = o tanh(c')
-    (reference convLSTM.py:72-85).  The 4R-wide gate tensor is activated in place and, in backward, overwritten in place
-    by the pre-activation gradients, so the largest activation of the model exists once (no clones).  Consequently the
-    node supports a single backward pass (no retain_graph double backward)."""
+    (reference convLSTM.py:72-85).  The 4R-wide gate tensor is kept as the conv wrote it (the activated gates are never
+    stored: backward evaluates the activations again) and, in backward, overwritten in place by the pre-activation gradients, so
+    the largest activation of the model exists once (no clones).  Consequently the node supports a single backward pass (no
+    retain_graph double backward)."""
 
     @staticmethod
     def forward(ctx, weight, bias, h_cur, c_cur, *inputs):

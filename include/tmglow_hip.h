@@ -146,8 +146,9 @@ int tmg_affine_bwd_scaled(const void* gout, const int64_t* go_d, const void* yre
                           const void* g, void* gin, const int64_t* gi_d, void* dhh, const int64_t* dh_d, const void* kappa,
                           const int64_t* dims, tmg_stream_t st);
 
-/* ConvLSTM gates (convLSTM.py:76-83): gates [npix][4R] in order i,f,o,g are activated in place.
- * dims = {npix, R} */
+/* ConvLSTM gates (convLSTM.py:76-83): gates [npix][4R] pre-activation in order i,f,o,g.  The forward call only READS them
+ * (c_next, h_next out); the backward call takes the same pre-activation tensor as `acts`, evaluates the gate activations on it
+ * again and overwrites it in place with the pre-activation gradients.  dims = {npix, R} */
 int tmg_lstm_pointwise_fwd(void* gates, const void* c_prev, const int64_t* cprev_d, void* c_next, void* h_next,
                            const int64_t* dims, tmg_stream_t st);
 int tmg_lstm_pointwise_bwd(void* acts, const void* c_prev, const int64_t* cprev_d, const void* c_next, const void* dh,

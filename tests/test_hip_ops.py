@@ -186,6 +186,7 @@ def test_lstm_pointwise(with_c):
     gd = _nhwc(gates).requires_grad_(True)
     cd = _nhwc(c).requires_grad_(True) if with_c else None
     h2, c2 = ops.LSTMPointwiseFn.apply(gd, cd)
+    assert torch.equal(gd.detach(), _nhwc(gates))      # the forward launch only reads the pre-activation gates
     _close(_back(h2), hn, what="h")
     _close(_back(c2), cn, what="c")
     ((h2 * _nhwc(w1.float())).sum() + (c2 * _nhwc(w2.float())).sum()).backward()
