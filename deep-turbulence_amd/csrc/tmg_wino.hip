@@ -960,14 +960,18 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
 }
 
 // Fold the slabs of wino_wgrad_kernel over the pixel shares, apply A'^T . A' and add the 9 taps onto dW (+ the bias sums onto dbias).
-// One 256-thread block per pair of channel tiles: thread (lane, group g) sums the slabs bx = g, g + 4, ... for its 4 input channels x 1
-// output channel at all 16 positions, transforms its partial sum (the tap transform is linear), the four groups meet in LDS and group
-// 0 adds the result onto dW.  (A single serial walk over all gx slabs per thread left the chip idle for 120 us per launch.)
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
-                                                                int gx, int gy, int gz, int CIT, int NCO, int Cin, int Cout, int cin_dst,
-                                                                int cin_valid, int ci_split, int ci_off0, int ci_off1, int bpg,
-                                                                long long dw_gstride, int db_gstride) {
-    __shared__ float red[3][64][37];
+// One block of NG x 64 threads per pair of channel tiles: thread (lane, group g) sums the slabs bx = g, g + NG, ... for its 4 input
+// channels x 1 output channel at all 16 positions, transforms its partial sum (the tap transform is linear), the NG groups meet in LDS
+// and group 0 adds the result onto dW in a fixed order.  (A single serial walk over all gx slabs per thread left the chip idle for 120 us
+// per launch; with only gy gz CIT NCO = 24..64 blocks per launch the walk of gx / NG slabs per thread is a chain of exposed load
+// latencies: NG = 8 for the launches with many slabs.)
+template <int NG>
+__global__ __launch_bounds__(64 * NG) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
+                                                                   int gx, int gy, int gz, int CIT, int NCO, int Cin, int Cout, int cin_dst,
+                                                                   int cin_valid, int ci_split, int ci_off0, int ci_off1, int bpg,
+                                                                   long long dw_gstride, int db_gstride) {
+    extern __shared__ __attribute__((aligned(16))) float red_[];
+    float (*red)[64][37] = reinterpret_cast<float (*)[64][37]>(red_);   // [NG - 1][64][37]
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     int r_ = blockIdx.x;
     const int n = r_ % NCO; r_ /= NCO;
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     float4 m[16];
 #pragma unroll
     for (int pz = 0; pz < 16; ++pz) m[pz] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int bx = grp; bx < gx; bx += 4) {
+    for (int bx = grp; bx < gx; bx += NG) {
         const size_t bl = ((size_t)bx * gy + by) * gz + bz;
 #pragma unroll
         for (int pz = 0; pz < 16; ++pz) {
@@ -1029,7 +1033,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
             if (co >= Cout || ci >= Cin || ci >= cin_valid) continue;
             float* dst = dW + ((size_t)co * cin_dst + ci + (ci < ci_split ? ci_off0 : ci_off1)) * 9;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) dst[k] += tap[r][k] + red[0][lane][r * 9 + k] + red[1][lane][r * 9 + k] + red[2][lane][r * 9 + k];
+            for (int k = 0; k < 9; ++k) {
+                float v = tap[r][k];
+#pragma unroll
+                for (int g_ = 0; g_ < NG - 1; ++g_) v += red[g_][lane][r * 9 + k];
+                dst[k] += v;
+            }
         }
     }
     if (dbias && bz == 0 && i == 0 && n == 0 && threadIdx.x < NCO * 16) {
@@ -1120,9 +1129,23 @@ static int wino_wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, i
     TMG_WW_CASE(4, 4)
 #undef TMG_WW_CASE
     if (rc != 0) return rc;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(256), 0, st, (const float*)p.ws, (float*)dW,
-                       (float*)dbias, pl.gx, pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid, ci_split, ci_off0, ci_off1,
-                       p.bpg, dw_gstride, db_gstride);
+    static const int ng_env = getenv("TMG_WW_REDUCE_NG") ? atoi(getenv("TMG_WW_REDUCE_NG")) : 0;
+    const int ng = ng_env ? ng_env : (pl.gx >= 64 ? 16 : (pl.gx >= 32 ? 8 : 4));
+    if (ng == 16) {
+        TMG_LDS_OPTIN((&wino_wgrad_reduce_kernel<16>));
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<16>, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(1024), 15 * 64 * 37 * sizeof(float), st,
+                           (const float*)p.ws, (float*)dW, (float*)dbias, pl.gx, pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid,
+                           ci_split, ci_off0, ci_off1, p.bpg, dw_gstride, db_gstride);
+    } else if (ng == 8) {
+        TMG_LDS_OPTIN((&wino_wgrad_reduce_kernel<8>));
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<8>, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(512), 7 * 64 * 37 * sizeof(float), st,
+                           (const float*)p.ws, (float*)dW, (float*)dbias, pl.gx, pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid,
+                           ci_split, ci_off0, ci_off1, p.bpg, dw_gstride, db_gstride);
+    } else {
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<4>, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(256), 3 * 64 * 37 * sizeof(float), st,
+                           (const float*)p.ws, (float*)dW, (float*)dbias, pl.gx, pl.gy, pl.gz, pl.CIT, pl.NCO, p.Cin, p.Cout, cin_dst, cin_valid,
+                           ci_split, ci_off0, ci_off1, p.bpg, dw_gstride, db_gstride);
+    }
     TMG_CHECK_LAUNCH();
     return 0;
 }
