@@ -1205,7 +1205,9 @@ __global__ void conv_rep_border_fix_kernel(BorderP p) {
 // adds its 4 consecutive channels onto dx with one float4 read-modify-write.
 struct BorderMP {
     BorderP b;
-    int tile0[9];   // first 16-pixel tile of class c (tile0[8] = total)
+    int tile0[17];  // first 16-pixel tile of virtual class v (tile0[16] = total).  v < 4: the edge classes; v = 4 + 3 k + g: corner k
+                    // with pair group g (pairs [0,3), [3,6), [6,7) of its list: a corner's 7 pairs as one serial chain of operand
+                    // loads made the 16 corner tiles the long pole of the launch)
     int cnt[8];     // pixels of class c per image
     int ksplit;     // waves sharing one tile's dy-channel range (long contractions over few border pixels)
 };
@@ -1226,21 +1228,22 @@ static __device__ const unsigned g_border_pairs[8][8] = {
 template <int NT>
 __global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
     const BorderP& p = m.b;
-    constexpr int U = NT <= 3 ? 4 : 2;   // k-blocks whose operand loads are in flight together (the chain is latency-bound)
+    constexpr int U = NT <= 5 ? 4 : 2;   // k-blocks whose operand loads are in flight together (the chain is latency-bound)
     const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const float osc = out_scale_of(p.kappa);
     const size_t tap_stride = (size_t)p.KB * p.Npad * 16, kb_stride = (size_t)p.Npad * 16;
     const int S = m.ksplit, KBs = (p.KB + S - 1) / S;
-    for (int item = (int)blockIdx.x * 4 + wave; item < m.tile0[8] * S; item += (int)gridDim.x * 4) {
+    for (int item = (int)blockIdx.x * 4 + wave; item < m.tile0[16] * S; item += (int)gridDim.x * 4) {
         const int t = item / S, ks = item - t * S;
         const int kb0 = ks * KBs, kb1 = min(p.KB, kb0 + KBs);
         if (kb0 >= kb1) continue;
-        int c = 0;
+        int v = 0;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) c += (t >= m.tile0[k]) ? 1 : 0;
+        for (int k = 1; k < 16; ++k) v += (t >= m.tile0[k]) ? 1 : 0;
+        const int c = v < 4 ? v : 4 + (v - 4) / 3, pg = v < 4 ? 0 : (v - 4) % 3;
         const int cnt = m.cnt[c];
-        const int i = (t - m.tile0[c]) * 16 + li;          // this lane's pixel of the class
+        const int i = (t - m.tile0[v]) * 16 + li;          // this lane's pixel of the class
         const bool pv = i < p.B * cnt;
         const int b = pv ? i / cnt : 0, j = pv ? i - b * cnt : 0;
         int qy, qx;
@@ -1252,8 +1255,8 @@ __global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int npairs = (int)g_border_pairs[c][0];
-        for (int e = 0; e < npairs; ++e) {
+        const int npairs = min((int)g_border_pairs[c][0], 3 * pg + 3);
+        for (int e = 3 * pg; e < npairs; ++e) {
             const unsigned ent = g_border_pairs[c][1 + e];
             const int sy = qy + (int)((ent >> 4) & 3u) - 1, sx = qx + (int)((ent >> 6) & 3u) - 1;
             const bool sv = pv && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
@@ -1290,8 +1293,9 @@ __global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
                     int nl = n0;
                     TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
                     float* dst = optr + opx * ostride + ooff + nl;
-                    if (S > 1) {
-                        // the dy channels of this pixel are split over S waves: hardware float adds (a few thousand border pixels)
+                    if (S > 1 || v >= 4) {
+                        // the dy channels (or, at a corner, the pairs) of this pixel are split over several waves: hardware float adds
+                        // (a few thousand border pixels)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + r, acc[n][r] * osc);
                     } else {
@@ -1940,9 +1944,9 @@ extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, c
     if (p.H == 1 && p.W == 1) p.nborder = 1;
     else if (p.H == 1) p.nborder = p.W;
     else p.nborder = 2 * p.W + (p.W > 1 ? 2 : 1) * (p.H - 2);
-    // matrix-core path: images with an interior (H, W >= 2), float4-addressable dy and dx segments, <= 6 channel tiles
+    // matrix-core path: images with an interior (H, W >= 2), float4-addressable dy and dx segments, <= 8 channel tiles
     bool mf = p.H >= 2 && p.W >= 2 && (p.Cdy & 3) == 0 && (((p.dy_stride | p.dy_off) & 3) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
-              (p.Cx & 3) == 0 && p.Npad <= 96;
+              (p.Cx & 3) == 0 && p.Npad <= 128;
     for (int i = 0; i < (int)nout; ++i)
         if (((p.out[i].stride | p.out[i].off | p.out[i].n) & 3) || (((uintptr_t)p.out[i].p) & 15)) mf = false;
     static const int no_mf = getenv("TMG_BORDER_SCALAR") ? 1 : 0;
@@ -1951,12 +1955,13 @@ extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, c
         m.b = p;
         const int cnt[8] = {p.H - 2, p.H - 2, p.W - 2, p.W - 2, 1, 1, 1, 1};
         int t0 = 0;
-        for (int c = 0; c < 8; ++c) {
+        for (int v = 0; v < 16; ++v) {
+            const int c = v < 4 ? v : 4 + (v - 4) / 3;
             m.cnt[c] = cnt[c] > 0 ? cnt[c] : 1;
-            m.tile0[c] = t0;
+            m.tile0[v] = t0;
             t0 += cnt[c] > 0 ? (p.B * cnt[c] + 15) / 16 : 0;
         }
-        m.tile0[8] = t0;
+        m.tile0[16] = t0;
         // enough waves to fill the chip: split the dy channels of a tile over several waves when there are few tiles
         int S = (4096 + t0 - 1) / t0;
         if (S > p.KB / 4) S = p.KB / 4;
@@ -1970,7 +1975,9 @@ extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, c
             case 3: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<3>, dim3(blocks), dim3(256), 0, st, m); break;
             case 4: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<4>, dim3(blocks), dim3(256), 0, st, m); break;
             case 5: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<5>, dim3(blocks), dim3(256), 0, st, m); break;
-            default: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<6>, dim3(blocks), dim3(256), 0, st, m); break;
+            case 6: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<6>, dim3(blocks), dim3(256), 0, st, m); break;
+            case 7: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<7>, dim3(blocks), dim3(256), 0, st, m); break;
+            default: hipLaunchKernelGGL(conv_rep_border_mfma_kernel<8>, dim3(blocks), dim3(256), 0, st, m); break;
         }
         TMG_CHECK_LAUNCH();
         return 0;
