@@ -1709,7 +1709,17 @@ __global__ __launch_bounds__(256) void lu_fold_fwd_kernel(LuFoldP p, double* __r
         // row r of lower times column j of upper: terms q < min(r, j) are plain products, the last one involves a unit / diagonal entry
         const int kmin = min(r, j);
         double acc = r < j ? (double)u[r * C + j] : (r == j ? diag[j] : (double)l[r * C + j] * diag[j]);
-        for (int q = 0; q < kmin; ++q) acc = fma((double)l[r * C + q], (double)u[q * C + j], acc);
+        // four partial sums: one fma chain of up to C terms with a global load per term is a chain of exposed latencies
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int q = 0;
+        for (; q + 4 <= kmin; q += 4) {
+            acc = fma((double)l[r * C + q], (double)u[q * C + j], acc);
+            a1 = fma((double)l[r * C + q + 1], (double)u[(q + 1) * C + j], a1);
+            a2 = fma((double)l[r * C + q + 2], (double)u[(q + 2) * C + j], a2);
+            a3 = fma((double)l[r * C + q + 3], (double)u[(q + 3) * C + j], a3);
+        }
+        for (; q < kmin; ++q) acc = fma((double)l[r * C + q], (double)u[q * C + j], acc);
+        acc = (acc + a1) + (a2 + a3);
         W[((size_t)k * C + i) * C + j] = acc;       // fp64 copy of W = P L U for the backward launch
         Wm[((size_t)k * C + i) * C + j] = (float)(acc * (p.reverse ? sa[i] : sa[j]));
     }
@@ -1770,7 +1780,9 @@ __global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const doubl
     const float* dbk = tail ? dbt : (dbm ? dbm + (size_t)k * C : nullptr);
     const double g = dld ? (double)dld[0] : 0.0;
     __shared__ double diag[256], sa[256], sb[256], sdb[256];
+    __shared__ int sip[256];      // the inverse permutation: read per term of the upper-factor sums (a dependent global load otherwise)
     for (int i = threadIdx.x; i < C; i += 256) {
+        sip[i] = iperm[i];
         diag[i] = exp((double)ls[i]) * (double)sg[i] + 0.01;
         sa[i] = a ? (p.reverse ? 1.0 / (double)a[i] : (double)a[i]) : 1.0;
         sb[i] = (!p.reverse && b && dbk) ? (double)b[i] : 0.0;
@@ -1783,14 +1795,32 @@ __global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const doubl
         const int x = e / C, y = e - x * C;
         double vl = 0.0, vu = 0.0;
         if (x > y) {
-            // dlower[x][y] = sum_j M[x][j] upper[y][j], M = P^T dW: M[x][j] = dW[iperm[x]][j]; upper[y][j] = 0 for j < y
-            const int i = iperm[x];
+            // dlower[x][y] = sum_j M[x][j] upper[y][j], M = P^T dW: M[x][j] = dW[sip[x]][j]; upper[y][j] = 0 for j < y
+            const int i = sip[x];
             vl = TMG_LU_DW(i, y) * diag[y];
-            for (int j = y + 1; j < C; ++j) vl = fma(TMG_LU_DW(i, j), (double)u[y * C + j], vl);
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;   // four partial sums (see the forward kernel)
+            int j = y + 1;
+            for (; j + 4 <= C; j += 4) {
+                vl = fma(TMG_LU_DW(i, j), (double)u[y * C + j], vl);
+                v1 = fma(TMG_LU_DW(i, j + 1), (double)u[y * C + j + 1], v1);
+                v2 = fma(TMG_LU_DW(i, j + 2), (double)u[y * C + j + 2], v2);
+                v3 = fma(TMG_LU_DW(i, j + 3), (double)u[y * C + j + 3], v3);
+            }
+            for (; j < C; ++j) vl = fma(TMG_LU_DW(i, j), (double)u[y * C + j], vl);
+            vl = (vl + v1) + (v2 + v3);
         } else {
             // dupper[x][y] = sum_r lower[r][x] M[r][y]; lower[r][x] = 0 for r < x
-            vu = TMG_LU_DW(iperm[x], y);
-            for (int r = x + 1; r < C; ++r) vu = fma((double)l[r * C + x], TMG_LU_DW(iperm[r], y), vu);
+            vu = TMG_LU_DW(sip[x], y);
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int r = x + 1;
+            for (; r + 4 <= C; r += 4) {
+                vu = fma((double)l[r * C + x], TMG_LU_DW(sip[r], y), vu);
+                v1 = fma((double)l[(r + 1) * C + x], TMG_LU_DW(sip[r + 1], y), v1);
+                v2 = fma((double)l[(r + 2) * C + x], TMG_LU_DW(sip[r + 2], y), v2);
+                v3 = fma((double)l[(r + 3) * C + x], TMG_LU_DW(sip[r + 3], y), v3);
+            }
+            for (; r < C; ++r) vu = fma((double)l[r * C + x], TMG_LU_DW(sip[r], y), vu);
+            vu = (vu + v1) + (v2 + v3);
         }
         dl[((size_t)k * C + x) * C + y] = (float)vl;
         du[((size_t)k * C + x) * C + y] = x < y ? (float)vu : 0.f;
@@ -1804,13 +1834,29 @@ __global__ __launch_bounds__(256) void lu_fold_bwd_kernel(LuFoldP p, const doubl
             if (a) {
                 if (p.reverse) {
                     // Wm = W / a_i, bm = -b_i / a_i
-                    double s = 0.0;
-                    for (int j = 0; j < C; ++j) s = fma((double)dWk[i * C + j], Wk[i * C + j], s);
+                    double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    int j = 0;
+                    for (; j + 4 <= C; j += 4) {
+                        s = fma((double)dWk[i * C + j], Wk[i * C + j], s);
+                        s1 = fma((double)dWk[i * C + j + 1], Wk[i * C + j + 1], s1);
+                        s2 = fma((double)dWk[i * C + j + 2], Wk[i * C + j + 2], s2);
+                        s3 = fma((double)dWk[i * C + j + 3], Wk[i * C + j + 3], s3);
+                    }
+                    for (; j < C; ++j) s = fma((double)dWk[i * C + j], Wk[i * C + j], s);
+                    s = (s + s1) + (s2 + s3);
                     va = -s / (ai * ai) + ((dbk && b) ? (double)dbk[i] * (double)b[i] / (ai * ai) : 0.0) + g * (double)p.hw / ai;
                 } else {
                     // Wm = W a_j: da_j = sum_i dWm[i][j] W[i][j]   (index i of this thread plays the role of j)
-                    double s = 0.0;
-                    for (int r = 0; r < C; ++r) s = fma((double)dWk[r * C + i], Wk[r * C + i], s);
+                    double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    int r = 0;
+                    for (; r + 4 <= C; r += 4) {
+                        s = fma((double)dWk[r * C + i], Wk[r * C + i], s);
+                        s1 = fma((double)dWk[(r + 1) * C + i], Wk[(r + 1) * C + i], s1);
+                        s2 = fma((double)dWk[(r + 2) * C + i], Wk[(r + 2) * C + i], s2);
+                        s3 = fma((double)dWk[(r + 3) * C + i], Wk[(r + 3) * C + i], s3);
+                    }
+                    for (; r < C; ++r) s = fma((double)dWk[r * C + i], Wk[r * C + i], s);
+                    s = (s + s1) + (s2 + s3);
                     va = s + g * (double)p.hw / ai;
                 }
             }
