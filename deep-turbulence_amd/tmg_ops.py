@@ -927,11 +927,14 @@ class LevelCouplingFn(torch.autograd.Function):
             mix_wg = None
         # conditioning side of the whole level: one input-gradient pass, three weight-gradient passes
         Gc = torch.empty(cond.shape, device=dev, dtype=torch.float32)
-        wzc_t = H.conv3x3_auto([DH], Wzc, Cc, [Gc], dgrad=True)
-        H.conv_rep_border_fix(DH, wzc_t if wzc_t is not None else H.conv_pack(Wzc, 1), [Gc])
-        Wd4 = zeros((4 * NL, Cc, 3, 3), dev)   # rows 4k / 4k+1: cond columns of w1_k / w2_k
-        Wd4.view(NL, 4, Cc, 3, 3)[:, :2] = Wdc.view(NLp, 2, Cc, 3, 3)[:NL]
-        H.conv_fwd([DD], H.conv_pack(Wd4, 1), Cc, 3, 1, [Gc], accumulate=True)
+        # zero-conv part (dy = DH) and growth-layer part (dy = DD) of d(cond) as ONE contraction over [DH | DD] (K = NL (C + 4)): the
+        # padding mode of the forward convs does not enter the interior of an input gradient, the replicate fold below adds the ring
+        # terms of the zero convs alone (operand of Wzc by itself)
+        Wcat = zeros((NL * C + 4 * NL, Cc, 3, 3), dev)   # rows NL C + 4k / + 4k+1: cond columns of w1_k / w2_k
+        Wcat[:NL * C] = Wzc
+        Wcat[NL * C:].view(NL, 4, Cc, 3, 3)[:, :2] = Wdc.view(NLp, 2, Cc, 3, 3)[:NL]
+        H.conv3x3_auto([DH, DD], Wcat, Cc, [Gc], dgrad=True)
+        H.conv_rep_border_fix(DH, H.conv_pack(Wzc, 1), [Gc])
         H.masked_add(Gc, src=Gc, ref=cond)
         H.conv_wgrad([cond], DH, dWz, None, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=Cc, ci_off0=ch)
         tmpC = zeros((NL, 4, Cc, 3, 3), dev)   # one launch for both growth layers of all layers
