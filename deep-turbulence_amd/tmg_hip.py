@@ -394,7 +394,7 @@ def conv_wgrad(inputs, dy, dW, dbias, ksize, stride, kappa=None, in_scale=None, 
     ip, idesc, n_in = _segs(inputs)
     Cin = sum(t.shape[3] for t in inputs)
     if (ksize == 3 and stride == 1 and kappa is None and in_scale is None and use_ws and Cin >= 32
-            and (os.environ.get("TMG_WINO_WGRAD_ALL") is not None or Cout >= 128 or (Cout >= 32 and Cin >= 64 and B * Hin * Win >= (1 << 20)))
+            and (os.environ.get("TMG_WINO_WGRAD_ALL") is not None or Cout >= 128 or (Cout >= 32 and Cin >= int(os.environ.get("TMG_WW_CIN_MIN", 32)) and B * Hin * Win >= int(os.environ.get("TMG_WW_PIX_MIN", 1 << 20))))
             and os.environ.get("TMG_NO_WINOGRAD") is None and os.environ.get("TMG_NO_WINOGRAD_WGRAD") is None
             # Winograd F(3x3, 2x2), 2.25x fewer matrix-core operations.  Measured per call site at config M: it wins wherever the
             # contraction is matrix-pipe bound (many output channels, or many pixels x input channels) and loses to the direct kernel
