@@ -1177,6 +1177,151 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
     }
 }
 
+// The same backward WITHOUT the weight gradients (the level node computes those with the grouped 4x4x1-MFMA kernel) for the shape the
+// level node calls it with: inputs = (x1 [cin_nn channels], D), one G0 / output segment, everything float4-addressable.  No patch is
+// staged: the only use of the inputs here is the ReLU mask of the thread's OWN pixel, read straight from x1; a block owns NQ channel
+// quads (blockIdx.y) and prefetches mask, upstream gradient and add operand of its pixel for all of them before the two barriers.
+// The general kernel above needs 193 VGPRs (two blocks per CU: SQ counters show its waves 52 % of their life in s_waitcnt, 30 %
+// issuing); this one is built for four waves per SIMD.
+// (TWL = log2 of the tile width as a template parameter: with the patch widths known at compile time every tap of the two stencils is
+// an immediate offset from one LDS address per thread; with a run-time width the compiler hoists ~50 tap addresses out of the tile
+// loop and spills.)
+template <int NQ, int TWL>
+__global__ __launch_bounds__(256, NQ <= 2 ? 4 : 3) void dense2_bwd_lean_kernel(D2BP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    constexpr int TWl = TWL, TW = 1 << TWl, TH = 256 >> TWl;
+    constexpr int PW = TW + 2, PH = TH + 2, QW = TW + 4, QH = TH + 4;
+    const int row = tid >> TWl, col = tid & (TW - 1);
+    constexpr int KC = 4 * NQ;
+    const int c0 = blockIdx.y * KC;
+    float* A2 = lds;                              // [QH*QW] dd2m, halo 2
+    float* A1 = A2 + ((QH * QW + 3) & ~3);        // [PH*PW] dd1m, halo 1
+    float* lw1 = A1 + ((PH * PW + 3) & ~3);       // [9][KC]
+    float* lw2 = lw1 + 9 * KC;                    // [9][KC]
+    float w2d[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w2d[t] = p.w2[(size_t)(p.cin_nn + (p.cin_nn < p.split2 ? 0 : p.gap2)) * 9 + t];
+    for (int i = tid; i < 9 * KC; i += 256) {
+        const int tap = i / KC, c = c0 + (i - tap * KC);
+        lw1[i] = (c < p.cin_nn && c < p.rows1) ? p.w1[(size_t)c * 9 + tap] : 0.f;
+        lw2[i] = (c < p.cin_nn && c < p.rows2) ? p.w2[(size_t)(c + (c < p.split2 ? 0 : p.gap2)) * 9 + tap] : 0.f;
+    }
+    // Addresses are a block-uniform base (scalar registers) + a 32-bit BYTE offset per lane (the launcher checks that every tensor
+    // stays below 4 GB): 64-bit per-lane pointers for the ~20 loads issued up front were what filled the register file.  Lanes with
+    // nothing to read load a valid clamped address and drop the value.
+    const char* xb = reinterpret_cast<const char*>(p.in[0].p + p.in[0].off + c0);
+    const char* gb = reinterpret_cast<const char*>(p.g0[0].p + p.g0[0].off + c0);
+    char* ob = reinterpret_cast<char*>(p.out[0].p + p.out[0].off + c0);
+    const char* ab = reinterpret_cast<const char*>(p.add0 ? p.add0 + c0 : tmg_zero_page);
+    const unsigned xs4 = 4u * (unsigned)p.in[0].stride, gs4 = 4u * (unsigned)p.g0[0].stride, os4 = 4u * (unsigned)p.out[0].stride;
+    const unsigned as4 = p.add0 ? 4u * (unsigned)p.add0_stride : 0u, gds4 = 4u * (unsigned)p.gd_stride, ds4 = 4u * (unsigned)p.d_stride;
+    const char* gdb = reinterpret_cast<const char*>(p.GD);
+    const char* dpb = reinterpret_cast<const char*>(p.Dp);
+    const int nq_here = min(NQ, (p.cin_nn - c0) >> 2);     // live channel quads of this block (block-uniform)
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        const int b = t / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        const int oy = oy0 + row, ox = ox0 + col;
+        const bool own = oy < p.Hin && ox < p.Win;
+        const unsigned opix = ((unsigned)b * (unsigned)p.Hin + (unsigned)min(oy, p.Hin - 1)) * (unsigned)p.Win + (unsigned)min(ox, p.Win - 1);
+        // all global loads of the tile up front, branch-free (lanes with nothing to read load the zero page)
+        float a2g[2], a2d[2], a1g[2], a1d[2];
+        bool a2in[2], a1in[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            {
+                const int py = i / QW, px = i - py * QW;
+                const int y = oy0 - 2 + py, x = ox0 - 2 + px;
+                a2in[u] = i < QH * QW && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+                const unsigned pix = ((unsigned)b * (unsigned)p.Hin + (unsigned)min(max(y, 0), p.Hin - 1)) * (unsigned)p.Win + (unsigned)min(max(x, 0), p.Win - 1);
+                a2g[u] = *reinterpret_cast<const float*>(gdb + (pix * gds4 + 4u));
+                a2d[u] = *reinterpret_cast<const float*>(dpb + (pix * ds4 + 4u));
+            }
+            {
+                const int py = i / PW, px = i - py * PW;
+                const int y = oy0 - 1 + py, x = ox0 - 1 + px;
+                a1in[u] = i < PH * PW && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+                const unsigned pix = ((unsigned)b * (unsigned)p.Hin + (unsigned)min(max(y, 0), p.Hin - 1)) * (unsigned)p.Win + (unsigned)min(max(x, 0), p.Win - 1);
+                a1g[u] = *reinterpret_cast<const float*>(gdb + pix * gds4);
+                a1d[u] = *reinterpret_cast<const float*>(dpb + pix * ds4);
+            }
+        }
+        float4 mq[NQ], gq[NQ], aq[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const unsigned cj = 16u * (unsigned)min(j, nq_here - 1);     // a quad past the end re-reads the last live one (never stored)
+            mq[j] = *reinterpret_cast<const float4*>(xb + (opix * xs4 + cj));
+            gq[j] = *reinterpret_cast<const float4*>(gb + (opix * gs4 + cj));
+            aq[j] = *reinterpret_cast<const float4*>(ab + (opix * as4 + (p.add0 ? cj : 0u)));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            if (i < QH * QW) A2[i] = (a2in[u] && a2d[u] > 0.f) ? a2g[u] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            if (i < PH * PW) {
+                const int py = i / PW, px = i - py * PW;
+                float v = 0.f;
+                if (a1in[u] && a1d[u] > 0.f) {
+                    v = a1g[u];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int ky = tap / 3, kx = tap - ky * 3;
+                        v += w2d[tap] * A2[(py + 2 - ky) * QW + px + 2 - kx];
+                    }
+                }
+                A1[i] = v;
+            }
+        }
+        __syncthreads();
+        if (p.dd1_out && blockIdx.y == 0 && own) {
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.dd1_out) + opix * (4u * (unsigned)p.dd_stride)) =
+                make_float4(A1[(row + 1) * PW + col + 1], A2[(row + 2) * QW + col + 2], 0.f, 0.f);   // no zero fill of the stash needed
+        }
+        if (own) {
+            float n1[9], n2[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                n1[tap] = A1[(row + 2 - ky) * PW + col + 2 - kx];
+                n2[tap] = A2[(row + 3 - ky) * QW + col + 3 - kx];
+            }
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (j < nq_here) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const float4 a = *reinterpret_cast<const float4*>(lw1 + tap * KC + 4 * j);
+                        const float4 bq = *reinterpret_cast<const float4*>(lw2 + tap * KC + 4 * j);
+                        v.x += a.x * n1[tap] + bq.x * n2[tap];
+                        v.y += a.y * n1[tap] + bq.y * n2[tap];
+                        v.z += a.z * n1[tap] + bq.z * n2[tap];
+                        v.w += a.w * n1[tap] + bq.w * n2[tap];
+                    }
+                    float4 o;
+                    o.x = (mq[j].x > 0.f ? gq[j].x + v.x : 0.f) + aq[j].x;
+                    o.y = (mq[j].y > 0.f ? gq[j].y + v.y : 0.f) + aq[j].y;
+                    o.z = (mq[j].z > 0.f ? gq[j].z + v.z : 0.f) + aq[j].z;
+                    o.w = (mq[j].w > 0.f ? gq[j].w + v.w : 0.f) + aq[j].w;
+                    *reinterpret_cast<float4*>(ob + (opix * os4 + 16u * j)) = o;
+                }
+            }
+        }
+    }
+}
+
 // d(kappa) of a Conv2dZeros from its parameter gradients: h = e^k (W*x + b) is degree-1 homogeneous in (W, b), so
 // sum dh*h = <W, dW> + <b, db>; zero when kappa sits outside the clamp range (flowUtils.py:247).
 __global__ __launch_bounds__(256) void dkappa_kernel(const float* __restrict__ w, const float* __restrict__ dw, int nw,
@@ -1631,6 +1776,25 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
         gx = (p.ntiles + per_blk - 1) / per_blk;
     }
     TmgProf prof(TMG_PROF_D2B, 4.0 * p.B * (double)p.Hin * p.Win * (3.0 * p.cin_nn + 4 + 4 + 4 + 2), st);   // x, G0 read, dx written; D, GD; add0 ~ included in 3 cin
+    static const bool no_lean = getenv("TMG_D2_NO_LEAN") != nullptr;
+    if (!no_lean && !p.dW1 && !p.dW2 && p.vec4 && ng == 1 && p.nseg == 2 && p.in[0].n == p.cin_nn && p.in[1].n == 4 && (p.cin_nn & 3) == 0 &&
+        p.g0[0].n == p.cin_nn && p.dd1_out && p.dd_quad &&
+        (double)p.B * p.Hin * p.Win * 4.0 * (double)std::max(std::max(std::max(p.in[0].stride, p.g0[0].stride), std::max(p.out[0].stride, p.add0_stride)),
+                                                              std::max(std::max(p.gd_stride, p.d_stride), p.dd_stride)) < 4.0e9) {
+        // the level node's call: no staged patch, <= 128 registers (see dense2_bwd_lean_kernel)
+        const int nq = p.cin_nn / 4, NQ = nq <= 2 ? 2 : 4, nch = (nq + NQ - 1) / NQ;
+        int gl = d2_blocks / nch;
+        if (gl < 1) gl = 1;
+        const int per_blk = (p.ntiles + gl - 1) / gl;
+        gl = (p.ntiles + per_blk - 1) / per_blk;
+        const size_t lb = ((size_t)((QQ + 3) & ~3) + ((PP + 3) & ~3) + 18 * 4 * NQ) * 4;
+#define TMG_D2L(NQ_, TWL_) hipLaunchKernelGGL((dense2_bwd_lean_kernel<NQ_, TWL_>), dim3(gl, nch), dim3(256), lb, st, p)
+        if (NQ == 2) { if (p.TW_log2 == 5) TMG_D2L(2, 5); else if (p.TW_log2 == 4) TMG_D2L(2, 4); else TMG_D2L(2, 3); }
+        else { if (p.TW_log2 == 5) TMG_D2L(4, 5); else if (p.TW_log2 == 4) TMG_D2L(4, 4); else TMG_D2L(4, 3); }
+#undef TMG_D2L
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     if (p.dW1) hipLaunchKernelGGL(dense2_bwd_kernel<true>, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
     else hipLaunchKernelGGL(dense2_bwd_kernel<false>, dim3(gx, nchunks), dim3(256), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();

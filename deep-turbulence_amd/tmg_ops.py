@@ -565,10 +565,9 @@ class CouplingTailFn(torch.autograd.Function):
         hh = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
         H.conv_fwd(nn_in + [D], H.conv_pack(wz, 0, cin + 4), C, 3, 1, [hh], bias=bz, kappa=kappa, relu_in=True, pad_rep=True)
         y = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
-        H.masked_add(y[..., :ch], src=x[..., :ch])
         r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
         logdet = zeros(B, dev)
-        H.affine_apply(hh, x[..., ch:], y[..., ch:], r, logdet, reverse)
+        H.affine_apply(hh, x[..., ch:], y[..., ch:], r, logdet, reverse, x1=x[..., :ch], y1=y[..., :ch])   # pass-through half in the same launch
         ctx.reverse, ctx.mode, ctx.cin = reverse, mode, cin
         ctx.save_for_backward(x, aux, D, r, y, w1, w2, wz, bz, kappa)
         return y, logdet
