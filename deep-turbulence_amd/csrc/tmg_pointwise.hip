@@ -518,9 +518,10 @@ __global__ __launch_bounds__(256) void chan_moments_kernel(const float* __restri
 // bn_finalize_kernel on the fp64 moments of chan_moments_kernel: mean = S1 / n, var = S2 / n - mean^2 (biased), evaluated in fp64
 __global__ void bn_finalize64_kernel(const double* __restrict__ acc, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ out, int C, double n, float eps,
-                                     float momentum) {
+                                     float momentum, long long* __restrict__ nbt) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (nbt && c == 0) *nbt += 1;      // nn.BatchNorm2d.num_batches_tracked (a launch of its own otherwise, 16 per step)
     const double m = acc[c] / n;
     double v = acc[C + c] / n - m * m;
     if (v < 0.0) v = 0.0;
@@ -1541,12 +1542,13 @@ extern "C" int tmg_chan_moments(const void* x, const int64_t* x_d, void* acc, co
     return 0;
 }
 
-// dims: [C, n]; fl: {eps, momentum}; acc = the fp64 moments of tmg_chan_moments; otherwise as tmg_bn_finalize
+// dims: [C, n, address of the module's int64 num_batches_tracked counter (0: none; incremented by one)]; fl: {eps, momentum};
+// acc = the fp64 moments of tmg_chan_moments; otherwise as tmg_bn_finalize
 extern "C" int tmg_bn_finalize64(const void* acc, const void* gamma, const void* beta, void* rmean, void* rvar, void* out, const int64_t* dims,
                                  const float* fl, hipStream_t st) {
     const int C = (int)dims[0];
     hipLaunchKernelGGL(bn_finalize64_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)acc, (const float*)gamma, (const float*)beta,
-                       (float*)rmean, (float*)rvar, (float*)out, C, (double)dims[1], fl[0], fl[1]);
+                       (float*)rmean, (float*)rvar, (float*)out, C, (double)dims[1], fl[0], fl[1], reinterpret_cast<long long*>(dims[2]));
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -758,10 +758,14 @@ def chan_moments(x, acc64):
     _chk(lib().tmg_chan_moments(_ptr(x), _d2(x), _ptr(acc64), _i64(B * H * W, C), _stream()), "tmg_chan_moments")
 
 
-def bn_finalize64(acc64, gamma, beta, running_mean, running_var, out, n, eps, momentum):
+def bn_finalize64(acc64, gamma, beta, running_mean, running_var, out, n, eps, momentum, counter=None):
+    """counter: the module's int64 num_batches_tracked tensor (device scalar), incremented by the same launch."""
     C = gamma.numel()
-    _chk(lib().tmg_bn_finalize64(_ptr(acc64), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(out), _i64(C, n),
-                                 _flts([eps, momentum]), _stream()), "tmg_bn_finalize64")
+    if counter is not None:
+        assert counter.dtype == torch.int64 and counter.numel() == 1 and counter.device == gamma.device
+    _chk(lib().tmg_bn_finalize64(_ptr(acc64), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(out),
+                                 _i64(C, n, counter.data_ptr() if counter is not None else 0), _flts([eps, momentum]), _stream()),
+         "tmg_bn_finalize64")
 
 
 def bn_finalize(sums, csq, gamma, beta, running_mean, running_var, out, n, eps, momentum):

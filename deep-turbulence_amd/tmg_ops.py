@@ -282,15 +282,18 @@ def bn_batch_stats(x, bn):
             # one pass: sum and sum of squares in fp64 (no cancellation error in E[x^2] - E[x]^2), the activation is read once
             acc64 = zeros((4 * C,), x.device).view(torch.float64)     # [2][C] doubles out of the pooled zero buffer (256-byte aligned)
             H.chan_moments(x, acc64)
+            nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None and bn.num_batches_tracked.device == x.device) else None
             H.bn_finalize64(acc64, bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
-                            bn.running_var if track else None, out, n, bn.eps, mom)
+                            bn.running_var if track else None, out, n, bn.eps, mom, counter=nbt)
+            if nbt is not None:
+                track = False        # counted by the launch above
         else:
             acc = zeros((4, C), x.device)
             H.chan_reduce(x, None, None, None, None, None, acc[0], acc[1], 0)
             H.chan_reduce(x, None, acc[0], None, None, None, acc[2], acc[3], 0, divisor=n)
             H.bn_finalize(acc[0], acc[3], bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
                           bn.running_var if track else None, out, n, bn.eps, mom)
-        if track:
+        if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
     return out[0], out[2], out[3], out[4]
 

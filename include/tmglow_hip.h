@@ -185,7 +185,8 @@ int tmg_bn_finalize(const void* sum, const void* csq, const void* gamma, const v
                     const int64_t* dims, const float* fl, tmg_stream_t st);
 /* BatchNorm batch moments in one pass (denseBlock.py:49 in training mode): per-channel sum and sum of squares of an NHWC tensor /
  * channel-slice view accumulated in fp64 into acc (double [2][C], zeroed by the caller; dims = {pixels, C}, x_d = {pixel stride, offset}),
- * and the finalize step on those moments (arguments as tmg_bn_finalize). */
+ * and the finalize step on those moments (arguments as tmg_bn_finalize; dims = {C, n, address of the module's int64
+ * num_batches_tracked device scalar or 0: incremented by one in the same launch}). */
 int tmg_chan_moments(const void* x, const int64_t* x_d, void* acc, const int64_t* dims, tmg_stream_t st);
 int tmg_bn_finalize64(const void* acc, const void* gamma, const void* beta, void* rmean, void* rvar, void* out, const int64_t* dims,
                       const float* fl, tmg_stream_t st);
