@@ -1108,6 +1108,40 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// Up to 16 independent packing jobs (different tensors, shapes and modes) in one launch: the jobs travel in the kernel arguments
+// (blockIdx.y selects one: a block-uniform read of the kernarg segment), so there is no device table to upload.  A dense block packs
+// the forward and the input-gradient operands of all its layers with one launch, a plain conv node both of its operands.
+struct PackJob {
+    const float* w; float* wpk;
+    int Cout, Cin, ntaps, Kpad, Npad, mode, cvalid, csplit, cgap;
+};
+struct PackJobs { PackJob j[16]; };
+
+__global__ void conv_pack_many_kernel(PackJobs J) {
+    const PackJob& jb = J.j[blockIdx.y];
+    const float* __restrict__ w = jb.w;
+    float* __restrict__ wpk = jb.wpk;
+    const int Cout = jb.Cout, Cin = jb.Cin, ntaps = jb.ntaps, Kpad = jb.Kpad, Npad = jb.Npad, mode = jb.mode;
+    const int cvalid = jb.cvalid, csplit = jb.csplit, cgap = jb.cgap;
+    const size_t total = (size_t)ntaps * Kpad * Npad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c16 = i & 15;
+        size_t r = i >> 4;
+        const int n = r % Npad;
+        r /= Npad;
+        const int kb = r % (Kpad >> 4);
+        const int tap = r / (Kpad >> 4);
+        const int k = kb * 16 + c16;
+        float v = 0.f;
+        if (mode == 0) {
+            if (k < cvalid && n < Cout) v = w[((size_t)n * Cin + k + (k < csplit ? 0 : cgap)) * ntaps + tap];
+        } else {
+            if (k < Cout && n < cvalid) v = w[((size_t)k * Cin + n + (n < csplit ? 0 : cgap)) * ntaps + (ntaps - 1 - tap)];
+        }
+        wpk[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Replicate-padding input-gradient fix-up.  The main kernel computes the gradient w.r.t. the
 // in-image part of the padded input; the ring of padded pixels folds onto the border pixels:
@@ -1579,6 +1613,31 @@ extern "C" int tmg_conv_pack_batched(const void* w, void* wpk, int64_t nbatch, i
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, (unsigned)nbatch), dim3(256), 0, st, (const float*)w, (float*)wpk, (int)Cout, (int)Cin, ntaps,
                        Kpad, Npad, (int)mode, (int)map[0], (int)map[1], (int)map[2], (size_t)(Cout * Cin * ntaps), total);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// njobs <= 16 packing jobs in one launch.  w / wpk: the source / destination pointer of every job; jobs: njobs x
+// {Cout, Cin, cin_eff, ksize, mode, cvalid, csplit, cgap} with the meaning of tmg_conv_pack_map (cvalid = Cin, csplit = INT_MAX, cgap = 0:
+// the identity map of tmg_conv_pack).
+extern "C" int tmg_conv_pack_many(const void* const* w, void* const* wpk, const int64_t* jobs, int64_t njobs, hipStream_t st) {
+    if (njobs < 1 || njobs > 16) return -3;
+    PackJobs J;
+    size_t maxtot = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int s_ = i < (int)njobs ? i : 0;     // unused slots repeat job 0 (never selected: gridDim.y = njobs)
+        const int64_t* d = jobs + 8 * s_;
+        const int Cout = (int)d[0], Cin = (int)d[1], ce = (int)d[2], ks = (int)d[3], mode = (int)d[4];
+        const int K = mode == 0 ? ce : Cout, N = mode == 0 ? Cout : ce;
+        PackJob& jb = J.j[i];
+        jb.w = (const float*)w[s_]; jb.wpk = (float*)wpk[s_];
+        jb.Cout = Cout; jb.Cin = Cin; jb.ntaps = ks * ks; jb.Kpad = (K + 15) & ~15; jb.Npad = (N + 15) & ~15; jb.mode = mode;
+        jb.cvalid = (int)d[5]; jb.csplit = (int)d[6]; jb.cgap = (int)d[7];
+        const size_t tot = (size_t)jb.ntaps * jb.Kpad * jb.Npad;
+        if (i < (int)njobs && tot > maxtot) maxtot = tot;
+    }
+    const int blocks = (int)((maxtot + 255) / 256 < 512 ? (maxtot + 255) / 256 : 512);
+    hipLaunchKernelGGL(conv_pack_many_kernel, dim3(blocks < 1 ? 1 : blocks, (unsigned)njobs), dim3(256), 0, st, J);
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -35,7 +35,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many",
 ]
 
 
@@ -212,6 +212,36 @@ def conv_pack(w, mode, cin_eff=0, cmap=None):
     wpk = torch.empty(k * k * Kp * Np, device=w.device, dtype=torch.float32)
     _chk(lib().tmg_conv_pack(_ptr(w), _ptr(wpk), c_i64(Cout), c_i64(Cin), c_i64(ce), c_i64(k), c_i64(mode), _stream()), "tmg_conv_pack")
     return wpk
+
+
+def conv_pack_many(jobs):
+    """jobs: list of (w, mode) or (w, mode, cin_eff, cmap) as conv_pack takes them -> list of packed operands, <= 16 jobs per launch
+    (tmg_conv_pack_many).  All operands of a call live in one allocation."""
+    outs = []
+    for g0 in range(0, len(jobs), 16):
+        grp = [tuple(j) + (0, None)[len(j) - 2:] for j in jobs[g0:g0 + 16]]
+        desc, sizes, ws = [], [], []
+        for w, mode, cin_eff, cmap in grp:
+            check_act(w)
+            assert w.is_contiguous()
+            Cout, Cin, k, _ = w.shape
+            ce = int(cin_eff) if cmap is not None else max(int(cin_eff), Cin)
+            K, N = (ce, Cout) if mode == 0 else (Cout, ce)
+            Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
+            m = cmap if cmap is not None else (Cin, 0x7fffffff, 0)
+            desc += [Cout, Cin, ce, k, mode, m[0], m[1], m[2]]
+            sizes.append(k * k * Kp * Np)
+            ws.append(w)
+        flat = torch.empty(sum(sizes), device=ws[0].device, dtype=torch.float32)
+        views, o = [], 0
+        for n_ in sizes:
+            views.append(flat[o:o + n_])
+            o += n_
+        wp = (c_vp * len(ws))(*[w.data_ptr() for w in ws])
+        op = (c_vp * len(ws))(*[v.data_ptr() for v in views])
+        _chk(lib().tmg_conv_pack_many(wp, op, _i64(*desc), c_i64(len(ws)), _stream()), "tmg_conv_pack_many")
+        outs += views
+    return outs
 
 
 def conv_pack_batched(w, mode, cin_eff=0, cmap=None):

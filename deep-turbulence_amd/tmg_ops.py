@@ -215,6 +215,9 @@ class DenseBlockFn(torch.autograd.Function):
         growth = [params[3 * i + 2].shape[0] for i in range(L)]
         buf = torch.empty((B, Hh, Ww, c0 + sum(growth)), device=x.device, dtype=torch.float32)
         H.masked_add(buf[..., :c0], src=x)
+        # forward and input-gradient operands of all L layers in one launch per 16 (one pack launch per layer and direction otherwise)
+        ws = [params[3 * i + 2].contiguous() for i in range(L)]
+        packs = H.conv_pack_many([(w, 0) for w in ws] + [(w, 1) for w in ws])
         stats, use_batch, c = [], [], c0
         for i in range(L):
             gamma, beta, weight = params[3 * i:3 * i + 3]
@@ -228,11 +231,12 @@ class DenseBlockFn(torch.autograd.Function):
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
                 a = gamma.detach() * rstd
                 bsh = beta.detach() - mean * a
-            H.conv_fwd([xin], H.conv_pack(weight, 0), growth[i], 3, 1, [buf[..., c:c + growth[i]]], in_scale=a, in_shift=bsh, relu_in=True)
+            H.conv_fwd([xin], packs[i], growth[i], 3, 1, [buf[..., c:c + growth[i]]], in_scale=a, in_shift=bsh, relu_in=True)
             stats.append((mean, rstd, a, bsh))
             c += growth[i]
         ctx.meta = (L, c0, growth, use_batch)
         ctx.stats = stats
+        ctx.packs_t = packs[L:]
         ctx.save_for_backward(buf, *params)
         return buf
 
@@ -255,7 +259,7 @@ class DenseBlockFn(torch.autograd.Function):
             dW = zeros_like(weight)
             H.conv_wgrad([xin], dy, dW, None, 3, 1, in_scale=a, in_shift=bsh, relu_in=True)
             G = torch.empty((B, Hh, Ww, c), device=buf.device, dtype=torch.float32)
-            H.conv_fwd([dy], H.conv_pack(weight, 1), c, 3, 1, [G])
+            H.conv_fwd([dy], ctx.packs_t[i], c, 3, 1, [G])
             s = zeros((3, c), buf.device)   # sums of du, du*xhat, and a zero row for the eval-mode call
             H.chan_reduce(xin, G, a, bsh, mean, rstd, s[0], s[1], 1)
             if use_batch[i]:
@@ -264,6 +268,7 @@ class DenseBlockFn(torch.autograd.Function):
                 H.bn_bwd_apply(xin, G, a, bsh, mean, rstd, gamma, s[2], s[2], dbuf[..., :c], True)
             grads[3 * i:3 * i + 3] = [s[1], s[0], dW]
         ctx.stats = None
+        ctx.packs_t = None
         return (dbuf[..., :c0], None, None) + tuple(grads)
 
 
