@@ -59,10 +59,11 @@ class ResidLSTMBlock(nn.Module):
         self.out_seq.add_module('LSTM_out_conv', nn.Conv2d(in_channels=hidden_dim + input_dim, out_channels=output_dim,
                                                            kernel_size=3, padding=1, stride=1))
 
-    def run(self, inputs, state):
+    def run(self, inputs, state, out_grad_premasked=False):
+        """out_grad_premasked: see tmg_ops.conv (the LSTM coupling layer's tail masks the gradient it sends back by [out > 0])."""
         h_next, c_next = self.convLSTM.run(inputs, state)
         oc = self.out_seq.LSTM_out_conv
-        out = ops.conv(list(inputs) + [h_next], oc.weight, oc.bias, relu_out=True)
+        out = ops.conv(list(inputs) + [h_next], oc.weight, oc.bias, relu_out=True, grad_premasked=out_grad_premasked)
         return out, h_next, c_next
 
     def forward(self, input_tensor, cur_state=None):

@@ -77,7 +77,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, bias, kappa, opts, *inputs):
-        ksize, stride, relu_in, pad_rep, relu_out = opts
+        ksize, stride, relu_in, pad_rep, relu_out = opts[:5]
         inputs = tuple(t if t.stride(3) == 1 else t.contiguous() for t in inputs)
         B, Hin, Win, _ = inputs[0].shape
         Cout = weight.shape[0]
@@ -97,11 +97,12 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        ksize, stride, relu_in, pad_rep, relu_out = ctx.opts
+        ksize, stride, relu_in, pad_rep, relu_out = ctx.opts[:5]
+        premasked = len(ctx.opts) > 5 and ctx.opts[5]
         weight, bias, kappa, out = ctx.saved_tensors[:4]
         inputs = ctx.saved_tensors[4:]
         dout = dout.contiguous()
-        if relu_out:
+        if relu_out and not premasked:
             dy = torch.empty_like(dout)
             H.masked_add(dy, src=dout, ref=out)
         else:
@@ -152,8 +153,11 @@ class ConvFn(torch.autograd.Function):
         return (dW, db, dk, None) + tuple(dins)
 
 
-def conv(inputs, weight, bias=None, kappa=None, ksize=3, stride=1, relu_in=False, pad_rep=False, relu_out=False):
-    return ConvFn.apply(weight, bias, kappa, (ksize, stride, relu_in, pad_rep, relu_out), *inputs)
+def conv(inputs, weight, bias=None, kappa=None, ksize=3, stride=1, relu_in=False, pad_rep=False, relu_out=False, grad_premasked=False):
+    """grad_premasked (with relu_out): the caller guarantees that the gradient arriving at the output is already zero wherever the
+    output is (every consumer applies relu to it and masks its input gradient by [out > 0], as CouplingTailFn does): the backward pass
+    then skips its own mask pass over the gradient - the same values, one full-tensor launch less."""
+    return ConvFn.apply(weight, bias, kappa, (ksize, stride, relu_in, pad_rep, relu_out, bool(grad_premasked and relu_out)), *inputs)
 
 
 class BNReLUConvFn(torch.autograd.Function):
