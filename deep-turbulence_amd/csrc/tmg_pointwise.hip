@@ -151,7 +151,7 @@ __global__ void lstm_pointwise_bwd_kernel(float* __restrict__ acts, const float*
         gp[R] = dc * cp * gf * (1.f - gf);
         gp[2 * R] = dhv * tc * go * (1.f - go);
         gp[3 * R] = dc * gi * (1.f - gg * gg);
-        dc_prev[pix * R + j] = dc * gf;
+        if (dc_prev) dc_prev[pix * R + j] = dc * gf;     // null: the previous cell state carries no gradient (nothing to write)
     }
 }
 
@@ -1413,7 +1413,7 @@ extern "C" int tmg_lstm_pointwise_bwd(void* acts, const void* c_prev, const int6
                                       const void* dc_in, void* dc_prev, const int64_t* dims, hipStream_t st) {
     const size_t npix = (size_t)dims[0];
     const int R = (int)dims[1];
-    TmgProf prof(TMG_PROF_LSTMB, 4.0 * (double)npix * R * (8 + (c_prev ? 1 : 0) + 1 + (dh ? 1 : 0) + (dc_in ? 1 : 0) + 1), st);
+    TmgProf prof(TMG_PROF_LSTMB, 4.0 * (double)npix * R * (8 + (c_prev ? 1 : 0) + 1 + (dh ? 1 : 0) + (dc_in ? 1 : 0) + (dc_prev ? 1 : 0)), st);
     hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (float*)acts, (const float*)c_prev,
                        (int)cprev_d[0], (int)cprev_d[1], (const float*)c_next, (const float*)dh, (const float*)dc_in, (float*)dc_prev, R,
                        npix);

@@ -418,7 +418,8 @@ class ConvLSTMCellFn(torch.autograd.Function):
         ctx.consumed = True
         weight, bias, h_cur, c_cur, acts, c_next = ctx.saved_tensors[:6]
         inputs = ctx.saved_tensors[6:]
-        dc_prev = torch.empty_like(c_next)
+        # (weight, bias, h_cur, c_cur, *inputs): the previous cell state's gradient is only written when someone asks for it
+        dc_prev = torch.empty_like(c_next) if (ctx.has_c and ctx.needs_input_grad[3]) else None
         H.lstm_pointwise_bwd(acts, c_cur, c_next, dh.contiguous() if dh is not None else None,
                              dc.contiguous() if dc is not None else None, dc_prev)
         dg = acts  # now the pre-activation gate gradients

@@ -148,7 +148,8 @@ int tmg_affine_bwd_scaled(const void* gout, const int64_t* go_d, const void* yre
 
 /* ConvLSTM gates (convLSTM.py:76-83): gates [npix][4R] pre-activation in order i,f,o,g.  The forward call only READS them
  * (c_next, h_next out); the backward call takes the same pre-activation tensor as `acts`, evaluates the gate activations on it
- * again and overwrites it in place with the pre-activation gradients.  dims = {npix, R} */
+ * again and overwrites it in place with the pre-activation gradients; dh, dc_in and dc_prev may each be null (no gradient arriving /
+ * none wanted for the previous cell state).  dims = {npix, R} */
 int tmg_lstm_pointwise_fwd(void* gates, const void* c_prev, const int64_t* cprev_d, void* c_next, void* h_next,
                            const int64_t* dims, tmg_stream_t st);
 int tmg_lstm_pointwise_bwd(void* acts, const void* c_prev, const int64_t* cprev_d, const void* c_next, const void* dh,
