@@ -897,3 +897,61 @@ def test_dense_block_node_matches_per_layer_path(training):
         _close(a[2][k], b[2][k].double(), tol=2e-5, what=k)
     for k in b[3]:
         assert torch.allclose(a[3][k].float(), b[3][k].float(), rtol=1e-6, atol=1e-7), k
+
+
+def test_conv_pack_many_matches_single_packs():
+    """tmg_conv_pack_many (<= 16 jobs per launch through the kernel arguments; more jobs = more launches) against tmg_conv_pack /
+    tmg_conv_pack_map job by job: mixed shapes, both modes, a zero-extended and a re-mapped input-channel dimension."""
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(21)
+    ws = [torch.randn(co, ci, k, k, generator=g).to(DEV) for co, ci, k in
+          [(8, 20, 3), (4, 36, 3), (64, 64, 1), (17, 5, 3), (32, 44, 3), (6, 12, 3), (16, 16, 1), (40, 104, 3), (12, 8, 3)]]
+    jobs = []
+    for w in ws:
+        jobs += [(w, 0), (w, 1)]
+    jobs += [(ws[0], 0, 24), (ws[4], 0, 16, (12, 8, 30)), (ws[4], 1, 16, (12, 8, 30)), (ws[7], 1, 44, (40, 8, 60))]
+    assert len(jobs) > 16                        # two launches
+    got = H.conv_pack_many(jobs)
+    assert len(got) == len(jobs)
+    for j, pk in zip(jobs, got):
+        ref = H.conv_pack(*j)
+        assert pk.shape == ref.shape and torch.equal(pk, ref), j[1:]
+
+
+def test_conv_node_with_premasked_output_gradient():
+    """ops.conv(relu_out=True, grad_premasked=True): with an upstream gradient that is already zero wherever the output is, the
+    backward pass without its own mask launch returns the gradients of the masked form bit for bit."""
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(5)
+    x = _nhwc(torch.randn(2, 8, 9, 11, generator=g))
+    w = (0.3 * torch.randn(12, 8, 3, 3, generator=g)).to(DEV)
+    b = torch.randn(12, generator=g).to(DEV)
+    res = []
+    for pre in (False, True):
+        xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv([xi], wi, bi, relu_out=True, grad_premasked=pre)
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(DEV) * (y.detach() > 0)     # the consumer's mask
+        y.backward(up)
+        res.append((y.detach(), xi.grad, wi.grad, bi.grad))
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)
+    assert float((res[0][0] == 0).float().mean()) > 0.2          # the ReLU really clipped something
+
+
+def test_lstm_pointwise_backward_without_cell_state_gradient():
+    """tmg_lstm_pointwise_bwd with dc_prev = NULL (the previous cell state carries no gradient): the gate gradients are those of the
+    call that also writes dc_prev."""
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(8)
+    B, Hh, Ww, R = 2, 5, 6, 8
+    gates = torch.randn(B, Hh, Ww, 4 * R, generator=g).to(DEV)
+    c_prev = torch.randn(B, Hh, Ww, R, generator=g).to(DEV)
+    dh = torch.randn(B, Hh, Ww, R, generator=g).to(DEV)
+    dc = torch.randn(B, Hh, Ww, R, generator=g).to(DEV)
+    c_next, h_next = torch.empty_like(c_prev), torch.empty_like(c_prev)
+    H.lstm_pointwise_fwd(gates, c_prev, c_next, h_next)
+    a1, a2 = gates.clone(), gates.clone()
+    dcp = torch.empty_like(c_prev)
+    H.lstm_pointwise_bwd(a1, c_prev, c_next, dh, dc, dcp)
+    H.lstm_pointwise_bwd(a2, c_prev, c_next, dh, dc, None)
+    assert torch.equal(a1, a2) and bool(torch.isfinite(dcp).all())
