@@ -72,13 +72,15 @@ def _cpu_baseline_worker(name, threads, B, max_steps, budget_s):
         C.loss_reverse(y, ld).backward()
         opt.step()
 
+    tw = time.time()
     step()  # warm-up (allocator, thread pool)
+    tw = time.time() - tw
     n, t0 = 0, time.time()
     while n < max_steps and (n == 0 or time.time() - t0 < budget_s):
         step()
         n += 1
     dt = time.time() - t0
-    print(json.dumps({"value": B * n / dt, "steps": n, "batch": B, "threads": threads}))
+    print(json.dumps({"value": B * n / dt, "steps": n, "batch": B, "threads": threads, "warmup_step_s": round(tw, 2), "timed_s": round(dt, 2)}))
 
 
 def cpu_baseline(name, hard_timeout_s=300, max_steps=12, budget_s=25.0):
@@ -95,7 +97,7 @@ def cpu_baseline(name, hard_timeout_s=300, max_steps=12, budget_s=25.0):
         res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         return {"value": round(res["value"], 4), "unit": "samples/s", "cores": threads, "kind": "port",
                 "sample": "config %s at batch %d, %d timed step(s) after 1 warm-up, torch CPU fp32 oracle, sample()+backward+Adam"
-                          % (name, res["batch"], res["steps"])}
+                          % (name, res["batch"], res["steps"]), "warmup_step_s": res.get("warmup_step_s"), "timed_s": res.get("timed_s")}
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "failed: %s" % type(e).__name__}
 
@@ -137,6 +139,20 @@ def pmc_traffic(kernel):
     return round(tot / n) if n else None
 
 
+_T0 = time.perf_counter()
+_PHASES = []
+
+
+def _phase(name):
+    """Host wall-clock bookkeeping of the whole run (the driver's clock around bench.py covers imports, model construction, seed
+    states, warm-up, the event passes and the CPU baselines - not only the timed region): printed to stderr as the run goes and
+    reported as `host_phases_s` in the JSON line."""
+    now = time.perf_counter()
+    last = _PHASES[-1][2] if _PHASES else _T0
+    _PHASES.append((name, round(now - last, 2), now))
+    print("[bench %7.1f s] %s: %.2f s" % (now - _T0, name, now - last), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +173,7 @@ def main():
                          "cfg5, whose BASELINE.json line names fp16 MFMA 1x1 convs)")
     args = ap.parse_args()
 
+    _phase("imports (torch, tests/common)")
     import tmg_dist
     import tmg_hip
     rank, world, local = tmg_dist.init_from_env()
@@ -172,7 +189,9 @@ def main():
     import tmg_ops
     mix = args.mix or ("f16" if args.config == "cfg5" else "f32")
     tmg_ops.set_mix_precision(mix)
+    _phase("process group, library load")
     model = build_model(cfg, dev)
+    _phase("model construction + upload")
     tmg_dist.broadcast_parameters(model)
     bucket = tmg_dist.GradBucket(model.parameters(), measure=True) if world > 1 else None
     use_graph = args.graph and world == 1
@@ -194,6 +213,8 @@ def main():
     states = [(h.contiguous(memory_format=torch.channels_last), c.contiguous(memory_format=torch.channels_last)) for h, c in states]
 
     y_fwd = torch.randn(B, cfg["out_features"], Hin * up, Win * up, generator=g).to(dev) if args.direction == "forward" else None
+    torch.cuda.synchronize()
+    _phase("inputs + seed states (host RNG of the reference, once per seed)")
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -241,6 +262,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    _phase("warm-up steps (first launches load the code objects)")
     # which matrix-core kernel dominates the step: two untimed steps with every contraction launch bracketed by HIP events;
     # inside the timed region only THAT kernel keeps its events (a handful of pairs per step: timing all ~500 contraction
     # launches of a step cost 2 % of the headline number)
@@ -256,6 +278,7 @@ def main():
         if cand:
             dom = max(cand.items(), key=lambda kv: kv[1][1])[0]
     barrier()
+    _phase("event pass over all contraction launches (2 steps)")
     torch.cuda.reset_peak_memory_stats(dev)
     if dom is not None:
         tmg_hip.prof_enable(100 + tmg_hip.prof_kernel_id(dom))
@@ -264,6 +287,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    _phase("TIMED REGION (%d steps)" % args.steps)
     prof, prof_steps = {}, {}
     if not args.no_events:
         live = tmg_hip.prof_collect()      # the dominant kernel, timed live inside the timed region
@@ -283,6 +307,7 @@ def main():
         prof_steps.update({k: 3 for k in hb})
         tmg_hip.prof_enable(False)
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    _phase("event pass over the bandwidth-bound classes (3 steps)")
     mix_speedup = None
     if mix == "f16" and graph is None:
         # the fp16-operand 1x1 mixes against this package's own fp32 mixes on the same workload, a few steps each AFTER the timed
@@ -364,8 +389,12 @@ def main():
                                "note": "stand-alone 1x1 mixes only (wide levels, LSTM blocks); on the narrow levels the mix runs inside cpl_fwd_kernel"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)
+        _phase("cpu_baseline child (%s)" % args.config)
         if args.config != "cfg1":   # BASELINE configs[0], the reference's own CPU-runnable case, at its stated batch 8
             out["cpu_baseline_cfg1"] = cpu_baseline("cfg1", max_steps=10, budget_s=15.0)
+            _phase("cpu_baseline child (cfg1)")
+    out["host_phases_s"] = {n: d for n, d, _ in _PHASES}
+    out["host_total_s"] = round(time.perf_counter() - _T0, 1)
     print(json.dumps(out))
 
 

@@ -255,6 +255,29 @@ __global__ void checker_kernel(const float* __restrict__ src, int ss, int so, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// zero-padded channel halves: compact [npix][2 ch] <-> padded [npix][2 (ch + pad)] = [x1 | 0.. | x2 | 0..]
+// (3-channel fields: ch = 6 on the first level; every kernel of the fast path wants float4-addressable halves)
+// to_padded: every element of the padded tensor is written (the padding channels with zeros): no fill launch
+// ---------------------------------------------------------------------------------------------
+__global__ void pad_halves_kernel(const float* __restrict__ src, int ss, float* __restrict__ dst, int ds, size_t npix, int ch, int pad,
+                                  int to_padded) {
+    const int chp = ch + pad;
+    const int cw = to_padded ? 2 * chp : 2 * ch;        // channels written per pixel
+    const size_t total = npix * (size_t)cw;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cw);
+        const size_t pix = i / cw;
+        if (to_padded) {
+            const int half = c >= chp, k = c - half * chp;
+            dst[pix * ds + c] = k < ch ? src[pix * ss + half * ch + k] : 0.f;
+        } else {
+            const int half = c >= ch, k = c - half * ch;
+            dst[pix * ds + c] = src[pix * ss + half * chp + k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bilinear up-sampling, align_corners = True
 // ---------------------------------------------------------------------------------------------
 __global__ void upsample_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int hi, int wi, int ho, int wo,
@@ -1451,6 +1474,17 @@ extern "C" int tmg_gauss_bwd(const void* hz, const int64_t* hz_d, const void* zi
                        (const float*)zin, (int)zi_d[0], (int)zi_d[1], (const float*)dzin, (int)dzi_d[0], (int)dzi_d[1], (const float*)g,
                        (float*)dzout, (int)dzo_d[0], (int)dzo_d[1], (float*)dhz, (int)dh_d[0], (int)dh_d[1], ppi, Ch, npix, (int)dims[3],
                        (int)dims[4], fl[0], fl[1], fl[2], fl[3]);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// dims: [npix, ch, pad, to_padded]; s_d / d_d: {pixel stride, channel offset} of the source / destination
+extern "C" int tmg_pad_halves(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, hipStream_t st) {
+    const size_t npix = (size_t)dims[0];
+    const int ch = (int)dims[1], pad = (int)dims[2], to_padded = (int)dims[3];
+    const size_t total = npix * (size_t)(to_padded ? 2 * (ch + pad) : 2 * ch);
+    hipLaunchKernelGGL(pad_halves_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)src + s_d[1], (int)s_d[0],
+                       (float*)dst + d_d[1], (int)d_d[0], npix, ch, pad, to_padded);
     TMG_CHECK_LAUNCH();
     return 0;
 }

@@ -63,7 +63,7 @@ class ResidLSTMBlock(nn.Module):
         """out_grad_premasked: see tmg_ops.conv (the LSTM coupling layer's tail masks the gradient it sends back by [out > 0])."""
         h_next, c_next = self.convLSTM.run(inputs, state)
         oc = self.out_seq.LSTM_out_conv
-        out = ops.conv(list(inputs) + [h_next], oc.weight, oc.bias, relu_out=True, grad_premasked=out_grad_premasked)
+        out = ops.conv(list(inputs) + [h_next], oc.weight, oc.bias, relu_out=True, _grad_premasked=out_grad_premasked)
         return out, h_next, c_next
 
     def forward(self, input_tensor, cur_state=None):

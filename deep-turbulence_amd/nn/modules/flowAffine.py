@@ -90,7 +90,7 @@ class LSTMAffineCouplingLayer(nn.Module):
             h_cur, c_cur = state
         h_next, c_next = ops.ConvLSTMCellFn.apply(ins(cell.conv.weight, ch), cell.conv.bias, h_cur, c_cur, x1, condn)
         ow = torch.cat([ins(oc.weight, ch), z(pad, oc.weight.shape[1] + pad, 3, 3)], 0)      # feature map widened by `pad` zero channels
-        out = ops.conv([x1, condn, h_next], ow, torch.cat([oc.bias, z(pad)]), relu_out=True, grad_premasked=True)
+        out = ops.conv([x1, condn, h_next], ow, torch.cat([oc.bias, z(pad)]), relu_out=True, _grad_premasked=True)
         w1 = torch.cat([db.denselayer1.conv1.weight, z(1, pad, 3, 3)], 1)
         w2 = ins(db.denselayer2.conv1.weight, cin)                                             # before the d1 row
         wz = torch.cat([ins(zc.conv.weight, cin), z(2 * pad, zc.conv.weight.shape[1] + pad, 3, 3)], 0)

@@ -275,13 +275,11 @@ class LSTMFLowBlock(nn.Module):
     # layer (shift = 0, r = 0 => scale 1, log-det 0) and un-padding the result gives the un-padded computation.
     @staticmethod
     def _pad_x(xn, ch, pad):
-        B, Hh, Ww, _ = xn.shape
-        z = torch.zeros((B, Hh, Ww, pad), device=xn.device, dtype=torch.float32)
-        return torch.cat([xn[..., :ch], z, xn[..., ch:], z], 3)
+        return ops.PadHalvesFn.apply(xn, ch, pad, True)       # one launch, zeros included (round 3: two fills + a cat)
 
     @staticmethod
     def _unpad_x(xp, ch, pad):
-        return torch.cat([xp[..., :ch], xp[..., ch + pad:2 * ch + pad]], 3)
+        return ops.PadHalvesFn.apply(xp, ch, pad, False)
 
     @staticmethod
     def _pad_mix(W, b, ch, pad):

@@ -184,7 +184,11 @@ class TMGlow(nn.Module):
     # one generator per (level, sample): 180 M numbers at the metric shape and 64 samples, 1.3 s - twice a 10-step BPTT window on
     # this device.  But the loaders draw the seeds from random_(0, 1000) (dataLoader.py:284, :422): at most 1 000 distinct states
     # exist, 11 MB each at the metric shape, so they live in HBM after their first use and a mini-batch is a device gather.
-    SEED_CACHE_GB = float(os.environ.get("TMG_SEED_CACHE_GB", "48"))
+    # Only seeds below SEED_CACHE_MAX_SEED are admitted: TrainFlow.test and utils.modelPred draw fresh seeds from random_(0, 1e8)
+    # for every batch (trainFlowParallel.py:333, utils.py:205) - they never repeat, and caching them would pin 11 MB of HBM per test
+    # sample until the budget is full and the training seeds fall back to the host draw.
+    SEED_CACHE_GB = float(os.environ.get("TMG_SEED_CACHE_GB", "16"))
+    SEED_CACHE_MAX_SEED = 1000
 
     def _draw_seed_states(self, seed_list, input_dim):
         """The reference's host draw (tmGlow.py:494-509) for the given seeds -> per seed a list over levels of (h, c), [1,R,h,w]."""
@@ -206,18 +210,20 @@ class TMGlow(nn.Module):
             res = [draw(j) for j in jobs]
         return [res[k * L:(k + 1) * L] for k in range(len(seed_list))]
 
-    def initLSTMStates(self, seeds, input_dim):
+    def initLSTMStates(self, seeds, input_dim, cache=True):
         """Per (level, sample) a fresh CPU generator with the sample's seed: hidden ~ U[-1,1], cell ~ N(0,1)
         (reference :481-509).  Host RNG by construction (the streams are part of the reference's semantics): every DISTINCT seed is
         drawn once on the host - the (level, sample) draws are independent and run on a small thread pool, torch releases the GIL
         inside rand / randn - and kept on the model's device in the channels-last layout the flow works in; a call is then one
         gather per level.  Returns the reference's structure: a list over levels of (h, c), [B,R,h,w] (values bit-identical to the
-        reference's, strides channels-last).  The cache is keyed by (seed, field size), dropped when the model changes device, and
-        bounded by TMG_SEED_CACHE_GB (seeds beyond it are drawn per call, as before)."""
+        reference's, strides channels-last).  The cache is keyed by (seed, field size), dropped when the model changes device,
+        bounded by TMG_SEED_CACHE_GB, and admits only the loaders' seed range [0, SEED_CACHE_MAX_SEED) and only with cache=True;
+        every other seed is drawn per call, as in the reference."""
         device = next(self.parameters()).device
         seed_list = [int(s) for s in torch.as_tensor(seeds).tolist()]
         L = len(self.glow_blocks)
         key = (str(device), self.rec_features, int(input_dim[0]), int(input_dim[1]), L)
+        cache_ok = bool(cache)
         cache = self.__dict__.get("_seed_states")
         if cache is None or cache["key"] != key:
             cache = {"key": key, "rows": {}, "bytes": 0}
@@ -230,7 +236,7 @@ class TMGlow(nn.Module):
             for s, lv in zip(missing, self._draw_seed_states(missing, input_dim)):
                 # [1,R,h,w] -> [h,w,R] contiguous on the device: stacking such rows gives the flow's NHWC layout directly
                 dev_lv = [(h[0].permute(1, 2, 0).contiguous().to(device), c[0].permute(1, 2, 0).contiguous().to(device)) for h, c in lv]
-                if cache["bytes"] + per_seed <= self.SEED_CACHE_GB * 2 ** 30:
+                if cache_ok and 0 <= s < self.SEED_CACHE_MAX_SEED and cache["bytes"] + per_seed <= self.SEED_CACHE_GB * 2 ** 30:
                     rows[s] = dev_lv
                     cache["bytes"] += per_seed
                 else:

@@ -209,7 +209,7 @@ class TrainFlow(object):
                 yPred = torch.zeros((samples,) + tuple(ytarget.shape), device=dev, dtype=ytarget.dtype)
                 for i in range(samples):
                     seeds = torch.LongTensor(inp.size(0)).random_(0, int(1e8))
-                    aKey = core.initLSTMStates(seeds, [ytarget.size(-2), ytarget.size(-1)])
+                    aKey = core.initLSTMStates(seeds, [ytarget.size(-2), ytarget.size(-1)], cache=False)   # fresh seeds every batch: never resident
                     a0 = [(h.clone(), c.clone()) for h, c in aKey]
                     for tstep in range(steps + 1):
                         yPred0, logp, a0 = core.sample(inp[:, tstep], a0)

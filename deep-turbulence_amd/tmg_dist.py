@@ -29,55 +29,78 @@ def init_from_env(backend=None):
 
 
 def broadcast_parameters(module, src=0):
-    """One-time parameter / buffer broadcast so every replica starts identical."""
+    """One-time parameter / buffer broadcast so every replica starts identical: ONE collective per dtype over a flat copy of all
+    tensors of that dtype (fp32 parameters + buffers, the int64 BatchNorm counters) instead of one per tensor (~1 000 at the metric
+    configuration: each a launch + a rendezvous on the RCCL stream)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
+    groups = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        groups.setdefault((t.dtype, t.device), []).append(t.data)
+    for (_, _), ts in groups.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src)
+        o = 0
+        outs = []
+        for t in ts:
+            outs.append(flat[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+        torch._foreach_copy_(ts, outs)
 
 
 class GradBucket:
     """Bucketed gradient all-reduce (mean over ranks), overlapped with backward.
 
-    The first call of `allreduce_mean()` runs synchronously after backward and learns which parameters receive gradients at
-    all (the reference's dead `norm2`, SURVEY fact 8, never does: no find_unused_parameters pass, no hang).  From then on
-    every live parameter carries a post-accumulate-grad hook; a bucket (parameters in reverse registration order, <=
-    `bucket_mb`) owns ONE persistent flat buffer: its gradients are copied into it with one multi-tensor launch and the
-    all-reduce (RCCL over xGMI with backend "nccl", async) is issued the moment its last gradient has been produced, i.e. while
-    backward is still running on the earlier layers.  `allreduce_mean()` then only waits for the handles, divides each flat
-    bucket by the world size (one launch) and re-binds every `p.grad` to its slice of the reduced bucket - no copy back, no
-    allocation per step.  Works unchanged with gloo on CPU tensors.
+    Layout (static, identical on every rank by construction): ALL parameters that require a gradient, in reverse registration
+    order, cut into buckets of <= `bucket_mb`; a bucket owns ONE persistent flat buffer [gradients | one has-gradient flag per
+    parameter].  The collectives of a step are ALWAYS bucket 0, 1, .., n-1 in that order, whatever gradients a rank happens to
+    have: no rank-local decision changes the sequence or the sizes of the collectives, so ranks whose live sets differ cannot
+    dead-lock each other (round 3 rebuilt the buckets on a rank-local test).
 
-    Contract: ONE backward per `allreduce_mean()` (no gradient accumulation, no retain_graph second pass) - a second gradient
-    for a parameter whose bucket has already been handed to the collective raises.  The live set may change between steps: a
-    parameter that first receives a gradient later triggers a rebuild of the buckets (all ranks run the same graph, so they
-    rebuild together); a bucketed parameter without a gradient in some step contributes zeros.
+    The first `allreduce_mean()` runs synchronously after backward and learns which parameters receive gradients (the reference's
+    dead `norm2`, SURVEY fact 8, never does).  From then on every parameter carries a post-accumulate-grad hook and a bucket is
+    handed to the collective (RCCL over xGMI with backend "nccl", async) the moment its expected gradients exist and every
+    earlier bucket has gone - while backward is still running on the earlier layers.  `allreduce_mean()` then only issues what is
+    left, waits for the handles, divides each flat bucket by the world size (one launch) and re-binds every `p.grad` to its slice
+    of the reduced bucket - no copy back, no allocation per step.  The reduced flags say which parameters had a gradient on ANY
+    rank: the others get `p.grad = None`, exactly as in a single-process run (the optimizer skips them: no moment decay, no weight
+    decay); the flags are read on the host (a device sync) only in the first step and when this rank's live set changed.  A
+    parameter that is live somewhere but has no gradient on this rank contributes zeros.  Works unchanged with gloo on CPU.
+
+    Contract: ONE backward per `allreduce_mean()` (no gradient accumulation, no retain_graph second pass) - a second gradient for
+    the same parameter raises.  A parameter whose FIRST gradient arrives after its bucket has gone (the live set grew) makes
+    that bucket go a second time in `allreduce_mean()` - all ranks are expected to run the same graph, as in the reference.
 
     `measure=True`: event pairs around the exchange (see `overlap_report`)."""
 
     def __init__(self, params, bucket_mb=32, measure=False):
         self.params = [p for p in params if p.requires_grad]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
-        self.buckets = None        # list of parameter lists once the live set is known
-        self._flat = []            # persistent flat buffer per bucket
+        self.buckets = None        # list of parameter lists (built on first use: the parameters may still move device)
+        self._flat = []            # persistent flat buffer per bucket: gradients, then one flag per parameter
         self._views = []           # per bucket: views of the flat buffer, one per parameter
-        self._where = {}           # id(p) -> bucket index
-        self._pending = []         # gradients still missing per bucket in this backward
+        self._flags = []           # per bucket: the flag tail of the flat buffer
+        self._flag_src = {}        # (bucket, has-gradient pattern) -> device tensor of 0 / 1
+        self._where = {}           # id(p) -> (bucket index, position)
+        self._expected = None      # per bucket: ids of the parameters that had a gradient in the previous step (None: not learned)
+        self._arrived = set()      # ids of the parameters whose gradient arrived in this backward
+        self._got = []             # per bucket: expected gradients that arrived so far
         self._work = []            # (bucket index, async handle)
         self._launched = set()
+        self._dirty = set()        # buckets that received a first-ever gradient after they had gone
+        self._next = 0             # next bucket index in the fixed collective order
         self._hooks = []
+        self._live_local = None    # ids with a gradient on this rank in the last step
+        self._live_any = None      # ids with a gradient on ANY rank (from the reduced flags)
         self.launched_during_backward = 0   # diagnostics: buckets whose all-reduce was issued from a hook
-        self.rebuilds = 0
+        self.flag_reads = 0        # diagnostics: host reads of the reduced flags
         self.measure = bool(measure)
         self._ev = []              # per step: (first bucket ready, backward done, last all-reduce done) events
         self._ev_first = None
 
-    # ---- bucket construction (after the first backward, or when the live set grew) ----------------------------------
-    def _build(self, live):
-        for h in self._hooks:
-            h.remove()
-        self._hooks, self._where = [], {}
-        order = list(reversed(live))   # backward produces the last-registered parameters' gradients first (roughly)
+    # ---- static layout ------------------------------------------------------------------------------------------------------
+    def _build(self):
+        order = list(reversed(self.params))   # backward produces the last-registered parameters' gradients first (roughly)
         self.buckets, cur, n = [], [], 0
         for p in order:
             if cur and n + p.numel() > self.bucket_elems:
@@ -87,23 +110,27 @@ class GradBucket:
             n += p.numel()
         if cur:
             self.buckets.append(cur)
-        self._flat, self._views = [], []
         for bi, bk in enumerate(self.buckets):
-            flat = torch.empty(sum(p.numel() for p in bk), device=bk[0].device, dtype=bk[0].dtype)
+            ng = sum(p.numel() for p in bk)
+            flat = torch.zeros(ng + len(bk), device=bk[0].device, dtype=bk[0].dtype)
             views, o = [], 0
-            for p in bk:
+            for k, p in enumerate(bk):
                 views.append(flat[o:o + p.numel()].view_as(p))
                 o += p.numel()
-                self._where[id(p)] = bi
+                self._where[id(p)] = (bi, k)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             self._flat.append(flat)
             self._views.append(views)
+            self._flags.append(flat[ng:])
         self._reset()
 
     def _reset(self):
-        self._pending = [len(bk) for bk in self.buckets]
+        self._got = [0] * len(self.buckets)
+        self._arrived = set()
         self._work = []
         self._launched = set()
+        self._dirty = set()
+        self._next = 0
         self._ev_first = None
 
     def _launch(self, bi):
@@ -111,23 +138,38 @@ class GradBucket:
         have = [(v, p.grad) for v, p in zip(views, bk) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        for v, p in zip(views, bk):
-            if p.grad is None:      # no gradient this step: this rank contributes zeros (the other ranks run the same graph)
-                v.zero_()
+        none = [v for v, p in zip(views, bk) if p.grad is None]     # no gradient here this step: zeros
+        if none:
+            torch._foreach_zero_(none)
+        pat = tuple(p.grad is not None for p in bk)
+        src = self._flag_src.get((bi, pat))
+        if src is None:                            # (one upload per distinct pattern: the same every step in practice)
+            src = self._flag_src[(bi, pat)] = torch.tensor([1.0 if f else 0.0 for f in pat], dtype=self._flat[bi].dtype).to(self._flat[bi].device)
+        self._flags[bi].copy_(src)
         if self.measure and self._ev_first is None and self._flat[bi].is_cuda:
             self._ev_first = torch.cuda.Event(enable_timing=True)
             self._ev_first.record()
         self._launched.add(bi)
         self._work.append((bi, dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)))
 
+    def _ready(self, bi):
+        return self._expected is not None and len(self._expected[bi]) > 0 and self._got[bi] == len(self._expected[bi])
+
     def _on_grad(self, p):
-        bi = self._where[id(p)]
-        self._pending[bi] -= 1
-        if self._pending[bi] < 0 or (bi in self._launched and self._pending[bi] != 0):
-            raise RuntimeError("GradBucket: a second gradient arrived for a parameter of bucket %d before allreduce_mean() - one "
-                               "backward per all-reduce (no gradient accumulation / retain_graph passes)" % bi)
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        if self.buckets is None or self._expected is None:
+            return                      # first step: everything goes after backward
+        if id(p) in self._arrived:
+            raise RuntimeError("GradBucket: a second gradient arrived for a parameter before allreduce_mean() - one backward per "
+                               "all-reduce (no gradient accumulation / retain_graph passes)")
+        self._arrived.add(id(p))
+        bi, _ = self._where[id(p)]
+        if id(p) in self._expected[bi]:
+            self._got[bi] += 1
+        elif bi in self._launched:
+            self._dirty.add(bi)         # a first-ever gradient for a bucket that has gone: it goes again in allreduce_mean()
+        while self._next < len(self.buckets) and self._ready(self._next) and self._next not in self._launched:
+            self._launch(self._next)
+            self._next += 1
             self.launched_during_backward += 1
 
     # ---- called between backward and the optimizer step ---------------------------------------------------------------
@@ -135,36 +177,49 @@ class GradBucket:
         if not (dist.is_initialized() and dist.get_world_size() > 1):
             return 0
         world = dist.get_world_size()
-        live = [p for p in self.params if p.grad is not None]
+        if self.buckets is None:
+            self._build()
         ev_done = None
-        if self.measure and live and live[0].is_cuda:
+        if self.measure and self.params and self.params[0].is_cuda:
             ev_done = torch.cuda.Event(enable_timing=True)
             ev_done.record()                       # backward has been issued up to here on the compute stream
-        if self.buckets is None or any(id(p) not in self._where for p in live):
-            # first step, or a parameter outside the bucket layout received a gradient: (re)build from the union - every rank runs
-            # the same graph, hence sees the same live set and rebuilds in the same step
-            for bi, work in self._work:            # buckets already in flight from hooks: finish them, their values are re-reduced below
-                work.wait()
-                # p.grad still holds this rank's OWN gradient (re-binding to the reduced buffer has not happened), so a fresh pass
-                # over the new layout is exact - unless the gradients were accumulated in place into the old buffers
-                if any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for v, p in zip(self._views[bi], self.buckets[bi])):
-                    raise RuntimeError("GradBucket: the set of parameters with gradients changed while gradients alias the reduced "
-                                       "buckets (zero_grad(set_to_none=False)); use set_to_none=True")
-            if self.buckets is not None:
-                self.rebuilds += 1
-            known = set(self._where)
-            self._build([p for p in self.params if p.grad is not None or id(p) in known])
-            for bi in range(len(self.buckets)):
+        for bi in range(len(self.buckets)):        # what the hooks did not hand over, in the fixed order
+            if bi not in self._launched:
                 self._launch(bi)
-        else:
-            for bi in range(len(self.buckets)):    # buckets a hook did not complete (a parameter without gradient this time)
-                if bi not in self._launched:
-                    self._launch(bi)
+        for bi in sorted(self._dirty):             # the live set grew after the bucket had gone: once more, with every gradient
+            for b2, work in self._work:
+                if b2 == bi:
+                    work.wait()
+            # p.grad still holds this rank's OWN gradient (re-binding happens below), so a second pass is exact - unless the
+            # gradients were accumulated in place into the bucket the first pass has just overwritten with the sum
+            if any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for v, p in zip(self._views[bi], self.buckets[bi])):
+                raise RuntimeError("GradBucket: the set of parameters with gradients grew while gradients alias the reduced "
+                                   "buckets (zero_grad(set_to_none=False)); use set_to_none=True")
+            self._launch(bi)
+        local = {id(p) for p in self.params if p.grad is not None}
+        read = self._live_any is None or local != self._live_local
         for bi, work in self._work:
             work.wait()
+        if read:
+            # which parameters have a gradient on ANY rank: a host read of the reduced flags (device sync), first step and whenever
+            # this rank's own live set changed
+            self.flag_reads += 1
+            self._live_any = set()
+            for bk, fl in zip(self.buckets, self._flags):
+                for p, f in zip(bk, fl.tolist()):
+                    if f > 0.0:
+                        self._live_any.add(id(p))
+        self._live_local = local
+        done = set()
+        for bi, _ in self._work:
+            if bi in done:
+                continue
+            done.add(bi)
             self._flat[bi].div_(world)
             for v, p in zip(self._views[bi], self.buckets[bi]):
-                p.grad = v
+                p.grad = v if id(p) in self._live_any else None
+        # the next backward's hooks wait for the gradients this rank produced now
+        self._expected = [{id(p) for p in bk if id(p) in local} for bk in self.buckets]
         if ev_done is not None and self._ev_first is not None:
             ev_last = torch.cuda.Event(enable_timing=True)
             ev_last.record()

@@ -35,7 +35,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves",
 ]
 
 
@@ -53,14 +53,25 @@ def build(force=False, verbose=False):
     nopk = os.environ.get("TMG_NOPK")
     nopk = NO_PACKED_F32 if nopk is None else [("tmg_%s.hip" % n) for n in nopk.split(",") if n]
     jobs, objs = [], []
+    stamps = []
     for src in SOURCES:
         sp, ob = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(ob)
-        if force or not os.path.exists(ob) or os.path.getmtime(ob) < max(os.path.getmtime(sp), hmt):
-            extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if src in nopk else []
-            extra += os.environ.get("TMG_EXTRA_DEFS", "").split()      # diagnostic builds (e.g. -DTMG_WINO_STAMP), never the product's
+        extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if src in nopk else []
+        extra += os.environ.get("TMG_EXTRA_DEFS", "").split()      # diagnostic builds (e.g. -DTMG_WINO_STAMP), never the product's
+        # an object is stale when its source / a header is newer OR when it was compiled with other flags (a diagnostic build
+        # leaves objects that are newer than their sources: the next plain build must not link them into the product library)
+        line = " ".join(flags + extra)
+        stamp = ob + ".flags"
+        old = open(stamp).read() if os.path.exists(stamp) else None
+        if (force or not os.path.exists(ob) or os.path.getmtime(ob) < max(os.path.getmtime(sp), hmt)
+                or (old is not None and old != line) or (old is None and extra)):
             jobs.append([hipcc] + flags + extra + ["-c", sp, "-o", ob])
+        stamps.append((stamp, line))
     if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        for stamp, line in stamps:
+            if not os.path.exists(stamp):
+                open(stamp, "w").write(line)
         return LIB_PATH
 
     def run(cmd):
@@ -70,6 +81,8 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    for stamp, line in stamps:
+        open(stamp, "w").write(line)
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])
     return LIB_PATH
 
@@ -750,6 +763,14 @@ def checker(src, dst, to_small):
         B, h, w, _ = src.shape
         C = dst.shape[3]
     _chk(lib().tmg_checker(_ptr(src), _d2(src), _ptr(dst), _d2(dst), _i64(B, h, w, C, to_small), _stream()), "tmg_checker")
+
+
+def pad_halves(src, dst, ch, pad, to_padded):
+    """compact [B,H,W,2 ch] <-> zero-padded [B,H,W,2 (ch + pad)] = [x1 | 0.. | x2 | 0..] (one launch, zeros included)."""
+    B, Hh, Ww, _ = src.shape
+    assert src.shape[3] == (2 * ch if to_padded else 2 * (ch + pad)) and dst.shape[3] == (2 * (ch + pad) if to_padded else 2 * ch)
+    _chk(lib().tmg_pad_halves(_ptr(src), _d2(src), _ptr(dst), _d2(dst), _i64(B * Hh * Ww, ch, pad, 1 if to_padded else 0), _stream()),
+         "tmg_pad_halves")
 
 
 def upsample_fwd(src, dst):

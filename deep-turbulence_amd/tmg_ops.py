@@ -107,6 +107,11 @@ class ConvFn(torch.autograd.Function):
             H.masked_add(dy, src=dout, ref=out)
         else:
             dy = dout
+            if premasked and os.environ.get("TMG_CHECK_PREMASK"):
+                leak = float((dout * (out <= 0)).abs().max())
+                if leak != 0.0:
+                    raise RuntimeError("ConvFn: _grad_premasked contract violated - the output gradient is non-zero (%.3e) where the "
+                                       "ReLU output is zero: `out` has a consumer that does not mask its gradient" % leak)
         dW = db = dk = None
         ss = None
         if ctx.needs_input_grad[0] or ctx.has_kappa:
@@ -153,11 +158,13 @@ class ConvFn(torch.autograd.Function):
         return (dW, db, dk, None) + tuple(dins)
 
 
-def conv(inputs, weight, bias=None, kappa=None, ksize=3, stride=1, relu_in=False, pad_rep=False, relu_out=False, grad_premasked=False):
-    """grad_premasked (with relu_out): the caller guarantees that the gradient arriving at the output is already zero wherever the
-    output is (every consumer applies relu to it and masks its input gradient by [out > 0], as CouplingTailFn does): the backward pass
-    then skips its own mask pass over the gradient - the same values, one full-tensor launch less."""
-    return ConvFn.apply(weight, bias, kappa, (ksize, stride, relu_in, pad_rep, relu_out, bool(grad_premasked and relu_out)), *inputs)
+def conv(inputs, weight, bias=None, kappa=None, ksize=3, stride=1, relu_in=False, pad_rep=False, relu_out=False, _grad_premasked=False):
+    """_grad_premasked (with relu_out) is PRIVATE to the ResidLSTMBlock -> CouplingTailFn(mode 1) pairing (nn/modules/convLSTM.py): the
+    only consumer of the output is a node that applies relu to it and masks its input gradient by [out > 0], so the gradient arriving
+    here is already zero wherever the output is and the backward pass skips its own mask pass - the same values, one full-tensor
+    launch less.  A second consumer of `out` would get wrong gradients silently: TMG_CHECK_PREMASK=1 verifies the contract on every
+    backward pass (one reduction + a host sync per call: a debugging switch)."""
+    return ConvFn.apply(weight, bias, kappa, (ksize, stride, relu_in, pad_rep, relu_out, bool(_grad_premasked and relu_out)), *inputs)
 
 
 class BNReLUConvFn(torch.autograd.Function):
@@ -247,6 +254,9 @@ class DenseBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         L, c0, growth, use_batch = ctx.meta
+        if ctx.stats is None:
+            raise RuntimeError("DenseBlockFn: the per-layer statistics were released by a previous backward pass "
+                               "(a second backward through the same graph is not supported)")
         buf = ctx.saved_tensors[0]
         params = ctx.saved_tensors[1:]
         B, Hh, Ww, Ct = buf.shape
@@ -526,6 +536,30 @@ class CheckerFn(torch.autograd.Function):
             dx = torch.empty((B, Hh // 2, Ww // 2, 4 * C), device=dy.device, dtype=torch.float32)
         H.checker(dy, dx, not ctx.to_small)
         return dx, None
+
+
+class PadHalvesFn(torch.autograd.Function):
+    """compact [B,H,W,2 ch] <-> zero-padded halves [x1 | 0.. | x2 | 0..] (LSTMFLowBlock's layout for channel halves that are not a
+    multiple of 4): one launch each way, its own adjoint with the direction swapped (the reference has no counterpart: it works on
+    the un-padded tensors, flowAffine.py:73 / :98)."""
+
+    @staticmethod
+    def forward(ctx, x, ch, pad, to_padded):
+        x = x if x.stride(3) == 1 else x.contiguous()
+        B, Hh, Ww, _ = x.shape
+        y = torch.empty((B, Hh, Ww, 2 * (ch + pad) if to_padded else 2 * ch), device=x.device, dtype=torch.float32)
+        H.pad_halves(x, y, ch, pad, to_padded)
+        ctx.cfg = (ch, pad, to_padded)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ch, pad, to_padded = ctx.cfg
+        dy = dy if dy.stride(3) == 1 else dy.contiguous()
+        B, Hh, Ww, _ = dy.shape
+        dx = torch.empty((B, Hh, Ww, 2 * ch if to_padded else 2 * (ch + pad)), device=dy.device, dtype=torch.float32)
+        H.pad_halves(dy, dx, ch, pad, not to_padded)
+        return dx, None, None, None
 
 
 class UpsampleFn(torch.autograd.Function):

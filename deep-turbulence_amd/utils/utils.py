@@ -80,7 +80,7 @@ def modelPred(args, model, testing_loader, log, samples=1, stride=1, tmax=1):
             for i in range(samples):
                 log.log('Running sample {:d}.'.format(i))
                 seeds = torch.LongTensor(inp.size(0)).random_(0, int(1e8))
-                key = core.initLSTMStates(seeds, [tgt.size(-2), tgt.size(-1)])
+                key = core.initLSTMStates(seeds, [tgt.size(-2), tgt.size(-1)], cache=False)
                 h0 = [(h.clone(), c.clone()) for h, c in key]
                 for tstep in range(tmax):
                     y0, _logp, h0 = core.sample(inp[:, tstep], h0)

@@ -167,6 +167,11 @@ int tmg_gauss_bwd(const void* hz, const int64_t* hz_d, const void* zin, const in
 /* Checker squeeze / un-squeeze (flowUtils.py:114-122,137-145). dims = {B,h,w,C,to_small} */
 int tmg_checker(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, tmg_stream_t st);
 
+/* Zero-padded channel halves for fields whose channel half is not a multiple of 4 (the reference's 3-channel data sets; the
+ * halves are the chunk(2, 1) of flowAffine.py:73 / :98): compact [npix][2 ch] <-> [x1 | 0.. | x2 | 0..] with ch + pad channels
+ * per half; to_padded writes the padding zeros itself.  dims = {npix, ch, pad, to_padded}; s_d / d_d = {pixel stride, offset} */
+int tmg_pad_halves(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, tmg_stream_t st);
+
 /* Bilinear align_corners=True resize (misc.py:34-35) and its adjoint. dims = {B,hi,wi,ho,wo,C} */
 int tmg_upsample_fwd(const void* src, void* dst, const int64_t* dims, tmg_stream_t st);
 int tmg_upsample_bwd(const void* dout, void* din, const int64_t* dims, tmg_stream_t st);

@@ -138,15 +138,13 @@ def assert_logdet(a, b, what="logdet", rtol=LOGDET_RTOL, atol=1e-4):
     assert bool((err <= atol + rtol * b.abs()).all()), "%s: %s vs %s" % (what, a.flatten()[:4].tolist(), b.flatten()[:4].tolist())
 
 
-def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_tol=GRAD_TENSOR_REL_MAX, skip=(), outliers=(0, 1.0)):
-    """got/ref: name -> tensor.  Global relative L2 and worst per-tensor relative max.
-    outliers = (count, factor): at most `count` tensors may exceed tensor_tol, by at most `factor` - for the large-configuration
-    comparisons against an fp64 evaluation, where single ReLU pre-activations within 1e-6 of zero land on the other side in ANY
-    fp32 evaluation (tools/kink_scan.py: 14-63 of 48 M per case) and one such element of a deep, small map moves one or two
-    small weight-gradient tensors by a few per cent of their scale; which elements flip differs between two fp32 evaluations
-    (the reference's own and this one), so the reference's measured floor bounds the typical tensor, not the worst one.  A kernel
-    fault is not confused with this: it moves a tensor by tens of per cent (the round-3 staging bug: 126 %) and fails the factor
-    and the global bound."""
+def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_tol=GRAD_TENSOR_REL_MAX, skip=(), kink=None, report=None):
+    """got/ref: name -> tensor.  Global relative L2 (no allowance of any kind) and per-tensor relative max.
+    kink: optional name -> relative allowance measured by KinkProbe on the fp64 evaluation that produced `ref`: the size, relative
+    to the tensor's scale, of the gradient change that flipping the case's near-zero ReLU pre-activations causes in THAT tensor.
+    A tensor may exceed tensor_tol only by its own kink allowance: a tensor that no near-kink ReLU feeds gets none (round 3 allowed
+    any two tensors 3x the bound; a kernel fault confined to a small tensor could hide there).
+    report: optional dict, filled with the tensors that needed their kink allowance."""
     num = den = 0.0
     rels = []
     for k, r in ref.items():
@@ -165,10 +163,80 @@ def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_t
     worst, worst_k = rels[0] if rels else (0.0, None)
     glob = (num / max(den, 1e-300)) ** 0.5
     assert glob <= global_tol, "%s: global rel-L2 %.3e > %.1e (worst tensor %s %.3e)" % (what, glob, global_tol, worst_k, worst)
-    over = [(v, k) for v, k in rels if v > tensor_tol]
-    assert len(over) <= outliers[0], "%s: %d tensors beyond rel-max %.1e (allowed %d): %s" % (what, len(over), tensor_tol, outliers[0], over[:4])
-    assert worst <= tensor_tol * outliers[1], "%s: tensor %s rel-max %.3e > %.1e x %.1f" % (what, worst_k, worst, tensor_tol, outliers[1])
+    over = [(v, k, (kink or {}).get(k, 0.0)) for v, k in rels if v > tensor_tol]
+    if report is not None:
+        report["beyond_base_bound"] = [{"tensor": k, "rel_max": v, "base_bound": tensor_tol, "kink_allowance": a} for v, k, a in over]
+    bad = [(v, k, a) for v, k, a in over if v > tensor_tol + a]
+    assert not bad, "%s: %d tensors beyond rel-max %.1e + their own ReLU-kink allowance: %s" % (
+        what, len(bad), tensor_tol, [(k, "%.3e" % v, "kink %.2e" % a) for v, k, a in bad[:4]])
     return glob, worst
+
+
+class KinkProbe:
+    """Measures, on an fp64 oracle evaluation, how much of every parameter gradient hangs on ReLU pre-activations so close to zero
+    that an fp32 evaluation may put them on the other side (tools/kink_scan.py: at the metric configuration 14-63 of 48 M ReLUs per
+    sample, |pre-activation| up to 1.1e-5 on a tensor scale of 7, differ between the reference's own fp32 arithmetic and fp64).
+
+    with KinkProbe() as kp: run the oracle forward in fp64 and call loss.backward(retain_graph=True) inside the block;
+    kp.allowances(params, grads) then returns name -> max |sum_e s_e delta_e d t_e / d p| / max |grad p|, the sum running over every
+    near-kink element e (|t_e| < THR x max(1, max |t|) of its ReLU call), delta_e = the loss gradient at that ReLU's OUTPUT,
+    s_e = -sign(t_e): the gradient change of parameter tensor p if all of them flipped.  Tensors that no near-kink element feeds get
+    0.  One extra backward pass through the retained graph.  Patches torch.nn.functional.relu for the duration of the block
+    (the oracle calls F.relu at every ReLU site: oracle/tmglow_oracle.py)."""
+    THR = 1e-5
+
+    def __init__(self):
+        self.sites = []
+        self.calls = 0          # ReLU calls seen with a differentiable argument (a site's "call" = its position in that order)
+        self._real = None
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._real = F.relu
+        real, sites, thr = self._real, self.sites, self.THR
+
+        def relu(t, inplace=False):
+            out = real(t)
+            if t.requires_grad:
+                call = self.calls
+                self.calls += 1
+                td = t.detach()
+                idx = (td.abs() < thr * max(1.0, float(td.abs().max()))).nonzero(as_tuple=True)
+                if idx[0].numel():
+                    site = {"t": t, "idx": idx, "sign": -torch.sign(td[idx]), "delta": None, "call": call}
+                    out.register_hook(lambda g, site=site: site.__setitem__("delta", g[site["idx"]].detach().clone()))
+                    sites.append(site)
+            return out
+
+        F.relu = relu
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.relu = self._real
+        return False
+
+    @property
+    def n_elements(self):
+        return int(sum(s["idx"][0].numel() for s in self.sites))
+
+    def allowances(self, params, grads):
+        """params: name -> leaf tensor of the evaluated graph; grads: name -> its loss gradient (the scale)."""
+        live = [s for s in self.sites if s["delta"] is not None]
+        self.sites = []
+        if not live:
+            return {}
+        total = sum(((s["sign"] * s["delta"]) * s["t"][s["idx"]]).sum() for s in live)
+        names = [k for k in params if params[k].requires_grad]
+        gs = torch.autograd.grad(total, [params[k] for k in names], allow_unused=True)
+        out = {}
+        for k, g in zip(names, gs):
+            if g is None or k not in grads or grads[k] is None:
+                continue
+            scale = float(torch.as_tensor(grads[k]).abs().max())
+            if scale > 0:
+                out[k] = float(g.abs().max()) / scale
+        return out
 
 
 # ---- synthetic simulation files for the data-loader tests (row F4) -------------------------------------------------

@@ -79,6 +79,16 @@ def test_seed_state_cache_is_bit_identical_and_draws_each_seed_once():
     assert other[0][0].shape[2] == hw[0] and calls[-1] == [1]
     # the cache never enters the state_dict
     assert not any("seed" in k for k in m.state_dict())
+    # seeds outside the loaders' range [0, 1000) (TrainFlow.test / modelPred draw from random_(0, 1e8) for every batch and sample) and
+    # calls with cache=False are drawn per call and never become resident: a test epoch must not pin HBM
+    held = m._seed_states["bytes"]
+    n_rows = len(m._seed_states["rows"])
+    big = m.initLSTMStates(torch.tensor([12345678, 1]), [2 * hw[0], 2 * hw[1]])
+    nocache = m.initLSTMStates(torch.tensor([5]), [2 * hw[0], 2 * hw[1]], cache=False)
+    assert m._seed_states["bytes"] == held and len(m._seed_states["rows"]) == n_rows
+    assert calls[-2:] == [[12345678], [5]]
+    ref_big = fresh.initLSTMStates(torch.tensor([12345678, 1]), [2 * hw[0], 2 * hw[1]], cache=False)
+    assert all(torch.equal(h, h2) and torch.equal(c, c2) for (h, c), (h2, c2) in zip(big, ref_big)) and nocache[0][0].shape[0] == 1
 
 
 def test_public_api_surface():
@@ -112,23 +122,32 @@ def test_no_cpu_fallback():
 def test_zero_padded_channel_layout_is_exact():
     """Levels whose channel half is not a multiple of 4 (3-channel fields) run on [x1 | 0.. | x2 | 0..]: the padded mix applied to
     the padded activations must reproduce the un-padded mix on the real channels and keep the padding channels exactly zero
-    (host-side helpers of LSTMFLowBlock; the kernels only ever see the padded, float4-aligned problem)."""
+    (host-side parameter helper of LSTMFLowBlock; the activations are padded by tmg_pad_halves, which tests/test_hip_ops.py holds to
+    the same concatenation on the GPU; the kernels only ever see the padded, float4-aligned problem)."""
     import torch
     from nn.modules.flowLSTMBlock import LSTMFLowBlock as B
     g = torch.Generator().manual_seed(0)
+
+    def pad_x(x, ch, pad):        # the layout: [x1 | 0.. | x2 | 0..]
+        z = torch.zeros(x.shape[:-1] + (pad,))
+        return torch.cat([x[..., :ch], z, x[..., ch:], z], -1)
+
+    def unpad_x(xp, ch, pad):
+        return torch.cat([xp[..., :ch], xp[..., ch + pad:2 * ch + pad]], -1)
+
     for C_ in (12, 20, 6):
         ch = C_ // 2
         pad = (-ch) % 4
         W, b = torch.randn(3, C_, C_, generator=g), torch.randn(3, C_, generator=g)
         x = torch.randn(2, 5, 7, C_, generator=g)
-        xp = B._pad_x(x, ch, pad)
+        xp = pad_x(x, ch, pad)
         assert xp.shape[-1] == 2 * (ch + pad) and (ch + pad) % 4 == 0
-        assert torch.equal(B._unpad_x(xp, ch, pad), x)
+        assert torch.equal(unpad_x(xp, ch, pad), x)
         Wp, bp = B._pad_mix(W, b, ch, pad)
         for k in range(3):
             yp = xp @ Wp[k].t() + bp[k]
             y = x @ W[k].t() + b[k]
-            assert torch.allclose(B._unpad_x(yp, ch, pad), y, atol=1e-6)
+            assert torch.allclose(unpad_x(yp, ch, pad), y, atol=1e-6)
             assert float(yp[..., ch:ch + pad].abs().max()) == 0.0 and float(yp[..., 2 * ch + pad:].abs().max()) == 0.0
 
 

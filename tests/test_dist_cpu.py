@@ -165,8 +165,8 @@ def _run_bucket_edges(rank, world, port, ret):
         out[name] = {"own": own, "mean": {i: p.grad.clone() for i, p in enumerate((a, b, c)) if p.grad is not None}}
         if name == "late":
             flat_ptrs = [f.data_ptr() for f in bucket._flat]
-    out["persistent"] = flat_ptrs == [f.data_ptr() for f in bucket._flat]      # no new flat buffers after the layout settled
-    out["rebuilds"], out["nbuckets"] = bucket.rebuilds, len(bucket.buckets)
+    out["persistent"] = flat_ptrs == [f.data_ptr() for f in bucket._flat]      # the flat buffers are allocated once
+    out["flag_reads"], out["nbuckets"], out["n_hooked"] = bucket.flag_reads, len(bucket.buckets), bucket.launched_during_backward
     # a second backward before the exchange must raise instead of silently reducing partial gradients
     for p in (a, b, c):
         p.grad = None
@@ -183,9 +183,10 @@ def _run_bucket_edges(rank, world, port, ret):
 
 
 def test_bucket_live_set_changes_and_misuse():
-    """GradBucket hygiene: a parameter that first receives a gradient in a later step is picked up (bucket rebuild, on all ranks
-    together), a bucketed parameter without a gradient contributes zeros instead of silently skipping the bucket, the flat
-    buffers persist across steps, and a second backward before the exchange raises."""
+    """GradBucket hygiene: the bucket layout is static (all parameters that require a gradient), so a parameter that first receives
+    a gradient in a later step is reduced without any re-layout, a parameter without a gradient on ANY rank keeps `grad = None` as
+    in a single-process run (the optimizer skips it), the flat buffers persist, the reduced has-gradient flags are read on the host
+    only when the live set changes, and a second backward before the exchange raises."""
     world = 2
     port = 31500 + (os.getpid() % 2000)
     mgr = mp.Manager()
@@ -194,12 +195,87 @@ def test_bucket_live_set_changes_and_misuse():
     r0, r1 = ret[0], ret[1]
     for name in ("first", "hooked", "late", "missing", "steady"):
         keys = set(r0[name]["own"]) | set(r1[name]["own"])
-        for i in sorted(set(r0[name]["mean"]) | keys):
+        assert set(r0[name]["mean"]) == keys and set(r1[name]["mean"]) == keys, (name, keys)    # no gradient anywhere -> None
+        for i in sorted(keys):
             want = 0.5 * (r0[name]["own"].get(i, 0.0) + r1[name]["own"].get(i, 0.0))
-            if i in keys:
-                assert torch.allclose(r0[name]["mean"][i], want, rtol=1e-6, atol=1e-6), (name, i)
-                assert torch.equal(r0[name]["mean"][i], r1[name]["mean"][i]), (name, i)
-            else:                                     # bucketed, no gradient this step: the reduced value is exactly zero
-                assert float(r0[name]["mean"][i].abs().max()) == 0.0, (name, i)
-    assert r0["rebuilds"] == 1 and r0["nbuckets"] == 3 and r0["persistent"]
+            assert torch.allclose(r0[name]["mean"][i], want, rtol=1e-6, atol=1e-6), (name, i)
+            assert torch.equal(r0[name]["mean"][i], r1[name]["mean"][i]), (name, i)
+    # live sets: {0,1} {0,1} {0,1,2} {0,2} {0,1,2}: the flags are read in steps 1, 3, 4, 5 - not in the steady second step
+    assert r0["flag_reads"] == 4 and r0["nbuckets"] == 3 and r0["persistent"] and r0["n_hooked"] > 0
     assert r0["second_backward"] == "raised" and r1["second_backward"] == "raised"
+
+
+def _run_divergent_live_sets(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, C.PKG)
+    import tmg_dist
+    torch.set_num_threads(1)
+    tmg_dist.init_from_env("gloo")
+    torch.manual_seed(5)
+    a, b, c = (torch.nn.Parameter(torch.randn(7, 3)) for _ in range(3))
+    x = torch.randn(4, 3) + rank
+    bucket = tmg_dist.GradBucket([a, b, c], bucket_mb=1e-4)
+    out = []
+    # ranks DISAGREE about which parameters have gradients (rank 0: a, b; rank 1: a, c), then swap: the fixed collective sequence
+    # must neither hang nor mis-pair buffers; a parameter live on one rank is reduced with zeros from the other
+    for use in ((0, 1) if rank == 0 else (0, 2), (0, 2) if rank == 0 else (0, 1), (0, 1, 2)):
+        for p in (a, b, c):
+            p.grad = None
+        sum(((p @ x.t()) ** 2).sum() * (i + 1) for i, p in enumerate((a, b, c)) if i in use).backward()
+        own = {i: p.grad.clone() for i, p in enumerate((a, b, c)) if p.grad is not None}
+        bucket.allreduce_mean()
+        out.append({"own": own, "mean": {i: p.grad.clone() for i, p in enumerate((a, b, c)) if p.grad is not None}})
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_live_sets_do_not_deadlock():
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_divergent_live_sets, args=(world, port, ret), nprocs=world, join=True)
+    for s0, s1 in zip(ret[0], ret[1]):
+        assert set(s0["mean"]) == {0, 1, 2} and set(s1["mean"]) == {0, 1, 2}
+        for i in range(3):
+            want = 0.5 * (s0["own"].get(i, 0.0) + s1["own"].get(i, 0.0))
+            assert torch.allclose(s0["mean"][i], want, rtol=1e-6, atol=1e-6) and torch.equal(s0["mean"][i], s1["mean"][i])
+
+
+def _run_flat_broadcast(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, C.PKG)
+    import tmg_dist
+    torch.set_num_threads(1)
+    tmg_dist.init_from_env("gloo")
+    torch.manual_seed(100 + rank)            # every rank starts with DIFFERENT weights and buffers
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Conv2d(5, 2, 1))
+    with torch.no_grad():
+        m[1].running_mean.add_(rank + 1.0)
+        m[1].num_batches_tracked.add_(3 + rank)
+    calls = []
+    real = dist.broadcast
+    dist.broadcast = lambda t, src, *a, **k: (calls.append(t.numel()), real(t, src, *a, **k))[1]
+    try:
+        tmg_dist.broadcast_parameters(m)
+    finally:
+        dist.broadcast = real
+    ret[rank] = ({k: v.clone() for k, v in m.state_dict().items()}, calls)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameter_broadcast_is_one_collective_per_dtype():
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_flat_broadcast, args=(world, port, ret), nprocs=world, join=True)
+    torch.manual_seed(100)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Conv2d(5, 2, 1))
+    (sd0, calls0), (sd1, _) = ret[0], ret[1]
+    assert len(calls0) == 2, calls0                          # fp32 tensors, int64 counter
+    for k, v in ref.state_dict().items():
+        want = v + 1.0 if k == "1.running_mean" else (v + 3 if k == "1.num_batches_tracked" else v)
+        assert torch.equal(sd0[k], want) and torch.equal(sd1[k], want), k

@@ -268,6 +268,31 @@ def test_checker_and_upsample():
         _close(_back(xd.grad), xr.grad, what="upsample bwd")
 
 
+@pytest.mark.parametrize("ch,pad", [(6, 2), (3, 1), (5, 3), (2, 2)])
+def test_pad_halves_is_the_concatenation_with_zeros_and_its_own_adjoint(ch, pad):
+    """tmg_pad_halves (the zero-padded channel layout of 3-channel fields, flowLSTMBlock._pad_x): bit-identical to
+    cat(x1, 0, x2, 0) / its inverse, gradients are the opposite direction, slices of wider tensors are addressed in place."""
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(ch * 10 + pad)
+    wide = torch.randn(3, 5, 7, 2 * ch + 3, generator=g).to(DEV)
+    x = wide[..., 1:1 + 2 * ch]                                   # a channel-slice view: pixel stride != channel count
+    z = torch.zeros(3, 5, 7, pad, device=DEV)
+    want = torch.cat([x[..., :ch], z, x[..., ch:], z], 3)
+    xi = x.detach().clone().requires_grad_(True)
+    y = ops.PadHalvesFn.apply(xi, ch, pad, True)
+    y2 = ops.PadHalvesFn.apply(x, ch, pad, True)
+    assert torch.equal(y, want) and torch.equal(y2, want)
+    gy = torch.randn(want.shape, generator=g).to(DEV)
+    (y * gy).sum().backward()
+    assert torch.equal(xi.grad, torch.cat([gy[..., :ch], gy[..., ch + pad:2 * ch + pad]], 3))
+    yp = want.clone().requires_grad_(True)
+    back = ops.PadHalvesFn.apply(yp, ch, pad, False)
+    assert torch.equal(back, x)
+    gb = torch.randn(back.shape, generator=g).to(DEV)
+    (back * gb).sum().backward()
+    assert torch.equal(yp.grad, torch.cat([gb[..., :ch], z, gb[..., ch:], z], 3))
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, [8, 32]), (1, 7, 9, [6, 5]), (2, 32, 32, [8, 32, 4]), (2, 12, 12, [40])])
 def test_c1_forward_and_backward(shape):
     import tmg_hip as Hh_
@@ -919,7 +944,7 @@ def test_conv_pack_many_matches_single_packs():
 
 
 def test_conv_node_with_premasked_output_gradient():
-    """ops.conv(relu_out=True, grad_premasked=True): with an upstream gradient that is already zero wherever the output is, the
+    """ops.conv(relu_out=True, _grad_premasked=True): with an upstream gradient that is already zero wherever the output is, the
     backward pass without its own mask launch returns the gradients of the masked form bit for bit."""
     import tmg_ops as ops
     g = torch.Generator().manual_seed(5)
@@ -929,13 +954,23 @@ def test_conv_node_with_premasked_output_gradient():
     res = []
     for pre in (False, True):
         xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        y = ops.conv([xi], wi, bi, relu_out=True, grad_premasked=pre)
+        y = ops.conv([xi], wi, bi, relu_out=True, _grad_premasked=pre)
         up = torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(DEV) * (y.detach() > 0)     # the consumer's mask
         y.backward(up)
         res.append((y.detach(), xi.grad, wi.grad, bi.grad))
     for a, b_ in zip(*res):
         assert torch.equal(a, b_)
     assert float((res[0][0] == 0).float().mean()) > 0.2          # the ReLU really clipped something
+    # the contract check (TMG_CHECK_PREMASK=1): an un-masked upstream gradient - a second consumer of `out` - is reported
+    import os
+    os.environ["TMG_CHECK_PREMASK"] = "1"
+    try:
+        xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv([xi], wi, bi, relu_out=True, _grad_premasked=True)
+        with pytest.raises(RuntimeError, match="contract violated"):
+            y.backward(torch.ones_like(y))
+    finally:
+        os.environ.pop("TMG_CHECK_PREMASK", None)
 
 
 def test_lstm_pointwise_backward_without_cell_state_gradient():

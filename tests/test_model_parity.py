@@ -111,11 +111,12 @@ GRAD_YARDSTICK = 1.5   # gradients: bound = max(stated tolerance, 1.5 x the fp32
 # scale: the SAME HIP build lands at 6.5e-5 or at 2.9e-4 global rel-L2 from fp64 on config M (profiles/r3_parity_report_M.json, the
 # variant run twice), the second value within 4e-5 of the fp32 oracle, which sits at 2.9e-4 itself.  The arithmetic noise proper of
 # the HIP path is the smaller number; the flips are a property of the case, shared with the reference.
-# Which elements flip differs between two fp32 evaluations, so on these cases (loss on 1-2 samples: a deep 16x16 map contributes
-# 256-512 pixels to a weight gradient) up to FLIP_OUTLIERS[0] of the ~900 tensors may exceed the per-tensor bound, by at most
-# FLIP_OUTLIERS[1]x (observed: encoder.cond_convs.3.0.weight at 2.6e-2 against a bound of 2.1e-2 in one run, at 2e-4 in the next);
-# the global bound has no such allowance.
-FLIP_OUTLIERS = (2, 3.0)
+# Which elements flip differs between two fp32 evaluations.  Round 3 let any 2 of the ~900 tensors exceed the per-tensor bound 3x;
+# round 4 ties the allowance to evidence: the fp64 oracle pass runs under common.KinkProbe, which records every ReLU pre-activation
+# within 1e-5 (relative to its tensor's scale) of zero and measures - one extra backward pass through the retained graph - how far
+# flipping them moves EACH parameter gradient.  A tensor may exceed the per-tensor bound by its own measured allowance only; a tensor
+# that no near-kink ReLU feeds has none, and the global bound has none.  Comparisons of two HIP paths that share the arithmetic order
+# (test_level_kernels_across_field_and_batch_sizes) get no allowance at all.
 
 
 def _maxabs(a, b):
@@ -135,25 +136,35 @@ def _grad_err(got, ref):
     return (num / max(den, 1e-300)) ** 0.5, worst
 
 
-def _oracle_pass(O, sd, cfg, x, y, seeds, dtype, eps=None):
+def _oracle_pass(O, sd, cfg, x, y, seeds, dtype, eps=None, probe=False):
     """forward(+grads) and reconstruct(+grads) of the CPU oracle in `dtype`; eps: latents for the generative direction
-    (default: the forward pass's own)."""
+    (default: the forward pass's own).  probe: also measure the per-tensor ReLU-kink allowances of both directions
+    (common.KinkProbe; keys kf / kr, and the number of near-kink elements nkf / nkr)."""
     H_, W_ = y.shape[2], y.shape[3]
     P = O.params_from_state_dict(sd, dtype=dtype)
     st = [(h.to(dtype), c.to(dtype)) for h, c in O.init_lstm_states(cfg, seeds, [H_, W_])]
     xx, yy = x.to(dtype), y.to(dtype)
-    z, lp, ho, eo = O.tmglow_forward(P, cfg, xx, yy, st, return_eps=True, training=True)
-    C.loss_forward(lp, yy).backward()
+    import contextlib
+    kp = C.KinkProbe() if probe else contextlib.nullcontext()
+    with kp:
+        z, lp, ho, eo = O.tmglow_forward(P, cfg, xx, yy, st, return_eps=True, training=True)
+        C.loss_forward(lp, yy).backward(retain_graph=probe)
     gf = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
+    nkf = kp.n_elements if probe else 0
+    kf = kp.allowances(O.trainable(P), gf) if probe else None
     P = O.params_from_state_dict(sd, dtype=dtype)
     # identical inputs for every evaluation: the latents are ROUNDED to fp32 (what the fp32 paths can be given) before the fp64 pass too
     e_in = [t.detach().float().to(dtype) for t in (eps if eps is not None else eo)]
-    yr, ld, ho2 = O.tmglow_reconstruct(P, cfg, xx, st, e_in, training=True)
-    C.loss_reverse(yr, ld).backward()
+    kp = C.KinkProbe() if probe else contextlib.nullcontext()
+    with kp:
+        yr, ld, ho2 = O.tmglow_reconstruct(P, cfg, xx, st, e_in, training=True)
+        C.loss_reverse(yr, ld).backward(retain_graph=probe)
     gr = {k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None}
+    nkr = kp.n_elements if probe else 0
+    kr = kp.allowances(O.trainable(P), gr) if probe else None
     det = lambda t: t.detach()  # noqa: E731
     return dict(z=det(z), lp=det(lp), h=[(det(a), det(b)) for a, b in ho], eps=[det(t) for t in eo], gf=gf, y=det(yr), ld=det(ld),
-                h2=[(det(a), det(b)) for a, b in ho2], gr=gr)
+                h2=[(det(a), det(b)) for a, b in ho2], gr=gr, kf=kf, kr=kr, nkf=nkf, nkr=nkr)
 
 
 @pytest.mark.parametrize("name,cfg,B", [("cfg2", C.CFG2, 2), ("cfg3", C.CFG3, 1), ("M", C.CFG_M, 1), ("cfg5-64x64", CFG5_REDUCED, 2)])
@@ -193,7 +204,7 @@ def test_baseline_configs_match_fp64_oracle(name, cfg, B):
     x = torch.randn(B, cfg["in_features"], h, w, generator=g)
     y = torch.randn(B, cfg["out_features"], H_, W_, generator=g)
     seeds = torch.arange(B) + 3
-    r64 = _oracle_pass(O, sd, cfg, x, y, seeds, torch.float64)
+    r64 = _oracle_pass(O, sd, cfg, x, y, seeds, torch.float64, probe=True)
     r32 = _oracle_pass(O, sd, cfg, x, y, seeds, torch.float32, eps=r64["eps"])
     # ---- HIP
     st = m.initLSTMStates(seeds, [H_, W_])
@@ -225,10 +236,12 @@ def test_baseline_configs_match_fp64_oracle(name, cfg, B):
     def grads(tag, got, key):
         fl = _grad_err(r32[key], r64[key])
         er = _grad_err(got, r64[key])
+        kink = r64["k" + key[1]]
         rep[tag] = {"hip_vs_fp64": er, "oracle_fp32_vs_fp64": fl, "hip_vs_oracle_fp32": _grad_err(got, r32[key]),
-                    "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK}
+                    "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK,
+                    "near_kink_relus": r64["nk" + key[1]], "tensors_with_kink_allowance": len(kink)}
         C.assert_grads(got, r64[key], "%s %s" % (name, tag), global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
-                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), outliers=FLIP_OUTLIERS)
+                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), kink=kink, report=rep[tag])
 
     try:
         field("z", z, "z", C.FIELD_ATOL)
@@ -296,18 +309,25 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
 
     yr, ld, ho, gr = hip_step(x.to(DEV), st, eps, slice(0, n))
     assert float((yr - y.to(DEV)).abs().max()) < 2e-3          # forward -> reconstruct round trip over the WHOLE batch
+    import contextlib
     res = {}
     for dt in (torch.float64, torch.float32):
         P = O.params_from_state_dict(sd, dtype=dt)
-        z_out, c_out = O.encoder(P, cfg, x.to(dt), True)
-        cmean, clsd = z_out[:n].chunk(2, 1)
-        clsd = clsd.clamp(-10.0, O.LOG5)
-        z = cmean + torch.exp(clsd) * eps[-1][:n].cpu().to(dt)
-        sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
-        yo, ldo, hoo = O.decoder_reverse(P, cfg, z, [c[:n] for c in c_out], sto, [e[:n].cpu().to(dt) for e in eps[:-1]])
-        C.loss_reverse(yo, ldo).backward()
+        kp = C.KinkProbe() if dt == torch.float64 else contextlib.nullcontext()
+        with kp:
+            z_out, c_out = O.encoder(P, cfg, x.to(dt), True)
+            cmean, clsd = z_out[:n].chunk(2, 1)
+            clsd = clsd.clamp(-10.0, O.LOG5)
+            z = cmean + torch.exp(clsd) * eps[-1][:n].cpu().to(dt)
+            sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
+            yo, ldo, hoo = O.decoder_reverse(P, cfg, z, [c[:n] for c in c_out], sto, [e[:n].cpu().to(dt) for e in eps[:-1]])
+            C.loss_reverse(yo, ldo).backward(retain_graph=(dt == torch.float64))
         res[dt] = dict(y=yo.detach(), ld=ldo.detach(), h=[(a.detach(), b.detach()) for a, b in hoo],
                        g={k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None})
+        if dt == torch.float64:
+            res[dt]["nk"] = kp.n_elements
+            res[dt]["kink"] = kp.allowances(O.trainable(P), res[dt]["g"])
+        del yo, ldo, hoo, z, z_out, c_out
     r64, r32 = res[torch.float64], res[torch.float32]
     rep = {"config": name, "batch": B, "loss_samples": n}
     try:
@@ -323,10 +343,11 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
         fl = _grad_err(r32["g"], r64["g"])
         er = _grad_err(gr, r64["g"])
         rep["reverse grads"] = {"hip_vs_fp64": er, "oracle_fp32_vs_fp64": fl, "hip_vs_oracle_fp32": _grad_err(gr, r32["g"]),
-                                "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK}
+                                "stated": (C.GRAD_GLOBAL_REL_L2, C.GRAD_TENSOR_REL_MAX), "yardstick": GRAD_YARDSTICK,
+                                "near_kink_relus": r64["nk"], "tensors_with_kink_allowance": len(r64["kink"])}
         assert set(gr) == set(r64["g"]), sorted(set(gr) ^ set(r64["g"]))[:5]
         C.assert_grads(gr, r64["g"], name + " reverse grads at the stated batch", global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
-                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), outliers=FLIP_OUTLIERS)
+                       tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), kink=r64["kink"], report=rep["reverse grads"])
         # ---- density direction (forward(x, y), loss on the same n samples): its backward runs the per-op chain, not the fused kernels
         # (on the metric configuration only: two more oracle passes per case, and the per-op chain is what cfg2 / cfg3's wide levels
         # run in the generative direction anyway)
@@ -339,14 +360,19 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
             fres = {}
             for dt in (torch.float64, torch.float32):
                 P = O.params_from_state_dict(sd, dtype=dt)
-                z_out, c_out = O.encoder(P, cfg, x.to(dt), True)
-                cmean, clsd = z_out[:n].chunk(2, 1)
-                clsd = clsd.clamp(-10.0, O.LOG5)
-                sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
-                zo, ldo, _, _ = O.decoder_forward(P, cfg, y[:n].to(dt), [c[:n] for c in c_out], sto, False)
-                lpo = O.gauss_logp(cmean, clsd, zo) + ldo
-                C.loss_forward(lpo, y[:n].to(dt)).backward()
+                kp = C.KinkProbe() if dt == torch.float64 else contextlib.nullcontext()
+                with kp:
+                    z_out, c_out = O.encoder(P, cfg, x.to(dt), True)
+                    cmean, clsd = z_out[:n].chunk(2, 1)
+                    clsd = clsd.clamp(-10.0, O.LOG5)
+                    sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
+                    zo, ldo, _, _ = O.decoder_forward(P, cfg, y[:n].to(dt), [c[:n] for c in c_out], sto, False)
+                    lpo = O.gauss_logp(cmean, clsd, zo) + ldo
+                    C.loss_forward(lpo, y[:n].to(dt)).backward(retain_graph=(dt == torch.float64))
                 fres[dt] = dict(z=zo.detach(), lp=lpo.detach(), g={k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None})
+                if dt == torch.float64:
+                    fres[dt]["kink"] = kp.allowances(O.trainable(P), fres[dt]["g"])
+                del zo, ldo, lpo, z_out, c_out
             f64, f32 = fres[torch.float64], fres[torch.float32]
             C.assert_field(zf[:n], f64["z"], name + " z at the stated batch", atol=max(C.FIELD_ATOL, YARDSTICK * _maxabs(f32["z"], f64["z"])))
             lfl = float(((f32["lp"].double() - f64["lp"]).abs() / f64["lp"].abs().clamp_min(1.0)).max())
@@ -354,7 +380,7 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
             ffl = _grad_err(f32["g"], f64["g"])
             rep["forward grads"] = {"hip_vs_fp64": _grad_err(gfw, f64["g"]), "oracle_fp32_vs_fp64": ffl, "hip_vs_oracle_fp32": _grad_err(gfw, f32["g"])}
             C.assert_grads(gfw, f64["g"], name + " forward grads at the stated batch", global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * ffl[0]),
-                           tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * ffl[1]), outliers=FLIP_OUTLIERS)
+                           tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * ffl[1]), kink=f64["kink"], report=rep["forward grads"])
         # the same samples at the END of the batch
         roll = lambda t: torch.roll(t, -n, 0)  # noqa: E731
         yr2, ld2, _, gr2 = hip_step(roll(x).to(DEV), [(roll(a), roll(b)) for a, b in st], [roll(e) for e in eps], slice(B - n, B))
@@ -362,9 +388,10 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
         C.assert_logdet(ld2[B - n:], ld[:n], name + " logdet, loss samples last", rtol=2e-6, atol=1e-3)
         rep["rolled batch grads vs first"] = _grad_err(gr2, gr)
         # (equal up to the order of the atomics and of the BatchNorm sums; the reference's fp32 noise floor is the scale)
-        # (two fp32 evaluations that differ in the order of the BatchNorm sums flip different near-zero ReLUs: same allowance)
+        # (two fp32 evaluations that differ in the order of the BatchNorm sums flip different near-zero ReLUs: each tensor's own
+        # measured kink allowance, nothing more)
         C.assert_grads(gr2, gr, name + " grads with the loss samples at the end of the batch", global_tol=max(1e-4, fl[0]),
-                       tensor_tol=max(2e-3, fl[1]), outliers=FLIP_OUTLIERS)
+                       tensor_tol=max(2e-3, fl[1]), kink=r64["kink"])
     finally:
         print("\nparity %s at batch %d: %s" % (name, B, json.dumps(rep, default=float)))
         out = os.path.join(C.ROOT, "gpurun_out")
@@ -373,12 +400,15 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
                 json.dump(rep, f, indent=1, default=float)
 
 
-@pytest.mark.parametrize("name,cfg,B,n", [("cfg2", C.CFG2, 32, 2), ("cfg3", C.CFG3, 64, 2), ("M", C.CFG_M, 64, 2), ("cfg5", C.CFG5, 32, 1)])
+@pytest.mark.parametrize("name,cfg,B,n", [("cfg2", C.CFG2, 32, 2), ("cfg3", C.CFG3, 64, 2), ("M", C.CFG_M, 64, 2), ("cfg4", C.CFG_M, 32, 2),
+                                          ("cfg5", C.CFG5, 32, 1)])
 def test_stated_batches_match_oracle_with_gradients(name, cfg, B, n):
     """BASELINE configs[1] / configs[2] / the metric configuration at their STATED batch sizes (32 / 64 / 64: the benchmarked
-    shapes), with gradients - see _stated_batch_case - and configs[4]'s five-level network at its FULL 512x512 field at batch 32
+    shapes), configs[3] (cfg4: the metric network at 32 samples per GPU = global 256 over 8; the launch plans depend on the pixel
+    count), with gradients - see _stated_batch_case - and configs[4]'s five-level network at its FULL 512x512 field at batch 32
     (its 256-channel level then works on 8 192 pixels, the size at which the launch plans of the 128-channel level went wrong),
-    loss on one sample, fp32 mixes (the fp16-operand variant is outside the fp32 tolerances by construction)."""
+    loss on one sample, fp32 mixes (the fp16-operand variant is outside the fp32 tolerances by construction: its stated batch
+    is test_cfg5_stated_batch_with_fp16_mixes)."""
     _stated_batch_case(name, cfg, B, n=n, density=(name == "M"))
 
 
@@ -420,6 +450,76 @@ def test_cfg5_full_size_properties():
             assert all(k in gr and bool(torch.isfinite(gr[k]).all()) for k in live), [k for k in live if k not in gr][:5]
     finally:
         ops.set_mix_precision("f32")
+
+
+def test_cfg5_stated_batch_with_fp16_mixes():
+    """BASELINE configs[4] as stated: 512x512x4, five flow levels, 64 samples per GPU, fp16-operand / fp32-accumulate 1x1 mixes
+    (reference call sites glowConv.py:193-194, :219-220).  The fp16 variant is outside the fp32 tolerances by construction
+    (SURVEY 8-C), so the yardstick is this package's own fp32 path on the SAME batch (which test_stated_batches_match_oracle_with_
+    gradients pins against the fp64 oracle at batch 32): forward -> reconstruct over the whole batch in both precisions, the A.8
+    log-det identity, and one generative training step whose gradients are compared tensor by tensor with loose fp16 bounds.
+    At this batch the 128- and 256-channel levels run the launch plans of 65 536 / 16 384 pixels that no smaller case reaches."""
+    import json
+    import os
+    import tmg_ops as ops
+    from nn.tmGlow import TMGlow
+    from nn.modules.flowUtils import GaussianDiag
+    cfg, B = C.CFG5, 64
+    C.seed_all(12345)
+    m = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m, 7, *C.perturb_scales(cfg))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 4, 256, 256, generator=g).to(DEV)
+    y = torch.randn(B, 4, 512, 512, generator=g).to(DEV)
+    st = m.initLSTMStates(torch.arange(B) + 2, [512, 512])
+    res = {}
+    try:
+        for prec in ("f32", "f16"):
+            ops.set_mix_precision(prec)
+            m.load_state_dict(sd)
+            with torch.no_grad():
+                z, logp, _, eps = m.forward(x, y, st, return_eps=True)
+                z_out, _ = m.encoder.forward(x)
+                cmean, clsd = z_out.chunk(2, 1)
+                top = GaussianDiag(cmean, clsd).log_prob(z)
+                m.load_state_dict(sd)
+                # the generative direction on the FP32 run's latents in both precisions: the same function evaluated twice
+                e_in = [t.detach() for t in (res["f32"]["eps"] if prec == "f16" else eps)]
+                y_own, ld_own, _ = m.reconstruct(x, st, [t.detach() for t in eps])      # round trip / A.8 on this precision's own latents
+            m.load_state_dict(sd)
+            m.zero_grad()
+            yr, ld, _ = m.reconstruct(x, st, e_in)
+            C.loss_reverse(yr, ld).backward()
+            res[prec] = dict(z=z, logp=logp, top=top, eps=eps, y=yr.detach(), ld=ld.detach(), ld_own=ld_own,
+                             g={k: v.clone() for k, v in _grads(m).items()}, roundtrip=float((y_own - y).abs().max()))
+            del z, logp, eps, yr, ld, y_own, ld_own
+    finally:
+        ops.set_mix_precision("f32")
+    a, b = res["f16"], res["f32"]
+    live = [k for k, _ in m.named_parameters() if ".norm2." not in k]
+    assert all(k in a["g"] and bool(torch.isfinite(a["g"][k]).all()) for k in live)
+    ge = _grad_err(a["g"], b["g"])
+    rep = {"batch": B, "roundtrip_f32": b["roundtrip"], "roundtrip_f16": a["roundtrip"],
+           "z_maxabs": _maxabs(a["z"], b["z"]), "z_scale": float(b["z"].abs().max()),
+           "y_maxabs": _maxabs(a["y"], b["y"]),
+           "logp_rel": float(((a["logp"] - b["logp"]).abs() / b["logp"].abs().clamp_min(1.0)).max()),
+           "logdet_rel": float(((a["ld"] - b["ld"]).abs() / b["ld"].abs().clamp_min(1.0)).max()),
+           "reverse_grads_f16_vs_f32": ge}
+    print("\ncfg5 at batch %d, fp16-operand mixes against the fp32 HIP path: %s" % (B, json.dumps(rep, default=float)))
+    out = os.path.join(C.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_cfg5_batch64_fp16_mix.json"), "w") as f:
+            json.dump(rep, f, indent=1, default=float)
+    assert rep["z_maxabs"] > 0.0, "the fp16 variant must actually run"
+    assert b["roundtrip"] < 2e-3 and a["roundtrip"] < 5e-2, (b["roundtrip"], a["roundtrip"])
+    for r in (a, b):     # A.8: forward log-prob minus the top prior = the generative direction's log-det on the same latents
+        C.assert_logdet(r["logp"] - r["top"], r["ld_own"], "cfg5 batch 64: logp - top prior vs reverse logdet",
+                        rtol=2e-5 if r is b else 2e-3, atol=1.0)
+    assert rep["z_maxabs"] < 5e-2 * max(rep["z_scale"], 1.0) and rep["y_maxabs"] < 5e-2
+    assert rep["logp_rel"] < 2e-3 and rep["logdet_rel"] < 2e-3
+    assert ge[0] < 5e-2, ge
 
 
 def test_fp16_mix_variant_deviation_is_reported_separately():
@@ -1122,6 +1222,8 @@ def test_bptt_window_at_stated_batch_matches_oracle():
         P = O.params_from_state_dict(sd, dtype=dt)
         sto = [(a[:n].to(dt), b[:n].to(dt)) for a, b in O.init_lstm_states(cfg, seeds[:n], [H_, W_])]
         lo = 0.0
+        if dt == torch.float64:
+            kp = C.KinkProbe().__enter__()
         for t in range(T):
             z_out, c_out = O.encoder(P, cfg, xs[t].to(dt), True)
             cmean, clsd = z_out[:n].chunk(2, 1)
@@ -1129,8 +1231,11 @@ def test_bptt_window_at_stated_batch_matches_oracle():
             z = cmean + torch.exp(clsd) * eps[t][-1][:n].to(dt)
             yo, ldo, sto = O.decoder_reverse(P, cfg, z, [c[:n] for c in c_out], sto, [e[:n].to(dt) for e in eps[t][:-1]])
             lo = lo + C.loss_reverse(yo, ldo)
-        lo.backward()
+        lo.backward(retain_graph=(dt == torch.float64))
         res[dt] = dict(y=yo.detach(), loss=float(lo.detach()), g={k: v.grad.clone() for k, v in O.trainable(P).items() if v.grad is not None})
+        if dt == torch.float64:
+            kp.__exit__(None, None, None)
+            res[dt]["kink"] = kp.allowances(O.trainable(P), res[dt]["g"])
     r64, r32 = res[torch.float64], res[torch.float32]
     C.assert_field(yt[:n], r64["y"], "y of the second step", atol=max(C.FIELD_ATOL, YARDSTICK * _maxabs(r32["y"], r64["y"])))
     assert abs(float(loss) - r64["loss"]) <= 1e-5 * abs(r64["loss"]) + 1e-6
@@ -1139,7 +1244,7 @@ def test_bptt_window_at_stated_batch_matches_oracle():
     print("\nBPTT window %s at batch %d: hip vs fp64 %s, fp32 oracle vs fp64 %s" % (name, B, er, fl))
     assert set(gr) == set(r64["g"])
     C.assert_grads(gr, r64["g"], "two-step window grads at the stated batch", global_tol=max(C.GRAD_GLOBAL_REL_L2, GRAD_YARDSTICK * fl[0]),
-                   tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), outliers=FLIP_OUTLIERS)
+                   tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), kink=r64["kink"])
 
 
 @pytest.mark.parametrize("cin,hw,B", [(4, (64, 64), 64), (8, (17, 33), 32), (16, (16, 16), 128), (16, (9, 23), 64), (32, (8, 16), 64), (3, (30, 30), 64)])
@@ -1147,7 +1252,7 @@ def test_level_kernels_across_field_and_batch_sizes(cin, hw, B):
     """One flow level (generative direction + backward, recurrent states with gradients, loss on two samples) through the level-fused
     node and its fused / grouped kernels against the per-layer path on the general kernels (TMG_NO_LEVEL_FUSION=1), over the model's
     channel widths (16 .. 128, and the padded 12), ragged fields and batch sizes up to 128: the launch plans of the persistent, grouped
-    and fused kernels depend on the pixel count (tools/scratch/level_sweep.py is the long form)."""
+    and fused kernels depend on the pixel count (tools/level_sweep.py is the long form)."""
     import os
     from nn.modules.flowLSTMBlock import LSTMFLowBlock
     hs, ws = hw
@@ -1177,4 +1282,4 @@ def test_level_kernels_across_field_and_batch_sizes(cin, hw, B):
     C.assert_field(a[0], b[0], "level output", atol=1e-4 * float(b[0].abs().max()), rtol=1e-5)
     C.assert_logdet(a[1], b[1], rtol=5e-6, atol=1e-3)
     # (two fp32 evaluation orders flip different near-zero ReLUs: a local difference in @dz of a per cent of its scale, nothing global)
-    C.assert_grads(a[2], b[2], "level-fused vs per-layer path", global_tol=2e-4, tensor_tol=5e-3, outliers=FLIP_OUTLIERS)
+    C.assert_grads(a[2], b[2], "level-fused vs per-layer path", global_tol=2e-4, tensor_tol=5e-3)

@@ -189,3 +189,72 @@ def test_training_loop_capture_matches_reference():
         assert abs(float(gn) - float(d["step%d.gradnorm" % a])) < 2e-3 * float(d["step%d.gradnorm" % a]) * tol
         C.assert_field(P[str(d["log_s_key"])], d["step%d.log_s" % a], "log_s", atol=2e-5 * tol)
         a0 = [(0.5 * h.detach() + 0.5 * hk, 0.5 * c.detach() + 0.5 * ck) for (h, c), (hk, ck) in zip(a0, a_key)]
+
+
+def test_kink_probe_measures_what_a_relu_flip_does():
+    """common.KinkProbe (the evidence behind the per-tensor gradient allowances of the large GPU parity cases): on the tiny model in
+    fp64 with a wide threshold, (i) parameters that no ReLU follows in the generative direction - the first layer's zero conv and
+    1x1 mix, evaluated last - get NO allowance, (ii) re-evaluating with the recorded near-kink masks actually flipped leaves exactly
+    those gradients unchanged and moves the others by about what the probe predicted."""
+    import torch.nn.functional as F
+    cfg = C.CFG_TINY
+    d = C.load_npz("tiny_model.npz")
+    L = len(cfg["glow_blocks"])
+    x = torch.from_numpy(d["x"]).double()
+    h_in = [(h.double(), c.double()) for h, c in C.states_from(d, "h_in.", L)]
+    eps_in = [torch.from_numpy(d["fwd.eps.%d" % i]).double() for i in range(L + 1)]
+    old_thr = C.KinkProbe.THR
+    C.KinkProbe.THR = 2e-3
+    try:
+        P = _P(d, dtype=torch.float64)
+        with C.KinkProbe() as kp:
+            yr, ld, _ = O.tmglow_reconstruct(P, cfg, x, h_in, eps_in)
+            C.loss_reverse(yr, ld).backward(retain_graph=True)
+        g0 = {k: v.clone() for k, v in _grads(P).items()}
+        calls = {s["call"]: s["idx"] for s in kp.sites}
+        n_near = kp.n_elements
+        allow = kp.allowances(O.trainable(P), g0)
+    finally:
+        C.KinkProbe.THR = old_thr
+    assert n_near >= 3 and allow, (n_near, len(allow))
+    last = "glow.flow_blocks.0.revlayers.affine_layer1."
+    silent = [k for k in g0 if k.startswith(last + "conv.") or k.startswith(last + "coupling.coupling_nn.zero_conv.")]
+    assert silent and not any(k in allow for k in silent), [k for k in silent if k in allow]
+    assert any(k.startswith("encoder.") for k in allow)
+    # ---- the same evaluation with every recorded near-kink element on the other side of its ReLU
+    real = F.relu
+    seen = [0]
+
+    def flipped_relu(t, inplace=False):
+        if not t.requires_grad:
+            return real(t)
+        idx = calls.get(seen[0])
+        seen[0] += 1
+        if idx is None:
+            return real(t)
+        mask = (t.detach() > 0).to(t.dtype)
+        mask[idx] = 1.0 - mask[idx]
+        return t * mask
+
+    P = _P(d, dtype=torch.float64)
+    F.relu = flipped_relu
+    try:
+        yr, ld, _ = O.tmglow_reconstruct(P, cfg, x, h_in, eps_in)
+        C.loss_reverse(yr, ld).backward()
+    finally:
+        F.relu = real
+    assert seen[0] > max(calls), "every recorded site must be met again"
+    g1 = _grads(P)
+    moved = 0
+    for k, g in g0.items():
+        scale = float(g.abs().max())
+        if scale == 0:
+            continue
+        rel = float((g1[k] - g).abs().max()) / scale
+        if k in silent:
+            # (not zero: the flipped elements' forward values move by up to the - here very wide - threshold)
+            assert rel < 1e-2, (k, rel)
+        else:
+            assert rel <= 3.0 * allow.get(k, 0.0) + 1e-2, (k, rel, allow.get(k, 0.0))     # (40 % changes here: far from linear)
+            moved += rel > 2e-2
+    assert moved >= 5, "the flips must move some gradients well beyond the silent ones, or the test shows nothing"

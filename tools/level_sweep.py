@@ -2,7 +2,7 @@
 per-layer / per-op HIP path (TMG_NO_LEVEL_FUSION=1: every contraction through the general kernels): the fused / grouped kernels'
 launch plans depend on the pixel count.  GPU only."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

@@ -1,7 +1,7 @@
 """Sweep the launch plans of the contraction kernels over pixel counts for the model's channel configurations (all levels of
 configs M / cfg5): forward, input gradient and weight gradient through the autograd node against fp64."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd")):
     sys.path.insert(0, p)
 import torch
