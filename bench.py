@@ -15,11 +15,12 @@ The JSON line also carries
   cpu_baseline: the CPU oracle (oracle/tmglow_oracle.py, a port of the reference's torch-CPU path) timed on
                 this box's host cores on a bounded sample of the same workload.
 """
-import argparse
-import json
-import os
-import sys
 import time
+_T0 = time.perf_counter()      # (before the heavy imports: on a fresh box the first `import torch` alone can take a minute or two)
+import argparse  # noqa: E402
+import json  # noqa: E402
+import os  # noqa: E402
+import sys  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd"), os.path.join(ROOT, "tests")):
@@ -139,7 +140,6 @@ def pmc_traffic(kernel):
     return round(tot / n) if n else None
 
 
-_T0 = time.perf_counter()
 _PHASES = []
 
 

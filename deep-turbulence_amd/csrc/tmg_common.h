@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -151,6 +152,33 @@ __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int i
 
 // Zero-filled global memory: lanes of a load batch that have nothing to read point here, so the batch has no control flow.
 static __device__ float tmg_zero_page[64];
+
+// ---- XCD-aware tile order (speed only, never correctness) --------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2: MI355X_MICROARCH.md, Workgroup dispatch), so with
+// tile = blockIdx.x neighbouring tiles of an image always sit on DIFFERENT L2s and every halo line is fetched from the fabric
+// by each of them.  The tile kernels below walk a LOGICAL block order instead in which an XCD owns one contiguous eighth of the
+// tiles (whole images at the large levels): halo lines and the half-used cache lines of neighbouring tiles are then shared in
+// one L2.  TMG_NO_XCD_MAP=1 (read once per process by the launchers) restores the plain order for A/B measurements.
+static inline int tmg_xcd_map_on() {
+    static const int on = getenv("TMG_NO_XCD_MAP") ? 0 : 1;
+    return on;
+}
+// logical id of physical block b of a grid of G: XCD x = b % 8 owns the contiguous logical ids [x G/8 + min(x, G%8), ...)
+__device__ __forceinline__ int tmg_xcd_block(int b, int G, int on) {
+    if (!on || G < 16) return b;
+    const int qn = G >> 3, rn = G & 7, x = b & 7;
+    return x * qn + min(x, rn) + (b >> 3);
+}
+// grid-stride tile loop of block b: for (t = first; t < end; t += step).  XCD x walks the tiles [n x / 8, n (x + 1) / 8) with
+// the blocks it holds.
+struct TmgTileRange { int first, end, step; };
+__device__ __forceinline__ TmgTileRange tmg_xcd_tiles(int ntiles, int b, int G, int on) {
+    if (!on || G < 16 || ntiles < 64) return TmgTileRange{b, ntiles, G};
+    const int x = b & 7;
+    const int nb = (G >> 3) + (x < (G & 7) ? 1 : 0);
+    const int lo = (int)(((long long)ntiles * x) >> 3), hi = (int)(((long long)ntiles * (x + 1)) >> 3);
+    return TmgTileRange{lo + (b >> 3), hi, nb};
+}
 
 // Address of 4 consecutive (concatenated) input channels c..c+3 of pixel (b,iy,ix) under the padding rule, for
 // float4-addressable segment lists (p.vec4); the zero page when there is nothing to read.

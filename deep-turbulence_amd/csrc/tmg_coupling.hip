@@ -31,8 +31,15 @@ __device__ __forceinline__ float cpl_exp(float v) { return __expf(v); }
 __device__ __forceinline__ float cpl_rcp(float v) { return __frcp_rn(v); }
 
 struct CplFP {
-    const float* x; int xs;          // layer input, C channels: x1 = [0, ch), x2 = [ch, C)
-    float* out; int os;              // layer output (C channels)
+    // The two channel halves of an activation are addressed separately: half 1 = channels [0, ch) at x + pixel * xs, half 2 =
+    // channels [ch, C) at x2 + pixel * x2s.  One interleaved [npix][C] tensor is x2 = x + ch, x2s = xs; the narrow levels keep the
+    // halves in tensors of their own (round 4: the kernels that read x1 alone - growth layers, their backward, three weight
+    // gradients - then fetch whole cache lines of what they use, and this kernel's x1 patch and x2 epilogue loads stop evicting
+    // each other's half-used lines).
+    const float* x; int xs;          // layer input, half 1 (x1)
+    const float* x2; int x2s;        // layer input, half 2 (x2)
+    float* out; int os;              // layer output, half 1
+    float* out2; int o2s;            // layer output, half 2
     float* rsave;                    // [npix][ch] softsign arguments r
     float* y2save;                   // [npix][ch] transformed half (null: not stored)
     const float* D;                  // [npix][4] raw (d1, d2, 0, 0)
@@ -44,6 +51,7 @@ struct CplFP {
     float* logdet;                   // [B], accumulated
     int B, H, W, C, reverse;
     int tiles_x, tiles_y, ntiles;
+    int xmap;                        // XCD-aware tile order (tmg_common.h)
 };
 
 // CT: 16-channel output tiles (C <= 16 CT); K4: input-channel quads of the zero conv = ch/4 + 1 (the last quad is d1, d2, 0, 0)
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
     // a block owns a contiguous range of tiles (neighbouring tiles share halo lines in L2, and the log-det partial sums of an
     // image stay in registers until the range moves on to the next image: one atomic per wave and image, not per tile)
     const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t0 = (int)blockIdx.x * per, t1 = min(t0 + per, p.ntiles);
+    const int t0 = tmg_xcd_block((int)blockIdx.x, (int)gridDim.x, p.xmap) * per, t1 = min(t0 + per, p.ntiles);
     if (t0 < t1) TMG_CPL_ISSUE(t0)
     int par = 0, ldb = -1;
     float ldacc = 0.f;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
             _Pragma("unroll") for (int mt = 0; mt < CT; ++mt) {                                                      \
                 const bool ok_ = 16 * mt + 4 * q < C;                                                                \
                 HV[mt] = *reinterpret_cast<const float4*>(ok_ ? p.hc + gp_ * p.hcs + 16 * mt + 4 * q : tmg_zero_page); \
-                XV[mt] = *reinterpret_cast<const float2*>(ok_ ? p.x + gp_ * p.xs + ch + 8 * mt + 2 * q : tmg_zero_page); \
+                XV[mt] = *reinterpret_cast<const float2*>(ok_ ? p.x2 + gp_ * p.x2s + 8 * mt + 2 * q : tmg_zero_page); \
             }                                                                                                        \
         }
         TMG_CPL_EPI_LOAD(hcur, xcur, 0)
@@ -248,16 +256,19 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
                     for (int mo = 0; mo < CT; ++mo) oacc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[mo][t], bfm, oacc[mo], 0, 0, 0);
                 }
 #pragma unroll
-                for (int mo = 0; mo < CT; ++mo)
-                    if (pin && 16 * mo + 4 * q < C)
-                        *reinterpret_cast<float4*>(p.out + gp * p.os + 16 * mo + 4 * q) = make_float4(oacc[mo][0], oacc[mo][1], oacc[mo][2], oacc[mo][3]);
+                for (int mo = 0; mo < CT; ++mo) {
+                    const int c = 16 * mo + 4 * q;      // a channel quad lies in one half (ch is a multiple of 4)
+                    if (pin && c < C)
+                        *reinterpret_cast<float4*>(c < ch ? p.out + gp * p.os + c : p.out2 + gp * p.o2s + (c - ch)) =
+                            make_float4(oacc[mo][0], oacc[mo][1], oacc[mo][2], oacc[mo][3]);
+                }
             } else {
                 // no trailing mix: out = [x1 | y2]
                 const int cpx = (row0 + nt) * 16 + li;
 #pragma unroll
                 for (int mt = 0; mt < CT; ++mt)
                     if (pin && 8 * mt + 2 * q < ch) {
-                        *reinterpret_cast<float2*>(p.out + gp * p.os + ch + 8 * mt + 2 * q) = make_float2(y2r[mt][0], y2r[mt][1]);
+                        *reinterpret_cast<float2*>(p.out2 + gp * p.o2s + 8 * mt + 2 * q) = make_float2(y2r[mt][0], y2r[mt][1]);
                         const int c = 8 * mt + 2 * q;
                         *reinterpret_cast<float2*>(p.out + gp * p.os + c) = *reinterpret_cast<const float2*>(XR + ((c >> 1) * 256 + cpx) * 2);
                     }
@@ -305,20 +316,40 @@ static int launch_cpl_fwd(const CplFP& p, hipStream_t st) {
 // Tensors are NHWC fp32; every channel count / stride is a multiple of 4.
 // dims = {B, H, W, C, reverse, x pixel stride, out pixel stride, hc pixel stride, row length of wz, column of d1 in wz}.
 // Returns -100 when the shape is outside the kernel's envelope (C/2 a multiple of 4, 8 <= C <= 32): the caller uses the per-op path.
+extern "C" int tmg_coupling_fwd_halves(const void* x1, const void* x2, void* out1, void* out2, void* rsave, void* y2save, const void* D,
+                                       const void* hc, const void* wz, const void* bz, const void* kappa, const void* Wm, const void* bm,
+                                       void* logdet, const int64_t* dims, hipStream_t st);
+
 extern "C" int tmg_coupling_fwd(const void* x, void* out, void* rsave, void* y2save, const void* D, const void* hc, const void* wz,
                                 const void* bz, const void* kappa, const void* Wm, const void* bm, void* logdet, const int64_t* dims,
                                 hipStream_t st) {
+    // one interleaved [npix][C] tensor each: the second halves start C / 2 channels in, same pixel stride
+    const int64_t ch = dims[3] / 2;
+    const int64_t d2[12] = {dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7], dims[8], dims[9], dims[5], dims[6]};
+    return tmg_coupling_fwd_halves(x, (const float*)x + ch, out, (float*)out + ch, rsave, y2save, D, hc, wz, bz, kappa, Wm, bm, logdet, d2, st);
+}
+
+// As tmg_coupling_fwd with the channel halves of the layer input and output addressed separately (see CplFP).
+// dims = {B, H, W, C, reverse, x1 pixel stride, out1 pixel stride, hc pixel stride, row length of wz, column of d1 in wz, x2 pixel
+// stride, out2 pixel stride}.
+extern "C" int tmg_coupling_fwd_halves(const void* x1, const void* x2, void* out1, void* out2, void* rsave, void* y2save, const void* D,
+                                       const void* hc, const void* wz, const void* bz, const void* kappa, const void* Wm, const void* bm,
+                                       void* logdet, const int64_t* dims, hipStream_t st) {
     CplFP p;
+    p.xmap = tmg_xcd_map_on();
     p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.C = (int)dims[3]; p.reverse = (int)dims[4];
-    p.x = (const float*)x; p.xs = (int)dims[5];
-    p.out = (float*)out; p.os = (int)dims[6];
+    p.x = (const float*)x1; p.xs = (int)dims[5];
+    p.x2 = (const float*)x2; p.x2s = (int)dims[10];
+    p.out = (float*)out1; p.os = (int)dims[6];
+    p.out2 = (float*)out2; p.o2s = (int)dims[11];
     p.rsave = (float*)rsave; p.y2save = (float*)y2save; p.D = (const float*)D;
     p.hc = (const float*)hc; p.hcs = (int)dims[7];
     p.wz = (const float*)wz; p.wz_rows = (int)dims[8]; p.wz_d1col = (int)dims[9];
     p.bz = (const float*)bz; p.kappa = (const float*)kappa; p.Wm = (const float*)Wm; p.bm = (const float*)bm;
     p.logdet = (float*)logdet;
     const int ch = p.C / 2;
-    if (p.C < 8 || p.C > 32 || (ch & 3) || (p.xs & 3) || (p.os & 3) || (p.hcs & 3)) return -100;
+    if (p.C < 8 || p.C > 32 || (ch & 3) || (p.xs & 3) || (p.os & 3) || (p.hcs & 3) || (p.x2s & 3) || (p.o2s & 3)) return -100;
+    if ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)out1) | ((uintptr_t)out2)) & 15) return -100;
     p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 15) / 16; p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.ntiles <= 0) return 0;
     switch (ch / 4) {
@@ -348,19 +379,23 @@ extern "C" int tmg_coupling_fwd(const void* x, void* out, void* rsave, void* y2s
 // (2, ux) applied to the data of row q.y itself (instead of q.y + 1), likewise bottom / left / right, plus one tap for each image
 // corner.  These extra MFMA steps are skipped (wave- / block-uniform branches) away from the border.
 struct CplBP {
-    const float* dout; int dos;      // gradient w.r.t. the layer output (C channels)
-    const float* x; int xs;          // layer input (tin): only tin2 = channels [ch, C) is read
+    // channel halves addressed separately, as in CplFP: half 1 = [0, ch) at base + pixel * stride, half 2 = [ch, C) at base2 + ..
+    const float* dout; int dos;      // gradient w.r.t. the layer output, half 1
+    const float* dout2; int do2s;    //                                   half 2
+    const float* x; int xs;          // tin2: the SECOND half of the layer input (the only one read), channel 0 = model channel ch
     const float* r;                  // [npix][ch] saved softsign arguments
     const float* g;                  // [B] gradient arriving on the log-det (null: 0)
     const float* Wm;                 // [C][C] trailing mix of the forward pass
     const float* wz; int wz_rows, wz_d1col;
     const float* kappa;
     float* DH; int dhs;              // [npix] x C slice: e^kappa * dhh
-    float* dtin; int dts;            // [npix] x C: second half = dtin2; first half = dto1 (pass-through gradient, completed by dense2_bwd)
+    float* dtin; int dts;            // gradient w.r.t. the layer input, half 1 = dto1 (pass-through gradient, completed by dense2_bwd)
+    float* dtin2; int dt2s;          //                                  half 2 = dtin2
     float* G0;                       // [npix][ch]
     float* GD;                       // [npix][4]
     int B, H, W, C;
     int tiles_x, tiles_y, ntiles;
+    int xmap;                        // XCD-aware tile order (tmg_common.h)
 };
 
 // CT = 16-channel tiles of C; MT = 16-channel tiles of the dgrad output (ch + 2 channels); KS = C / 4 channel quads of dhh
@@ -397,7 +432,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
             }
 
     const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t0 = (int)blockIdx.x * per, t1 = min(t0 + per, p.ntiles);
+    const int t0 = tmg_xcd_block((int)blockIdx.x, (int)gridDim.x, p.xmap) * per, t1 = min(t0 + per, p.ntiles);
     for (int tile = t0; tile < t1; ++tile) {
         int t_ = tile;
         const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
@@ -416,11 +451,11 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
             const size_t gp_ = img + (size_t)min(max(gy_, 0), p.H - 1) * p.W + min(max(gx_, 0), p.W - 1);              \
             _Pragma("unroll") for (int h = 0; h < CT; ++h) {                                                           \
                 const int c_ = 16 * h + 4 * q;                                                                         \
-                DV[h] = *reinterpret_cast<const float4*>((in_ && c_ < C) ? p.dout + gp_ * p.dos + c_ : tmg_zero_page);  \
+                DV[h] = *reinterpret_cast<const float4*>((in_ && c_ < C) ? (c_ < ch ? p.dout + gp_ * p.dos + c_ : p.dout2 + gp_ * p.do2s + (c_ - ch)) : tmg_zero_page);  \
                 /* the lanes whose accumulator quad of m-tile h is a dto2 quad (channel c_ >= ch) need r / tin2 of j0 = c_ - ch */ \
                 const bool two_ = in_ && c_ >= ch && c_ < C;                                                           \
                 RV[h] = *reinterpret_cast<const float4*>(two_ ? p.r + gp_ * ch + (c_ - ch) : tmg_zero_page);           \
-                TV[h] = *reinterpret_cast<const float4*>(two_ ? p.x + gp_ * p.xs + c_ : tmg_zero_page);                \
+                TV[h] = *reinterpret_cast<const float4*>(two_ ? p.x + gp_ * p.xs + (c_ - ch) : tmg_zero_page);         \
             }                                                                                                          \
         }
         constexpr int NTA = (PP + 15) / 16;   // 21
@@ -473,7 +508,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
                         for (int e = 0; e < 4; ++e) *reinterpret_cast<float2*>(DHL + ((j0 + e) * PP + rp) * 2) = make_float2(da[e], dr[e]);
                     }
                     if (center) {
-                        *reinterpret_cast<float4*>(p.dtin + gp * p.dts + c) = make_float4(di[0], di[1], di[2], di[3]);
+                        *reinterpret_cast<float4*>(p.dtin2 + gp * p.dt2s + j0) = make_float4(di[0], di[1], di[2], di[3]);
                         *reinterpret_cast<float4*>(p.DH + gp * p.dhs + 2 * j0) = make_float4(da[0], dr[0], da[1], dr[1]);
                         *reinterpret_cast<float4*>(p.DH + gp * p.dhs + 2 * j0 + 4) = make_float4(da[2], dr[2], da[3], dr[3]);
                     }
@@ -562,20 +597,40 @@ static int launch_cpl_bwd(const CplBP& p, hipStream_t st) {
 // Backward of tmg_coupling_fwd's generative-direction layer up to the coupling network's input gradients (see above).
 // dims = {B, H, W, C, dout pixel stride, x pixel stride, DH pixel stride, dtin pixel stride, row length of wz, column of d1 in wz}.
 // Returns -100 outside the envelope (8 <= C <= 32, C/2 a multiple of 4).
+extern "C" int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, const void* x2, const void* r, const void* g, const void* Wm,
+                                       const void* wz, const void* kappa, void* DH, void* dtin1, void* dtin2, void* G0, void* GD,
+                                       const int64_t* dims, hipStream_t st);
+
 extern "C" int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void* g, const void* Wm, const void* wz,
                                 const void* kappa, void* DH, void* dtin, void* G0, void* GD, const int64_t* dims, hipStream_t st) {
+    const int64_t ch = dims[3] / 2;
+    const int64_t d2[12] = {dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7], dims[8], dims[9], dims[4], dims[7]};
+    return tmg_coupling_bwd_halves(dout, (const float*)dout + ch, (const float*)x + ch, r, g, Wm, wz, kappa, DH, dtin, (float*)dtin + ch, G0, GD,
+                                   d2, st);
+}
+
+// As tmg_coupling_bwd with the channel halves of dout / dtin addressed separately and x2 = the second half of the layer input.
+// dims = {B, H, W, C, dout1 pixel stride, x2 pixel stride, DH pixel stride, dtin1 pixel stride, row length of wz, column of d1 in wz,
+// dout2 pixel stride, dtin2 pixel stride}.
+extern "C" int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, const void* x2, const void* r, const void* g, const void* Wm,
+                                       const void* wz, const void* kappa, void* DH, void* dtin1, void* dtin2, void* G0, void* GD,
+                                       const int64_t* dims, hipStream_t st) {
     CplBP p;
+    p.xmap = tmg_xcd_map_on();
     p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.C = (int)dims[3];
-    p.dout = (const float*)dout; p.dos = (int)dims[4];
-    p.x = (const float*)x; p.xs = (int)dims[5];
+    p.dout = (const float*)dout1; p.dos = (int)dims[4];
+    p.dout2 = (const float*)dout2; p.do2s = (int)dims[10];
+    p.x = (const float*)x2; p.xs = (int)dims[5];
     p.r = (const float*)r; p.g = (const float*)g; p.Wm = (const float*)Wm;
     p.wz = (const float*)wz; p.wz_rows = (int)dims[8]; p.wz_d1col = (int)dims[9];
     p.kappa = (const float*)kappa;
     p.DH = (float*)DH; p.dhs = (int)dims[6];
-    p.dtin = (float*)dtin; p.dts = (int)dims[7];
+    p.dtin = (float*)dtin1; p.dts = (int)dims[7];
+    p.dtin2 = (float*)dtin2; p.dt2s = (int)dims[11];
     p.G0 = (float*)G0; p.GD = (float*)GD;
     const int ch = p.C / 2;
-    if (p.C < 8 || p.C > 32 || (ch & 3) || (p.dos & 3) || (p.xs & 3) || (p.dhs & 3) || (p.dts & 3)) return -100;
+    if (p.C < 8 || p.C > 32 || (ch & 3) || (p.dos & 3) || (p.xs & 3) || (p.dhs & 3) || (p.dts & 3) || (p.do2s & 3) || (p.dt2s & 3)) return -100;
+    if ((((uintptr_t)dout1) | ((uintptr_t)dout2) | ((uintptr_t)x2) | ((uintptr_t)dtin1) | ((uintptr_t)dtin2)) & 15) return -100;
     p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 15) / 16; p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.ntiles <= 0) return 0;
     switch (ch / 4) {

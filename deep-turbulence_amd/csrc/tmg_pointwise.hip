@@ -714,6 +714,7 @@ struct C1X2P {
     const float* add2; int a2_stride, a2_off;
     float* out; int out_stride;  // float4 (d1, d2, 0, 0) per pixel
     int TW_log2, tiles_x, tiles_y, KCH;
+    int xmap;                    // XCD-aware tile order (tmg_common.h)
 };
 
 // CG: threads per pixel.  The kernel is a chain of LDS-read latencies with one pixel per thread, so a 256-pixel tile per block leaves the
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(256) void c1x2_fwd_kernel(C1X2P p) {
     const int tid = threadIdx.x;
     const int pid = tid / CG, cg = tid % CG;   // the CG lanes of a pixel are adjacent lanes of one wave
     const bool lead = cg == 0;
-    int t = blockIdx.x;
+    int t = tmg_xcd_block((int)blockIdx.x, (int)gridDim.x, p.xmap);
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
     const int ty = t % p.tiles_y;
@@ -992,6 +993,7 @@ struct D2BP {
     float* dd1_out; float* dd2_out; int dd_stride;  // optional: masked gradients w.r.t. d1 / d2 per pixel (null: not written)
     int dd_quad;                                    // the two are channels 0, 1 of a float4 slot whose channels 2, 3 are to be zero: one 16-byte store
     int TW_log2, tiles_x, tiles_y, ntiles, KCH;
+    int xmap;                                       // XCD-aware tile order (tmg_common.h)
 };
 
 // WG: with the weight gradients of both layers (false: the caller computes them with the MFMA weight-gradient kernel)
@@ -1026,7 +1028,8 @@ __global__ __launch_bounds__(256) void dense2_bwd_kernel(D2BP p) {
     const bool wo_ok = WG && tid < kch * 9;
     const int wo_ky = wo_tap / 3, wo_kx = wo_tap - wo_ky * 3;
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const TmgTileRange tr_ = tmg_xcd_tiles(p.ntiles, (int)blockIdx.x, (int)gridDim.x, p.xmap);
+    for (int tile = tr_.first; tile < tr_.end; tile += tr_.step) {
         int t = tile;
         const int tx = t % p.tiles_x;
         t /= p.tiles_x;
@@ -1243,7 +1246,8 @@ __global__ __launch_bounds__(256, NQ <= 2 ? 4 : 3) void dense2_bwd_lean_kernel(D
     const char* gdb = reinterpret_cast<const char*>(p.GD);
     const char* dpb = reinterpret_cast<const char*>(p.Dp);
     const int nq_here = min(NQ, (p.cin_nn - c0) >> 2);     // live channel quads of this block (block-uniform)
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const TmgTileRange tr_ = tmg_xcd_tiles(p.ntiles, (int)blockIdx.x, (int)gridDim.x, p.xmap);
+    for (int tile = tr_.first; tile < tr_.end; tile += tr_.step) {
         int t = tile;
         const int tx = t % p.tiles_x;
         t /= p.tiles_x;
@@ -1636,6 +1640,7 @@ extern "C" int tmg_c1x2_fwd(const void* const* in_ptrs, const int64_t* in_desc, 
                             const void* add1, const int64_t* add1_d, const void* add2, const int64_t* add2_d, void* out,
                             const int64_t* out_d, const int64_t* dims, hipStream_t st) {
     C1X2P p;
+    p.xmap = tmg_xcd_map_on();
     p.nseg = (int)nseg;
     p.vec4 = 1;
     fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);
@@ -1766,6 +1771,7 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
                               const void* const* g0_ptrs, const int64_t* g0_desc, void* const* out_ptrs, const int64_t* out_desc,
                               int64_t ng, const void* add0, int64_t add0_stride, const int64_t* dims, hipStream_t st) {
     D2BP p;
+    p.xmap = tmg_xcd_map_on();
     p.nseg = (int)nseg;
     p.vec4 = 1;
     fill_segs_pw(p.in, in_ptrs, in_desc, (int)nseg, &p.vec4);

@@ -201,8 +201,22 @@ __global__ __launch_bounds__(256) void mix_wgrad_kernel(MixWgP p) {
     const int g = blockIdx.x % p.G, part = blockIdx.x / p.G;
     const long long* gt = p.gtab + (size_t)g * 16;
     const int n0 = (int)gt[3], n1 = (int)gt[7];
-    const float* dyp = reinterpret_cast<const float*>(gt[12]);
-    const long long dys = gt[13];
+    // upstream gradient: channel halves addressed separately (row entries 12 / 13: half 1, 14 / 15: half 2; a null second pointer =
+    // one interleaved tensor, half 2 starting C / 2 channels in)
+    const float* ap[CT];
+    long long as_[CT];
+    {
+        const float* dy1 = reinterpret_cast<const float*>(gt[12]);
+        const float* dy2 = reinterpret_cast<const float*>(gt[14]);
+        const int chh = p.C >> 1;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int c = 16 * t + li;
+            const bool two = dy2 != nullptr && c >= chh;
+            ap[t] = two ? dy2 + (c - chh) : dy1 + c;
+            as_[t] = two ? gt[15] : gt[13];
+        }
+    }
     // per-lane source of the B operand (mix input channel 16 nt + li): segment pointer and pixel stride
     const float* bp[CT];
     long long bs[CT];
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(256) void mix_wgrad_kernel(MixWgP p) {
             const bool ok = px < p1;
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
-                a[u][t] = *(ok ? dyp + px * dys + 16 * t + li : tmg_zero_page);
+                a[u][t] = *(ok ? ap[t] + px * as_[t] : tmg_zero_page);
                 b[u][t] = *(ok ? bp[t] + px * bs[t] : tmg_zero_page);
             }
         }

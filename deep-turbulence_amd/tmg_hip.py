@@ -35,7 +35,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves",
 ]
 
 
@@ -511,9 +511,18 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
     dy: [B,H,W,>= G*Cg] with group g at channels [g*Cg, (g+1)*Cg), or None with group_dy = list of G tensors [B,H,W,Cg]
     of identical layout; dW: [G, Cg, cin_dst, k, k] contiguous; dbias: [G, Cg] or None.  Returns False when the library
     cannot group this shape (nothing was launched)."""
+    dy_pairs = group_dy is not None and isinstance(group_dy[0], (tuple, list))     # every group's dy as (half 1, half 2) tensors
+    if dy_pairs:
+        # only the streaming 1x1 kernel below reads an upstream gradient in two halves
+        if not (ksize == 1 and stride == 1 and int(dy_group_channels) in (16, 32) and os.environ.get("TMG_NO_MIX_WGRAD_KERNEL") is None):
+            group_dy = [torch.cat(list(t), 3) for t in group_dy]
+            dy_pairs = False
     if dy is None:
-        dy = group_dy[0]
-        assert all(t.shape == dy.shape and t.stride() == dy.stride() for t in group_dy)
+        dy = group_dy[0][0] if dy_pairs else group_dy[0]
+        if dy_pairs:
+            assert all(a.shape == dy.shape and b.shape == dy.shape for a, b in group_dy)     # (strides per group: from the table)
+        else:
+            assert all(t.shape == dy.shape and t.stride() == dy.stride() for t in group_dy)
     if torch.cuda.is_current_stream_capturing():
         return False  # the segment table is a host-to-device copy, which a graph capture cannot record: per-group launches
     G = len(group_inputs)
@@ -525,12 +534,20 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
     Cin = sum(t.shape[3] for t in first)
     rows = []
     for segs in group_inputs:
-        assert len(segs) == n_in and all(a.shape == b.shape and a.stride() == b.stride() for a, b in zip(segs, first))
+        # same shapes in every group; the pixel strides may differ (a group's row of the device table carries its own: the first and
+        # last layer of a level's node address channel-slice views of [.., C] tensors, the others [.., C/2] tensors of their own)
+        assert len(segs) == n_in and all(a.shape == b.shape and a.stride(2) % 4 == b.stride(2) % 4 for a, b in zip(segs, first))
         row = []
         for t in segs:
             row += list(seg(t))  # (pointer incl. the view's channel offset, pixel stride, 0, channels)
         row += [0, 0, 0, 0] * (3 - n_in)
-        row += ([seg(group_dy[len(rows)])[0], seg(group_dy[len(rows)])[1], 0, 0] if group_dy is not None else [0, 0, 0, 0])
+        if group_dy is None:
+            row += [0, 0, 0, 0]
+        elif dy_pairs:
+            a, b = group_dy[len(rows)]
+            row += [seg(a)[0], seg(a)[1], seg(b)[0], seg(b)[1]]
+        else:
+            row += [seg(group_dy[len(rows)])[0], seg(group_dy[len(rows)])[1], 0, 0]
         rows.append(row)
     gtab = _segment_table(rows, dy.device)
     if (group_dy is None and ksize == 3 and stride == 1 and Cin >= 20 and Cg >= 32 and os.environ.get("TMG_NO_WINOGRAD") is None
@@ -548,12 +565,17 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
                 return True
     if (group_dy is not None and ksize == 1 and stride == 1 and Cg == Cin and Cin in (16, 32) and cin_dst in (0, Cin)
             and cin_valid in (0, Cin) and ci_split == 0 and os.environ.get("TMG_NO_MIX_WGRAD_KERNEL") is None
-            and all(_pixel_linear(t) for segs in group_inputs for t in segs) and all(_pixel_linear(t) for t in group_dy)):
+            and all(_pixel_linear(t) for segs in group_inputs for t in segs)
+            and all(_pixel_linear(t) for e in group_dy for t in (e if dy_pairs else (e,)))):
         # the 1x1 mixes' weight gradients: streaming GEMM over the pixels, operands straight from global memory
         rc = lib().tmg_mix_wgrad_grouped(_ptr(gtab), c_i64(G), _ptr(dW), _ptr(dbias), _i64(B * Hin * Win, Cin), _stream())
         if rc != -100:
             _chk(rc, "tmg_mix_wgrad_grouped")
             return True
+    if dy_pairs:    # outside the streaming kernel's envelope after all: the general kernels read one tensor per group
+        return conv_wgrad_grouped(group_inputs, None, dy_group_channels, dW, dbias, ksize, stride, relu_in=relu_in, pad_rep=pad_rep,
+                                  cin_dst=cin_dst, cin_valid=cin_valid, ci_split=ci_split, ci_off0=ci_off0, ci_off1=ci_off1,
+                                  group_dy=[torch.cat(list(t), 3) for t in group_dy])
     if (group_dy is None and ksize == 3 and stride == 1 and Cg == 4 and not pad_rep and dbias is None and cin_dst in (0, Cin)
             and cin_valid in (0, Cin) and ci_split == 0 and Cin in (12, 20, 36, 68) and os.environ.get("TMG_NO_THIN_WGRAD") is None
             and all(t.stride(2) % 4 == 0 and t.data_ptr() % 16 == 0 for segs in group_inputs for t in segs)):
@@ -574,34 +596,53 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
     return True
 
 
+def _halves(t):
+    """(half 1, half 2) of an activation given as ONE [B,H,W,C] tensor (channel-slice views of it) or as a pair of [B,H,W,C/2]
+    tensors (the split layout of the narrow levels)."""
+    if isinstance(t, (tuple, list)):
+        a, b = t
+        assert a.shape == b.shape
+        return a, b
+    ch = t.shape[3] // 2
+    return t[..., :ch], t[..., ch:]
+
+
 def coupling_fwd(x, out, rsave, y2save, D, hc, wz, bz, kappa, Wm, bm, logdet, reverse, wz_d1col):
-    """Zero conv + affine coupling + log-det (+ trailing channel mix) of one coupling layer in one launch (tmg_coupling_fwd).
-    x / out: [B,H,W,C] NHWC (or channel-slice views); D: [B,H,W,4] from c1x2_fwd; hc: [B,H,W,C] view of the level's conditioning
-    contribution.  Returns False when the shape is outside the kernel's envelope (nothing was launched)."""
-    B, Hh, Ww, C = x.shape
-    sx, so, sh = seg(x), seg(out), seg(hc)
+    """Zero conv + affine coupling + log-det (+ trailing channel mix) of one coupling layer in one launch (tmg_coupling_fwd_halves).
+    x / out: [B,H,W,C] NHWC (or channel-slice views), or PAIRS of [B,H,W,C/2] tensors (channel halves in tensors of their own);
+    D: [B,H,W,4] from c1x2_fwd; hc: [B,H,W,C] view of the level's conditioning contribution.  Returns False when the shape is
+    outside the kernel's envelope (nothing was launched)."""
+    x1, x2 = _halves(x)
+    o1, o2 = _halves(out)
+    B, Hh, Ww, ch = x1.shape
+    s1, s2, t1, t2, sh = seg(x1), seg(x2), seg(o1), seg(o2), seg(hc)
     assert rsave.is_contiguous() and D.is_contiguous() and (y2save is None or y2save.is_contiguous()) and wz.is_contiguous()
-    dims = _i64(B, Hh, Ww, C, 1 if reverse else 0, sx[1], so[1], sh[1], wz.shape[1], wz_d1col)
-    rc = lib().tmg_coupling_fwd(c_vp(sx[0]), c_vp(so[0]), _ptr(rsave), _ptr(y2save), _ptr(D), c_vp(sh[0]), _ptr(wz), _ptr(bz), _ptr(kappa),
-                                _ptr(Wm), _ptr(bm), _ptr(logdet), dims, _stream())
+    dims = _i64(B, Hh, Ww, 2 * ch, 1 if reverse else 0, s1[1], t1[1], sh[1], wz.shape[1], wz_d1col, s2[1], t2[1])
+    rc = lib().tmg_coupling_fwd_halves(c_vp(s1[0]), c_vp(s2[0]), c_vp(t1[0]), c_vp(t2[0]), _ptr(rsave), _ptr(y2save), _ptr(D), c_vp(sh[0]),
+                                       _ptr(wz), _ptr(bz), _ptr(kappa), _ptr(Wm), _ptr(bm), _ptr(logdet), dims, _stream())
     if rc == -100:
         return False
-    _chk(rc, "tmg_coupling_fwd")
+    _chk(rc, "tmg_coupling_fwd_halves")
     return True
 
 
-def coupling_bwd(dout, x, r, g, Wm, wz, kappa, DH, dtin, G0, GD, wz_d1col):
+def coupling_bwd(dout, x2, r, g, Wm, wz, kappa, DH, dtin, G0, GD, wz_d1col):
     """Mix input gradient + affine-coupling backward + zero-conv input gradient (exact replicate adjoint) of one generative-
-    direction coupling layer in one launch (tmg_coupling_bwd).  DH: [B,H,W,C] channel-slice view of the level's stash."""
-    B, Hh, Ww, C = dout.shape
-    sd, sx, sh, st = seg(dout), seg(x), seg(DH), seg(dtin)
+    direction coupling layer in one launch (tmg_coupling_bwd_halves).  dout / dtin: [B,H,W,C] tensors or pairs of [B,H,W,C/2] halves;
+    x2: the SECOND half of the layer input [B,H,W,C/2] (a channel-slice view or a tensor of its own); DH: [B,H,W,C] channel-slice
+    view of the level's stash."""
+    d1, d2 = _halves(dout)
+    t1, t2 = _halves(dtin)
+    B, Hh, Ww, ch = d1.shape
+    assert x2.shape[3] == ch
+    sd1, sd2, sx, sh, st1, st2 = seg(d1), seg(d2), seg(x2), seg(DH), seg(t1), seg(t2)
     assert r.is_contiguous() and G0.is_contiguous() and GD.is_contiguous() and Wm.is_contiguous() and wz.is_contiguous()
-    dims = _i64(B, Hh, Ww, C, sd[1], sx[1], sh[1], st[1], wz.shape[1], wz_d1col)
-    rc = lib().tmg_coupling_bwd(c_vp(sd[0]), c_vp(sx[0]), _ptr(r), _ptr(g), _ptr(Wm), _ptr(wz), _ptr(kappa), c_vp(sh[0]), c_vp(st[0]),
-                                _ptr(G0), _ptr(GD), dims, _stream())
+    dims = _i64(B, Hh, Ww, 2 * ch, sd1[1], sx[1], sh[1], st1[1], wz.shape[1], wz_d1col, sd2[1], st2[1])
+    rc = lib().tmg_coupling_bwd_halves(c_vp(sd1[0]), c_vp(sd2[0]), c_vp(sx[0]), _ptr(r), _ptr(g), _ptr(Wm), _ptr(wz), _ptr(kappa), c_vp(sh[0]),
+                                       c_vp(st1[0]), c_vp(st2[0]), _ptr(G0), _ptr(GD), dims, _stream())
     if rc == -100:
         return False
-    _chk(rc, "tmg_coupling_bwd")
+    _chk(rc, "tmg_coupling_bwd_halves")
     return True
 
 

@@ -796,15 +796,26 @@ class LevelCouplingFn(torch.autograd.Function):
         # (tmg_coupling_fwd) after the growth layers' launch; wide levels keep one launch per op
         fuse = (8 <= C <= 32 and ch % 4 == 0 and _MIX_PRECISION == "f32" and os.environ.get("TMG_NO_FUSED_COUPLING") is None
                 and all(w.is_contiguous() for w in wts))
+        # Split-halves layout (round 4; generative direction on the levels whose per-layer kernels are bandwidth-bound): between
+        # the layers of the node an activation lives as TWO [B,h,w,C/2] tensors (x1, x2) instead of one [B,h,w,C].  The kernels
+        # that read x1 alone - growth layers, their backward, three weight gradients - then use every byte of the lines they
+        # fetch (a 64-byte pixel of the 16-channel level shares its 128-byte line with the neighbour's other half), and the fused
+        # coupling kernel's x1 patch loads and x2 epilogue loads no longer pull each other's half-used lines through L2 twice.
+        # The node's input and output stay single tensors (addressed as two channel-slice views).
+        split = fuse and reverse and C in (16, 32) and os.environ.get("TMG_NO_SPLIT_HALVES") is None
         mixaff = (reverse and C in (64, 128) and _MIX_PRECISION == "f32" and Wm.is_contiguous() and bm.is_contiguous()
                   and os.environ.get("TMG_NO_MIX_AFFINE") is None)
         for k in (range(NL - 1, -1, -1) if reverse else range(NL)):
             xin = cur
             if fuse:
                 tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
+                t1 = H._halves(tin)[0]
                 D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
-                H.c1x2_fwd([tin[..., :ch]], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=dc_of(k)[0], add2=dc_of(k)[1])
-                out = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+                H.c1x2_fwd([t1], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=dc_of(k)[0], add2=dc_of(k)[1])
+                if split and k != 0:     # (k = 0 is the node's last layer in this direction: its output is the node's)
+                    out = (torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32), torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32))
+                else:
+                    out = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
                 r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
                 y2 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32) if reverse else None
                 ok = H.coupling_fwd(tin, out, r, y2, D, Hc[..., k * C:(k + 1) * C], wzs[k], bzs[k], kps[k], Wm[k] if reverse else None,
@@ -812,7 +823,7 @@ class LevelCouplingFn(torch.autograd.Function):
                 assert ok
                 cur = out
                 # the coupling output y: reverse -> (x1 of the input, y2) as two segments (never materialised), forward -> out
-                saved[k] = (xin, tin, D, r, [tin[..., :ch], y2] if reverse else out)
+                saved[k] = (xin, tin, D, r, [t1, y2] if reverse else out)
                 continue
             tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
             x1 = tin[..., :ch]
@@ -845,6 +856,7 @@ class LevelCouplingFn(torch.autograd.Function):
         # grad_fn -> ctx reference) is not itself an element of `saved`: no reference cycle when backward never runs
         ctx.saved = saved
         ctx.fuse = fuse
+        ctx.split = split
         ctx.meta = (NL, NLp, reverse, ch, Cc)
         ctx.save_for_backward(cond, Wm, bm, Wzc, Wdc, *wts)
         return cur.view(cur.shape), logdet
@@ -896,22 +908,26 @@ class LevelCouplingFn(torch.autograd.Function):
             saved[k] = None
             if reverse and ctx.fuse and os.environ.get("TMG_NO_FUSED_COUPLING_BWD") is None:
                 # one launch: mix input gradient -> coupling backward -> zero-conv input gradient (exact replicate adjoint)
-                dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+                if ctx.split and k != NL - 1:    # gradient w.r.t. a layer input that lives as two halves: the same layout
+                    dtin = (torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32), torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32))
+                else:                            # (k = NL - 1: the node's own input gradient)
+                    dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
                 G0 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
                 GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
                 dhh = DH[..., k * C:(k + 1) * C]
-                ok = H.coupling_bwd(dcur, tin, r, g, Wm[k].contiguous(), wzs[k], kps[k], dhh, dtin, G0, GD, ch + Cc)
+                x1, x2 = H._halves(tin)
+                dt1 = H._halves(dtin)[0]
+                ok = H.coupling_bwd(dcur, x2, r, g, Wm[k].contiguous(), wzs[k], kps[k], dhh, dtin, G0, GD, ch + Cc)
                 assert ok
-                x1 = tin[..., :ch]
                 if grouped:
                     wg_in[k] = [x1, D]
                     mix_wg[k] = (y, dcur)
                 else:
                     H.conv_wgrad([x1, D], dhh, dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
                                  ci_split=ch, ci_off0=0, ci_off1=Cc)
-                    H.conv_wgrad(y, dcur, dWm[k], dbm[k], 1, 1)
-                H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
-                             add0=dtin[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
+                    H.conv_wgrad(y, dcur if torch.is_tensor(dcur) else torch.cat(list(dcur), 3), dWm[k], dbm[k], 1, 1)
+                H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dt1], ch,
+                             add0=dt1, rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
                              split2=ch, gap2=Cc, dd_quad=True)
                 dcur = dtin
                 del xin, tin, D, r, y
@@ -967,9 +983,13 @@ class LevelCouplingFn(torch.autograd.Function):
                     H.conv_wgrad(wg_in[k], DD[..., 4 * k:4 * k + 4], tmpX[k], None, 3, 1, relu_in=True)
             wg_in = None
             # the 1x1 mix weight gradients of all layers: same trick, every group with its own upstream gradient tensor
-            if not H.conv_wgrad_grouped([a for a, _ in mix_wg], None, C, dWm.view(NL, C, C, 1, 1), dbm, 1, 1, group_dy=[g_ for _, g_ in mix_wg]):
+            gdy = [g_ for _, g_ in mix_wg]
+            if any(not torch.is_tensor(g_) for g_ in gdy):      # split-halves layout: every group's upstream gradient as two halves
+                gdy = [H._halves(g_) for g_ in gdy]
+            if not H.conv_wgrad_grouped([a for a, _ in mix_wg], None, C, dWm.view(NL, C, C, 1, 1), dbm, 1, 1, group_dy=gdy):
                 for k in range(NL):
-                    H.conv_wgrad(mix_wg[k][0], mix_wg[k][1], dWm[k], dbm[k], 1, 1)
+                    gk = mix_wg[k][1]
+                    H.conv_wgrad(mix_wg[k][0], gk if torch.is_tensor(gk) else torch.cat(list(gk), 3), dWm[k], dbm[k], 1, 1)
             mix_wg = None
         # conditioning side of the whole level: one input-gradient pass, three weight-gradient passes
         Gc = torch.empty(cond.shape, device=dev, dtype=torch.float32)

@@ -283,6 +283,19 @@ int tmg_coupling_fwd(const void* x, void* out, void* rsave, void* y2save, const 
 int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void* g, const void* Wm, const void* wz, const void* kappa,
                      void* DH, void* dtin, void* G0, void* GD, const int64_t* dims, tmg_stream_t st);
 
+/* tmg_coupling_fwd / tmg_coupling_bwd with the two channel halves of every [npix][C] activation addressed separately (the halves
+ * are the chunk(2, 1) of flowAffine.py:73 / :98; the narrow flow levels keep them in tensors of their own so that the kernels
+ * reading x1 alone fetch whole cache lines of what they use).  The entry points above are these with half 2 = half 1 + C/2.
+ * fwd dims = {B,H,W,C,reverse, x1 stride, out1 stride, hc stride, wz row length, d1 column, x2 stride, out2 stride}
+ * bwd dims = {B,H,W,C, dout1 stride, x2 stride, DH stride, dtin1 stride, wz row length, d1 column, dout2 stride, dtin2 stride};
+ * x2 = the second half of the layer input (the only part of it the backward pass reads). */
+int tmg_coupling_fwd_halves(const void* x1, const void* x2, void* out1, void* out2, void* rsave, void* y2save, const void* D,
+                            const void* hc, const void* wz, const void* bz, const void* kappa, const void* Wm, const void* bm,
+                            void* logdet, const int64_t* dims, tmg_stream_t st);
+int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, const void* x2, const void* r, const void* g, const void* Wm,
+                            const void* wz, const void* kappa, void* DH, void* dtin1, void* dtin2, void* G0, void* GD,
+                            const int64_t* dims, tmg_stream_t st);
+
 /* ---- reduced-precision 1x1 channel mix (tmg_mix16.hip) ---------------------------------------------------------- */
 
 /* y = fp16(W) . fp16(x) + bias per pixel with fp32 accumulation on v_mfma_f32_16x16x16_f16: the "fp16 MFMA 1x1 conv" variant
