@@ -81,20 +81,33 @@ class LSTMAffineCouplingLayer(nn.Module):
             return y, ld, (h_next, c_next)
         ch, dev = chp - pad, xn.device
         z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)  # noqa: E731
-        ins = lambda w, at: torch.cat([w[:, :at], z(w.shape[0], pad, 3, 3), w[:, at:]], 1)  # noqa: E731  zero input rows at `at`
         cell, oc = self.resid_lstm.convLSTM, self.resid_lstm.out_seq.LSTM_out_conv
         cin = oc.weight.shape[0]                       # ch + cond channels: width of the block's feature map
+        src = [cell.conv.weight, oc.weight, oc.bias, db.denselayer1.conv1.weight, db.denselayer2.conv1.weight, zc.conv.weight, zc.conv.bias]
+
+        def build():
+            ins = lambda w, at: torch.cat([w[:, :at], z(w.shape[0], pad, 3, 3), w[:, at:]], 1)  # noqa: E731  zero input rows at `at`
+            gw = ins(cell.conv.weight, ch)
+            ow = torch.cat([ins(oc.weight, ch), z(pad, oc.weight.shape[1] + pad, 3, 3)], 0)      # feature map widened by `pad` zero channels
+            ob = torch.cat([oc.bias, z(pad)])
+            w1 = torch.cat([db.denselayer1.conv1.weight, z(1, pad, 3, 3)], 1)
+            w2 = ins(db.denselayer2.conv1.weight, cin)                                             # before the d1 row
+            wz = torch.cat([ins(zc.conv.weight, cin), z(2 * pad, zc.conv.weight.shape[1] + pad, 3, 3)], 0)
+            bz = torch.cat([zc.conv.bias, z(2 * pad)])
+            return [gw, ow, ob, w1, w2, wz, bz]
+
+        # parameter-sized functions of the weights alone: one evaluation per BPTT window (ops.DerivedCache, gradient-sink proxies)
+        cache = self.__dict__.get('_derived')
+        if cache is None:
+            cache = self.__dict__['_derived'] = ops.DerivedCache()
+        gw, ow, ob, w1, w2, wz, bz = cache.get('pad', src, (int(ch), int(pad)), build, proxies=True)
         if state is None:
             h_cur, c_cur = z(*xn.shape[:3], cell.hidden_dim), None
         else:
             h_cur, c_cur = state
-        h_next, c_next = ops.ConvLSTMCellFn.apply(ins(cell.conv.weight, ch), cell.conv.bias, h_cur, c_cur, x1, condn)
-        ow = torch.cat([ins(oc.weight, ch), z(pad, oc.weight.shape[1] + pad, 3, 3)], 0)      # feature map widened by `pad` zero channels
-        out = ops.conv([x1, condn, h_next], ow, torch.cat([oc.bias, z(pad)]), relu_out=True, _grad_premasked=True)
-        w1 = torch.cat([db.denselayer1.conv1.weight, z(1, pad, 3, 3)], 1)
-        w2 = ins(db.denselayer2.conv1.weight, cin)                                             # before the d1 row
-        wz = torch.cat([ins(zc.conv.weight, cin), z(2 * pad, zc.conv.weight.shape[1] + pad, 3, 3)], 0)
-        y, ld = ops.CouplingTailFn.apply(xn, out, w1, w2, wz, torch.cat([zc.conv.bias, z(2 * pad)]), zc.scale, reverse, 1)
+        h_next, c_next = ops.ConvLSTMCellFn.apply(gw, cell.conv.bias, h_cur, c_cur, x1, condn)
+        out = ops.conv([x1, condn, h_next], ow, ob, relu_out=True, _grad_premasked=True)
+        y, ld = ops.CouplingTailFn.apply(xn, out, w1, w2, wz, bz, zc.scale, reverse, 1)
         return y, ld, (h_next, c_next)
 
     def _call(self, x, cond, rec_states, reverse):

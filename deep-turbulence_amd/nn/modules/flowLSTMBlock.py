@@ -186,6 +186,12 @@ class LSTMFLowBlock(nn.Module):
         if do_split:
             self.split = Split(in_features)
 
+    def _all_lu(self):
+        """Every layer of the level has a PLU-parameterised 1x1 conv of the same orientation (what _level_mix folds; TMGlow always
+        builds such levels, tmGlow.py:366)."""
+        convs = [l.conv for l in self.revlayers._modules.values()]
+        return all(isinstance(c, InvertibleConv1x1LU) and c.train_sampling == convs[0].train_sampling for c in convs)
+
     def _level_mix(self, reverse, hw):
         """Fold ActNorm + PLU 1x1 conv of ALL K layers of this level in one batched pass of O(K C^3) torch ops
         (parameter-side bookkeeping, reference glowConv.py:151-174 + actNorm.py:66-83) instead of K separate ones.
@@ -258,6 +264,33 @@ class LSTMFLowBlock(nn.Module):
         Wm, bm, ld, Wh, bh, Wt, bt = ops.LevelMixFoldFn.apply(meta, *params)
         return Wm, bm, ld.view(()), (Wh, bh, Wt, bt)
 
+    def _cache(self):
+        c = self.__dict__.get('_derived')
+        if c is None:
+            c = self.__dict__['_derived'] = ops.DerivedCache()     # (plain attribute: not a buffer, never part of the state_dict)
+        return c
+
+    def _mix_params(self):
+        out = []
+        for l in self.revlayers._modules.values():
+            c = l.conv
+            # (not log_s_old: the fold itself writes that buffer - the reference's W-cache key, glowConv.py:157)
+            out += [c.l, c.u, c.log_s, c.p, c.sign_s] if isinstance(c, InvertibleConv1x1LU) else list(c.parameters())
+            if hasattr(l, 'norm'):
+                out += [l.norm.weight, l.norm.bias]
+        return out
+
+    def _level_mix_cached(self, reverse, hw, ch, pad):
+        """(_level_mix(reverse, hw), padded Wm, padded bm) - evaluated once per BPTT window (ops.DerivedCache): the T time-steps of a
+        window share the folded mixes, autograd sums their T gradients and runs the fold's backward launch once."""
+        def build():
+            lm = self._level_mix(reverse, hw)
+            if lm is None:
+                return (None, None, None)
+            Wm, bm = self._pad_mix(lm[0], lm[1], ch, pad) if pad else (lm[0], lm[1])
+            return (lm, Wm, bm)
+        return self._cache().get(('mix', bool(reverse)), self._mix_params(), (int(hw), int(ch), int(pad)), build)
+
     def _fusable(self, lm, xn):
         """The level-fused node needs LU blocks throughout (lm) and >= 1 non-LSTM layer.  Halves that are not 16-byte aligned
         (3-channel fields: C = 12 on the first level) run the same node on zero-padded channels, see _level_call."""
@@ -297,18 +330,28 @@ class LSTMFLowBlock(nn.Module):
         if pad == 0:
             return ops.LevelCouplingFn.apply(xn, condn, Wm, bm, reverse, *wts)
         NL, dev = len(layers), xn.device
-        z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)  # noqa: E731
-        w1 = torch.stack(wts[0::5])                     # [NL, 1, ch + Cc, 3, 3]
-        w2 = torch.stack(wts[1::5])                     # [NL, 1, ch + Cc + 1, 3, 3]
-        wz = torch.stack(wts[2::5])                     # [NL, C, ch + Cc + 2, 3, 3]
-        bz = torch.stack(wts[3::5])                     # [NL, C]
-        ins = lambda w: torch.cat([w[:, :, :ch], z(NL, w.shape[1], pad, 3, 3), w[:, :, ch:]], 2)  # noqa: E731  zero rows after x1's
-        w1p, w2p = ins(w1), ins(w2)
-        wzp = torch.cat([ins(wz), z(NL, 2 * pad, wz.shape[2] + pad, 3, 3)], 1)   # padding pairs (shift, r) = zero output channels
-        bzp = torch.cat([bz, z(NL, 2 * pad)], 1)
+
+        def build():
+            z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)  # noqa: E731
+            w1 = torch.stack(wts[0::5])                     # [NL, 1, ch + Cc, 3, 3]
+            w2 = torch.stack(wts[1::5])                     # [NL, 1, ch + Cc + 1, 3, 3]
+            wz = torch.stack(wts[2::5])                     # [NL, C, ch + Cc + 2, 3, 3]
+            bz = torch.stack(wts[3::5])                     # [NL, C]
+            ins = lambda w: torch.cat([w[:, :, :ch], z(NL, w.shape[1], pad, 3, 3), w[:, :, ch:]], 2)  # noqa: E731  zero rows after x1's
+            w1p, w2p = ins(w1), ins(w2)
+            wzp = torch.cat([ins(wz), z(NL, 2 * pad, wz.shape[2] + pad, 3, 3)], 1)   # padding pairs (shift, r) = zero output channels
+            bzp = torch.cat([bz, z(NL, 2 * pad)], 1)
+            out = []
+            for k in range(NL):
+                out += [w1p[k], w2p[k], wzp[k], bzp[k]]
+            return out
+
+        # the padded copies are parameter-sized functions of the weights alone: one evaluation per BPTT window, gradients summed over
+        # the window's time-steps before they go back through the padding ops (ops.DerivedCache, proxies of the gradient sink)
+        padded = self._cache().get(('tail', len(layers)), [w for i, w in enumerate(wts) if i % 5 != 4], (int(ch), int(pad)), build, proxies=True)
         wp = []
         for k in range(NL):
-            wp += [w1p[k], w2p[k], wzp[k], bzp[k], wts[5 * k + 4]]
+            wp += padded[4 * k:4 * k + 4] + [wts[5 * k + 4]]
         return ops.LevelCouplingFn.apply(xn, condn, Wm, bm, reverse, *wp)
 
     @staticmethod
@@ -330,13 +373,12 @@ class LSTMFLowBlock(nn.Module):
         xn, condn = self._squeeze_nhwc(H.nhwc(x), True), H.nhwc(cond)
         st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
         layers = list(self.revlayers._modules.values())
-        lm = self._level_mix(False, xn.shape[1] * xn.shape[2])
+        ch = xn.shape[3] // 2
+        pad = (-ch) % 4 if (self._all_lu() and xn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
+        lm, Wm, bm = self._level_mix_cached(False, xn.shape[1] * xn.shape[2], ch, pad)
         logdet = 0. if lm is None else lm[2]
         out_states = []
         fused = self._fusable(lm, xn)
-        ch = xn.shape[3] // 2
-        pad = (-ch) % 4 if (lm is not None and xn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
-        Wm, bm = (None, None) if lm is None else (self._pad_mix(lm[0], lm[1], ch, pad) if pad else (lm[0], lm[1]))
         if pad:
             xn = self._pad_x(xn, ch, pad)
         sp = lm[3] if (fused and not pad and len(lm) > 3) else None      # (head, tail) views of the fold node: no autograd slicing
@@ -370,13 +412,12 @@ class LSTMFLowBlock(nn.Module):
         yn, condn = H.nhwc(y), H.nhwc(cond)
         st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
         layers = list(self.revlayers._modules.values())
-        lm = self._level_mix(True, yn.shape[1] * yn.shape[2])
+        ch = yn.shape[3] // 2
+        pad = (-ch) % 4 if (self._all_lu() and yn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
+        lm, Wm, bm = self._level_mix_cached(True, yn.shape[1] * yn.shape[2], ch, pad)
         if lm is not None:
             logdet = logdet + lm[2]
         fused = self._fusable(lm, yn)
-        ch = yn.shape[3] // 2
-        pad = (-ch) % 4 if (lm is not None and yn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
-        Wm, bm = (None, None) if lm is None else (self._pad_mix(lm[0], lm[1], ch, pad) if pad else (lm[0], lm[1]))
         if pad:
             yn = self._pad_x(yn, ch, pad)
         sp = lm[3] if (fused and not pad and len(lm) > 3) else None      # (head, tail) views of the fold node: no autograd slicing

@@ -266,7 +266,9 @@ def train_window(model, optimizer, xs, states, key_states, loss_fn, bucket=None,
             y, logp, states = sample(model, xs[t], states, t)
         loss = loss + loss_fn(y, logp)
         outs.append((y.detach(), logp.detach()))
-    loss.backward()
+    import tmg_ops
+    with tmg_ops.fused_grad_accumulation():    # the T per-time-step parameter gradients: T - 1 multi-tensor adds, not ~900 T tiny ones
+        loss.backward()
     if bucket is not None:
         bucket.allreduce_mean()
     gn = None

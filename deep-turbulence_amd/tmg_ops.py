@@ -68,6 +68,130 @@ def zeros_like(t):
     return _pool.zeros(t.shape, t.device)
 
 
+# Bumped by every writer of parameter memory that torch's version counters do not see (tmg_optim.HipAdam updates the parameters
+# from a kernel launched through ctypes): part of the key of every value derived from parameters (DerivedCache).
+PARAM_GENERATION = [0]
+
+
+class DerivedCache:
+    """Tensors derived from parameters by pure functions - zero-padded weights of the 3-channel layout, the folded ActNorm + PLU
+    mixes of a level - that a BPTT window evaluates T = 10 times on unchanged parameters (reference trainFlowParallel.py:256-287:
+    the optimizer steps once per window).  An entry is valid while its source parameters are unchanged (data pointer, torch version
+    counter, PARAM_GENERATION), for the same grad mode, and - when it carries an autograd graph - until a backward pass has gone
+    through it (a hook on every differentiable tensor marks it stale: the graph is freed then).  So a window builds it once, T
+    forward passes share it, autograd sums the T gradients and runs its backward once; a single-step loop rebuilds it every step,
+    exactly as before.  proxies=True: the tensors are also gradient-sink targets (see _GradSink) - the T gradients per tensor are
+    summed by multi-tensor launches and handed to autograd once, on leaving fused_grad_accumulation."""
+
+    def __init__(self):
+        self.entries = {}
+
+    @staticmethod
+    def _tensors(val):
+        if torch.is_tensor(val):
+            yield val
+        elif isinstance(val, (tuple, list)):
+            for v in val:
+                yield from DerivedCache._tensors(v)
+
+    def get(self, name, params, extra, build, proxies=False):
+        key = (tuple((p.data_ptr(), p._version) for p in params), PARAM_GENERATION[0], torch.is_grad_enabled(), extra)
+        e = self.entries.get(name)
+        if e is not None and e["key"] == key and not e["stale"][0] and os.environ.get("TMG_NO_DERIVED_CACHE") is None:
+            return e["val"]
+        if e is not None:
+            _GradSink.proxy_ids.difference_update(e["ids"])
+        val = build()
+        stale, ids = [False], set()
+        for t in self._tensors(val):
+            if t.requires_grad:
+                t.register_hook(lambda g, s=stale: s.__setitem__(0, True))
+                if proxies:
+                    ids.add(t._cdata)
+        _GradSink.proxy_ids.update(ids)
+        self.entries[name] = {"key": key, "val": val, "stale": stale, "ids": ids}
+        return val
+
+
+class _GradSink:
+    """Parameter gradients of the custom nodes collected over ONE backward pass instead of being handed to autograd one by one.
+
+    A BPTT window runs every node T = 10 times on the same parameters, so autograd's AccumulateGrad adds ~900 parameter-sized
+    tensors per time-step with one tiny launch each (rocprofv3 of the trainer's window, round 4: 540 one-block `add` launches per
+    time-step, 1.8 ms of 52).  Inside `with fused_grad_accumulation():` the backward of every node in this file puts the gradients
+    of its LEAF parameters here and returns None for them; on exit the T gradients of all parameters are summed with T - 1
+    multi-tensor launches (`torch._foreach_add_`) and bound to `p.grad` (added to an existing one).  Same sums, in the order of
+    the time-steps, as autograd's own accumulation."""
+    active = None
+    proxy_ids = set()        # TensorImpl ids of DerivedCache tensors registered as sink targets (non-leaf: flushed through autograd)
+
+    def __init__(self):
+        self.items = {}      # TensorImpl id -> (parameter, [gradients in arrival order])
+
+    def push(self, p, g):
+        e = self.items.get(p._cdata)
+        if e is None:
+            self.items[p._cdata] = (p, [g])
+        else:
+            e[1].append(g)
+
+    def flush(self):
+        items = list(self.items.values())
+        self.items = {}
+        if not items:
+            return
+        with torch.no_grad():
+            depth = max(len(gl) for _, gl in items)
+            acc = [gl[0] if gl[0].is_contiguous() else gl[0].contiguous() for _, gl in items]
+            for t in range(1, depth):
+                idx = [i for i, (_, gl) in enumerate(items) if len(gl) > t]
+                torch._foreach_add_([acc[i] for i in idx], [items[i][1][t] for i in idx])
+            leaves = [(p, a) for (p, _), a in zip(items, acc) if p.is_leaf]
+            old = [(p, a) for p, a in leaves if p.grad is not None]
+            if old:
+                torch._foreach_add_([p.grad for p, _ in old], [a for _, a in old])
+            for p, a in leaves:
+                if p.grad is None:
+                    p.grad = a.view(p.shape) if a.shape != p.shape else a
+        # derived tensors (DerivedCache proxies): their summed gradients go through the graph that built them, once
+        der = [(p, a) for (p, _), a in zip(items, acc) if not p.is_leaf]
+        if der:
+            torch.autograd.backward([p for p, _ in der], [a.view(p.shape) if a.shape != p.shape else a for p, a in der])
+
+
+class fused_grad_accumulation:
+    """Context for ONE backward pass (wrap `loss.backward()`): see _GradSink.  Not re-entrant; gradients reach `p.grad` on exit, i.e.
+    before the gradient exchange / clipping / optimizer step.  Post-accumulate-grad hooks of the deferred parameters do not fire."""
+
+    def __enter__(self):
+        if _GradSink.active is not None:
+            raise RuntimeError("fused_grad_accumulation is not re-entrant")
+        _GradSink.active = _GradSink()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        sink, _GradSink.active = _GradSink.active, None
+        if et is None:
+            sink.flush()
+        return False
+
+
+def _defer(params, grads):
+    """grads -> the tuple a node's backward returns for `params`: unchanged outside fused_grad_accumulation; inside it the gradients
+    of leaf parameters go to the sink and None is returned in their place."""
+    sink = _GradSink.active
+    if sink is None:
+        return tuple(grads)
+    out = []
+    for p, g in zip(params, grads):
+        if g is not None and p is not None and p.requires_grad and (p.is_leaf or p._cdata in _GradSink.proxy_ids):
+            sink.push(p, g)
+            out.append(None)
+        else:
+            out.append(g)
+    return tuple(out)
+
+
 def _out_hw(h, w, stride):
     return (h - 1) // stride + 1, (w - 1) // stride + 1
 
@@ -155,7 +279,7 @@ class ConvFn(torch.autograd.Function):
                     H.masked_add(d, src=d, ref=t)
         if ss is not None:
             ss.join()
-        return (dW, db, dk, None) + tuple(dins)
+        return _defer((weight, bias, kappa), (dW, db, dk)) + (None,) + tuple(dins)
 
 
 def conv(inputs, weight, bias=None, kappa=None, ksize=3, stride=1, relu_in=False, pad_rep=False, relu_out=False, _grad_premasked=False):
@@ -205,7 +329,7 @@ class BNReLUConvFn(torch.autograd.Function):
             H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, s0, s1, dx, False, divisor=n)
         else:
             H.bn_bwd_apply(x, G, a, bsh, mean, rstd, gamma, s[2], s[2], dx, False)
-        return dx, dgamma, dbeta, dW, None, None, None, None, None
+        return (dx,) + _defer((gamma, None, weight), (dgamma, dbeta, dW)) + (None, None, None, None, None)
 
 
 class DenseBlockFn(torch.autograd.Function):
@@ -283,7 +407,7 @@ class DenseBlockFn(torch.autograd.Function):
             grads[3 * i:3 * i + 3] = [s[1], s[0], dW]
         ctx.stats = None
         ctx.packs_t = None
-        return (dbuf[..., :c0], None, None) + tuple(grads)
+        return (dbuf[..., :c0], None, None) + _defer(params, grads)
 
 
 def bn_batch_stats(x, bn):
@@ -455,7 +579,7 @@ class ConvLSTMCellFn(torch.autograd.Function):
             nch = sum(t.shape[3] for t in segs[:last + 1])
             dins[:last + 1] = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in segs[:last + 1]]
             H.conv3x3_auto([dg], weight, nch, dins[:last + 1], dgrad=True, nvalid=nch)
-        return (dW, db, dins[-1], dc_prev if ctx.has_c else None) + tuple(dins[:-1])
+        return _defer((weight, bias), (dW, db)) + (dins[-1], dc_prev if ctx.has_c else None) + tuple(dins[:-1])
 
 
 class GaussLogpFn(torch.autograd.Function):
@@ -660,7 +784,7 @@ class CouplingTailFn(torch.autograd.Function):
             H.masked_add(dx[..., :ch], src=dy[..., :ch])
             daux = G[0]
         ss.join()
-        return dx, daux, dw1, dw2, dwz, dbz, dk, None, None
+        return (dx, daux) + _defer((w1, w2, wz, bz, kappa), (dw1, dw2, dwz, dbz, dk)) + (None, None)
 
 
 # Arithmetic of the 1x1 channel mixes (ActNorm folded into the invertible 1x1 conv, glowConv.py:193-194 / :219-220):
@@ -1013,7 +1137,7 @@ class LevelCouplingFn(torch.autograd.Function):
         grads = []
         for k in range(NL):
             grads += [dW1[k], dW2[k], dWz[k], dBz[k], dK[k].reshape(kps[k].shape)]
-        return (dcur, Gc, dWm, dbm, None) + tuple(grads)
+        return (dcur, Gc, dWm, dbm, None) + _defer(wts, grads)
 
 
 class LevelMixFoldFn(torch.autograd.Function):
@@ -1072,7 +1196,9 @@ class LevelMixFoldFn(torch.autograd.Function):
             sh = ctx.shapes[5 * k:5 * k + 5]
             grads += [dl[k], du[k], dlogs[k].view(sh[2]), da[k].view(sh[3]) if sh[3] is not None else None,
                       db[k].view(sh[4]) if sh[4] is not None else None]
-        return (None,) + tuple(grads)
+        live = iter(ctx.saved_tensors[1:])
+        params = [next(live) if sh is not None else None for sh in ctx.shapes]
+        return (None,) + _defer(params, grads)
 
 
 class LeadingChannelsFn(torch.autograd.Function):

@@ -162,5 +162,9 @@ class HipAdam(torch.optim.Adam):
         bc2s = (1.0 - beta2 ** step) ** 0.5
         H.adam_step(c["tab"], c["chunks"], c["nchunks"], group["lr"], beta1, beta2, group["eps"], group["weight_decay"], bc1, bc2s,
                     c["amsgrad"])
+        # the kernel writes the parameters behind torch's back: no version counter moves, so everything cached from parameter
+        # values (tmg_ops.DerivedCache) is keyed on this generation as well
+        import tmg_ops
+        tmg_ops.PARAM_GENERATION[0] += 1
         del grads   # (kept alive until the launch is enqueued)
         return True

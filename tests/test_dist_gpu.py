@@ -74,7 +74,11 @@ def test_two_ranks_on_one_device_match_single_process(tmp_path):
         for a in range(N_WINDOWS):
             assert abs(res[k]["loss"][a] - losses[a][k]) < 2e-5 * (1 + a)
             assert abs(res[k]["gn"][a] - gns[a]) < 5e-4 * gns[a] * (1 + a)
-        assert res[k]["nbuckets"] > 1 and res[k]["hooked"] >= res[k]["nbuckets"] - 1
+        # (train_window sums the window's per-time-step parameter gradients in tmg_ops.fused_grad_accumulation: they reach p.grad when
+        # backward has finished, so the buckets of the custom nodes' parameters go right after it instead of from the hooks - 0.2 ms
+        # of exposed exchange per 0.5 s window against 1.5 ms of tiny adds per time-step; the hook-driven launches are exercised by
+        # tests/test_dist_cpu.py and by bench.py's single-step path)
+        assert res[k]["nbuckets"] > 1 and res[k]["hooked"] >= 0
 
 
 def test_bench_two_rank_path_on_one_device():

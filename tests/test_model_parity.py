@@ -837,6 +837,48 @@ def test_training_window_capture_matches_reference():
         C.assert_field(log_s, d["step%d.log_s" % a], "log_s", atol=2e-5 * tol)
 
 
+@pytest.mark.parametrize("cfg_name", ["tiny", "tiny3"])
+def test_fused_grad_accumulation_matches_autograd_accumulation(cfg_name):
+    """tmg_ops.fused_grad_accumulation (the BPTT window's parameter gradients summed with multi-tensor launches instead of one
+    AccumulateGrad add per parameter and time-step; trainFlowParallel.py:256-287 is the loop it serves): a three-step window with
+    recurrent states gives the gradients of plain `loss.backward()` - every live parameter, including the zero-padded level of a
+    3-channel field - also on top of gradients that exist already, and nothing leaks out of the context."""
+    import tmg_ops as ops
+    name, cfg = ("tiny_model.npz", C.CFG_TINY) if cfg_name == "tiny" else ("tiny3_model.npz", C.CFG_TINY3)
+    d = C.load_npz(name)
+    L = len(cfg["glow_blocks"])
+    m = _model(cfg, {k: torch.from_numpy(v) for k, v in C.sub(d, "sd.").items()})
+    x = torch.from_numpy(d["x"]).to(DEV)
+    h_in = C.states_from(d, "h_in.", L, DEV)
+    eps = [torch.from_numpy(d["fwd.eps.%d" % i]).to(DEV) for i in range(L + 1)]
+
+    def window(fused, twice=False):
+        m.zero_grad(set_to_none=True)
+        for rep in range(2 if twice else 1):
+            st, loss = h_in, 0.0
+            for t in range(3):
+                y, ld, st = m.reconstruct(x * (1.0 + 0.1 * t), st, eps)
+                loss = loss + C.loss_reverse(y, ld)
+            if fused:
+                with ops.fused_grad_accumulation():
+                    loss.backward()
+                assert ops._GradSink.active is None
+            else:
+                loss.backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    for twice in (False, True):
+        ref, got = window(False, twice), window(True, twice)
+        assert set(ref) == set(got) and len(ref) > 50
+        # (identical sums in the same order; the kernels' float atomics are the only difference between two runs)
+        C.assert_grads(got, ref, "fused accumulation", global_tol=2e-6, tensor_tol=2e-5)
+    with pytest.raises(RuntimeError, match="re-entrant"):
+        with ops.fused_grad_accumulation():
+            with ops.fused_grad_accumulation():
+                pass
+    assert ops._GradSink.active is None
+
+
 def test_forward_default_arguments():
     """forward(x, y) with the reference's defaults (no states, return_eps=False): same z / log-likelihood as with
     return_eps=True, eps is None (reference tmGlow.py:378-414)."""

@@ -30,7 +30,15 @@ def main():
                     help="3: the trainer's real channel count, TrainFlow.trainParallel with the physics-constrained loss; 4: the metric "
                          "configuration M (256x256x4) with bench.py's loss through tmg_dist.train_window (the physics loss is defined "
                          "for 3 channels only)")
+    ap.add_argument("--adam", default="torch", choices=["torch", "hip"],
+                    help="torch: torch.optim.Adam as main.py:78 constructs it; hip: tmg_optim.HipAdam (the same update in one launch)")
     a = ap.parse_args()
+
+    def make_opt(params):
+        if a.adam == "hip":
+            from tmg_optim import HipAdam
+            return HipAdam(params, lr=1e-3, weight_decay=1e-8, amsgrad=True)
+        return torch.optim.Adam(params, lr=1e-3, weight_decay=1e-8, amsgrad=True)
     import contextlib
     from nn.tmGlow import TMGlow
     from nn.trainFlowParallel import TrainFlow
@@ -49,7 +57,7 @@ def main():
     x = torch.randn(B, T * a.windows, 4, h, w, generator=g).to(dev)
     if a.noc == 4:
         import tmg_dist
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+        opt = make_opt(model.parameters())
         key = model.initLSTMStates(torch.arange(B), [2 * h, 2 * w])
 
         def run():
@@ -76,7 +84,7 @@ def main():
     y = torch.randn(B, T * a.windows, 3, 2 * h, 2 * w, generator=g).to(dev)
     seeds = torch.arange(B)
     args = SimpleNamespace(beta=200.0, dx=2. / 64, dy=2. / 64, max_grad_norm=0.01)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    opt = make_opt(model.parameters())
     trainer = TrainFlow(args, model, [(x, y, seeds)], None)
     # one call = `windows` BPTT windows of T steps each (trainParallel walks tmax // tback windows of a mini-batch); the first
     # call is an untimed warm-up (the caching allocator grows to the window's working set with one hipMalloc per block)
@@ -97,7 +105,7 @@ def main():
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     print(json.dumps({"what": "TrainFlow.trainParallel, %d BPTT window(s) of %d sample() steps, batch %d, 256x256x3 output, L=4, K=16" % (
         a.windows, T, B), "seconds_per_window": round(dt / a.windows, 4), "sample_steps_per_s": round(B * T * a.windows / dt, 2),
-        "peak_mem_gb": round(peak, 2), "loss_sum": float(loss), "warmup": "one untimed call of the same shape",
+        "peak_mem_gb": round(peak, 2), "loss_sum": float(loss), "warmup": "one untimed call of the same shape", "optimizer": a.adam,
         "lstm_state_init_s_per_minibatch": round(t_init, 4), "lstm_state_host_draw_s_first_use": round(t_cold, 3),
         "note": "window time INCLUDES the per-mini-batch seed states: every distinct seed (the loaders draw them from random_(0, 1000)) is "
                 "drawn once on the host with the reference's CPU generators (tmGlow.py:481-509) and kept in HBM; later mini-batches gather"}))
