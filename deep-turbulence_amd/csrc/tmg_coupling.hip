@@ -396,6 +396,10 @@ struct CplBP {
     int B, H, W, C;
     int tiles_x, tiles_y, ntiles;
     int xmap;                        // XCD-aware tile order (tmg_common.h)
+    // fwd = 1: the DENSITY direction's layer (mix -> coupling, flowAffine.py:76-83): no mix in front of the coupling's backward (dout
+    // IS the gradient w.r.t. the coupling output; the mix input gradient is a launch of its own after tmg_dense2_bwd), x = the second
+    // half of the coupling OUTPUT y2, and  dtin2 = dy2 e^{sg};  da = dy2 e^{sg};  dsg = 2 dy2 y2 + 2 g_b;  dr = dsg / (1 + |r|)^2
+    int fwd;
 };
 
 // CT = 16-channel tiles of C; MT = 16-channel tiles of the dgrad output (ch + 2 channels); KS = C / 4 channel quads of dhh
@@ -472,16 +476,22 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
             const bool center = inimg && ry >= 1 && ry <= 16 && rx >= 1 && rx <= 16;
             const size_t gp = img + (size_t)min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1);
             f32x4 acc[CT];
+            if (p.fwd) {
+                // density direction: the gradient arrives at the coupling output itself (this lane's quad of m-tile mo is the quad it loaded)
 #pragma unroll
-            for (int mo = 0; mo < CT; ++mo) acc[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int mo = 0; mo < CT; ++mo) acc[mo] = (f32x4){dcu[mo].x, dcu[mo].y, dcu[mo].z, dcu[mo].w};
+            } else {
 #pragma unroll
-            for (int h = 0; h < CT; ++h) {
-                const float dv[4] = {dcu[h].x, dcu[h].y, dcu[h].z, dcu[h].w};
+                for (int mo = 0; mo < CT; ++mo) acc[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int h = 0; h < CT; ++h) {
+                    const float dv[4] = {dcu[h].x, dcu[h].y, dcu[h].z, dcu[h].w};
 #pragma unroll
-                    for (int mo = 0; mo < CT; ++mo)
-                        acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wmT[mo][4 * h + e], dv[e], acc[mo], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mo = 0; mo < CT; ++mo)
+                            acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wmT[mo][4 * h + e], dv[e], acc[mo], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int mo = 0; mo < CT; ++mo) {
@@ -497,11 +507,18 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float den = 1.f + fabsf(rr[e]), rden = cpl_rcp(den);
-                        const float inv = cpl_exp(-2.f * rr[e] * rden);
                         const float go = acc[mo][e];
-                        di[e] = go * inv;
-                        da[e] = inimg ? -go * osc : 0.f;
-                        dr[e] = inimg ? osc * (-2.f * go * (tt[e] * inv) + 2.f * gb) * (rden * rden) : 0.f;
+                        if (p.fwd) {
+                            const float sc = cpl_exp(2.f * rr[e] * rden);          // e^{sg}
+                            di[e] = go * sc;
+                            da[e] = inimg ? go * sc * osc : 0.f;
+                            dr[e] = inimg ? osc * (2.f * go * tt[e] + 2.f * gb) * (rden * rden) : 0.f;   // tt = y2
+                        } else {
+                            const float inv = cpl_exp(-2.f * rr[e] * rden);
+                            di[e] = go * inv;
+                            da[e] = inimg ? -go * osc : 0.f;
+                            dr[e] = inimg ? osc * (-2.f * go * (tt[e] * inv) + 2.f * gb) * (rden * rden) : 0.f;
+                        }
                     }
                     if (rp < PP) {
 #pragma unroll
@@ -604,14 +621,14 @@ extern "C" int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, con
 extern "C" int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void* g, const void* Wm, const void* wz,
                                 const void* kappa, void* DH, void* dtin, void* G0, void* GD, const int64_t* dims, hipStream_t st) {
     const int64_t ch = dims[3] / 2;
-    const int64_t d2[12] = {dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7], dims[8], dims[9], dims[4], dims[7]};
+    const int64_t d2[13] = {dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7], dims[8], dims[9], dims[4], dims[7], 0};
     return tmg_coupling_bwd_halves(dout, (const float*)dout + ch, (const float*)x + ch, r, g, Wm, wz, kappa, DH, dtin, (float*)dtin + ch, G0, GD,
                                    d2, st);
 }
 
 // As tmg_coupling_bwd with the channel halves of dout / dtin addressed separately and x2 = the second half of the layer input.
 // dims = {B, H, W, C, dout1 pixel stride, x2 pixel stride, DH pixel stride, dtin1 pixel stride, row length of wz, column of d1 in wz,
-// dout2 pixel stride, dtin2 pixel stride}.
+// dout2 pixel stride, dtin2 pixel stride, density direction (0 / 1: see CplBP::fwd - then x2 is the second half of the coupling OUTPUT)}.
 extern "C" int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, const void* x2, const void* r, const void* g, const void* Wm,
                                        const void* wz, const void* kappa, void* DH, void* dtin1, void* dtin2, void* G0, void* GD,
                                        const int64_t* dims, hipStream_t st) {
@@ -627,6 +644,7 @@ extern "C" int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, con
     p.DH = (float*)DH; p.dhs = (int)dims[6];
     p.dtin = (float*)dtin1; p.dts = (int)dims[7];
     p.dtin2 = (float*)dtin2; p.dt2s = (int)dims[11];
+    p.fwd = (int)dims[12];
     p.G0 = (float*)G0; p.GD = (float*)GD;
     const int ch = p.C / 2;
     if (p.C < 8 || p.C > 32 || (ch & 3) || (p.dos & 3) || (p.xs & 3) || (p.dhs & 3) || (p.dts & 3) || (p.do2s & 3) || (p.dt2s & 3)) return -100;

@@ -271,6 +271,9 @@ class LSTMFLowBlock(nn.Module):
         return c
 
     def _mix_params(self):
+        out = self.__dict__.get('_mix_param_list')     # (module attribute walks are slow: ~1 us each, 160 per level and call)
+        if out is not None and len(out[1]) == len(self.revlayers._modules) and all(a is b for a, b in zip(out[1], self.revlayers._modules.values())):
+            return out[0]
         out = []
         for l in self.revlayers._modules.values():
             c = l.conv
@@ -278,6 +281,7 @@ class LSTMFLowBlock(nn.Module):
             out += [c.l, c.u, c.log_s, c.p, c.sign_s] if isinstance(c, InvertibleConv1x1LU) else list(c.parameters())
             if hasattr(l, 'norm'):
                 out += [l.norm.weight, l.norm.bias]
+        self.__dict__['_mix_param_list'] = (out, list(self.revlayers._modules.values()))
         return out
 
     def _level_mix_cached(self, reverse, hw, ch, pad):

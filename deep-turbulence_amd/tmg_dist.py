@@ -158,6 +158,10 @@ class GradBucket:
     def _on_grad(self, p):
         if self.buckets is None or self._expected is None:
             return                      # first step: everything goes after backward
+        if p.grad is None:
+            # the hook also fires when the node in front handed autograd NO gradient for this parameter (tmg_ops.fused_grad_accumulation
+            # collects the window's parameter gradients itself and binds them after backward): nothing has arrived yet
+            return
         if id(p) in self._arrived:
             raise RuntimeError("GradBucket: a second gradient arrived for a parameter before allreduce_mean() - one backward per "
                                "all-reduce (no gradient accumulation / retain_graph passes)")

@@ -626,18 +626,19 @@ def coupling_fwd(x, out, rsave, y2save, D, hc, wz, bz, kappa, Wm, bm, logdet, re
     return True
 
 
-def coupling_bwd(dout, x2, r, g, Wm, wz, kappa, DH, dtin, G0, GD, wz_d1col):
+def coupling_bwd(dout, x2, r, g, Wm, wz, kappa, DH, dtin, G0, GD, wz_d1col, fwd=False):
     """Mix input gradient + affine-coupling backward + zero-conv input gradient (exact replicate adjoint) of one generative-
     direction coupling layer in one launch (tmg_coupling_bwd_halves).  dout / dtin: [B,H,W,C] tensors or pairs of [B,H,W,C/2] halves;
     x2: the SECOND half of the layer input [B,H,W,C/2] (a channel-slice view or a tensor of its own); DH: [B,H,W,C] channel-slice
-    view of the level's stash."""
+    view of the level's stash.  fwd=True: the density direction's layer (mix -> coupling): dout = gradient w.r.t. the coupling
+    output, x2 = second half of the coupling OUTPUT, no mix in front (Wm is not read)."""
     d1, d2 = _halves(dout)
     t1, t2 = _halves(dtin)
     B, Hh, Ww, ch = d1.shape
     assert x2.shape[3] == ch
     sd1, sd2, sx, sh, st1, st2 = seg(d1), seg(d2), seg(x2), seg(DH), seg(t1), seg(t2)
     assert r.is_contiguous() and G0.is_contiguous() and GD.is_contiguous() and Wm.is_contiguous() and wz.is_contiguous()
-    dims = _i64(B, Hh, Ww, 2 * ch, sd1[1], sx[1], sh[1], st1[1], wz.shape[1], wz_d1col, sd2[1], st2[1])
+    dims = _i64(B, Hh, Ww, 2 * ch, sd1[1], sx[1], sh[1], st1[1], wz.shape[1], wz_d1col, sd2[1], st2[1], 1 if fwd else 0)
     rc = lib().tmg_coupling_bwd_halves(c_vp(sd1[0]), c_vp(sd2[0]), c_vp(sx[0]), _ptr(r), _ptr(g), _ptr(Wm), _ptr(wz), _ptr(kappa), c_vp(sh[0]),
                                        c_vp(st1[0]), c_vp(st2[0]), _ptr(G0), _ptr(GD), dims, _stream())
     if rc == -100:

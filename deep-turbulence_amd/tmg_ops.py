@@ -166,10 +166,14 @@ class fused_grad_accumulation:
     def __enter__(self):
         if _GradSink.active is not None:
             raise RuntimeError("fused_grad_accumulation is not re-entrant")
-        _GradSink.active = _GradSink()
+        self.off = os.environ.get("TMG_NO_FUSED_ACCUM") is not None      # ablation switch: autograd's own accumulation
+        if not self.off:
+            _GradSink.active = _GradSink()
         return self
 
     def __exit__(self, et, ev, tb):
+        if self.off:
+            return False
         sink, _GradSink.active = _GradSink.active, None
         if et is None:
             sink.flush()
@@ -1054,6 +1058,31 @@ class LevelCouplingFn(torch.autograd.Function):
                              add0=dt1, rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
                              split2=ch, gap2=Cc, dd_quad=True)
                 dcur = dtin
+                del xin, tin, D, r, y
+                continue
+            if (not reverse) and ctx.fuse and os.environ.get("TMG_NO_FUSED_COUPLING_BWD") is None:
+                # density direction (mix -> coupling): coupling backward + zero-conv input gradient in one launch (tmg_coupling_bwd in its
+                # `fwd` mode: the gradient arrives at the coupling output itself), then the growth layers' backward, then the input
+                # gradient of the leading mix (round 4: this direction ran affine_bwd + conv dgrad + border fold per layer before)
+                mdef = [] if grouped else None
+                dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+                G0 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+                GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
+                dhh = DH[..., k * C:(k + 1) * C]
+                x1 = tin[..., :ch]
+                ok = H.coupling_bwd(dcur, y[..., ch:], r, g, Wm[k].contiguous(), wzs[k], kps[k], dhh, dtin, G0, GD, ch + Cc, fwd=True)
+                assert ok
+                if grouped:
+                    wg_in[k] = [x1, D]
+                else:
+                    H.conv_wgrad([x1, D], dhh, dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
+                                 ci_split=ch, ci_off0=0, ci_off1=Cc)
+                H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
+                             add0=dtin[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
+                             split2=ch, gap2=Cc, dd_quad=True)
+                dcur = _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k], mdef)
+                if grouped:
+                    mix_wg[k] = mdef[0]
                 del xin, tin, D, r, y
                 continue
             mdef = [] if grouped else None

@@ -287,8 +287,10 @@ int tmg_coupling_bwd(const void* dout, const void* x, const void* r, const void*
  * are the chunk(2, 1) of flowAffine.py:73 / :98; the narrow flow levels keep them in tensors of their own so that the kernels
  * reading x1 alone fetch whole cache lines of what they use).  The entry points above are these with half 2 = half 1 + C/2.
  * fwd dims = {B,H,W,C,reverse, x1 stride, out1 stride, hc stride, wz row length, d1 column, x2 stride, out2 stride}
- * bwd dims = {B,H,W,C, dout1 stride, x2 stride, DH stride, dtin1 stride, wz row length, d1 column, dout2 stride, dtin2 stride};
- * x2 = the second half of the layer input (the only part of it the backward pass reads). */
+ * bwd dims = {B,H,W,C, dout1 stride, x2 stride, DH stride, dtin1 stride, wz row length, d1 column, dout2 stride, dtin2 stride, fwd};
+ * x2 = the second half of the layer input (the only part of it the backward pass reads).  fwd = 1: backward of the DENSITY
+ * direction's layer (flowAffine.py:76-83: mix first, coupling second): dout is the gradient w.r.t. the coupling output (no mix
+ * in front; Wm is not read), x2 = the second half of the coupling OUTPUT, dtin = the gradient w.r.t. the coupling input. */
 int tmg_coupling_fwd_halves(const void* x1, const void* x2, void* out1, void* out2, void* rsave, void* y2save, const void* D,
                             const void* hc, const void* wz, const void* bz, const void* kappa, const void* Wm, const void* bm,
                             void* logdet, const int64_t* dims, tmg_stream_t st);
