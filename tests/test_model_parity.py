@@ -167,11 +167,13 @@ def _oracle_pass(O, sd, cfg, x, y, seeds, dtype, eps=None, probe=False):
                 h2=[(det(a), det(b)) for a, b in ho2], gr=gr, kf=kf, kr=kr, nkf=nkf, nkr=nkr)
 
 
-@pytest.mark.parametrize("name,cfg,B", [("cfg2", C.CFG2, 2), ("cfg3", C.CFG3, 1), ("M", C.CFG_M, 1), ("cfg5-64x64", CFG5_REDUCED, 2)])
+@pytest.mark.parametrize("name,cfg,B", [("cfg2", C.CFG2, 2), ("cfg3", C.CFG3, 1), ("cfg5-64x64", CFG5_REDUCED, 2)])
 def test_baseline_configs_match_fp64_oracle(name, cfg, B):
-    """BASELINE configs[1] (64x64x3 -> 128x128x3, L=3), configs[2] (64x128x4 -> 128x256x4, L=4), the metric configuration M /
-    configs[3] (256x256x4, L=4) and configs[4]'s five-level network (reduced field) at the default widths: forward,
-    reconstruct and all gradients of the HIP path against the CPU oracle evaluated in FP64 on the same seeded weights.
+    """BASELINE configs[1] (64x64x3 -> 128x128x3, L=3), configs[2] (64x128x4 -> 128x256x4, L=4) and configs[4]'s five-level network
+    (reduced field) at the default widths, small batch: forward, reconstruct and all gradients of the HIP path against the CPU
+    oracle evaluated in FP64 on the same seeded weights.  (The metric configuration M / configs[3] is held to the same oracle at
+    its stated batches 64 and 32, both directions, by test_stated_batches_match_oracle_with_gradients; its batch-1 case of rounds
+    2-3 - 85 s of the suite - went when those came: `tools/parity_report.py --config M` is the long form.)
 
     Tolerance rule.  SURVEY 8-C states fp32 tolerances as 10x the reference's fp32-vs-fp64 noise measured on config 1; that
     noise grows with depth and field size (48-80 coupling layers here), so every bound below is
@@ -400,7 +402,7 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
                 json.dump(rep, f, indent=1, default=float)
 
 
-@pytest.mark.parametrize("name,cfg,B,n", [("cfg2", C.CFG2, 32, 2), ("cfg3", C.CFG3, 64, 2), ("M", C.CFG_M, 64, 2), ("cfg4", C.CFG_M, 32, 2),
+@pytest.mark.parametrize("name,cfg,B,n", [("cfg2", C.CFG2, 32, 2), ("cfg3", C.CFG3, 64, 2), ("M", C.CFG_M, 64, 2), ("cfg4", C.CFG_M, 32, 1),
                                           ("cfg5", C.CFG5, 32, 1)])
 def test_stated_batches_match_oracle_with_gradients(name, cfg, B, n):
     """BASELINE configs[1] / configs[2] / the metric configuration at their STATED batch sizes (32 / 64 / 64: the benchmarked
