@@ -200,3 +200,89 @@ def test_leading_channels_node_matches_plain_slicing():
     _, x1 = tmg_ops.LeadingChannelsFn.apply(x * 1.0, 2)
     (x1 * w_lead).sum().backward()
     assert torch.equal(x.grad[..., :2], w_lead) and not bool(x.grad[..., 2:].any())
+
+
+def test_derived_cache_validity_rules():
+    """tmg_ops.DerivedCache (padded weights / folded mixes evaluated once per BPTT window): a value is reused only while its source
+    parameters are unchanged (torch version counter, data pointer, PARAM_GENERATION for writers torch does not see), in the same grad
+    mode, and until a backward pass has consumed its graph; a rebuilt value carries a fresh graph."""
+    import torch
+    import tmg_ops as ops
+    p = torch.nn.Parameter(torch.arange(6.0).reshape(2, 3))
+    builds = []
+
+    def build():
+        builds.append(1)
+        return [torch.cat([p, torch.zeros(2, 1)], 1), p.sum(0)]
+
+    c = ops.DerivedCache()
+    a = c.get("x", [p], (1,), build)
+    b = c.get("x", [p], (1,), build)
+    assert a is b and len(builds) == 1                       # T time-steps of a window share one evaluation
+    assert c.get("x", [p], (2,), build) is not a and len(builds) == 2      # another `extra` (shape key) is another value
+    a = c.get("x", [p], (1,), build)
+    (a[0].sum() * 2.0 + a[1].sum()).backward()               # a backward pass goes through the cached graph: stale
+    assert torch.equal(p.grad, torch.full((2, 3), 3.0))
+    a2 = c.get("x", [p], (1,), build)
+    assert a2 is not a
+    a2[0].sum().backward()                                    # the rebuilt value has a graph of its own
+    with torch.no_grad():
+        a3 = c.get("x", [p], (1,), build)                     # grad mode is part of the key
+        assert a3 is not a2 and not a3[0].requires_grad
+        assert c.get("x", [p], (1,), build) is a3
+        p.add_(1.0)                                            # an in-place update moves the version counter
+        a4 = c.get("x", [p], (1,), build)
+        assert a4 is not a3 and float(a4[0][0, 0]) == 1.0
+        ops.PARAM_GENERATION[0] += 1                           # a writer torch does not see (tmg_optim.HipAdam's kernel)
+        assert c.get("x", [p], (1,), build) is not a4
+
+
+def test_fused_grad_accumulation_sums_like_autograd_on_cpu():
+    """tmg_ops.fused_grad_accumulation with a plain-torch node that routes its parameter gradient through the sink (as the HIP nodes
+    do): three uses of two parameters in one backward pass give autograd's own sums, on top of an existing .grad as well; a derived
+    (DerivedCache proxy) tensor's summed gradient goes back through the graph that built it, once."""
+    import torch
+    import tmg_ops as ops
+
+    class Lin(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, x):
+            ctx.save_for_backward(w, x)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            w, x = ctx.saved_tensors
+            return ops._defer((w,), (g.t() @ x,)) + (g @ w,)
+
+    g = torch.Generator().manual_seed(1)
+    w1, w2 = (torch.nn.Parameter(torch.randn(4, 3, generator=g)) for _ in range(2))
+    xs = [torch.randn(5, 3, generator=g) for _ in range(3)]
+
+    def loss(pad=None):
+        tot = 0.0
+        for t, x in enumerate(xs):
+            wa = w1 if pad is None else pad
+            xx = x if pad is None else torch.cat([x, torch.zeros(5, 1)], 1)
+            tot = tot + (Lin.apply(wa, xx) ** 2).sum() * (t + 1) + (Lin.apply(w2, x) ** 3).sum()
+        return tot
+
+    loss().backward()
+    ref = [w1.grad.clone(), w2.grad.clone()]
+    w1.grad = w2.grad = None
+    with ops.fused_grad_accumulation():
+        loss().backward()
+        assert w1.grad is None                                 # nothing reaches .grad before the context closes
+    assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6) and torch.allclose(w2.grad, ref[1], rtol=1e-6, atol=1e-6)
+    with ops.fused_grad_accumulation():                        # on top of existing gradients
+        loss().backward()
+    assert torch.allclose(w1.grad, 2 * ref[0], rtol=1e-6, atol=1e-5)
+    # a derived tensor (zero-padded copy of w1, shared by the three uses) as a sink proxy
+    w1.grad = w2.grad = None
+    cache = ops.DerivedCache()
+    pad = cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0]
+    assert pad._cdata in ops._GradSink.proxy_ids
+    with ops.fused_grad_accumulation():
+        loss(pad).backward()
+    assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6) and torch.allclose(w2.grad, ref[1], rtol=1e-6, atol=1e-6)
+    assert cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0] is not pad    # consumed: rebuilt
