@@ -46,6 +46,10 @@ def broadcast_parameters(module, src=0):
             outs.append(flat[o:o + t.numel()].view(t.shape))
             o += t.numel()
         torch._foreach_copy_(ts, outs)
+    # the copies went through `.data` aliases, whose version counters are not the parameters': everything derived from parameter
+    # values (tmg_ops.DerivedCache) is keyed on this generation as well
+    import tmg_ops
+    tmg_ops.PARAM_GENERATION[0] += 1
 
 
 class GradBucket:

@@ -204,7 +204,8 @@ class KinkProbe:
                 call = self.calls
                 self.calls += 1
                 td = t.detach()
-                idx = (td.abs() < thr * max(1.0, float(td.abs().max()))).nonzero(as_tuple=True)
+                # (exact zeros - a ReLU applied to an already rectified tensor - have no side to flip to: sign 0, no contribution)
+                idx = ((td.abs() < thr * max(1.0, float(td.abs().max()))) & (td != 0)).nonzero(as_tuple=True)
                 if idx[0].numel():
                     site = {"t": t, "idx": idx, "sign": -torch.sign(td[idx]), "delta": None, "call": call}
                     out.register_hook(lambda g, site=site: site.__setitem__("delta", g[site["idx"]].detach().clone()))

@@ -80,6 +80,8 @@ wrap("dense2_bwd", lambda inputs, *a, **k: "in[%s]" % ",".join(shp(t) for t in i
 wrap("c1x2_fwd", lambda inputs, *a, **k: "in[%s]" % ",".join(shp(t) for t in inputs))
 wrap("coupling_fwd", lambda x, *a, **k: shp(x))
 wrap("coupling_bwd", lambda x, *a, **k: shp(x))
+wrap("conv_wino_fwd", lambda inputs, U, Cout, outs, **k: "in[%s] -> %d %s" % (",".join(shp(t) for t in inputs), Cout, " ".join(sorted(kk for kk, vv in k.items() if vv is not None and vv is not False))))
+wrap("conv_wino_narrow", lambda inputs, U, Cout, outs, **k: "in[%s] -> %d %s" % (",".join(shp(t) for t in inputs), Cout, " ".join(sorted(kk for kk, vv in k.items() if vv is not None and vv is not False))))
 
 
 def first_shape(*a, **k):
@@ -93,7 +95,8 @@ def first_shape(*a, **k):
 
 for nm in ("affine_apply", "affine_bwd", "lstm_pointwise_fwd", "lstm_pointwise_bwd", "gauss_fwd", "gauss_bwd", "checker", "upsample_fwd",
            "upsample_bwd", "chan_reduce", "bn_bwd_apply", "masked_add", "c1_fwd", "c1_bwd", "dkappa", "mix_f16", "conv_dgrad_direct",
-           "conv_pack", "conv_pack_batched"):
+           "conv_pack", "conv_pack_batched", "mix_affine_fwd", "mix_affine_bwd", "mix_f32", "layer_planes", "pad_halves", "lu_fold_fwd", "lu_fold_bwd",
+           "conv_wino_pack", "conv_pack_many", "chan_moments"):
     wrap(nm, first_shape)
 step()
 torch.cuda.synchronize()
@@ -113,5 +116,5 @@ for (hh, name), (n, t) in sorted(lev.items(), key=lambda kv: (kv[0][0], -kv[1][1
     print("   H=%-4s %-22s %4d launches %8.3f ms" % (hh, name, n, t))
 tot = sum(v[1] for v in rec.values())
 print("total %.2f ms in %d launches" % (tot, sum(v[0] for v in rec.values())))
-for (name, d, s), (n, t) in sorted(rec.items(), key=lambda kv: -kv[1][1])[:70]:
+for (name, d, s), (n, t) in sorted(rec.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("TOP", 70))]:
     print("%7.3f ms %3d x %8.1f us  %-20s %-34s %s" % (t, n, 1e3 * t / n, name, s, d[:150]))
