@@ -164,15 +164,16 @@ class TrainFlow(object):
             for i in range(tmax // tback):
                 xin, ytarget = input0[:, i * tback:(i + 1) * tback], target0[:, i * tback:(i + 1) * tback]
                 ys, lps = [], []
-                for tstep in range(tback):
-                    y, logp, a0 = core.sample(xin[:, tstep], a0)
-                    ys.append(y)
-                    lps.append(logp)
-                loss = self.loss(torch.stack(ys, dim=1), torch.stack(lps, dim=1), ytarget, target0_mean, target0_rms)
-                # one backward through all `tback` time-steps: the per-time-step parameter gradients of the custom nodes are summed
-                # with a few multi-tensor launches instead of ~900 one-block adds per time-step (tmg_ops._GradSink)
-                with ops.fused_grad_accumulation():
-                    loss.backward()
+                # one window = `tback` forward passes on unchanged parameters + ONE backward: parameter-only tensors (folded mixes, padded
+                # weights) are evaluated once, and the per-time-step parameter gradients of the custom nodes are summed with a few
+                # multi-tensor launches instead of ~900 one-block adds per time-step (tmg_ops.bptt_window)
+                with ops.bptt_window() as win:
+                    for tstep in range(tback):
+                        y, logp, a0 = core.sample(xin[:, tstep], a0)
+                        ys.append(y)
+                        lps.append(logp)
+                    loss = self.loss(torch.stack(ys, dim=1), torch.stack(lps, dim=1), ytarget, target0_mean, target0_rms)
+                    win.backward(loss)
                 bucket = self._grad_bucket(core)
                 if bucket is not None:
                     bucket.allreduce_mean()

@@ -264,19 +264,21 @@ def train_window(model, optimizer, xs, states, key_states, loss_fn, bucket=None,
     """One BPTT window of the reference's inner loop (trainFlowParallel.py:256-297): `tback` time-steps of the
     generative direction, one backward, gradient mean over ranks, clip, optimizer step, then the LSTM states
     are re-anchored half-way to their seed states.  `sample(model, x_t, states, t)` defaults to model.sample."""
+    import tmg_ops
     optimizer.zero_grad(set_to_none=True)
     loss = 0.0
     outs = []
-    for t in range(len(xs)):
-        if sample is None:
-            y, logp, states = model.sample(xs[t], states)
-        else:
-            y, logp, states = sample(model, xs[t], states, t)
-        loss = loss + loss_fn(y, logp)
-        outs.append((y.detach(), logp.detach()))
-    import tmg_ops
-    with tmg_ops.fused_grad_accumulation():    # the T per-time-step parameter gradients: T - 1 multi-tensor adds, not ~900 T tiny ones
-        loss.backward()
+    # one window = T forward passes on unchanged parameters + one backward: parameter-only tensors (folded mixes, padded weights) are
+    # evaluated once, the T per-time-step parameter gradients are summed by T - 1 multi-tensor adds instead of ~900 T tiny ones
+    with tmg_ops.bptt_window() as win:
+        for t in range(len(xs)):
+            if sample is None:
+                y, logp, states = model.sample(xs[t], states)
+            else:
+                y, logp, states = sample(model, xs[t], states, t)
+            loss = loss + loss_fn(y, logp)
+            outs.append((y.detach(), logp.detach()))
+        win.backward(loss)
     if bucket is not None:
         bucket.allreduce_mean()
     gn = None

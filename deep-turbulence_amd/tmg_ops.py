@@ -83,6 +83,8 @@ class DerivedCache:
     exactly as before.  proxies=True: the tensors are also gradient-sink targets (see _GradSink) - the T gradients per tensor are
     summed by multi-tensor launches and handed to autograd once, on leaving fused_grad_accumulation."""
 
+    window_depth = 0         # > 0 inside `with bptt_window():` - the only place where values that carry an autograd graph are shared
+
     def __init__(self):
         self.entries = {}
 
@@ -95,6 +97,12 @@ class DerivedCache:
                 yield from DerivedCache._tensors(v)
 
     def get(self, name, params, extra, build, proxies=False):
+        # Sharing a value WITH a graph between forward passes is only right when ONE backward pass follows them all (a second,
+        # separate backward would find the shared part of the graph freed): that is the BPTT window, which says so with
+        # `with bptt_window():`.  Everywhere else a grad-mode call builds its own value, exactly as before round 4; without grad
+        # mode (sampling loops of TrainFlow.test / modelPred) there is no graph and the cache is always on.
+        if torch.is_grad_enabled() and DerivedCache.window_depth == 0:
+            return build()
         key = (tuple((p.data_ptr(), p._version) for p in params), PARAM_GENERATION[0], torch.is_grad_enabled(), extra)
         e = self.entries.get(name)
         if e is not None and e["key"] == key and not e["stale"][0] and os.environ.get("TMG_NO_DERIVED_CACHE") is None:
@@ -157,6 +165,30 @@ class _GradSink:
         der = [(p, a) for (p, _), a in zip(items, acc) if not p.is_leaf]
         if der:
             torch.autograd.backward([p for p, _ in der], [a.view(p.shape) if a.shape != p.shape else a for p, a in der])
+
+
+class bptt_window:
+    """Context of ONE BPTT window (reference trainFlowParallel.py:256-287): T forward passes on unchanged parameters followed by one
+    backward pass.  Inside it the tensors derived from parameters alone are evaluated once (DerivedCache) and `backward(loss)` runs
+    the backward pass with the parameter gradients summed by multi-tensor launches (fused_grad_accumulation).
+
+        with tmg_ops.bptt_window() as win:
+            for t in range(T): y, logp, states = model.sample(x[t], states); ...
+            win.backward(loss)
+    """
+
+    def __enter__(self):
+        DerivedCache.window_depth += 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        DerivedCache.window_depth -= 1
+        return False
+
+    @staticmethod
+    def backward(loss):
+        with fused_grad_accumulation():
+            loss.backward()
 
 
 class fused_grad_accumulation:

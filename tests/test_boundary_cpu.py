@@ -216,16 +216,22 @@ def test_derived_cache_validity_rules():
         return [torch.cat([p, torch.zeros(2, 1)], 1), p.sum(0)]
 
     c = ops.DerivedCache()
-    a = c.get("x", [p], (1,), build)
-    b = c.get("x", [p], (1,), build)
-    assert a is b and len(builds) == 1                       # T time-steps of a window share one evaluation
-    assert c.get("x", [p], (2,), build) is not a and len(builds) == 2      # another `extra` (shape key) is another value
-    a = c.get("x", [p], (1,), build)
-    (a[0].sum() * 2.0 + a[1].sum()).backward()               # a backward pass goes through the cached graph: stale
-    assert torch.equal(p.grad, torch.full((2, 3), 3.0))
-    a2 = c.get("x", [p], (1,), build)
-    assert a2 is not a
-    a2[0].sum().backward()                                    # the rebuilt value has a graph of its own
+    # grad mode OUTSIDE a BPTT window: every call builds its own value (two forward passes may be followed by two separate backward
+    # passes: a shared graph would be freed by the first)
+    assert c.get("x", [p], (1,), build) is not c.get("x", [p], (1,), build) and len(builds) == 2
+    builds.clear()
+    with ops.bptt_window():
+        a = c.get("x", [p], (1,), build)
+        b = c.get("x", [p], (1,), build)
+        assert a is b and len(builds) == 1                       # T time-steps of a window share one evaluation
+        assert c.get("x", [p], (2,), build) is not a and len(builds) == 2      # another `extra` (shape key) is another value
+        a = c.get("x", [p], (1,), build)
+        (a[0].sum() * 2.0 + a[1].sum()).backward()               # a backward pass goes through the cached graph: stale
+        assert torch.equal(p.grad, torch.full((2, 3), 3.0))
+        a2 = c.get("x", [p], (1,), build)
+        assert a2 is not a
+        a2[0].sum().backward()                                    # the rebuilt value has a graph of its own
+    assert ops.DerivedCache.window_depth == 0
     with torch.no_grad():
         a3 = c.get("x", [p], (1,), build)                     # grad mode is part of the key
         assert a3 is not a2 and not a3[0].requires_grad
@@ -280,9 +286,9 @@ def test_fused_grad_accumulation_sums_like_autograd_on_cpu():
     # a derived tensor (zero-padded copy of w1, shared by the three uses) as a sink proxy
     w1.grad = w2.grad = None
     cache = ops.DerivedCache()
-    pad = cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0]
-    assert pad._cdata in ops._GradSink.proxy_ids
-    with ops.fused_grad_accumulation():
-        loss(pad).backward()
-    assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6) and torch.allclose(w2.grad, ref[1], rtol=1e-6, atol=1e-6)
-    assert cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0] is not pad    # consumed: rebuilt
+    with ops.bptt_window() as win:
+        pad = cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0]
+        assert pad._cdata in ops._GradSink.proxy_ids
+        win.backward(loss(pad))
+        assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6) and torch.allclose(w2.grad, ref[1], rtol=1e-6, atol=1e-6)
+        assert cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0] is not pad    # consumed: rebuilt

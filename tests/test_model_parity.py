@@ -841,10 +841,11 @@ def test_training_window_capture_matches_reference():
 
 @pytest.mark.parametrize("cfg_name", ["tiny", "tiny3"])
 def test_fused_grad_accumulation_matches_autograd_accumulation(cfg_name):
-    """tmg_ops.fused_grad_accumulation (the BPTT window's parameter gradients summed with multi-tensor launches instead of one
-    AccumulateGrad add per parameter and time-step; trainFlowParallel.py:256-287 is the loop it serves): a three-step window with
-    recurrent states gives the gradients of plain `loss.backward()` - every live parameter, including the zero-padded level of a
-    3-channel field - also on top of gradients that exist already, and nothing leaks out of the context."""
+    """tmg_ops.bptt_window (parameter-only tensors evaluated once per window, the window's parameter gradients summed with multi-tensor
+    launches instead of one AccumulateGrad add per parameter and time-step; trainFlowParallel.py:256-287 is the loop it serves): a
+    three-step window with recurrent states gives the gradients of plain `loss.backward()` - every live parameter, including the
+    zero-padded level of a 3-channel field - also on top of gradients that exist already, and nothing leaks out of the contexts.
+    Two forward passes followed by two SEPARATE backward passes (outside a window) still work: nothing with a graph is shared there."""
     import tmg_ops as ops
     name, cfg = ("tiny_model.npz", C.CFG_TINY) if cfg_name == "tiny" else ("tiny3_model.npz", C.CFG_TINY3)
     d = C.load_npz(name)
@@ -857,15 +858,19 @@ def test_fused_grad_accumulation_matches_autograd_accumulation(cfg_name):
     def window(fused, twice=False):
         m.zero_grad(set_to_none=True)
         for rep in range(2 if twice else 1):
-            st, loss = h_in, 0.0
-            for t in range(3):
-                y, ld, st = m.reconstruct(x * (1.0 + 0.1 * t), st, eps)
-                loss = loss + C.loss_reverse(y, ld)
-            if fused:
-                with ops.fused_grad_accumulation():
-                    loss.backward()
-                assert ops._GradSink.active is None
-            else:
+            if fused:     # the trainer's form: shared parameter-only tensors + summed parameter gradients
+                with ops.bptt_window() as win:
+                    st, loss = h_in, 0.0
+                    for t in range(3):
+                        y, ld, st = m.reconstruct(x * (1.0 + 0.1 * t), st, eps)
+                        loss = loss + C.loss_reverse(y, ld)
+                    win.backward(loss)
+                assert ops._GradSink.active is None and ops.DerivedCache.window_depth == 0
+            else:         # plain autograd: every forward pass builds its own folded mixes / padded weights
+                st, loss = h_in, 0.0
+                for t in range(3):
+                    y, ld, st = m.reconstruct(x * (1.0 + 0.1 * t), st, eps)
+                    loss = loss + C.loss_reverse(y, ld)
                 loss.backward()
         return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
@@ -874,6 +879,12 @@ def test_fused_grad_accumulation_matches_autograd_accumulation(cfg_name):
         assert set(ref) == set(got) and len(ref) > 50
         # (identical sums in the same order; the kernels' float atomics are the only difference between two runs)
         C.assert_grads(got, ref, "fused accumulation", global_tol=2e-6, tensor_tol=2e-5)
+    # outside a window: two forward passes, then two separate backward passes
+    m.zero_grad(set_to_none=True)
+    ya, la, _ = m.reconstruct(x, h_in, eps)
+    yb, lb, _ = m.reconstruct(x * 1.1, h_in, eps)
+    C.loss_reverse(ya, la).backward()
+    C.loss_reverse(yb, lb).backward()
     with pytest.raises(RuntimeError, match="re-entrant"):
         with ops.fused_grad_accumulation():
             with ops.fused_grad_accumulation():
