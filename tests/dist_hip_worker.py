@@ -45,9 +45,6 @@ def main(out_path, n_windows):
                                                     sample=lambda mod, x, st, t: mod.reconstruct(x, st, eps[t]))
         res["loss"].append(float(loss))
         res["gn"].append(float(gn))
-        if os.environ.get("TMG_DUMP"):      # debugging aid: gradients (after the exchange and clipping) and parameters after every window
-            res.setdefault("dump", []).append({"grad": {k: (p.grad.detach().cpu().clone() if p.grad is not None else None) for k, p in m.named_parameters()},
-                                               "param": {k: p.detach().cpu().clone() for k, p in m.named_parameters()}})
     res["log_s"] = dict(m.named_parameters())[str(d["log_s_key"])].detach().cpu()
     res["hooked"], res["nbuckets"] = bucket.launched_during_backward, len(bucket.buckets)
     torch.save(res, "%s.rank%d" % (out_path, rank))
