@@ -27,6 +27,10 @@
 // exp and 1/x on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp): the IEEE-exact library forms cost ~10 vector
 // instructions each, and these kernels are bound by vector-instruction issue (1 900 per wave and tile against 180 MFMAs in the
 // backward kernel).  The results stay far inside the fp32 parity tolerances (exp feeds a factor in [e^-2, e^2]).
+// Element offset of pixel PX in a tensor with pixel stride STRIDE: the pixel index is a 32-bit unsigned (the launchers refuse
+// B H W >= 2^31), so the product is ONE v_mad_u64_u32 instead of the multi-instruction 64 x 32-bit multiply a size_t index costs -
+// these kernels are bound by vector-instruction issue, and their integer address arithmetic outnumbered the float math 3 : 1
+#define TMG_PXO(PX, STRIDE) ((size_t)(PX) * (unsigned)(STRIDE))
 __device__ __forceinline__ float cpl_exp(float v) { return __expf(v); }
 __device__ __forceinline__ float cpl_rcp(float v) { return __frcp_rn(v); }
 
@@ -128,15 +132,15 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
 #define TMG_CPL_ISSUE(TILE)                                                                                         \
     {                                                                                                               \
         TMG_CPL_ORIGIN(TILE)                                                                                        \
-        const size_t img_ = (size_t)b_ * p.H * p.W;                                                                 \
+        const unsigned img_ = (unsigned)b_ * (unsigned)(p.H * p.W);                                                 \
         _Pragma("unroll") for (int u = 0; u < NPI; ++u) {                                                           \
             const int i = min(tid + u * 256, NIT - 1);                                                              \
             const int pp = i / K4, s_ = i - pp * K4;                                                                \
             const int py = pp / PW, px = pp - py * PW;                                                              \
             /* replicate padding: clamp the coordinates (flowUtils.py:246) */                                       \
             const int gy = min(max(oy0_ - 1 + py, 0), p.H - 1), gx = min(max(ox0_ - 1 + px, 0), p.W - 1);           \
-            const size_t gp_ = img_ + (size_t)gy * p.W + gx;                                                        \
-            const float* a_ = s_ < CH4 ? (4 * s_ < ch ? p.x + gp_ * p.xs + 4 * s_ : tmg_zero_page) : p.D + gp_ * 4; \
+            const unsigned gp_ = img_ + (unsigned)gy * (unsigned)p.W + (unsigned)gx;                                \
+            const float* a_ = s_ < CH4 ? (4 * s_ < ch ? p.x + TMG_PXO(gp_, p.xs) + 4 * s_ : tmg_zero_page) : p.D + TMG_PXO(gp_, 4); \
             pv[u] = *reinterpret_cast<const float4*>(a_);                                                           \
         }                                                                                                           \
     }
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
     for (int tile = t0; tile < t1; ++tile, par ^= 1) {
         TMG_CPL_ORIGIN(tile)
         const int b = b_, oy0 = oy0_, ox0 = ox0_;
-        const size_t img = (size_t)b * p.H * p.W;
+        const unsigned img = (unsigned)b * (unsigned)(p.H * p.W);
         float* XQ = lds + par * BUFW;
         float* XR = XQ + (CHP + 1) * PP * 2;
         // ---- commit the staged registers: relu(x1 | d1, d2) on the patch, raw x1 of the tile -------------------------------
@@ -189,11 +193,11 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
 #define TMG_CPL_EPI_LOAD(HV, XV, NT)                                                                                 \
         {                                                                                                            \
             const int gy_ = min(oy0 + row0 + (NT), p.H - 1);                                                         \
-            const size_t gp_ = img + (size_t)gy_ * p.W + gxc;                                                        \
+            const unsigned gp_ = img + (unsigned)gy_ * (unsigned)p.W + (unsigned)gxc;                                \
             _Pragma("unroll") for (int mt = 0; mt < CT; ++mt) {                                                      \
                 const bool ok_ = 16 * mt + 4 * q < C;                                                                \
-                HV[mt] = *reinterpret_cast<const float4*>(ok_ ? p.hc + gp_ * p.hcs + 16 * mt + 4 * q : tmg_zero_page); \
-                XV[mt] = *reinterpret_cast<const float2*>(ok_ ? p.x2 + gp_ * p.x2s + 8 * mt + 2 * q : tmg_zero_page); \
+                HV[mt] = *reinterpret_cast<const float4*>(ok_ ? p.hc + TMG_PXO(gp_, p.hcs) + 16 * mt + 4 * q : tmg_zero_page); \
+                XV[mt] = *reinterpret_cast<const float2*>(ok_ ? p.x2 + TMG_PXO(gp_, p.x2s) + 8 * mt + 2 * q : tmg_zero_page); \
             }                                                                                                        \
         }
         TMG_CPL_EPI_LOAD(hcur, xcur, 0)
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
             // affine coupling in registers
             const int gy = oy0 + row0 + nt;
             const bool pin = gy < p.H && gx < p.W;
-            const size_t gp = img + (size_t)min(gy, p.H - 1) * p.W + gxc;
+            const unsigned gp = img + (unsigned)min(gy, p.H - 1) * (unsigned)p.W + (unsigned)gxc;
             float y2r[CT][2];
 #pragma unroll
             for (int mt = 0; mt < CT; ++mt) {
@@ -239,8 +243,8 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
                 y2r[mt][1] = ok ? o1 : 0.f;
                 if (ok) {
                     ld += sg0 + sg1;
-                    *reinterpret_cast<float2*>(p.rsave + gp * ch + 8 * mt + 2 * q) = make_float2(hh1, hh3);
-                    if (p.y2save) *reinterpret_cast<float2*>(p.y2save + gp * ch + 8 * mt + 2 * q) = make_float2(o0, o1);
+                    *reinterpret_cast<float2*>(p.rsave + TMG_PXO(gp, ch) + 8 * mt + 2 * q) = make_float2(hh1, hh3);
+                    if (p.y2save) *reinterpret_cast<float2*>(p.y2save + TMG_PXO(gp, ch) + 8 * mt + 2 * q) = make_float2(o0, o1);
                 }
             }
             if (p.Wm) {
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
                 for (int mo = 0; mo < CT; ++mo) {
                     const int c = 16 * mo + 4 * q;      // a channel quad lies in one half (ch is a multiple of 4)
                     if (pin && c < C)
-                        *reinterpret_cast<float4*>(c < ch ? p.out + gp * p.os + c : p.out2 + gp * p.o2s + (c - ch)) =
+                        *reinterpret_cast<float4*>(c < ch ? p.out + TMG_PXO(gp, p.os) + c : p.out2 + TMG_PXO(gp, p.o2s) + (c - ch)) =
                             make_float4(oacc[mo][0], oacc[mo][1], oacc[mo][2], oacc[mo][3]);
                 }
             } else {
@@ -268,9 +272,9 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
 #pragma unroll
                 for (int mt = 0; mt < CT; ++mt)
                     if (pin && 8 * mt + 2 * q < ch) {
-                        *reinterpret_cast<float2*>(p.out2 + gp * p.o2s + 8 * mt + 2 * q) = make_float2(y2r[mt][0], y2r[mt][1]);
+                        *reinterpret_cast<float2*>(p.out2 + TMG_PXO(gp, p.o2s) + 8 * mt + 2 * q) = make_float2(y2r[mt][0], y2r[mt][1]);
                         const int c = 8 * mt + 2 * q;
-                        *reinterpret_cast<float2*>(p.out + gp * p.os + c) = *reinterpret_cast<const float2*>(XR + ((c >> 1) * 256 + cpx) * 2);
+                        *reinterpret_cast<float2*>(p.out + TMG_PXO(gp, p.os) + c) = *reinterpret_cast<const float2*>(XR + ((c >> 1) * 256 + cpx) * 2);
                     }
             }
 #pragma unroll
@@ -352,6 +356,7 @@ extern "C" int tmg_coupling_fwd_halves(const void* x1, const void* x2, void* out
     if ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)out1) | ((uintptr_t)out2)) & 15) return -100;
     p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 15) / 16; p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.ntiles <= 0) return 0;
+    if ((long long)p.B * p.H * p.W >= (1LL << 31)) return -100;     // 32-bit pixel indices
     switch (ch / 4) {
         case 1: return launch_cpl_fwd<1, 2>(p, st);   // C = 8
         case 2: return launch_cpl_fwd<1, 3>(p, st);   // C = 16
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
         const int ty = t_ % p.tiles_y;
         const int b = t_ / p.tiles_y;
         const int oy0 = ty * 16, ox0 = tx * 16;
-        const size_t img = (size_t)b * p.H * p.W;
+        const unsigned img = (unsigned)b * (unsigned)(p.H * p.W);
         const float gb = p.g ? p.g[b] : 0.f;
         // ---- phase A: n-tiles of 16 region pixels (linear index) -------------------------------------------------------------
 #define TMG_CPLB_LOAD(DV, RV, TV, NT)                                                                                  \
@@ -452,14 +457,14 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
             const int ry_ = rp_ / PW, rx_ = rp_ - ry_ * PW;                                                            \
             const int gy_ = oy0 - 1 + ry_, gx_ = ox0 - 1 + rx_;                                                        \
             const bool in_ = gy_ >= 0 && gy_ < p.H && gx_ >= 0 && gx_ < p.W;                                          \
-            const size_t gp_ = img + (size_t)min(max(gy_, 0), p.H - 1) * p.W + min(max(gx_, 0), p.W - 1);              \
+            const unsigned gp_ = img + (unsigned)min(max(gy_, 0), p.H - 1) * (unsigned)p.W + (unsigned)min(max(gx_, 0), p.W - 1); \
             _Pragma("unroll") for (int h = 0; h < CT; ++h) {                                                           \
                 const int c_ = 16 * h + 4 * q;                                                                         \
-                DV[h] = *reinterpret_cast<const float4*>((in_ && c_ < C) ? (c_ < ch ? p.dout + gp_ * p.dos + c_ : p.dout2 + gp_ * p.do2s + (c_ - ch)) : tmg_zero_page);  \
+                DV[h] = *reinterpret_cast<const float4*>((in_ && c_ < C) ? (c_ < ch ? p.dout + TMG_PXO(gp_, p.dos) + c_ : p.dout2 + TMG_PXO(gp_, p.do2s) + (c_ - ch)) : tmg_zero_page);  \
                 /* the lanes whose accumulator quad of m-tile h is a dto2 quad (channel c_ >= ch) need r / tin2 of j0 = c_ - ch */ \
                 const bool two_ = in_ && c_ >= ch && c_ < C;                                                           \
-                RV[h] = *reinterpret_cast<const float4*>(two_ ? p.r + gp_ * ch + (c_ - ch) : tmg_zero_page);           \
-                TV[h] = *reinterpret_cast<const float4*>(two_ ? p.x + gp_ * p.xs + (c_ - ch) : tmg_zero_page);         \
+                RV[h] = *reinterpret_cast<const float4*>(two_ ? p.r + TMG_PXO(gp_, ch) + (c_ - ch) : tmg_zero_page);           \
+                TV[h] = *reinterpret_cast<const float4*>(two_ ? p.x + TMG_PXO(gp_, p.xs) + (c_ - ch) : tmg_zero_page);         \
             }                                                                                                          \
         }
         constexpr int NTA = (PP + 15) / 16;   // 21
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
             const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
             const bool inimg = rp < PP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const bool center = inimg && ry >= 1 && ry <= 16 && rx >= 1 && rx <= 16;
-            const size_t gp = img + (size_t)min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1);
+            const unsigned gp = img + (unsigned)min(max(gy, 0), p.H - 1) * (unsigned)p.W + (unsigned)min(max(gx, 0), p.W - 1);
             f32x4 acc[CT];
             if (p.fwd) {
                 // density direction: the gradient arrives at the coupling output itself (this lane's quad of m-tile mo is the quad it loaded)
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
                 const int c = 16 * mo + 4 * q;
                 if (c < ch) {
                     // pass-through half: dto1 -> first half of dtin (dense2_bwd adds the coupling network's share)
-                    if (center) *reinterpret_cast<float4*>(p.dtin + gp * p.dts + c) = make_float4(acc[mo][0], acc[mo][1], acc[mo][2], acc[mo][3]);
+                    if (center) *reinterpret_cast<float4*>(p.dtin + TMG_PXO(gp, p.dts) + c) = make_float4(acc[mo][0], acc[mo][1], acc[mo][2], acc[mo][3]);
                 } else if (c < C) {
                     const int j0 = c - ch;
                     const float rr[4] = {rcu[mo].x, rcu[mo].y, rcu[mo].z, rcu[mo].w};
@@ -525,9 +530,9 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
                         for (int e = 0; e < 4; ++e) *reinterpret_cast<float2*>(DHL + ((j0 + e) * PP + rp) * 2) = make_float2(da[e], dr[e]);
                     }
                     if (center) {
-                        *reinterpret_cast<float4*>(p.dtin2 + gp * p.dt2s + j0) = make_float4(di[0], di[1], di[2], di[3]);
-                        *reinterpret_cast<float4*>(p.DH + gp * p.dhs + 2 * j0) = make_float4(da[0], dr[0], da[1], dr[1]);
-                        *reinterpret_cast<float4*>(p.DH + gp * p.dhs + 2 * j0 + 4) = make_float4(da[2], dr[2], da[3], dr[3]);
+                        *reinterpret_cast<float4*>(p.dtin2 + TMG_PXO(gp, p.dt2s) + j0) = make_float4(di[0], di[1], di[2], di[3]);
+                        *reinterpret_cast<float4*>(p.DH + TMG_PXO(gp, p.dhs) + 2 * j0) = make_float4(da[0], dr[0], da[1], dr[1]);
+                        *reinterpret_cast<float4*>(p.DH + TMG_PXO(gp, p.dhs) + 2 * j0 + 4) = make_float4(da[2], dr[2], da[3], dr[3]);
                     }
                 }
             }
@@ -581,13 +586,13 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
             }
 #undef TMG_CPLB_TAP
             if (gy < p.H && gx < p.W) {
-                const size_t gp = img + (size_t)gy * p.W + gx;
+                const unsigned gp = img + (unsigned)gy * (unsigned)p.W + (unsigned)gx;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int c = 16 * mt + 4 * q;
                     const float4 v = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
-                    if (c < ch) *reinterpret_cast<float4*>(p.G0 + gp * ch + c) = v;
-                    else if (c == ch) *reinterpret_cast<float4*>(p.GD + gp * 4) = v;   // (d1, d2, 0, 0): rows past ch + 1 carry zero weights
+                    if (c < ch) *reinterpret_cast<float4*>(p.G0 + TMG_PXO(gp, ch) + c) = v;
+                    else if (c == ch) *reinterpret_cast<float4*>(p.GD + TMG_PXO(gp, 4)) = v;   // (d1, d2, 0, 0): rows past ch + 1 carry zero weights
                 }
             }
         }
@@ -651,6 +656,7 @@ extern "C" int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, con
     if ((((uintptr_t)dout1) | ((uintptr_t)dout2) | ((uintptr_t)x2) | ((uintptr_t)dtin1) | ((uintptr_t)dtin2)) & 15) return -100;
     p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 15) / 16; p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.ntiles <= 0) return 0;
+    if ((long long)p.B * p.H * p.W >= (1LL << 31)) return -100;     // 32-bit pixel indices
     switch (ch / 4) {
         case 1: return launch_cpl_bwd<1, 1, 2>(p, st);   // C = 8:  outputs ch + 2 = 6
         case 2: return launch_cpl_bwd<1, 1, 4>(p, st);   // C = 16: 10
