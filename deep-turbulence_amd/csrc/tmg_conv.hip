@@ -389,11 +389,11 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int oy = min(oy0_ + (mrc[i] >> 16), p.Hout - 1), ox = min(ox0_ + (mrc[i] & 0xffff), p.Wout - 1);
-                    const size_t opx = (size_t)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);
+                    const unsigned opx = (unsigned)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);     // u32 x u32 -> u64 products below: one v_mad_u64_u32
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
                         const int n0 = min((ntile0 + j) * 16 + 4 * q, p.Cout - 4);
-                        addv[PREADD ? i : 0][PREADD ? j : 0] = *reinterpret_cast<const float4*>(p.add.p + opx * p.add.stride + p.add.off + n0);
+                        addv[PREADD ? i : 0][PREADD ? j : 0] = *reinterpret_cast<const float4*>(p.add.p + (size_t)opx * (unsigned)p.add.stride + p.add.off + n0);
                     }
                 }
             }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                 for (int i = 0; i < MT; ++i) {
                     const int oy = oy0_ + (mrc[i] >> 16), ox = ox0_ + (mrc[i] & 0xffff);
                     if (oy < p.Hout && ox < p.Wout) {
-                        const size_t opx = (size_t)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);  // host: B*H < 2^24, W < 2^24
+                        const unsigned opx = (unsigned)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);  // host: B*H < 2^24, W < 2^24
 #pragma unroll
                         for (int j = 0; j < NTW; ++j) {
                             const int n0 = (ntile0 + j) * 16 + 4 * q;
@@ -457,10 +457,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                                 if (p.ovec4) {
                                     int nl = n0;
                                     TMG_PICK_OSEG(p.out, nl, op_, ostride, ooff)
-                                    float4* dst = reinterpret_cast<float4*>(op_ + opx * ostride + ooff + nl);
+                                    float4* dst = reinterpret_cast<float4*>(op_ + (size_t)opx * (unsigned)ostride + ooff + nl);
                                     if (p.add.p) {
                                         const float4 a4 = (PREADD) ? addv[PREADD ? i : 0][PREADD ? j : 0]
-                                                                   : *reinterpret_cast<const float4*>(p.add.p + opx * p.add.stride + p.add.off + n0);
+                                                                   : *reinterpret_cast<const float4*>(p.add.p + (size_t)opx * (unsigned)p.add.stride + p.add.off + n0);
                                         v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
                                     }
 #pragma unroll
@@ -481,10 +481,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                                             int nl = n;
                                             TMG_PICK_OSEG(p.out, nl, op_, ostride, ooff)
                                             float x = v[r];
-                                            if (p.add.p) x += p.add.p[opx * p.add.stride + p.add.off + n];
+                                            if (p.add.p) x += p.add.p[(size_t)opx * (unsigned)p.add.stride + p.add.off + n];
                                             x *= osc;
                                             if (p.relu_out) x = fmaxf(x, 0.f);
-                                            float* dst = op_ + opx * ostride + ooff + nl;
+                                            float* dst = op_ + (size_t)opx * (unsigned)ostride + ooff + nl;
                                             if (p.accumulate) x += *dst;
                                             *dst = x;
                                         }

@@ -208,13 +208,13 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                     tss = ss;
                 }
             }
-            const size_t tbv = (size_t)b_ * p.Hin * p.Win;
+            const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win);   // 32-bit pixel index: the launcher refuses B H W >= 2^31
 #pragma unroll
             for (int u = 0; u < UPI; ++u) {
                 const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);
                 const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
                 const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);
-                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (tbv + (size_t)iyc * p.Win + ixc) * tss;
+                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (size_t)(tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)tss;
                 pv[u] = *reinterpret_cast<const float4*>(a_);
             }
             if (++ci == nchunks) { ci = 0; ti += G; }
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                             for (int o = 0; o < 4; ++o) {
                                 const int oy = oyb + (o >> 1), ox = oxb + (o & 1);
                                 if (oy < p.Hin && ox < p.Win) {
-                                    const size_t opx = ((size_t)b_ * p.Hin + oy) * p.Win + ox;
-                                    *reinterpret_cast<float4*>(optr + opx * ostride + ooff + nl) =
+                                    const unsigned opx = ((unsigned)b_ * (unsigned)p.Hin + (unsigned)oy) * (unsigned)p.Win + (unsigned)ox;
+                                    *reinterpret_cast<float4*>(optr + (size_t)opx * (unsigned)ostride + ooff + nl) =
                                         make_float4(Y[o][m][n][0] + bv.x, Y[o][m][n][1] + bv.y, Y[o][m][n][2] + bv.z, Y[o][m][n][3] + bv.w);
                                 }
                             }
@@ -416,6 +416,7 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     p.nchunks = (p.Cin_pad + 31) / 32;
     if (p.ntiles <= 0) return 0;
+    if ((long long)p.B * p.Hin * p.Win >= (1LL << 31)) return -100;      // 32-bit pixel indices in the kernels
     const int ntt = p.Npad / 16;
     const int npw = ntt <= 8 ? 1 : 2;           // output-channel tiles per wave (see the kernel)
     const int gy = (ntt + 8 * npw - 1) / (8 * npw);
@@ -567,13 +568,13 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
                     tss = ss;
                 }
             }
-            const size_t tbv = (size_t)b_ * p.Hin * p.Win;
+            const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win);   // 32-bit pixel index: the launcher refuses B H W >= 2^31
 #pragma unroll
             for (int u = 0; u < UPI; ++u) {
                 const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);
                 const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
                 const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);
-                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (tbv + (size_t)iyc * p.Win + ixc) * tss;
+                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (size_t)(tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)tss;
                 pv[u] = *reinterpret_cast<const float4*>(a_);
             }
             if (++ci == nchunks) { ci = 0; ti += G; }
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
                             if (p.relu_out) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
                             const int py = ty_ * TH + 2 * (wt >> 3) + oy, px = tx_ * TW + 2 * (wt & 7) + ox;
                             if (py < p.Hin && px < p.Win)
-                                *reinterpret_cast<float4*>(optr + (((size_t)b_ * p.Hin + py) * p.Win + px) * ostride + ooff + nl) = y;
+                                *reinterpret_cast<float4*>(optr + (size_t)(((unsigned)b_ * (unsigned)p.Hin + (unsigned)py) * (unsigned)p.Win + (unsigned)px) * (unsigned)ostride + ooff + nl) = y;
                         }
                 }
                 cm = 0; tm += G;
@@ -729,6 +730,7 @@ extern "C" int tmg_conv_wino_narrow(const void* const* in_ptrs, const int64_t* i
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     p.nchunks = (p.Cin_pad + 31) / 32;
     if (p.ntiles <= 0) return 0;
+    if ((long long)p.B * p.Hin * p.Win >= (1LL << 31)) return -100;      // 32-bit pixel indices in the kernels
     const int G = p.ntiles < 256 ? p.ntiles : 256;
     switch (p.Npad >> 4) {
         case 1: return launch_wino_nn<1>(p, G, st);
@@ -856,19 +858,19 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
         const int ty_ = t_ % p.tiles_y;                                                                               \
         const int b_ = t_ / p.tiles_y;                                                                                \
         const int iy0 = ty_ * TH - 1, ix0 = tx_ * TW - 1;                                                             \
-        const size_t ib = (size_t)b_ * p.Hin * p.Win;                                                                 \
+        const unsigned ib = (unsigned)b_ * (unsigned)(p.Hin * p.Win);                                                 \
         _Pragma("unroll") for (int u = 0; u < UX; ++u) {                                                              \
             const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);                             \
             const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);                             \
             const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);                                                  \
-            const float* a_ = (oob || xpix0 + u * xstep >= PP) ? tmg_zero_page : xptr + (ib + (size_t)iyc * p.Win + ixc) * xss; \
+            const float* a_ = (oob || xpix0 + u * xstep >= PP) ? tmg_zero_page : xptr + (size_t)(ib + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)xss; \
             xv[u] = *reinterpret_cast<const float4*>(a_);                                                             \
         }                                                                                                             \
         _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                              \
             const int m = dpix0 + u * dstep;                                                                          \
             const int oy = ty_ * TH + (m >> 4), ox = tx_ * TW + (m & 15);                                             \
             const bool inb = m < 128 && oy < p.Hin && ox < p.Win;                                                     \
-            const float* a_ = inb ? dptr + (ib + (size_t)oy * p.Win + ox) * dss : tmg_zero_page;                      \
+            const float* a_ = inb ? dptr + (size_t)(ib + (unsigned)oy * (unsigned)p.Win + (unsigned)ox) * (unsigned)dss : tmg_zero_page; \
             dv[u] = *reinterpret_cast<const float4*>(a_);                                                             \
         }                                                                                                             \
     }
@@ -1124,6 +1126,7 @@ static int wino_wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, i
     p.tiles_x = (p.Win + 15) / 16; p.tiles_y = (p.Hin + 7) / 8;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     if (p.ntiles <= 0) return 0;
+    if ((long long)p.B * p.Hin * p.Win >= (1LL << 31)) return -100;      // 32-bit pixel indices in the kernels
     int rc = -7;
 #define TMG_WW_CASE(C_, N_) if (pl.CIT == C_ && pl.NCO == N_) rc = launch_wino_wgrad<C_, N_>(p, pl, st);
     TMG_WW_CASE(2, 2) TMG_WW_CASE(2, 3) TMG_WW_CASE(2, 4) TMG_WW_CASE(3, 2) TMG_WW_CASE(3, 3) TMG_WW_CASE(3, 4) TMG_WW_CASE(4, 2) TMG_WW_CASE(4, 3)
