@@ -167,7 +167,7 @@ def main():
                          "forward(x, y) with loss -mean(logp)/(noc*H*W), reported beside it (SURVEY 8-D)")
     ap.add_argument("--adam", default="hip", choices=["fused", "foreach", "hip"],
                     help="implementation of the Adam update: torch foreach (what main.py constructs), torch fused, or tmg_optim.HipAdam (one launch)")
-    ap.add_argument("--graph", action="store_true", help="capture the whole step in one hipGraph and replay it (N=1 only)")
+    ap.add_argument("--graph", action="store_true", help="forward + loss + backward of the step as one hipGraph replay (tmg_dist.CapturedWindow; N=1 only); the optimizer step stays eager")
     ap.add_argument("--mix", default=None, choices=["f32", "f16"],
                     help="arithmetic of the 1x1 channel mixes: f32 MFMA (default) or fp16 operands / fp32 accumulation (the variant "
                          "BASELINE.json configs[4] names; not faster here - cfg5 reports it beside the fp32 line)")
@@ -201,11 +201,11 @@ def main():
     use_graph = args.graph and world == 1
     # the reference's optimizer (main.py:78: Adam, weight decay 1e-8, amsgrad); `fused` = torch's single-kernel multi-tensor
     # implementation of the same update (about 100 launches per step fewer than the default foreach one)
-    if args.adam == "hip" and not use_graph:
+    if args.adam == "hip":
         from tmg_optim import HipAdam       # the same update, one launch for all ~1 000 parameter tensors
         opt = HipAdam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
     else:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True, capturable=use_graph,
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True,
                                fused=(args.adam == "fused") or None)
     Hin, Win = cfg["_in_hw"]
     up = cfg["_up"]
@@ -241,27 +241,21 @@ def main():
 
     graph = None
     if use_graph:
-        # standard whole-step capture: warm up on a side stream, then record forward + backward + Adam into one hipGraph;
-        # every replay draws fresh latents (graph-safe Philox offsets) and updates the weights in place
-        ws_ = torch.cuda.Stream()
-        ws_.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(ws_):
-            for _ in range(max(args.warmup, 2)):
-                step()
-        torch.cuda.current_stream().wait_stream(ws_)
-        torch.cuda.synchronize()
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            y_, ld_, _ = model.sample(x, states)
-            gloss = C.loss_reverse(y_, ld_)
-            gloss.backward()
-            opt.step()
-        eager_step = step
+        # forward + loss + backward recorded into one hipGraph (tmg_dist.CapturedWindow: a one-time-step window) and replayed; the
+        # optimizer step stays eager.  Every replay draws fresh latents (graph-safe Philox offsets) and reads the weights in place.
+        def body(x_, st_):
+            if y_fwd is None:
+                y_, ld_, _ = model.sample(x_, st_)
+                return C.loss_reverse(y_, ld_), ()
+            _, logp_, _, _ = model.forward(x_, y_fwd, st_)
+            return C.loss_forward(logp_, y_fwd), ()
+        graph = tmg_dist.CapturedWindow(model, body, (x, states))
 
         def step():  # noqa: F811
-            graph.replay()
-            return gloss
+            opt.zero_grad(set_to_none=True)
+            loss, _ = graph(x, states)
+            opt.step()
+            return loss
         args.no_events = True  # per-launch events cannot be recorded inside a replayed graph
     for _ in range(args.warmup):
         step()
@@ -409,7 +403,7 @@ def main():
             roof["end_to_end_tflops_per_gpu"] = round(e2e, 2)
             roof["end_to_end_frac"] = round(e2e / PEAK_FP32_MFMA_TF, 4)
     opt_name = {"hip": "HipAdam (one-launch Adam, same update as torch.optim.Adam)", "foreach": "torch.optim.Adam (foreach)",
-                "fused": "torch.optim.Adam (fused)"}[args.adam if not use_graph else "foreach"]
+                "fused": "torch.optim.Adam (fused)"}[args.adam]
     out = {"metric": ("flow-field samples/sec (fwd+log-det+bwd), 64x256x256x4" if args.config == "M" else "flow-field samples/sec (fwd+log-det+bwd)")
                      + "; optimizer step: " + opt_name,
            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

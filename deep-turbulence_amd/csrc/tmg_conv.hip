@@ -1515,12 +1515,20 @@ static int conv_fwd_lean(ConvP p, hipStream_t st) {
     if (ntt <= 4) { WM = 8; WN = 1; NTW = ntt; }
     else if (ntt <= 8) { WM = 4; WN = 2; NTW = ntt <= 6 ? 3 : 4; }
     else { WM = 2; WN = 4; NTW = ntt <= 12 ? 3 : 4; }
+    // TMG_FWD_PLAN=MT,WM,WN,NTW,GMUL,KCHMAX (0 = planner's choice): launch-plan override for measurements (tools/bench_wide.py)
+    static int fp[6] = {-1, 0, 0, 0, 0, 0};
+    if (fp[0] < 0) {
+        fp[0] = 0;
+        if (const char* e = getenv("TMG_FWD_PLAN")) sscanf(e, "%d,%d,%d,%d,%d,%d", &fp[0], &fp[1], &fp[2], &fp[3], &fp[4], &fp[5]);
+    }
+    if (fp[1] > 0 && fp[2] > 0 && fp[3] > 0 && p.ksize == 3) { WM = fp[1]; WN = fp[2]; NTW = fp[3]; }
     const int gy = (ntt + WN * NTW - 1) / (WN * NTW);
     const long npix = (long)p.B * p.Hout * p.Wout;
     const int halo = p.ksize >> 1;
     for (int MT = 4; MT >= 1; MT >>= 1) {
         // m-tiles per wave: 4 when the image is large; fewer when that would leave CUs idle (small levels)
-        if (MT > 1 && (npix / (16 * MT * WM)) * gy < 256) continue;
+        if (fp[0] > 0 && p.ksize == 3) { if (MT != fp[0]) continue; }
+        else if (MT > 1 && (npix / (16 * MT * WM)) * gy < 256) continue;
         const int MBLK = 16 * MT * WM;
         int twl = ilog2_ceil(p.Wout);
         if (twl > 5) twl = 5;
@@ -1533,6 +1541,7 @@ static int conv_fwd_lean(ConvP p, hipStream_t st) {
         // channel chunks: as few as possible, evenly sized, each fitting the register window (7 float4 x 512 threads,
         // float4 slots per pixel padded to a power of two) and two LDS buffers
         int nchunks = (p.Cin_pad + 63) / 64, kch = 0;
+        if (fp[5] >= 16 && p.ksize == 3) nchunks = (p.Cin_pad + fp[5] - 1) / fp[5];
         for (; nchunks <= p.Cin_pad / 16; ++nchunks) {
             kch = (((p.Cin_pad / 16) + nchunks - 1) / nchunks) * 16;
             const int k4p = kch <= 16 ? 4 : (kch <= 32 ? 8 : 16);
@@ -1547,6 +1556,7 @@ static int conv_fwd_lean(ConvP p, hipStream_t st) {
         p.KCH = kch;
         p.nchunks = (p.Cin_pad + kch - 1) / kch;
         int G = 256 / gy;
+        if (fp[4] > 0 && p.ksize == 3) G *= fp[4];
         if (G < 1) G = 1;
         if (G > p.ntiles) G = p.ntiles;
         const size_t lds_bytes = 2 * (size_t)PHPW * (kch + 8) * 4;
@@ -1558,6 +1568,7 @@ static int conv_fwd_lean(ConvP p, hipStream_t st) {
         }
         TMG_FWD_CASE(1, 8, 1) TMG_FWD_CASE(2, 8, 1) TMG_FWD_CASE(3, 8, 1) TMG_FWD_CASE(4, 8, 1)
         TMG_FWD_CASE(3, 4, 2) TMG_FWD_CASE(4, 4, 2) TMG_FWD_CASE(3, 2, 4) TMG_FWD_CASE(4, 2, 4)
+        TMG_FWD_CASE(2, 4, 2) TMG_FWD_CASE(1, 4, 2) TMG_FWD_CASE(2, 2, 4) TMG_FWD_CASE(1, 2, 4)
 #undef TMG_FWD_CASE
         return -100;
     }

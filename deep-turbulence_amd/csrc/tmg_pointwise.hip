@@ -1493,6 +1493,27 @@ extern "C" int tmg_pad_halves(const void* src, const int64_t* s_d, void* dst, co
     return 0;
 }
 
+// Host values -> device memory as KERNEL ARGUMENTS (by-value struct, 2 KB): the segment tables of the grouped launches hold raw
+// activation pointers; a host-to-device copy cannot be recorded by a hipGraph capture (pageable source), a kernel node carries
+// its arguments with it.
+struct TmgI64x256 { long long v[256]; };
+__global__ void fill_i64_kernel(long long* __restrict__ dst, TmgI64x256 t, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = t.v[i];
+}
+
+extern "C" int tmg_fill_i64(void* dst, const int64_t* vals, int64_t n, hipStream_t st) {
+    if (n < 0 || (n && (!dst || !vals))) return -3;
+    for (int64_t o = 0; o < n; o += 256) {
+        TmgI64x256 t;
+        const int m = (int)(n - o < 256 ? n - o : 256);
+        for (int i = 0; i < 256; ++i) t.v[i] = i < m ? (long long)vals[o + i] : 0;
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(256), 0, st, (long long*)dst + o, t, m);
+        TMG_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 // dims: [B, h, w, C, to_small]  (h, w: the SMALL spatial size; C: channels of the big tensor)
 extern "C" int tmg_checker(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, hipStream_t st) {
     const size_t total = (size_t)dims[0] * dims[1] * dims[2] * 4 * dims[3];

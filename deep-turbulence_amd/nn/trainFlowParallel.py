@@ -1,12 +1,16 @@
 """Trainer of TM-Glow on the HIP path.  API mirror of the reference's nn/trainFlowParallel.py: `TMGLowPredictionItem`
 (:29-101), `TMGLowLoss` (:104-177) and `TrainFlow` (:180-382: `trainParallel`, `test`)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 import tmg_hip as H
 import tmg_ops as ops
+
+
+_INV_COUNTS = {}
 
 
 class _PhysLossFn(torch.autograd.Function):
@@ -27,7 +31,9 @@ class _PhysLossFn(torch.autograd.Function):
         coef = torch.empty((B, 3, Hh, Ww), device=y.device, dtype=torch.float32)
         H.phys_rms(y, trms, mean, coef, sums[3:4])
         cnt = (N * (Hh - 2) * (Ww - 2), N * (Hh - 2) * Ww, N * 3 * Hh * Ww, B * 3 * Hh * Ww)
-        inv = torch.tensor([1.0 / c for c in cnt], dtype=torch.float32).to(y.device, non_blocking=True)
+        inv = _INV_COUNTS.get((cnt, y.device))
+        if inv is None:      # once per shape: no host-to-device copy per window (and none for a hipGraph capture to trip over)
+            inv = _INV_COUNTS[(cnt, y.device)] = torch.tensor([1.0 / c for c in cnt], dtype=torch.float32).to(y.device)
         ctx.save_for_backward(y, target, mean, coef)
         ctx.cfg = (sd, mu, beta, dx, dy, cnt, T)
         return beta * (sums * inv).sum()
@@ -125,6 +131,19 @@ class TrainFlow(object):
         core = getattr(model, "module", model)
         self.loss = TMGLowLoss(args, model).to(next(core.parameters()).device)
         self._bucket = None
+        self._capture = bool(getattr(args, "capture_window", False)) or os.environ.get("TMG_CAPTURE_WINDOW") == "1"
+        self._captured = {}     # window shape -> tmg_dist.CapturedWindow
+
+    def _window_body(self, core):
+        """The forward passes and the loss of one BPTT window (reference trainFlowParallel.py:256-281)."""
+        def body(xin, ytarget, target_mean, target_rms, a0):
+            ys, lps = [], []
+            for tstep in range(xin.size(1)):
+                y, logp, a0 = core.sample(xin[:, tstep], a0)
+                ys.append(y)
+                lps.append(logp)
+            return self.loss(torch.stack(ys, dim=1), torch.stack(lps, dim=1), ytarget, target_mean, target_rms), a0
+        return body
 
     @staticmethod
     def _world():
@@ -163,18 +182,23 @@ class TrainFlow(object):
             target0_rms = torch.sqrt(((target0 - target0_mean.unsqueeze(1)) ** 2).mean(dim=1))
             for i in range(tmax // tback):
                 xin, ytarget = input0[:, i * tback:(i + 1) * tback], target0[:, i * tback:(i + 1) * tback]
-                ys, lps = [], []
-                # one window = `tback` forward passes on unchanged parameters + ONE backward: parameter-only tensors (folded mixes, padded
-                # weights) are evaluated once, and the per-time-step parameter gradients of the custom nodes are summed with a few
-                # multi-tensor launches instead of ~900 one-block adds per time-step (tmg_ops.bptt_window)
-                with ops.bptt_window() as win:
-                    for tstep in range(tback):
-                        y, logp, a0 = core.sample(xin[:, tstep], a0)
-                        ys.append(y)
-                        lps.append(logp)
-                    loss = self.loss(torch.stack(ys, dim=1), torch.stack(lps, dim=1), ytarget, target0_mean, target0_rms)
-                    win.backward(loss)
                 bucket = self._grad_bucket(core)
+                if self._capture and dev.type == "cuda":
+                    # forward passes + loss + backward of the window as one hipGraph replay (tmg_dist.CapturedWindow; opt-in:
+                    # args.capture_window / TMG_CAPTURE_WINDOW=1); recorded once per window shape
+                    key = (tuple(xin.shape), tuple(ytarget.shape))
+                    cw = self._captured.get(key)
+                    if cw is None:
+                        cw = self._captured[key] = tmg_dist.CapturedWindow(core, self._window_body(core), (xin, ytarget, target0_mean, target0_rms, a0),
+                                                                           bucket=bucket)
+                    loss, a0 = cw(xin, ytarget, target0_mean, target0_rms, a0)
+                else:
+                    # one window = `tback` forward passes on unchanged parameters + ONE backward: parameter-only tensors (folded mixes,
+                    # padded weights) are evaluated once, and the per-time-step parameter gradients of the custom nodes are summed with a
+                    # few multi-tensor launches instead of ~900 one-block adds per time-step (tmg_ops.bptt_window)
+                    with ops.bptt_window() as win:
+                        loss, a0 = self._window_body(core)(xin, ytarget, target0_mean, target0_rms, a0)
+                        win.backward(loss)
                 if bucket is not None:
                     bucket.allreduce_mean()
                 torch.nn.utils.clip_grad_norm_([p for p in core.parameters() if p.grad is not None], self.args.max_grad_norm)

@@ -98,6 +98,8 @@ class GradBucket:
         self._live_any = None      # ids with a gradient on ANY rank (from the reduced flags)
         self.launched_during_backward = 0   # diagnostics: buckets whose all-reduce was issued from a hook
         self.flag_reads = 0        # diagnostics: host reads of the reduced flags
+        self.paused = False        # True: the hooks launch nothing (CapturedWindow: a replayed backward runs no hooks, and the recording
+                                   # one must not put collectives into the graph) - allreduce_mean() issues every bucket
         self.measure = bool(measure)
         self._ev = []              # per step: (first bucket ready, backward done, last all-reduce done) events
         self._ev_first = None
@@ -160,8 +162,8 @@ class GradBucket:
         return self._expected is not None and len(self._expected[bi]) > 0 and self._got[bi] == len(self._expected[bi])
 
     def _on_grad(self, p):
-        if self.buckets is None or self._expected is None:
-            return                      # first step: everything goes after backward
+        if self.buckets is None or self._expected is None or self.paused:
+            return                      # first step (or hooks switched off): everything goes after backward
         if p.grad is None:
             # the hook also fires when the node in front handed autograd NO gradient for this parameter (tmg_ops.fused_grad_accumulation
             # collects the window's parameter gradients itself and binds them after backward): nothing has arrived yet
@@ -260,25 +262,147 @@ def shard(t, rank, world):
     return t[rank * n:(rank + 1) * n]
 
 
-def train_window(model, optimizer, xs, states, key_states, loss_fn, bucket=None, max_grad_norm=None, sample=None):
-    """One BPTT window of the reference's inner loop (trainFlowParallel.py:256-297): `tback` time-steps of the
-    generative direction, one backward, gradient mean over ranks, clip, optimizer step, then the LSTM states
-    are re-anchored half-way to their seed states.  `sample(model, x_t, states, t)` defaults to model.sample."""
-    import tmg_ops
-    optimizer.zero_grad(set_to_none=True)
-    loss = 0.0
-    outs = []
-    # one window = T forward passes on unchanged parameters + one backward: parameter-only tensors (folded mixes, padded weights) are
-    # evaluated once, the T per-time-step parameter gradients are summed by T - 1 multi-tensor adds instead of ~900 T tiny ones
-    with tmg_ops.bptt_window() as win:
+def _flat_tensors(obj, out=None):
+    """The tensors of a nested list / tuple structure, depth first."""
+    out = [] if out is None else out
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _flat_tensors(o, out)
+    elif obj is not None:
+        raise TypeError("CapturedWindow: arguments are tensors or nested lists / tuples of tensors (got %s)" % type(obj).__name__)
+    return out
+
+
+def _map_tensors(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(o, fn) for o in obj)
+    return obj
+
+
+class CapturedWindow:
+    """The forward passes, the loss and the backward pass of ONE BPTT window (reference trainFlowParallel.py:256-281) recorded
+    once into a hipGraph and replayed for every later window of the same shape.
+
+    Why: a window is ~11 000 kernel launches; its T forward passes are short kernels issued from Python one by one and the host
+    does not keep up with the GPU there (rocprofv3 of the trainer's window, round 4: 46.9 ms of kernels in 50.9 ms per time-step).
+    A replay issues the same launches from the runtime with no Python in between.  The gradient exchange, clipping, the
+    optimizer step and the state re-anchoring stay eager (a few dozen launches; any optimizer works unchanged).
+
+        cw = CapturedWindow(model, body, example_args)     # runs `body` eagerly once (warm-up), then records it
+        loss, outs = cw(*args)                              # args: same nested structure / shapes as example_args
+
+    `body(*args) -> (loss, outs)` runs the T forward passes and returns the scalar loss and whatever tensors the caller wants
+    afterwards (new states, predictions: a nested list / tuple).  `args` are copied into the graph's own input tensors before
+    each replay; `loss` / `outs` are the graph's output tensors - overwritten by the next replay, so detach-and-use (or clone)
+    before it.  After a replay every parameter's `.grad` is bound to the gradient of THIS window (the graph's gradient buffers are
+    rewritten, not accumulated into, by each replay).
+
+    Everything the capture touches must already be able to run without host-to-device copies or synchronisation: the grouped
+    weight-gradient launches write their pointer tables with a kernel during capture (tmg_fill_i64), scratch comes from the
+    graph's pool, latent draws use torch's graph-safe Philox offsets.  Parameters are read in place: an optimizer step between
+    replays is seen by the next one.  The graph keeps the window's activations allocated (its private pool: ~70 GB at the metric
+    shape, batch 64, T = 10).  bucket: the GradBucket of a multi-GPU run - its hooks are switched off for good (the gradient
+    exchange then runs after the replay instead of overlapping the backward pass)."""
+
+    def __init__(self, model, body, example_args, warmup=1, bucket=None):
+        import tmg_ops
+        if bucket is not None:
+            bucket.paused = True     # the exchange follows the replay, un-overlapped (see GradBucket.paused)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.static_in = _map_tensors(tuple(example_args), lambda t: t.detach().clone())
+        self._in_flat = _flat_tensors(self.static_in)
+        dev = self._in_flat[0].device
+        assert dev.type == "cuda", "CapturedWindow records a hipGraph: HIP tensors only"
+        saved = [p.grad for p in self.params]
+
+        def run():
+            for p in self.params:
+                p.grad = None
+            with tmg_ops.bptt_window() as win:
+                loss, outs = body(*self.static_in)
+                win.backward(loss)
+            return loss, outs
+        # warm-up (lazy initialisation, code objects, cached operand tables) on the stream the capture will use: autograd's
+        # AccumulateGrad nodes remember the stream they were created on
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(int(warmup), 1)):
+                run()
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        for p in self.params:
+            p.grad = None
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()            # the warm-up's activations go back to the device: the graph's pool is a separate one
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            loss, outs = run()
+        self.loss = loss.detach()
+        self.outs = _map_tensors(outs, lambda t: t.detach())
+        self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
+        for p, g in zip(self.params, saved):
+            p.grad = g
+        self.replays = 0
+
+    def __call__(self, *args):
+        new = _flat_tensors(tuple(args))
+        if len(new) != len(self._in_flat) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(new, self._in_flat)):
+            raise ValueError("CapturedWindow: arguments differ in structure / shape from the ones the window was recorded with")
+        pairs = [(d, s) for d, s in zip(self._in_flat, new) if d is not s]
+        if pairs:
+            torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
+        self.graph.replay()
+        for p, g in self._grads:
+            p.grad = g
+        self.replays += 1
+        return self.loss, self.outs
+
+
+def window_body(model, loss_fn, sample=None):
+    """The forward part of train_window as a CapturedWindow body: (xs, states) -> (loss, (new states, [(y, logp) per step]))."""
+    def body(xs, states):
+        loss = 0.0
+        outs = []
         for t in range(len(xs)):
             if sample is None:
                 y, logp, states = model.sample(xs[t], states)
             else:
                 y, logp, states = sample(model, xs[t], states, t)
             loss = loss + loss_fn(y, logp)
-            outs.append((y.detach(), logp.detach()))
-        win.backward(loss)
+            outs.append((y, logp))
+        return loss, (states, outs)
+    return body
+
+
+def train_window(model, optimizer, xs, states, key_states, loss_fn, bucket=None, max_grad_norm=None, sample=None, captured=None):
+    """One BPTT window of the reference's inner loop (trainFlowParallel.py:256-297): `tback` time-steps of the
+    generative direction, one backward, gradient mean over ranks, clip, optimizer step, then the LSTM states
+    are re-anchored half-way to their seed states.  `sample(model, x_t, states, t)` defaults to model.sample.
+    captured: a CapturedWindow over window_body(model, loss_fn, sample) - forward passes, loss and backward are then one hipGraph
+    replay (the outputs returned are the graph's own tensors: valid until the next replay)."""
+    import tmg_ops
+    optimizer.zero_grad(set_to_none=True)
+    if captured is not None:
+        loss, (states, outs) = captured(list(xs), states)
+        outs = [(y, lp) for y, lp in outs]
+    else:
+        loss = 0.0
+        outs = []
+        # one window = T forward passes on unchanged parameters + one backward: parameter-only tensors (folded mixes, padded weights) are
+        # evaluated once, the T per-time-step parameter gradients are summed by T - 1 multi-tensor adds instead of ~900 T tiny ones
+        with tmg_ops.bptt_window() as win:
+            for t in range(len(xs)):
+                if sample is None:
+                    y, logp, states = model.sample(xs[t], states)
+                else:
+                    y, logp, states = sample(model, xs[t], states, t)
+                loss = loss + loss_fn(y, logp)
+                outs.append((y.detach(), logp.detach()))
+            win.backward(loss)
     if bucket is not None:
         bucket.allreduce_mean()
     gn = None

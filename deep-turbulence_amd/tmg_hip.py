@@ -35,7 +35,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64",
 ]
 
 
@@ -424,7 +424,10 @@ _WS = {}
 
 def workspace(nfloats, device):
     """Grow-only scratch buffer per (device, stream): kernels on one stream run in order, so sharing it is safe."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    if torch.cuda.is_current_stream_capturing():
+        # a captured launch must not write into a buffer that a later eager call may outgrow and free: scratch of the graph's own pool
+        return torch.empty(max(int(nfloats), 1), device=device, dtype=torch.float32)
+    key = (device.index, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
@@ -482,6 +485,14 @@ def _segment_table(rows, device):
     """Device copy of a grouped launch's segment table.  The table holds raw pointers of activations; in a steady training loop the
     caching allocator hands out the same blocks step after step, so the same table recurs and its device copy is reused - no
     pageable host-to-device copy (a synchronising one) per grouped launch.  The cache is bounded; a miss just copies."""
+    if torch.cuda.is_current_stream_capturing():
+        # hipGraph capture: no host-to-device copy can be recorded - the table is written by a kernel that carries the values as its
+        # arguments (tmg_fill_i64).  The pointers come from the graph's private pool and are the same at every replay.  Not cached:
+        # the table lives in the graph's pool like every other tensor of the capture.
+        flat = [int(v) for r in rows for v in r]
+        t = torch.empty((len(rows), len(rows[0])), dtype=torch.int64, device=device)
+        _chk(lib().tmg_fill_i64(_ptr(t), _i64(*flat), c_i64(len(flat)), _stream()), "tmg_fill_i64")
+        return t
     key = (device.index, tuple(tuple(r) for r in rows))
     t = _GTAB.get(key)
     if t is None:
@@ -525,8 +536,6 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
             assert all(a.shape == dy.shape and b.shape == dy.shape for a, b in group_dy)     # (strides per group: from the table)
         else:
             assert all(t.shape == dy.shape and t.stride() == dy.stride() for t in group_dy)
-    if torch.cuda.is_current_stream_capturing():
-        return False  # the segment table is a host-to-device copy, which a graph capture cannot record: per-group launches
     G = len(group_inputs)
     first = group_inputs[0]
     B, Hin, Win, _ = first[0].shape

@@ -1056,8 +1056,7 @@ class LevelCouplingFn(torch.autograd.Function):
         # The NL zero-conv weight gradients (x1 | D part) are independent of each other once DH holds every layer's
         # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
         # dominated by launch / pipeline-fill).  Their inputs stay alive until then (NL * C floats per pixel).
-        grouped = (NL > 1 and ch + 4 <= 132 and os.environ.get("TMG_NO_GROUPED_WGRAD") is None
-                   and not torch.cuda.is_current_stream_capturing())
+        grouped = NL > 1 and ch + 4 <= 132 and os.environ.get("TMG_NO_GROUPED_WGRAD") is None
         Wz = torch.stack(wzs)
         PZt = H.conv_pack_batched(Wz, 1, ch + 4, (ch + 2, ch, Cc))          # input-gradient operands of all layers: one launch
         PMt = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 1)

@@ -172,6 +172,11 @@ int tmg_checker(const void* src, const int64_t* s_d, void* dst, const int64_t* d
  * per half; to_padded writes the padding zeros itself.  dims = {npix, ch, pad, to_padded}; s_d / d_d = {pixel stride, offset} */
 int tmg_pad_halves(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, tmg_stream_t st);
 
+/* n host int64 values -> device memory through kernel arguments (256 per launch): the pointer tables of the grouped launches
+ * when the stream is being captured into a hipGraph (a pageable host-to-device copy cannot be recorded; a kernel node keeps its
+ * arguments).  No reference counterpart: the reference has no captured training window (trainFlowParallel.py:256-297 is eager). */
+int tmg_fill_i64(void* dst, const int64_t* vals, int64_t n, tmg_stream_t st);
+
 /* Bilinear align_corners=True resize (misc.py:34-35) and its adjoint. dims = {B,hi,wi,ho,wo,C} */
 int tmg_upsample_fwd(const void* src, void* dst, const int64_t* dims, tmg_stream_t st);
 int tmg_upsample_bwd(const void* dout, void* din, const int64_t* dims, tmg_stream_t st);

@@ -892,6 +892,75 @@ def test_fused_grad_accumulation_matches_autograd_accumulation(cfg_name):
     assert ops._GradSink.active is None
 
 
+@pytest.mark.parametrize("cfg_name", ["tiny", "tiny3"])
+def test_captured_window_matches_eager_window(cfg_name):
+    """tmg_dist.CapturedWindow (forward passes + loss + backward of a BPTT window as one hipGraph replay; the loop it serves is
+    trainFlowParallel.py:256-281): three windows of three time-steps with recurrent states, an optimizer step between them (the
+    replay must read the updated parameters in place) and new inputs per window (copied into the graph's input tensors) give the
+    loss, every parameter gradient, the new states and the parameters of the same windows run eagerly - also for the zero-padded
+    level of a 3-channel field, whose grouped weight-gradient tables are written by a kernel during capture (tmg_fill_i64)."""
+    import tmg_dist
+    import tmg_ops as ops
+    name, cfg = ("tiny_model.npz", C.CFG_TINY) if cfg_name == "tiny" else ("tiny3_model.npz", C.CFG_TINY3)
+    d = C.load_npz(name)
+    L = len(cfg["glow_blocks"])
+    sd = {k: torch.from_numpy(v) for k, v in C.sub(d, "sd.").items()}
+    me, mc = _model(cfg, sd), _model(cfg, sd)
+    x = torch.from_numpy(d["x"]).to(DEV)
+    h_in = C.states_from(d, "h_in.", L, DEV)
+    eps = [torch.from_numpy(d["fwd.eps.%d" % i]).to(DEV) for i in range(L + 1)]
+
+    def body_of(m):
+        def body(xs, states):
+            loss = 0.0
+            for t in range(len(xs)):
+                y, ld, states = m.reconstruct(xs[t], states, eps)
+                loss = loss + C.loss_reverse(y, ld)
+            return loss, states
+        return body
+
+    inputs = lambda w: [x * (1.0 + 0.1 * t + 0.05 * w) for t in range(3)]  # noqa: E731
+    cw = tmg_dist.CapturedWindow(mc, body_of(mc), (inputs(0), h_in))
+    assert all(p.grad is None for p in mc.parameters())      # recording leaves no gradient behind
+    oe, oc = torch.optim.SGD(me.parameters(), lr=1e-3), torch.optim.SGD(mc.parameters(), lr=1e-3)
+    st_e = st_c = h_in
+    for w in range(3):
+        xs = inputs(w)
+        oe.zero_grad(set_to_none=True)
+        with ops.bptt_window() as win:
+            loss_e, new_e = body_of(me)(xs, st_e)
+            win.backward(loss_e)
+        oc.zero_grad(set_to_none=True)
+        loss_c, new_c = cw(xs, st_c)
+        le, lc = float(loss_e.detach()), float(loss_c)
+        assert abs(lc - le) <= 2e-6 * abs(le) + 1e-6, (w, lc, le)
+        ge = {k: p.grad for k, p in me.named_parameters() if p.grad is not None}
+        gc = {k: p.grad for k, p in mc.named_parameters() if p.grad is not None}
+        assert set(ge) == set(gc) and len(ge) > 50
+        C.assert_grads(gc, ge, "captured window %d" % w, global_tol=2e-6, tensor_tol=2e-5)
+        for (he, ce), (hc, cc) in zip(new_e, new_c):
+            assert torch.allclose(hc, he.detach(), rtol=1e-5, atol=1e-6) and torch.allclose(cc, ce.detach(), rtol=1e-5, atol=1e-6)
+        oe.step()
+        oc.step()
+        st_e = [(0.5 * h.detach() + 0.5 * hk, 0.5 * c_.detach() + 0.5 * ck) for (h, c_), (hk, ck) in zip(new_e, h_in)]
+        st_c = [(0.5 * h + 0.5 * hk, 0.5 * c_ + 0.5 * ck) for (h, c_), (hk, ck) in zip(new_c, h_in)]
+    assert cw.replays == 3
+    for (k, pe), (_, pc) in zip(me.named_parameters(), mc.named_parameters()):
+        assert torch.allclose(pc, pe, rtol=1e-5, atol=1e-7), k
+    with pytest.raises(ValueError, match="structure / shape"):
+        cw(inputs(0)[:2], h_in)
+    # fresh latents inside a replayed graph (model.sample draws them with torch's graph-safe Philox offsets): two replays on the
+    # same inputs give different fields
+    def sample_body(xs, states):
+        y, ld, states = mc.sample(xs[0], states)
+        return C.loss_reverse(y, ld), (y, states)
+    cs = tmg_dist.CapturedWindow(mc, sample_body, (inputs(0)[:1], h_in))
+    _, (ya, _) = cs(inputs(0)[:1], h_in)
+    ya = ya.clone()
+    _, (yb, _) = cs(inputs(0)[:1], h_in)
+    assert torch.isfinite(ya).all() and torch.isfinite(yb).all() and float((ya - yb).abs().max()) > 1e-3
+
+
 def test_forward_default_arguments():
     """forward(x, y) with the reference's defaults (no states, return_eps=False): same z / log-likelihood as with
     return_eps=True, eps is None (reference tmGlow.py:378-414)."""

@@ -32,6 +32,9 @@ def main():
                          "for 3 channels only)")
     ap.add_argument("--adam", default="torch", choices=["torch", "hip"],
                     help="torch: torch.optim.Adam as main.py:78 constructs it; hip: tmg_optim.HipAdam (the same update in one launch)")
+    ap.add_argument("--capture", action="store_true",
+                    help="forward passes + loss + backward of a window as one hipGraph replay (tmg_dist.CapturedWindow); clip, optimizer "
+                         "step and state re-anchoring stay eager")
     a = ap.parse_args()
 
     def make_opt(params):
@@ -60,12 +63,17 @@ def main():
         opt = make_opt(model.parameters())
         key = model.initLSTMStates(torch.arange(B), [2 * h, 2 * w])
 
+        cw = None
+        if a.capture:
+            cw = tmg_dist.CapturedWindow(model, tmg_dist.window_body(model, C.loss_reverse),
+                                         ([x[:, t] for t in range(T)], [(hh.clone(), cc.clone()) for hh, cc in key]))
+
         def run():
             st = [(hh.clone(), cc.clone()) for hh, cc in key]
             tot = 0.0
             for wi in range(a.windows):
                 loss, _, st, _ = tmg_dist.train_window(model, opt, [x[:, wi * T + t] for t in range(T)], st, key, C.loss_reverse,
-                                                       max_grad_norm=0.01)
+                                                       max_grad_norm=0.01, captured=cw)
                 tot = tot + loss
             return tot
         run()
@@ -79,11 +87,11 @@ def main():
                           "loss of bench.py summed over the steps, clip, Adam(amsgrad), state re-anchoring" % (a.windows, T, B),
                           "seconds_per_window": round(dt / a.windows, 4), "sample_steps_per_s": round(B * T * a.windows / dt, 2),
                           "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "loss_sum": float(loss),
-                          "warmup": "one untimed call of the same shape"}))
+                          "warmup": "one untimed call of the same shape", "captured": bool(a.capture)}))
         return
     y = torch.randn(B, T * a.windows, 3, 2 * h, 2 * w, generator=g).to(dev)
     seeds = torch.arange(B)
-    args = SimpleNamespace(beta=200.0, dx=2. / 64, dy=2. / 64, max_grad_norm=0.01)
+    args = SimpleNamespace(beta=200.0, dx=2. / 64, dy=2. / 64, max_grad_norm=0.01, capture_window=bool(a.capture))
     opt = make_opt(model.parameters())
     trainer = TrainFlow(args, model, [(x, y, seeds)], None)
     # one call = `windows` BPTT windows of T steps each (trainParallel walks tmax // tback windows of a mini-batch); the first
@@ -105,7 +113,8 @@ def main():
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     print(json.dumps({"what": "TrainFlow.trainParallel, %d BPTT window(s) of %d sample() steps, batch %d, 256x256x3 output, L=4, K=16" % (
         a.windows, T, B), "seconds_per_window": round(dt / a.windows, 4), "sample_steps_per_s": round(B * T * a.windows / dt, 2),
-        "peak_mem_gb": round(peak, 2), "loss_sum": float(loss), "warmup": "one untimed call of the same shape", "optimizer": a.adam,
+        "peak_mem_gb": round(peak, 2), "reserved_mem_gb": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 2), "loss_sum": float(loss), "warmup": "one untimed call of the same shape", "optimizer": a.adam,
+        "captured": bool(a.capture),
         "lstm_state_init_s_per_minibatch": round(t_init, 4), "lstm_state_host_draw_s_first_use": round(t_cold, 3),
         "note": "window time INCLUDES the per-mini-batch seed states: every distinct seed (the loaders draw them from random_(0, 1000)) is "
                 "drawn once on the host with the reference's CPU generators (tmGlow.py:481-509) and kept in HBM; later mini-batches gather"}))
