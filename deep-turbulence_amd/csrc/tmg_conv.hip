@@ -1774,6 +1774,16 @@ static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_
     return 0;
 }
 
+// TMG_WG_PLAN=MPIXMAX,GXMUL (0 = planner's choice): plan override of conv_wgrad_kernel for measurements (tools/bench_wgrad_groups.py)
+static int tmg_wg_plan(int i) {
+    static int v[2] = {-1, 0};
+    if (v[0] < 0) {
+        v[0] = 0;
+        if (const char* e = getenv("TMG_WG_PLAN")) sscanf(e, "%d,%d", &v[0], &v[1]);
+    }
+    return v[i];
+}
+
 struct WgradPlan {
     int twl, TH, MPIX, tiles_x, tiles_y, ntiles, CITG, PPG, NCO, NP, ksplit, gx, gy, gz;
     size_t lds_bytes, ws_floats;
@@ -1853,7 +1863,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
         // the read/MFMA pipeline never fills.  Larger tiles (as far as registers, LDS and the tile count allow) give each
         // wave 2-4 units per tile and less halo per staged pixel.
         const int k4p = pl->CITG <= 1 ? 4 : (pl->CITG <= 2 ? 8 : (pl->CITG <= 4 ? 16 : 32));
-        for (int mp = 512; mp > 128; mp >>= 1) {
+        for (int mp = (tmg_wg_plan(0) >= 128 ? tmg_wg_plan(0) : 512); mp > 128; mp >>= 1) {
             const int th = mp >> twl, ph = th + 2 * halo;
             const int tiles = B * ((Wout + TW - 1) / TW) * ((Hout + th - 1) / th);
             if (ph * PW * k4p <= 7 * 512 && 2 * ((size_t)(ph * PW * 16 + 16) * pl->CITG + (size_t)(mp * 16 + 16) * NCO) * 4 <= 160 * 1024 &&
@@ -1924,6 +1934,7 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
         // (blockIdx.z still walks the input-channel blocks of a group wider than one block)
         pl.gy = bpg * ngroups;
         int gx = 256 / (pl.gy * pl.gz);
+        if (tmg_wg_plan(1) > 1) gx = tmg_wg_plan(1) * 256 / (pl.gy * pl.gz);
         if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
         if (gx < 1) gx = 1;
         pl.gx = gx;
@@ -1991,6 +2002,7 @@ extern "C" int64_t tmg_conv_wgrad_grouped_ws_floats(const int64_t* dims, int64_t
     if (plan_wgrad((int)dims[0], (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7], (int)dims[8], &pl) != 0) return 0;
     const int gy = pl.gy * (int)ngroups;
     int gx = 256 / (gy * pl.gz);
+    if (tmg_wg_plan(1) > 1) gx = tmg_wg_plan(1) * 256 / (gy * pl.gz);
     if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
     if (gx < 1) gx = 1;
     return (int64_t)((size_t)gx * gy * pl.gz * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * gy * 64);

@@ -457,7 +457,16 @@ struct WinoNP {
     int tiles_x, tiles_y, ntiles, nchunks;
 };
 
-template <int NTN>
+// SKEW: the eight waves of the block run in step (one barrier per round), so a staging phase in front of the MFMA groups is a phase
+// during which nobody feeds the matrix pipe (ablation builds, round 4: without commit + issue the 240 -> 32 contraction at 128^2 runs
+// in 0.74 ms instead of 0.94).  With SKEW the two waves that share a SIMD (w and w + 4) stage at OPPOSITE ends of the round: waves 0-3
+// commit / issue first and multiply afterwards, waves 4-7 multiply first and commit / issue before the barrier - each wave's staging
+// instructions issue while its SIMD partner's MFMAs keep the pipe busy.  Same LDS hazards as before: the stage after this one is
+// committed to the buffer nobody reads in this round, at any point between the two barriers.  Measured (tools/bench_wino.py, one box,
+// TMG_WN_NOSKEW=1 for the form without): 256 -> 40 at 128^2 1.259 -> 1.173 ms, 240 -> 32 0.935 -> 0.863, 480 -> 32 at 64^2 0.428 -> 0.408;
+// pairing the waves as (w, w ^ 1) instead: 1.222 / 0.902 (waves w and w + 4 are the ones that share a SIMD).  The same change in
+// wino_fwd_kernel, whose rounds also hold the all-thread input transform, lost 2-5 % and is not in the tree.
+template <int NTN, int SKEW = 1>
 __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = 512;
@@ -531,54 +540,55 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
         for (int d = 0; d < RD - 1; ++d) TMG_WN_LOADG(d, d % ngrp)
     }
 
+    const bool late = SKEW && wave >= 4;      // stages at the end of the round (see above)
+#define TMG_WN_STAGE \
+        if (k >= -1 && k + 1 < nst) { \
+            float* rb_ = lds + ((k + 1) & 1) * RAWW; \
+            _Pragma("unroll") for (int u = 0; u < UPI; ++u) { \
+                if (ppix0 + u * 64 < PP) { \
+                    float4 v = pv[u]; \
+                    if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
+                    *reinterpret_cast<float4*>(rb_ + (ppix0 + u * 64) * CS + 4 * pc4) = v; \
+                } \
+            } \
+        } \
+        if (k + 2 < nst) { \
+            int t_ = ti; \
+            const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x; \
+            const int ty_ = t_ % p.tiles_y; \
+            const int b_ = t_ / p.tiles_y; \
+            const int iy0 = ty_ * TH - 1, ix0 = tx_ * TW - 1; \
+            const float* tptr = tmg_zero_page; \
+            int tss = 0; \
+            { \
+                int cl = ci * KC + 4 * pc4; \
+                if (cl < p.Cin) { \
+                    const float* sp = p.in[0].p; \
+                    int ss = p.in[0].stride, so = p.in[0].off; \
+                    if (cl >= p.in[0].n) { \
+                        cl -= p.in[0].n; \
+                        sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off; \
+                        if (cl >= p.in[1].n) { \
+                            cl -= p.in[1].n; \
+                            sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off; \
+                        } \
+                    } \
+                    tptr = sp + so + cl; \
+                    tss = ss; \
+                } \
+            } \
+            const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win); \
+            _Pragma("unroll") for (int u = 0; u < UPI; ++u) { \
+                const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu); \
+                const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1); \
+                const bool oob = !p.pad_rep && (iy != iyc || ix != ixc); \
+                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (size_t)(tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)tss; \
+                pv[u] = *reinterpret_cast<const float4*>(a_); \
+            } \
+            if (++ci == nchunks) { ci = 0; ti += G; } \
+        }
     for (int k = -2; k < nst; ++k) {
-        if (k >= -1 && k + 1 < nst) {
-            float* rb_ = lds + ((k + 1) & 1) * RAWW;
-#pragma unroll
-            for (int u = 0; u < UPI; ++u) {
-                if (ppix0 + u * 64 < PP) {
-                    float4 v = pv[u];
-                    if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *reinterpret_cast<float4*>(rb_ + (ppix0 + u * 64) * CS + 4 * pc4) = v;
-                }
-            }
-        }
-        if (k + 2 < nst) {
-            int t_ = ti;
-            const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
-            const int ty_ = t_ % p.tiles_y;
-            const int b_ = t_ / p.tiles_y;
-            const int iy0 = ty_ * TH - 1, ix0 = tx_ * TW - 1;
-            const float* tptr = tmg_zero_page;
-            int tss = 0;
-            {
-                int cl = ci * KC + 4 * pc4;
-                if (cl < p.Cin) {
-                    const float* sp = p.in[0].p;
-                    int ss = p.in[0].stride, so = p.in[0].off;
-                    if (cl >= p.in[0].n) {
-                        cl -= p.in[0].n;
-                        sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
-                        if (cl >= p.in[1].n) {
-                            cl -= p.in[1].n;
-                            sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
-                        }
-                    }
-                    tptr = sp + so + cl;
-                    tss = ss;
-                }
-            }
-            const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win);   // 32-bit pixel index: the launcher refuses B H W >= 2^31
-#pragma unroll
-            for (int u = 0; u < UPI; ++u) {
-                const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);
-                const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
-                const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);
-                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (size_t)(tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)tss;
-                pv[u] = *reinterpret_cast<const float4*>(a_);
-            }
-            if (++ci == nchunks) { ci = 0; ti += G; }
-        }
+        if (!late || k < 0) { TMG_WN_STAGE }
         if (k >= 0) {
             const float* rbuf = lds + (k & 1) * RAWW;
 #define TMG_WN_COMPUTE(PH)                                                                                            \
@@ -624,6 +634,7 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
             }
             if (k & 1) TMG_WN_COMPUTE(1) else TMG_WN_COMPUTE(0)
 #undef TMG_WN_COMPUTE
+            if (late) { TMG_WN_STAGE }
             if (cm + 1 == nchunks) {
                 // ---- M_pos -> LDS, then A^T M A over the positions by all threads ----------------------------------------------
 #pragma unroll
@@ -682,6 +693,7 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
         }
         __syncthreads();
     }
+#undef TMG_WN_STAGE
 #undef TMG_WN_LOADG
 }
 
@@ -690,6 +702,13 @@ static int launch_wino_nn(const WinoNP& p, int G, hipStream_t st) {
     const size_t lds_bytes = (size_t)(2 * 180 * 40 + 16 * 32 * (NTN * 16 + (NTN < 3 ? 4 : 0))) * sizeof(float);
     TMG_LDS_OPTIN((&wino_nn_kernel<NTN>));
     TmgProf prof(TMG_PROF_WINO, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);
+    static const int noskew = getenv("TMG_WN_NOSKEW") ? atoi(getenv("TMG_WN_NOSKEW")) : 0;       // A / B switch
+    if (noskew == 1) {
+        TMG_LDS_OPTIN((&wino_nn_kernel<NTN, 0>));
+        hipLaunchKernelGGL((wino_nn_kernel<NTN, 0>), dim3(G), dim3(512), lds_bytes, st, p);
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL((wino_nn_kernel<NTN>), dim3(G), dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
