@@ -10,6 +10,7 @@ import math
 
 import os
 import threading
+import weakref
 
 import torch
 
@@ -108,7 +109,8 @@ class DerivedCache:
         if e is not None and e["key"] == key and not e["stale"][0] and os.environ.get("TMG_NO_DERIVED_CACHE") is None:
             return e["val"]
         if e is not None:
-            _GradSink.proxy_ids.difference_update(e["ids"])
+            for i_ in e["ids"]:
+                _GradSink.proxy_ids.pop(i_, None)
         val = build()
         stale, ids = [False], set()
         for t in self._tensors(val):
@@ -116,7 +118,10 @@ class DerivedCache:
                 t.register_hook(lambda g, s=stale: s.__setitem__(0, True))
                 if proxies:
                     ids.add(t._cdata)
-        _GradSink.proxy_ids.update(ids)
+                    _GradSink.proxy_ids[t._cdata] = weakref.ref(t)
+        if len(_GradSink.proxy_ids) > 4096:      # entries of caches that died with their model
+            for i_ in [i_ for i_, r_ in _GradSink.proxy_ids.items() if r_() is None]:
+                del _GradSink.proxy_ids[i_]
         self.entries[name] = {"key": key, "val": val, "stale": stale, "ids": ids}
         return val
 
@@ -131,7 +136,19 @@ class _GradSink:
     multi-tensor launches (`torch._foreach_add_`) and bound to `p.grad` (added to an existing one).  Same sums, in the order of
     the time-steps, as autograd's own accumulation."""
     active = None
-    proxy_ids = set()        # TensorImpl ids of DerivedCache tensors registered as sink targets (non-leaf: flushed through autograd)
+    # TensorImpl id -> weak reference of the DerivedCache tensors registered as sink targets (non-leaf: flushed through autograd).  The id
+    # alone is not enough: a cache dies with its model, and the address of a dead TensorImpl is handed to a later tensor - a plain set of
+    # ids then declared unrelated derived tensors sink targets (their gradients went BOTH through the sink and through the main backward
+    # pass: "backward through the graph a second time", seen only with several models in one process).
+    proxy_ids = {}
+
+    @staticmethod
+    def is_proxy(t):
+        r = _GradSink.proxy_ids.get(t._cdata)
+        if r is None:
+            return False
+        o = r()
+        return o is not None and o._cdata == t._cdata
 
     def __init__(self):
         self.items = {}      # TensorImpl id -> (parameter, [gradients in arrival order])
@@ -220,7 +237,7 @@ def _defer(params, grads):
         return tuple(grads)
     out = []
     for p, g in zip(params, grads):
-        if g is not None and p is not None and p.requires_grad and (p.is_leaf or p._cdata in _GradSink.proxy_ids):
+        if g is not None and p is not None and p.requires_grad and (p.is_leaf or _GradSink.is_proxy(p)):
             sink.push(p, g)
             out.append(None)
         else:

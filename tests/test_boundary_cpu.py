@@ -288,7 +288,17 @@ def test_fused_grad_accumulation_sums_like_autograd_on_cpu():
     cache = ops.DerivedCache()
     with ops.bptt_window() as win:
         pad = cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0]
-        assert pad._cdata in ops._GradSink.proxy_ids
+        assert ops._GradSink.is_proxy(pad)
         win.backward(loss(pad))
         assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6) and torch.allclose(w2.grad, ref[1], rtol=1e-6, atol=1e-6)
         assert cache.get("pad", [w1], (), lambda: [torch.cat([w1, torch.zeros(4, 1)], 1)], proxies=True)[0] is not pad    # consumed: rebuilt
+    # a proxy registration dies with its tensor: the TensorImpl address of a dead cache entry may be handed to any later tensor, which
+    # must not become a sink target by that accident (round 4: "backward through the graph a second time" with several models in one
+    # process) - simulated by registering a weak reference to a tensor that is gone under a live tensor's id
+    import weakref
+    dead = torch.zeros(3, requires_grad=True) * 2.0
+    live = torch.ones(3, requires_grad=True) * 2.0
+    ops._GradSink.proxy_ids[live._cdata] = weakref.ref(dead)
+    del dead
+    assert not ops._GradSink.is_proxy(live)
+    del ops._GradSink.proxy_ids[live._cdata]
