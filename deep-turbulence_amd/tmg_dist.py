@@ -305,7 +305,9 @@ class CapturedWindow:
     weight-gradient launches write their pointer tables with a kernel during capture (tmg_fill_i64), scratch comes from the
     graph's pool, latent draws use torch's graph-safe Philox offsets.  Parameters are read in place: an optimizer step between
     replays is seen by the next one.  The graph keeps the window's activations allocated (its private pool: ~70 GB at the metric
-    shape, batch 64, T = 10).  bucket: the GradBucket of a multi-GPU run - its hooks are switched off for good (the gradient
+    shape, batch 64, T = 10).  Construction runs the body twice on the example arguments (eager warm-up, then the recording): BatchNorm
+    running statistics and the random generator advance as for two windows, no gradient is left behind.  bucket: the GradBucket of a
+    multi-GPU run - its hooks are switched off for good (the gradient
     exchange then runs after the replay instead of overlapping the backward pass)."""
 
     def __init__(self, model, body, example_args, warmup=1, bucket=None):
@@ -378,16 +380,18 @@ def window_body(model, loss_fn, sample=None):
     return body
 
 
-def train_window(model, optimizer, xs, states, key_states, loss_fn, bucket=None, max_grad_norm=None, sample=None, captured=None):
+def train_window(model, optimizer, xs, states, key_states, loss_fn, bucket=None, max_grad_norm=None, sample=None, captured=None,
+                 captured_extra=()):
     """One BPTT window of the reference's inner loop (trainFlowParallel.py:256-297): `tback` time-steps of the
     generative direction, one backward, gradient mean over ranks, clip, optimizer step, then the LSTM states
     are re-anchored half-way to their seed states.  `sample(model, x_t, states, t)` defaults to model.sample.
     captured: a CapturedWindow over window_body(model, loss_fn, sample) - forward passes, loss and backward are then one hipGraph
-    replay (the outputs returned are the graph's own tensors: valid until the next replay)."""
+    replay (the outputs returned are the graph's own tensors: valid until the next replay); captured_extra: further arguments of its
+    body after (xs, states), e.g. injected latents."""
     import tmg_ops
     optimizer.zero_grad(set_to_none=True)
     if captured is not None:
-        loss, (states, outs) = captured(list(xs), states)
+        loss, (states, outs) = captured(list(xs), states, *captured_extra)
         outs = [(y, lp) for y, lp in outs]
     else:
         loss = 0.0

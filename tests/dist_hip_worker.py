@@ -14,7 +14,7 @@ import tmg_dist  # noqa: E402
 from nn.tmGlow import TMGlow  # noqa: E402
 
 
-def main(out_path, n_windows):
+def main(out_path, n_windows, captured=False):
     rank, world, _ = tmg_dist.init_from_env("gloo")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -35,14 +35,27 @@ def main(out_path, n_windows):
     key = m.initLSTMStates(tmg_dist.shard(seeds, rank, world), [16, 16])
     states = [(h.clone(), c.clone()) for h, c in key]
     res = {"loss": [], "gn": []}
+    cw = None
     for a in range(n_windows):
         xs_g = torch.from_numpy(d["xs"])[a]
         xs = [tmg_dist.shard(xs_g[t], rank, world).to(dev) for t in range(xs_g.shape[0])]
         eps = [[tmg_dist.shard(torch.from_numpy(d["eps.%d.%d.%d" % (a, t, i)]), rank, world).to(dev) for i in range(L + 1)]
                for t in range(len(xs))]
+        if captured and cw is None:
+            # forward passes + loss + backward of a window as one hipGraph replay (the latents are arguments of the recorded body);
+            # the bucket's hooks are switched off, the exchange follows the replay
+            def body(xs_, states_, eps_):
+                loss_, outs_ = 0.0, []
+                for t in range(len(xs_)):
+                    y, lp, states_ = m.reconstruct(xs_[t], states_, eps_[t])
+                    loss_ = loss_ + C.loss_reverse(y, lp)
+                    outs_.append((y, lp))
+                return loss_, (states_, outs_)
+            cw = tmg_dist.CapturedWindow(m, body, (xs, states, eps), bucket=bucket)
         loss, gn, states, _ = tmg_dist.train_window(m, opt, xs, states, key, C.loss_reverse, bucket=bucket,
                                                     max_grad_norm=float(d["max_grad_norm"]),
-                                                    sample=lambda mod, x, st, t: mod.reconstruct(x, st, eps[t]))
+                                                    sample=lambda mod, x, st, t: mod.reconstruct(x, st, eps[t]),
+                                                    captured=cw, captured_extra=(eps,))
         res["loss"].append(float(loss))
         res["gn"].append(float(gn))
     res["log_s"] = dict(m.named_parameters())[str(d["log_s_key"])].detach().cpu()
@@ -53,4 +66,4 @@ def main(out_path, n_windows):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]))
+    main(sys.argv[1], int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "captured")
