@@ -170,7 +170,7 @@ def _oracle_pass(O, sd, cfg, x, y, seeds, dtype, eps=None, probe=False):
 
 
 @pytest.mark.parametrize("name,cfg,B", [("cfg5-64x64", CFG5_REDUCED, 2)] + (
-    [("cfg2", C.CFG2, 2), ("cfg3", C.CFG3, 1)] if os.environ.get("TMG_TEST_SMALL_BATCH_CONFIGS") else []))
+    [("cfg2", C.CFG2, 2), ("cfg3", C.CFG3, 1), ("M", C.CFG_M, 1)] if os.environ.get("TMG_TEST_SMALL_BATCH_CONFIGS") else []))
 def test_baseline_configs_match_fp64_oracle(name, cfg, B):
     """BASELINE configs[4]'s five-level network (reduced field) at the default widths, small batch: forward, reconstruct and all
     gradients of the HIP path against the CPU oracle evaluated in FP64 on the same seeded weights.  configs[1] (64x64x3 -> 128x128x3,
