@@ -1314,8 +1314,10 @@ __global__ __launch_bounds__(256, NQ <= 2 ? 4 : 3) void dense2_bwd_lean_kernel(D
         }
         __syncthreads();
         if (p.dd1_out && blockIdx.y == 0 && own) {
-            *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.dd1_out) + opix * (4u * (unsigned)p.dd_stride)) =
-                make_float4(A1[(row + 1) * PW + col + 1], A2[(row + 2) * QW + col + 2], 0.f, 0.f);   // no zero fill of the stash needed
+            char* dq_ = reinterpret_cast<char*>(p.dd1_out) + opix * (4u * (unsigned)p.dd_stride);
+            const float d1v_ = A1[(row + 1) * PW + col + 1], d2v_ = A2[(row + 2) * QW + col + 2];
+            if (p.dd_quad) *reinterpret_cast<float4*>(dq_) = make_float4(d1v_, d2v_, 0.f, 0.f);   // no zero fill of the stash needed
+            else *reinterpret_cast<float2*>(dq_) = make_float2(d1v_, d2v_);                         // compact stash: two channels per layer
         }
         if (own) {
             float n1[9], n2[9];
@@ -1841,7 +1843,8 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
     TmgProf prof(TMG_PROF_D2B, 4.0 * p.B * (double)p.Hin * p.Win * (3.0 * p.cin_nn + 4 + 4 + 4 + 2), st);   // x, G0 read, dx written; D, GD; add0 ~ included in 3 cin
     static const bool no_lean = getenv("TMG_D2_NO_LEAN") != nullptr;
     if (!no_lean && !p.dW1 && !p.dW2 && p.vec4 && ng == 1 && p.nseg == 2 && p.in[0].n == p.cin_nn && p.in[1].n == 4 && (p.cin_nn & 3) == 0 &&
-        p.g0[0].n == p.cin_nn && p.dd1_out && p.dd_quad &&
+        p.g0[0].n == p.cin_nn && p.dd1_out &&
+        (p.dd_quad || (p.dd2_out == p.dd1_out + 1 && !(p.dd_stride & 1) && !(((uintptr_t)p.dd1_out) & 7))) &&
         (double)p.B * p.Hin * p.Win * 4.0 * (double)std::max(std::max(std::max(p.in[0].stride, p.g0[0].stride), std::max(p.out[0].stride, p.add0_stride)),
                                                               std::max(std::max(p.gd_stride, p.d_stride), p.dd_stride)) < 4.0e9) {
         // the level node's call: no staged patch, <= 128 registers (see dense2_bwd_lean_kernel)
@@ -2150,6 +2153,7 @@ struct LevelFinP {
     double* acc;
     unsigned* cnt;
     int NL, C, ch, Cc, S;
+    int rowsC;      // rows per layer in tmpC: 4 (the grouped launches' quad rows) or 2 (compact: the level-wide conditioning launch)
 };
 
 __global__ __launch_bounds__(256) void level_finish_kernel(LevelFinP p) {
@@ -2175,7 +2179,7 @@ __global__ __launch_bounds__(256) void level_finish_kernel(LevelFinP p) {
     if (s == p.S - 1) {
         // scatter of the grouped launches' rows into the native weight-gradient layout
         const float* tx = p.tmpX ? p.tmpX + (size_t)k * 4 * (p.ch + 4) * 9 : nullptr;
-        const float* tc = p.tmpC ? p.tmpC + (size_t)k * 4 * p.Cc * 9 : nullptr;
+        const float* tc = p.tmpC ? p.tmpC + (size_t)k * p.rowsC * p.Cc * 9 : nullptr;
         float* d1 = p.dW1 + (size_t)k * cin * 9;
         float* d2 = p.dW2 + (size_t)k * (cin + 1) * 9;
         for (int e = tid; e < (cin + 1) * 9; e += 256) {
@@ -2210,14 +2214,15 @@ __global__ __launch_bounds__(256) void level_finish_kernel(LevelFinP p) {
     }
 }
 
-// dims = {NL, C, ch, Cc}.  tmpX / tmpC may be null (nothing to scatter from that source).  ws: >= 4 * NL zero-initialised floats,
-// 8-byte aligned.
+// dims = {NL, C, ch, Cc, rows per layer in tmpC (0 -> 4)}.  tmpX / tmpC may be null (nothing to scatter from that source).
+// ws: >= 4 * NL zero-initialised floats, 8-byte aligned.
 extern "C" int tmg_level_finish(const void* Wz, const void* dWz, const void* Bz, const void* dBz, const void* Kp, const void* tmpX,
                                 const void* tmpC, void* dW1, void* dW2, void* dK, void* ws, const int64_t* dims, hipStream_t st) {
     LevelFinP p;
     p.Wz = (const float*)Wz; p.dWz = (const float*)dWz; p.Bz = (const float*)Bz; p.dBz = (const float*)dBz; p.Kp = (const float*)Kp;
     p.tmpX = (const float*)tmpX; p.tmpC = (const float*)tmpC; p.dW1 = (float*)dW1; p.dW2 = (float*)dW2; p.dK = (float*)dK;
     p.NL = (int)dims[0]; p.C = (int)dims[1]; p.ch = (int)dims[2]; p.Cc = (int)dims[3];
+    p.rowsC = dims[4] == 2 ? 2 : 4;
     if (p.NL < 1 || p.C < 1 || !ws || ((uintptr_t)ws & 7)) return -1;
     p.acc = (double*)ws;
     p.cnt = (unsigned*)((float*)ws + 2 * (size_t)p.NL);

@@ -20,8 +20,8 @@
 
 struct ThinP {
     const long long* gtab;   // [G][16]: 3 input segments {pointer, pixel stride, 0, channels} + {dy pointer or 0, ...}   (tmg_conv_wgrad_grouped)
-    const float* dy;         // shared upstream gradient: group g at channels [4 g, 4 g + 4)
-    int dys;
+    const float* dy;         // shared upstream gradient: group g at channels [dyc g, dyc g + dyc)
+    int dys, dyc;            // pixel stride; channels per group: 4, or 2 (compact: rows 2, 3 of a group's dW stay zero)
     float* dW;               // [G][4][Cin][3][3], accumulated into
     int B, H, W, relu_in;
     int tiles_x, tiles_y, ntiles;   // per group
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinP p) {
     const float* sp2 = reinterpret_cast<const float*>(gt[8]);
     const int ss0 = (int)gt[1], ss1 = (int)gt[5], ss2 = (int)gt[9];
     const int n0 = (int)gt[3], n1 = (int)gt[7];
-    const float* dyb = p.dy + 4 * g;
+    const float* dyb = p.dy + p.dyc * g;
 
     // lane offsets of the A operand inside the patch, per slot: block beta = 16 t + lane / 4 = tap * Q + quad (blocks past NB repeat
     // the last one; their results are dropped)
@@ -104,7 +104,11 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(ThinP p) {
             const int r = it >> 4, c = it & 15;
             const int oy = oy0 + r, ox = ox0 + c;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < p.H && ox < p.W) v = *reinterpret_cast<const float4*>(dyb + (img + (size_t)oy * p.W + ox) * p.dys);
+            if (oy < p.H && ox < p.W) {
+                const float* a_ = dyb + (img + (size_t)oy * p.W + ox) * p.dys;
+                if (p.dyc == 4) v = *reinterpret_cast<const float4*>(a_);
+                else { const float2 v2 = *reinterpret_cast<const float2*>(a_); v = make_float4(v2.x, v2.y, 0.f, 0.f); }
+            }
             *reinterpret_cast<float4*>(DY + it * 4) = v;
         }
         __syncthreads();
@@ -165,8 +169,9 @@ extern "C" int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const in
     ThinP p;
     p.gtab = (const long long*)gtab; p.dy = (const float*)dy; p.dys = (int)dy_stride; p.dW = (float*)dW;
     p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.relu_in = (int)dims[4];
+    p.dyc = dims[5] == 2 ? 2 : 4;      // dims[5]: dy channels per group (0 / 4: a float4 per pixel, 2: a float2)
     const int Cin = (int)dims[3];
-    if (G < 1 || !gtab || nseg < 1 || nseg > 3 || (dy_stride & 3) || ((uintptr_t)dy & 15)) return -100;
+    if (G < 1 || !gtab || nseg < 1 || nseg > 3 || (dy_stride & (p.dyc - 1)) || ((uintptr_t)dy & (4 * p.dyc - 1))) return -100;
     for (int i = 0; i < nseg; ++i)
         if (seg_channels[i] & 3) return -100;
     switch (Cin) {

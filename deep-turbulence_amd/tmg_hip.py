@@ -587,12 +587,13 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
         return conv_wgrad_grouped(group_inputs, None, dy_group_channels, dW, dbias, ksize, stride, relu_in=relu_in, pad_rep=pad_rep,
                                   cin_dst=cin_dst, cin_valid=cin_valid, ci_split=ci_split, ci_off0=ci_off0, ci_off1=ci_off1,
                                   group_dy=[torch.cat(list(t), 3) for t in group_dy])
-    if (group_dy is None and ksize == 3 and stride == 1 and Cg == 4 and not pad_rep and dbias is None and cin_dst in (0, Cin)
+    if (group_dy is None and ksize == 3 and stride == 1 and Cg in (2, 4) and dW.shape[1] == 4 and not pad_rep and dbias is None and cin_dst in (0, Cin)
             and cin_valid in (0, Cin) and ci_split == 0 and Cin in (12, 20, 36, 68) and os.environ.get("TMG_NO_THIN_WGRAD") is None
             and all(t.stride(2) % 4 == 0 and t.data_ptr() % 16 == 0 for segs in group_inputs for t in segs)):
-        # four output channels per group (the growth-1 layers): 4x4x1 MFMA blocks instead of 16x16 tiles that would be 2/16 used
+        # four output rows per group (the growth-1 layers; dy: (dd1, dd2, 0, 0) quads or compact (dd1, dd2) pairs): 4x4x1 MFMA blocks
+        # instead of 16x16 tiles that would be 2/16 used
         rc = lib().tmg_conv_wgrad_thin_grouped(_ptr(gtab), c_i64(G), _i64(*[t.shape[3] for t in first]), c_i64(n_in), _ptr(dy),
-                                               c_i64(dy.stride(2)), _ptr(dW), _i64(B, Hin, Win, Cin, relu_in), _stream())
+                                               c_i64(dy.stride(2)), _ptr(dW), _i64(B, Hin, Win, Cin, relu_in, Cg), _stream())
         if rc != -100:
             _chk(rc, "tmg_conv_wgrad_thin_grouped")
             return True
@@ -690,7 +691,7 @@ def level_finish(Wz, dWz, Bz, dBz, Kp, tmpX, tmpC, dW1, dW2, dK, ws, ch, Cc):
         assert t is None or t.is_contiguous()
     assert ws.numel() >= 4 * NL
     _chk(lib().tmg_level_finish(_ptr(Wz), _ptr(dWz), _ptr(Bz), _ptr(dBz), _ptr(Kp), _ptr(tmpX), _ptr(tmpC), _ptr(dW1), _ptr(dW2), _ptr(dK),
-                                _ptr(ws), _i64(NL, C, ch, Cc), _stream()), "tmg_level_finish")
+                                _ptr(ws), _i64(NL, C, ch, Cc, tmpC.shape[1] if tmpC is not None else 4), _stream()), "tmg_level_finish")
 
 
 def adam_step(tab, chunks, nchunks, lr, b1, b2, eps, wd, bc1, bc2s, amsgrad):

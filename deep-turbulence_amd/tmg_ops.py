@@ -1065,10 +1065,16 @@ class LevelCouplingFn(torch.autograd.Function):
         dWm = flat[o:o + NL * C * C].view(NL, C, C); o += NL * C * C
         dbm = flat[o:o + NL * C].view(NL, C)
         DH = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)     # exp(kappa_k) * dhh_k, all layers
-        # masked gradients w.r.t. the growth channels, 4 channels per layer (dd1_k, dd2_k, 0, 0): float4-addressable slices for
-        # the grouped weight-gradient launch below
-        # (written whole by the per-layer backward kernels, 16 bytes per pixel and layer: no zero fill)
-        DD = torch.empty((B, Hh, Ww, 4 * NL), device=dev, dtype=torch.float32)
+        # masked gradients w.r.t. the growth channels, COMPACT: channels 2k, 2k + 1 = (dd1_k, dd2_k), 2 NLp channels (round 4: the
+        # quad layout (dd1, dd2, 0, 0) per layer made the level-wide conditioning contractions below carry 2 NL zero channels - the
+        # weight gradient w.r.t. the conditioning columns 60 output channels for 30, the conditioning input gradient K = NL (C + 4)).
+        # Written whole by the per-layer backward kernels (8 bytes per pixel and layer; the LAST layer writes a (dd1, dd2, 0, 0) quad
+        # when there is ONE padding layer, which zeroes its two channels; more padding layers are filled): no zero fill at NL = 15
+        DD = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
+        quad_last = NLp - NL == 1        # (NL = 15 in the reference's models: one padding layer, zeroed by the last layer's quad store)
+        if NLp - NL > 1:
+            DD[..., 2 * NL:].zero_()
+        dd_of = lambda k: dict(dd1=DD[..., 2 * k:2 * k + 1], dd2=DD[..., 2 * k + 1:2 * k + 2], dd_quad=(quad_last and k == NL - 1))  # noqa: E731
         dcur = dy
         # The NL zero-conv weight gradients (x1 | D part) are independent of each other once DH holds every layer's
         # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
@@ -1103,8 +1109,7 @@ class LevelCouplingFn(torch.autograd.Function):
                                  ci_split=ch, ci_off0=0, ci_off1=Cc)
                     H.conv_wgrad(y, dcur if torch.is_tensor(dcur) else torch.cat(list(dcur), 3), dWm[k], dbm[k], 1, 1)
                 H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dt1], ch,
-                             add0=dt1, rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
-                             split2=ch, gap2=Cc, dd_quad=True)
+                             add0=dt1, rows1=ch, rows2=ch + 1, split2=ch, gap2=Cc, **dd_of(k))
                 dcur = dtin
                 del xin, tin, D, r, y
                 continue
@@ -1126,8 +1131,7 @@ class LevelCouplingFn(torch.autograd.Function):
                     H.conv_wgrad([x1, D], dhh, dWz[k], dBz[k], 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
                                  ci_split=ch, ci_off0=0, ci_off1=Cc)
                 H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
-                             add0=dtin[..., :ch], rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2],
-                             split2=ch, gap2=Cc, dd_quad=True)
+                             add0=dtin[..., :ch], rows1=ch, rows2=ch + 1, split2=ch, gap2=Cc, **dd_of(k))
                 dcur = _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k], mdef)
                 if grouped:
                     mix_wg[k] = mdef[0]
@@ -1163,8 +1167,7 @@ class LevelCouplingFn(torch.autograd.Function):
             H.conv_fwd([dhh], wt, ch + 4, 3, 1, [G0, GD])
             H.conv_rep_border_fix(dhh, wt, [G0, GD])
             H.dense2_bwd([x1, D], w1s[k], w2s[k], None if grouped else dW1[k], None if grouped else dW2[k], GD, D, [G0], [dtin[..., :ch]], ch,
-                         add0=add0, rows1=ch, rows2=ch + 1, dd1=DD[..., 4 * k:4 * k + 1], dd2=DD[..., 4 * k + 1:4 * k + 2], split2=ch,
-                         gap2=Cc, dd_quad=True)
+                         add0=add0, rows1=ch, rows2=ch + 1, split2=ch, gap2=Cc, **dd_of(k))
             dcur = dtin if reverse else _mix_bwd(xin, dtin, Wm[k], dWm[k], dbm[k], PMt[k], mdef)
             if grouped:
                 mix_wg[k] = mdef[0]
@@ -1179,9 +1182,9 @@ class LevelCouplingFn(torch.autograd.Function):
             # x1 | d1 rows of the growth-layer weight gradients: same inputs, dy = this layer's (dd1, dd2, 0, 0) quad; row 0 of the
             # result belongs to w1, row 1 to w2 (its column ch is the d1 input)
             tmpX = zeros((NL, 4, ch + 4, 3, 3), dev)
-            if not H.conv_wgrad_grouped(wg_in, DD, 4, tmpX, None, 3, 1, relu_in=True):
+            if not H.conv_wgrad_grouped(wg_in, DD, 2, tmpX, None, 3, 1, relu_in=True):
                 for k in range(NL):
-                    H.conv_wgrad(wg_in[k], DD[..., 4 * k:4 * k + 4], tmpX[k], None, 3, 1, relu_in=True)
+                    H.conv_wgrad(wg_in[k], DD[..., 2 * k:2 * k + 2], tmpX[k][:2], None, 3, 1, relu_in=True)
             wg_in = None
             # the 1x1 mix weight gradients of all layers: same trick, every group with its own upstream gradient tensor
             gdy = [g_ for _, g_ in mix_wg]
@@ -1197,15 +1200,13 @@ class LevelCouplingFn(torch.autograd.Function):
         # zero-conv part (dy = DH) and growth-layer part (dy = DD) of d(cond) as ONE contraction over [DH | DD] (K = NL (C + 4)): the
         # padding mode of the forward convs does not enter the interior of an input gradient, the replicate fold below adds the ring
         # terms of the zero convs alone (operand of Wzc by itself)
-        Wcat = zeros((NL * C + 4 * NL, Cc, 3, 3), dev)   # rows NL C + 4k / + 4k+1: cond columns of w1_k / w2_k
-        Wcat[:NL * C] = Wzc
-        Wcat[NL * C:].view(NL, 4, Cc, 3, 3)[:, :2] = Wdc.view(NLp, 2, Cc, 3, 3)[:NL]
+        Wcat = torch.cat([Wzc, Wdc], 0)                  # rows NL C + 2k / + 2k+1: cond columns of w1_k / w2_k (Wdc's own layout)
         H.conv3x3_auto([DH, DD], Wcat, Cc, [Gc], dgrad=True)
         H.conv_rep_border_fix(DH, H.conv_pack(Wzc, 1), [Gc])
         H.masked_add(Gc, src=Gc, ref=cond)
         H.conv_wgrad([cond], DH, dWz, None, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=Cc, ci_off0=ch)
-        tmpC = zeros((NL, 4, Cc, 3, 3), dev)   # one launch for both growth layers of all layers
-        H.conv_wgrad([cond], DD, tmpC.view(4 * NL, Cc, 3, 3), None, 3, 1, relu_in=True)
+        tmpC = zeros((NLp, 2, Cc, 3, 3), dev)  # one launch for both growth layers of all layers
+        H.conv_wgrad([cond], DD, tmpC.view(2 * NLp, Cc, 3, 3), None, 3, 1, relu_in=True)
         # one launch: rows of tmpX / tmpC -> dW1 / dW2, and d(kappa_k) = <wz_k, dwz_k> + <bz_k, dbz_k> inside the clamp range
         # (homogeneity of the zero conv in (W, b); the two inner products nearly cancel for small kappa gradients: fp64 sums)
         Kp = torch.stack([kp.reshape(()) for kp in kps])

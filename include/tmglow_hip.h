@@ -338,9 +338,10 @@ int tmg_lu_fold_bwd_split(const void* tab, const void* sign_s, const void* perm,
 /* Grouped 3x3 weight gradient with FOUR output channels per group (the growth-1 convs of the coupling networks, denseBlock.py:18-36, all
  * layers of a level in one launch) on v_mfma_f32_4x4x1 blocks - a (tap, input-channel quad) pair per block, one pixel per instruction -
  * instead of 16x16 tiles that would be 2/16 used.  gtab: device int64 [G][16] as for tmg_conv_wgrad_grouped; seg_channels[nseg]: channels of
- * the input segments; dy: shared upstream gradient, group g at channels [4g, 4g+4), pixel stride dy_stride; dW [G][4][Cin][3][3] is
- * accumulated into (atomics).  dims = {B, H, W, Cin, relu_in}; zero padding, stride 1.  -100: shape outside the envelope (Cin not in
- * {12, 20, 36, 68} or unaligned segments), nothing launched. */
+ * the input segments; dy: shared upstream gradient, group g at channels [c g, c g + c), c = dims[5] = 4 or 2 (2: the compact stash of
+ * (dd1, dd2) per layer - rows 2, 3 of a group's dW stay untouched), pixel stride dy_stride; dW [G][4][Cin][3][3] is accumulated into
+ * (atomics).  dims = {B, H, W, Cin, relu_in, dy channels per group}; zero padding, stride 1.  -100: shape outside the envelope (Cin not
+ * in {12, 20, 36, 68} or unaligned segments), nothing launched. */
 int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const int64_t* seg_channels, int64_t nseg, const void* dy, int64_t dy_stride,
                                 void* dW, const int64_t* dims, tmg_stream_t st);
 
@@ -360,7 +361,8 @@ int tmg_layer_planes(const void* src, void* dst, int64_t npix, int64_t CP, tmg_s
  * clamp range of the zero conv's log-scale (flowUtils.py:104-106; fp64 accumulation), and the scatter-add of the grouped 4-row
  * weight-gradient results tmpX [NL,4,ch+4,3,3] (x1 | d1 columns) and tmpC [NL,4,Cc,3,3] (conditioning columns) into the native
  * dW1 [NL,1,ch+Cc,3,3] / dW2 [NL,1,ch+Cc+1,3,3] of the two growth-1 convs (denseBlock.py:18-36).  Wz, dWz [NL,C,ch+Cc+2,3,3]; Bz, dBz [NL,C];
- * Kp, dK [NL]; tmpX / tmpC may be null; ws: 4*NL zero-initialised floats (8-byte aligned).  dims = {NL, C, ch, Cc}. */
+ * Kp, dK [NL]; tmpX / tmpC may be null; ws: 4*NL zero-initialised floats (8-byte aligned).  dims = {NL, C, ch, Cc, rows per layer in
+ * tmpC: 4, or 2 for a compact tmpC [NL,2,Cc,3,3]}. */
 int tmg_level_finish(const void* Wz, const void* dWz, const void* Bz, const void* dBz, const void* Kp, const void* tmpX, const void* tmpC,
                      void* dW1, void* dW2, void* dK, void* ws, const int64_t* dims, tmg_stream_t st);
 
