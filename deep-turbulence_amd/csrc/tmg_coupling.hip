@@ -408,8 +408,14 @@ struct CplBP {
 };
 
 // CT = 16-channel tiles of C; MT = 16-channel tiles of the dgrad output (ch + 2 channels); KS = C / 4 channel quads of dhh
-template <int CT, int MT, int KS>
+// PERM (C <= 16, generative direction): the rows of the transposed mix are dealt so that EVERY lane's accumulator quad holds two
+// pass-through channels (2 q, 2 q + 1 of dto1) and two coupling channels (ch + 2 q, ch + 2 q + 1).  In channel order the lanes q < 2
+// hold only pass-through channels and the lanes q >= 2 only coupling channels, so the wave executed BOTH epilogues under masks - the
+// coupling arithmetic of four elements per lane for half of the lanes; dealt out, every lane does two elements and the wave issues half
+// of those instructions (the kernel is bound by vector-instruction issue: ablation table in DESIGN.md).
+template <int CT, int MT, int KS, bool PERM = false>
 __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) {
+    static_assert(!PERM || CT == 1, "the dealt row order is built for one 16-row tile");
     constexpr int PW = 18, PP = PW * PW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int C = p.C, ch = C >> 1;
@@ -424,7 +430,12 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
     for (int mo = 0; mo < CT; ++mo)
 #pragma unroll
         for (int t = 0; t < 4 * CT; ++t) {
-            const int c = 16 * (t >> 2) + 4 * q + (t & 3), i = 16 * mo + li;
+            const int c = 16 * (t >> 2) + 4 * q + (t & 3);
+            int i = 16 * mo + li;
+            if (PERM) {      // accumulator row li = 4 q' + e of lane group q': e < 2 pass-through channel 2 q' + e, else coupling channel ch + 2 q' + e - 2
+                const int qp = li >> 2, e = li & 3, j = 2 * qp + (e & 1);
+                i = j < ch ? (e < 2 ? j : ch + j) : C;
+            }
             wmT[mo][t] = *((c < C && i < C) ? p.Wm + (size_t)c * C + i : tmg_zero_page);
         }
     // dgrad A fragments: A[i = li][k = q] of (tap u, quad s) = Wz[co = 4 s + q][col(i)][8 - u], rows i = (x1 | d1, d2)
@@ -461,10 +472,17 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
             _Pragma("unroll") for (int h = 0; h < CT; ++h) {                                                           \
                 const int c_ = 16 * h + 4 * q;                                                                         \
                 DV[h] = *reinterpret_cast<const float4*>((in_ && c_ < C) ? (c_ < ch ? p.dout + TMG_PXO(gp_, p.dos) + c_ : p.dout2 + TMG_PXO(gp_, p.do2s) + (c_ - ch)) : tmg_zero_page);  \
+                if (PERM) {   /* every lane: r / tin2 of its two coupling channels j0 = 2 q, 2 q + 1 */                \
+                    const bool two_ = in_ && 2 * q < ch;                                                               \
+                    const float2 r2_ = *reinterpret_cast<const float2*>(two_ ? p.r + TMG_PXO(gp_, ch) + 2 * q : tmg_zero_page);    \
+                    const float2 t2_ = *reinterpret_cast<const float2*>(two_ ? p.x + TMG_PXO(gp_, p.xs) + 2 * q : tmg_zero_page);  \
+                    RV[h] = make_float4(r2_.x, r2_.y, 0.f, 0.f); TV[h] = make_float4(t2_.x, t2_.y, 0.f, 0.f);         \
+                } else {                                                                                               \
                 /* the lanes whose accumulator quad of m-tile h is a dto2 quad (channel c_ >= ch) need r / tin2 of j0 = c_ - ch */ \
                 const bool two_ = in_ && c_ >= ch && c_ < C;                                                           \
                 RV[h] = *reinterpret_cast<const float4*>(two_ ? p.r + TMG_PXO(gp_, ch) + (c_ - ch) : tmg_zero_page);           \
                 TV[h] = *reinterpret_cast<const float4*>(two_ ? p.x + TMG_PXO(gp_, p.xs) + (c_ - ch) : tmg_zero_page);         \
+                }                                                                                                      \
             }                                                                                                          \
         }
         constexpr int NTA = (PP + 15) / 16;   // 21
@@ -498,6 +516,32 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
                             acc[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(wmT[mo][4 * h + e], dv[e], acc[mo], 0, 0, 0);
                 }
             }
+            if constexpr (PERM) {
+                // this lane: acc[0][0..1] = dto1 channels 2 q, 2 q + 1; acc[0][2..3] = dto2 of the coupling channels j0 = 2 q, 2 q + 1
+                const int j0 = 2 * q;
+                if (j0 < ch) {
+                    if (center) *reinterpret_cast<float2*>(p.dtin + TMG_PXO(gp, p.dts) + j0) = make_float2(acc[0][0], acc[0][1]);
+                    const float rr[2] = {rcu[0].x, rcu[0].y}, tt[2] = {tcu[0].x, tcu[0].y};
+                    float di[2], da[2], dr[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float den = 1.f + fabsf(rr[e]), rden = cpl_rcp(den);
+                        const float go = acc[0][2 + e];
+                        const float inv = cpl_exp(-2.f * rr[e] * rden);
+                        di[e] = go * inv;
+                        da[e] = inimg ? -go * osc : 0.f;
+                        dr[e] = inimg ? osc * (-2.f * go * (tt[e] * inv) + 2.f * gb) * (rden * rden) : 0.f;
+                    }
+                    if (rp < PP) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) *reinterpret_cast<float2*>(DHL + ((j0 + e) * PP + rp) * 2) = make_float2(da[e], dr[e]);
+                    }
+                    if (center) {
+                        *reinterpret_cast<float2*>(p.dtin2 + TMG_PXO(gp, p.dt2s) + j0) = make_float2(di[0], di[1]);
+                        *reinterpret_cast<float4*>(p.DH + TMG_PXO(gp, p.dhs) + 2 * j0) = make_float4(da[0], dr[0], da[1], dr[1]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int mo = 0; mo < CT; ++mo) {
                 const int c = 16 * mo + 4 * q;
@@ -611,6 +655,14 @@ static int launch_cpl_bwd(const CplBP& p, hipStream_t st) {
     const int grid = (p.ntiles + per_blk - 1) / per_blk;
     // algorithmic HBM bytes: dout (C), r (C/2), tin2 (C/2) read; DH (C), dtin (C), G0 (C/2), GD (4) written
     TmgProf prof(TMG_PROF_CPLB, 4.0 * p.B * (double)p.H * p.W * (4.5 * p.C + 4), st);
+    static const int noperm = getenv("TMG_CPLB_NOPERM") ? 1 : 0;       // A / B switch
+    if constexpr (CT == 1) {
+        if (!p.fwd && !noperm) {
+            hipLaunchKernelGGL((cpl_bwd_kernel<CT, MT, KS, true>), dim3(grid), dim3(256), lds, st, p);
+            TMG_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((cpl_bwd_kernel<CT, MT, KS>), dim3(grid), dim3(256), lds, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
