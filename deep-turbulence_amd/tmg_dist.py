@@ -349,11 +349,16 @@ class CapturedWindow:
         for p, g in zip(self.params, saved):
             p.grad = g
         self.replays = 0
+        # the graph reads the parameters in place: their storage must still be where it was recorded
+        self._param_ptrs = [p.data_ptr() for p in self.params]
 
     def __call__(self, *args):
         new = _flat_tensors(tuple(args))
         if len(new) != len(self._in_flat) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(new, self._in_flat)):
             raise ValueError("CapturedWindow: arguments differ in structure / shape from the ones the window was recorded with")
+        if [p.data_ptr() for p in self.params] != self._param_ptrs:
+            raise RuntimeError("CapturedWindow: a parameter's storage moved since the window was recorded (model.to(...), `p.data = ...`, "
+                               "a re-created parameter): the graph reads the old memory - record a new CapturedWindow")
         pairs = [(d, s) for d, s in zip(self._in_flat, new) if d is not s]
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])

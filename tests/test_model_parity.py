@@ -959,6 +959,14 @@ def test_captured_window_matches_eager_window(cfg_name):
     assert cw.replays == 3
     with pytest.raises(ValueError, match="structure / shape"):
         cw(inputs(0)[:2], h_in)
+    # the graph reads the parameters in place: a parameter whose storage moved makes the recorded window unusable, loudly
+    p0 = next(p_ for p_ in mc.parameters() if p_.requires_grad)
+    keep = p0.data
+    p0.data = keep.clone()
+    with pytest.raises(RuntimeError, match="storage moved"):
+        cw(inputs(0), h_in)
+    p0.data = keep
+    cw(inputs(0), h_in)
     # fresh latents inside a replayed graph (model.sample draws them with torch's graph-safe Philox offsets): two replays on the
     # same inputs give different fields
     def sample_body(xs, states):
