@@ -302,3 +302,18 @@ def test_fused_grad_accumulation_sums_like_autograd_on_cpu():
     del dead
     assert not ops._GradSink.is_proxy(live)
     del ops._GradSink.proxy_ids[live._cdata]
+
+
+def test_captured_window_argument_structures():
+    """tmg_dist.CapturedWindow copies nested list / tuple structures of tensors into the graph's own inputs: the flattening order and the
+    structure-preserving map it relies on (CPU: no graph is recorded here)."""
+    import tmg_dist
+    a, b, c = torch.zeros(2), torch.ones(3), torch.full((1,), 2.0)
+    args = ([a, (b, None)], [(c, a)])
+    flat = tmg_dist._flat_tensors(args)
+    assert [t.data_ptr() for t in flat] == [a.data_ptr(), b.data_ptr(), c.data_ptr(), a.data_ptr()]
+    m = tmg_dist._map_tensors(args, lambda t: t + 1)
+    assert isinstance(m, tuple) and isinstance(m[0], list) and isinstance(m[0][1], tuple) and m[0][1][1] is None
+    assert torch.equal(m[0][0], a + 1) and torch.equal(m[1][0][0], c + 1)
+    with pytest.raises(TypeError, match="tensors or nested lists"):
+        tmg_dist._flat_tensors([a, 3.0])

@@ -990,3 +990,33 @@ def test_lstm_pointwise_backward_without_cell_state_gradient():
     H.lstm_pointwise_bwd(a1, c_prev, c_next, dh, dc, dcp)
     H.lstm_pointwise_bwd(a2, c_prev, c_next, dh, dc, None)
     assert torch.equal(a1, a2) and bool(torch.isfinite(dcp).all())
+
+
+def test_fill_i64_writes_host_values_through_kernel_arguments():
+    """tmg_fill_i64 (the grouped launches' pointer tables while a hipGraph is being recorded: values travel as kernel arguments, 256 per
+    launch): 0, 1, 256, 257 and 700 values incl. negative and > 2^53 ones arrive bit-exactly; a captured fill replays its values."""
+    import tmg_hip as H
+    for n in (0, 1, 256, 257, 700):
+        vals = [(-1) ** i * (i * 0x1234567 + (1 << 60) * (i % 3)) for i in range(n)]
+        dst = torch.full((max(n, 1),), -7, dtype=torch.int64, device=DEV)
+        rc = H.lib().tmg_fill_i64(H._ptr(dst), H._i64(*vals) if n else None, H.c_i64(n), H._stream())
+        assert rc == 0
+        if n:
+            assert dst.cpu().tolist() == vals
+        else:
+            assert dst.cpu().tolist() == [-7]
+    # inside a capture: the table of a grouped launch is built this way (tmg_hip._segment_table)
+    rows = [[3 * i + j for j in range(16)] for i in range(5)]
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        H._segment_table(rows, torch.device(DEV, torch.cuda.current_device()))       # (warm-up: the eager, cached form)
+    torch.cuda.current_stream().wait_stream(st)
+    with torch.cuda.graph(g, stream=st):
+        tab = H._segment_table(rows, torch.device(DEV, torch.cuda.current_device()))
+        out = tab.clone()
+    tab.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert out.cpu().tolist() == rows
