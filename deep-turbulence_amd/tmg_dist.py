@@ -57,23 +57,32 @@ class GradBucket:
 
     Layout (static, identical on every rank by construction): ALL parameters that require a gradient, in reverse registration
     order, cut into buckets of <= `bucket_mb`; a bucket owns ONE persistent flat buffer [gradients | one has-gradient flag per
-    parameter].  The collectives of a step are ALWAYS bucket 0, 1, .., n-1 in that order, whatever gradients a rank happens to
-    have: no rank-local decision changes the sequence or the sizes of the collectives, so ranks whose live sets differ cannot
-    dead-lock each other (round 3 rebuilt the buckets on a rank-local test).
+    parameter].  The collectives of a step are ALWAYS bucket 0, 1, .., n-1 in that order, then ONE small control vector, then -
+    only when the REDUCED control vector says so - a second pass of the buckets it names, in order.  No rank-local decision changes
+    the sequence or the sizes of the collectives, so ranks whose live sets differ (or change at different times) can neither
+    dead-lock each other nor bind different gradient sets.
 
     The first `allreduce_mean()` runs synchronously after backward and learns which parameters receive gradients (the reference's
     dead `norm2`, SURVEY fact 8, never does).  From then on every parameter carries a post-accumulate-grad hook and a bucket is
     handed to the collective (RCCL over xGMI with backend "nccl", async) the moment its expected gradients exist and every
-    earlier bucket has gone - while backward is still running on the earlier layers.  `allreduce_mean()` then only issues what is
-    left, waits for the handles, divides each flat bucket by the world size (one launch) and re-binds every `p.grad` to its slice
-    of the reduced bucket - no copy back, no allocation per step.  The reduced flags say which parameters had a gradient on ANY
-    rank: the others get `p.grad = None`, exactly as in a single-process run (the optimizer skips them: no moment decay, no weight
-    decay); the flags are read on the host (a device sync) only in the first step and when this rank's live set changed.  A
-    parameter that is live somewhere but has no gradient on this rank contributes zeros.  Works unchanged with gloo on CPU.
+    earlier bucket has gone - while backward is still running on the earlier layers.  `allreduce_mean()` then issues what is
+    left, all-reduces the control vector `[late[0..n-1] | changed | aliased]` and reads its n + 2 reduced values on the host (the one
+    host read of a steady step):
+      * late[b] > 0: on SOME rank a gradient arrived for bucket b after it had gone (a parameter's first-ever gradient: the live set
+        grew) - EVERY rank sends bucket b again with all its gradients (round 4 re-sent it on the rank that saw it only: one collective
+        more than its peers);
+      * changed > 0: SOME rank's live set differs from its previous step's - every rank re-reads the reduced has-gradient flags
+        (round 4 re-read them only on the rank whose own set changed: a peer whose set grew left this rank binding `grad = None` for a
+        parameter the peer stepped);
+      * aliased > 0 together with a late bucket: some rank's gradients live inside the flat buffers the first pass has overwritten
+        (zero_grad(set_to_none=False)) - every rank raises.
+    Then it divides each flat bucket by the world size (one launch) and re-binds every `p.grad` to its slice of the reduced bucket -
+    no copy back, no allocation per step.  The reduced flags say which parameters had a gradient on ANY rank: the others get
+    `p.grad = None`, exactly as in a single-process run (the optimizer skips them: no moment decay, no weight decay).  A parameter
+    that is live somewhere but has no gradient on this rank contributes zeros.  Works unchanged with gloo on CPU.
 
     Contract: ONE backward per `allreduce_mean()` (no gradient accumulation, no retain_graph second pass) - a second gradient for
-    the same parameter raises.  A parameter whose FIRST gradient arrives after its bucket has gone (the live set grew) makes
-    that bucket go a second time in `allreduce_mean()` - all ranks are expected to run the same graph, as in the reference.
+    the same parameter raises.
 
     `measure=True`: event pairs around the exchange (see `overlap_report`)."""
 
@@ -85,19 +94,22 @@ class GradBucket:
         self._views = []           # per bucket: views of the flat buffer, one per parameter
         self._flags = []           # per bucket: the flag tail of the flat buffer
         self._flag_src = {}        # (bucket, has-gradient pattern) -> device tensor of 0 / 1
+        self._ctrl = None          # control vector [late per bucket | changed | aliased], all-reduced once per step after the buckets
         self._where = {}           # id(p) -> (bucket index, position)
         self._expected = None      # per bucket: ids of the parameters that had a gradient in the previous step (None: not learned)
         self._arrived = set()      # ids of the parameters whose gradient arrived in this backward
         self._got = []             # per bucket: expected gradients that arrived so far
         self._work = []            # (bucket index, async handle)
         self._launched = set()
-        self._dirty = set()        # buckets that received a first-ever gradient after they had gone
+        self._sent_pat = {}        # bucket -> has-gradient pattern it was sent with in this step
+        self._late = set()         # buckets that received a first-ever gradient after they had gone (THIS rank's view: goes into the control vector)
         self._next = 0             # next bucket index in the fixed collective order
         self._hooks = []
         self._live_local = None    # ids with a gradient on this rank in the last step
         self._live_any = None      # ids with a gradient on ANY rank (from the reduced flags)
         self.launched_during_backward = 0   # diagnostics: buckets whose all-reduce was issued from a hook
         self.flag_reads = 0        # diagnostics: host reads of the reduced flags
+        self.second_passes = 0     # diagnostics: buckets sent a second time (the live set grew behind a bucket that had gone)
         self.paused = False        # True: the hooks launch nothing (CapturedWindow: a replayed backward runs no hooks, and the recording
                                    # one must not put collectives into the graph) - allreduce_mean() issues every bucket
         self.measure = bool(measure)
@@ -128,6 +140,7 @@ class GradBucket:
             self._flat.append(flat)
             self._views.append(views)
             self._flags.append(flat[ng:])
+        self._ctrl = torch.zeros(len(self.buckets) + 2, device=self.buckets[0][0].device, dtype=torch.float32)
         self._reset()
 
     def _reset(self):
@@ -135,7 +148,8 @@ class GradBucket:
         self._arrived = set()
         self._work = []
         self._launched = set()
-        self._dirty = set()
+        self._late = set()
+        self._sent_pat = {}
         self._next = 0
         self._ev_first = None
 
@@ -156,6 +170,7 @@ class GradBucket:
             self._ev_first = torch.cuda.Event(enable_timing=True)
             self._ev_first.record()
         self._launched.add(bi)
+        self._sent_pat[bi] = pat
         self._work.append((bi, dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)))
 
     def _ready(self, bi):
@@ -176,7 +191,8 @@ class GradBucket:
         if id(p) in self._expected[bi]:
             self._got[bi] += 1
         elif bi in self._launched:
-            self._dirty.add(bi)         # a first-ever gradient for a bucket that has gone: it goes again in allreduce_mean()
+            self._late.add(bi)          # a first-ever gradient for a bucket that has gone: reported in the control vector, every rank
+                                        # sends the bucket again in allreduce_mean()
         while self._next < len(self.buckets) and self._ready(self._next) and self._next not in self._launched:
             self._launch(self._next)
             self._next += 1
@@ -189,30 +205,48 @@ class GradBucket:
         world = dist.get_world_size()
         if self.buckets is None:
             self._build()
+        nbk = len(self.buckets)
         ev_done = None
         if self.measure and self.params and self.params[0].is_cuda:
             ev_done = torch.cuda.Event(enable_timing=True)
             ev_done.record()                       # backward has been issued up to here on the compute stream
-        for bi in range(len(self.buckets)):        # what the hooks did not hand over, in the fixed order
+        for bi in range(nbk):                      # what the hooks did not hand over, in the fixed order
             if bi not in self._launched:
                 self._launch(bi)
-        for bi in sorted(self._dirty):             # the live set grew after the bucket had gone: once more, with every gradient
-            for b2, work in self._work:
-                if b2 == bi:
-                    work.wait()
-            # p.grad still holds this rank's OWN gradient (re-binding happens below), so a second pass is exact - unless the
-            # gradients were accumulated in place into the bucket the first pass has just overwritten with the sum
-            if any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for v, p in zip(self._views[bi], self.buckets[bi])):
-                raise RuntimeError("GradBucket: the set of parameters with gradients grew while gradients alias the reduced "
-                                   "buckets (zero_grad(set_to_none=False)); use set_to_none=True")
-            self._launch(bi)
+        # gradients bound after backward (tmg_ops.fused_grad_accumulation) never pass a hook: a bucket that went from a hook without one
+        # of them is late too - compare every bucket's has-gradient pattern now with the one it was sent with
+        for bi in range(nbk):
+            if self._sent_pat.get(bi) != tuple(p.grad is not None for p in self.buckets[bi]):
+                self._late.add(bi)
         local = {id(p) for p in self.params if p.grad is not None}
-        read = self._live_any is None or local != self._live_local
+        aliased = any(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                      for views, bk in zip(self._views, self.buckets) for v, p in zip(views, bk))
+        ctrl = [1.0 if bi in self._late else 0.0 for bi in range(nbk)]
+        ctrl += [1.0 if (self._live_local is None or local != self._live_local) else 0.0, 1.0 if aliased else 0.0]
+        self._ctrl.copy_(torch.tensor(ctrl, dtype=torch.float32))
+        cwork = dist.all_reduce(self._ctrl, op=dist.ReduceOp.SUM, async_op=True)
         for bi, work in self._work:
             work.wait()
-        if read:
-            # which parameters have a gradient on ANY rank: a host read of the reduced flags (device sync), first step and whenever
-            # this rank's own live set changed
+        cwork.wait()
+        red = self._ctrl.tolist()                  # the one host read of a steady step (n + 2 floats; identical on every rank)
+        late_any = [bi for bi in range(nbk) if red[bi] > 0.0]
+        if late_any:
+            # the live set grew behind a bucket that had gone - on some rank.  p.grad still holds every rank's OWN gradient (re-binding
+            # happens below), so a second pass is exact - unless the gradients were accumulated in place into the buckets the first
+            # pass has just overwritten with the sum
+            if red[nbk + 1] > 0.0:
+                raise RuntimeError("GradBucket: the set of parameters with gradients grew while gradients alias the reduced "
+                                   "buckets (zero_grad(set_to_none=False)); use set_to_none=True")
+            self._work = [(bi, w) for bi, w in self._work if bi not in late_any]
+            for bi in late_any:
+                self._launch(bi)
+                self.second_passes += 1
+            for bi, work in self._work:
+                if bi in late_any:
+                    work.wait()
+        if self._live_any is None or red[nbk] > 0.0 or late_any:
+            # which parameters have a gradient on ANY rank: a host read of the reduced flags - first step and whenever ANY rank's live
+            # set changed (the reduced control vector says so on every rank alike)
             self.flag_reads += 1
             self._live_any = set()
             for bk, fl in zip(self.buckets, self._flags):

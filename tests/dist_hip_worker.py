@@ -60,6 +60,18 @@ def main(out_path, n_windows, captured=False):
         res["gn"].append(float(gn))
     res["log_s"] = dict(m.named_parameters())[str(d["log_s_key"])].detach().cpu()
     res["hooked"], res["nbuckets"] = bucket.launched_during_backward, len(bucket.buckets)
+    if not captured:
+        # the SINGLE-STEP path (bench.py's: plain loss.backward(), no fused accumulation): the gradients reach p.grad through autograd's
+        # AccumulateGrad, the hooks see them arrive and hand complete buckets to the collective while backward is still running
+        h0 = bucket.launched_during_backward
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            y, lp, _ = m.reconstruct(xs[0], states, eps[0])
+            C.loss_reverse(y, lp).backward()
+            bucket.allreduce_mean()
+            opt.step()
+        res["hooked_single_step"] = bucket.launched_during_backward - h0
+        res["log_s_single"] = dict(m.named_parameters())[str(d["log_s_key"])].detach().cpu()
     torch.save(res, "%s.rank%d" % (out_path, rank))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

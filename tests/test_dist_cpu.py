@@ -243,6 +243,80 @@ def test_ranks_with_different_live_sets_do_not_deadlock():
             assert torch.allclose(s0["mean"][i], want, rtol=1e-6, atol=1e-6) and torch.equal(s0["mean"][i], s1["mean"][i])
 
 
+def _run_one_sided_growth(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, C.PKG)
+    import tmg_dist
+    import tmg_ops
+    torch.set_num_threads(1)
+    tmg_dist.init_from_env("gloo")
+
+    class Lin(torch.autograd.Function):      # routes its parameter gradient through the gradient sink (bound AFTER backward)
+        @staticmethod
+        def forward(ctx, p, x):
+            ctx.save_for_backward(p, x)
+            return p @ x.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            p, x = ctx.saved_tensors
+            return tmg_ops._defer((p,), (g @ x,)) + (None,)
+
+    torch.manual_seed(5)
+    prm = [torch.nn.Parameter(torch.randn(7, 3)) for _ in range(4)]      # a, b, c, d -> buckets [d, c], [b, a]
+    x = torch.randn(4, 3) + rank
+    bucket = tmg_dist.GradBucket(prm, bucket_mb=2.1 * 21 * 4 / 2 ** 20)
+    opt = torch.optim.Adam(prm, lr=1e-2, weight_decay=1e-3, amsgrad=True)
+    out = []
+    # both ranks: b and d live.  From step 2 on rank 1 ALONE also uses c - its gradient is bound after backward (deferred node), i.e.
+    # after bucket [d, c] has gone from d's hook; from step 4 on rank 1 alone uses a through plain autograd.  Rank 0's own live set
+    # never changes: it must still send the late bucket a second time, re-read the flags and step c / a like rank 1 does.
+    for step in range(6):
+        use = {1, 3} | ({2} if rank == 1 and step >= 2 else set()) | ({0} if rank == 1 and step >= 4 else set())
+        opt.zero_grad(set_to_none=True)
+        loss = 0.0
+        for i in sorted(use, reverse=True):
+            y = Lin.apply(prm[i], x) if i == 2 else prm[i] @ x.t()
+            loss = loss + (y ** 2).sum() * (i + 1)
+        with tmg_ops.fused_grad_accumulation():
+            loss.backward()
+        own = {i: p.grad.clone() for i, p in enumerate(prm) if p.grad is not None}
+        bucket.allreduce_mean()
+        out.append({"own": own, "mean": {i: p.grad.clone() for i, p in enumerate(prm) if p.grad is not None}})
+        opt.step()
+    ret[rank] = {"steps": out, "params": [p.detach().clone() for p in prm], "second": bucket.second_passes,
+                 "reads": bucket.flag_reads, "nbuckets": len(bucket.buckets), "hooked": bucket.launched_during_backward}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_live_set_grows_on_one_rank_only():
+    """Round-4 advisor finding: the re-read of the reduced has-gradient flags and the second pass of a bucket whose live set grew
+    behind it were decided from RANK-LOCAL state.  Here only rank 1's live set grows (once behind a bucket that has already gone
+    from a hook, once not); rank 0 - whose own set never changes - must issue the same collectives, bind the same gradient set and
+    keep its replica identical."""
+    world = 2
+    port = 34500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_one_sided_growth, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["nbuckets"] == 2 and r0["hooked"] > 0 and r1["hooked"] > 0
+    for k, (s0, s1) in enumerate(zip(r0["steps"], r1["steps"])):
+        keys = set(s0["own"]) | set(s1["own"])
+        assert set(s0["mean"]) == keys and set(s1["mean"]) == keys, (k, keys, set(s0["mean"]), set(s1["mean"]))
+        for i in sorted(keys):
+            want = 0.5 * (s0["own"].get(i, 0.0) + s1["own"].get(i, 0.0))
+            assert torch.allclose(s0["mean"][i], want, rtol=1e-6, atol=1e-6), (k, i)
+            assert torch.equal(s0["mean"][i], s1["mean"][i]), (k, i)
+    assert set(r0["steps"][1]["mean"]) == {1, 3} and set(r0["steps"][2]["mean"]) == {1, 2, 3} and set(r0["steps"][5]["mean"]) == {0, 1, 2, 3}
+    for p0, p1 in zip(r0["params"], r1["params"]):
+        assert torch.equal(p0, p1)                       # replicas stay identical through the optimizer steps
+    # the deferred gradient of c is late in EVERY step from 2 on (it never passes a hook): the bucket goes twice on BOTH ranks
+    assert r0["second"] == r1["second"] and r0["second"] >= 1
+    assert r0["reads"] == r1["reads"]
+
+
 def _run_flat_broadcast(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     sys.path.insert(0, C.PKG)
