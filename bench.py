@@ -48,10 +48,45 @@ def build_model(cfg, device):
     return model.to(device).train()
 
 
-def _cpu_baseline_worker(name, threads, B, max_steps, budget_s):
-    """Runs in a child process: the oracle on `threads` host threads."""
+def host_cores():
+    """Host cores THIS process may use: the scheduler affinity mask, cut by the cgroup CPU quota (a container that sees 128 CPUs in
+    os.cpu_count() may own 8 of them - 32 OpenMP threads on 8 cores spin against each other), capped at 32 (more threads are slower
+    on these small convolutions)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(32, n))
+
+
+def _cpu_baseline_worker(name, threads, B, max_steps, budget_s, t_spawn):
+    """Runs in a child process: the oracle on `threads` host threads.  Every phase of the child is stamped (the driver's box spent
+    185 s in the cfg1 child of round 4 for 4.9 s of timed steps and nothing said where)."""
+    ph, last = {}, [time.time()]
+
+    def stamp(k):
+        now = time.time()
+        ph[k] = round(now - last[0], 2)
+        last[0] = now
+    ph["spawn_to_worker_entry (interpreter start, import torch, import bench)"] = round(time.time() - t_spawn, 2)
     from oracle import tmglow_oracle as O
     from nn.tmGlow import TMGlow
+    stamp("import oracle + package")
     cfg = CONFIGS[name]
     torch.set_num_threads(threads)
     C.seed_all(12345)
@@ -61,11 +96,13 @@ def _cpu_baseline_worker(name, threads, B, max_steps, budget_s):
     del m
     params = list(O.trainable(P).values())
     opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    stamp("model construction (QR / LU initialisation on the host)")
     Hin, Win = cfg["_in_hw"]
     up = cfg["_up"]
     g = torch.Generator().manual_seed(12345)
     x = torch.randn(B, cfg["in_features"], Hin, Win, generator=g)
     st = O.init_lstm_states(cfg, torch.arange(B), [Hin * up, Win * up])
+    stamp("inputs + seed states")
 
     def step():
         opt.zero_grad()
@@ -76,31 +113,39 @@ def _cpu_baseline_worker(name, threads, B, max_steps, budget_s):
     tw = time.time()
     step()  # warm-up (allocator, thread pool)
     tw = time.time() - tw
+    stamp("warm-up step")
     n, t0 = 0, time.time()
     while n < max_steps and (n == 0 or time.time() - t0 < budget_s):
         step()
         n += 1
     dt = time.time() - t0
-    print(json.dumps({"value": B * n / dt, "steps": n, "batch": B, "threads": threads, "warmup_step_s": round(tw, 2), "timed_s": round(dt, 2)}))
+    stamp("timed steps")
+    print(json.dumps({"value": B * n / dt, "steps": n, "batch": B, "threads": threads, "torch_threads": torch.get_num_threads(),
+                      "os_cpu_count": os.cpu_count(), "warmup_step_s": round(tw, 2), "timed_s": round(dt, 2), "phases_s": ph}))
 
 
 def cpu_baseline(name, hard_timeout_s=300, max_steps=12, budget_s=25.0):
     """The CPU oracle (a port of the reference's torch-CPU path) on this box's host cores, on a bounded
     sample of the same workload: sample() + backward + Adam.  Runs in a child process under a hard timeout;
-    thread count capped at 32 (more threads are slower on these small convolutions)."""
+    thread count = the cores this process may use (host_cores(): affinity mask and cgroup quota), capped at 32."""
     import subprocess
-    threads = max(1, min(32, os.cpu_count() or 1))
+    threads = host_cores()
     B = {"M": 8, "cfg4": 8, "cfg3": 8, "cfg5": 2}.get(name, DEFAULT_BATCH[name])     # BASELINE.md section 4: the metric shape at batch 8
-    code = "import bench; bench._cpu_baseline_worker(%r, %d, %d, %d, %f)" % (name, threads, B, max_steps, budget_s)
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    code = "import time; t=%r; import bench; bench._cpu_baseline_worker(%r, %d, %d, %d, %f, t)" % (time.time(), name, threads, B, max_steps, budget_s)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    t0 = time.time()
     try:
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=hard_timeout_s)
         res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         return {"value": round(res["value"], 4), "unit": "samples/s", "cores": threads, "kind": "port",
                 "sample": "config %s at batch %d, %d timed step(s) after 1 warm-up, torch CPU fp32 oracle, sample()+backward+Adam"
-                          % (name, res["batch"], res["steps"]), "warmup_step_s": res.get("warmup_step_s"), "timed_s": res.get("timed_s")}
+                          % (name, res["batch"], res["steps"]), "warmup_step_s": res.get("warmup_step_s"), "timed_s": res.get("timed_s"),
+                "os_cpu_count": res.get("os_cpu_count"), "child_wall_s": round(time.time() - t0, 2), "child_phases_s": res.get("phases_s")}
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "failed: %s" % type(e).__name__}
+        return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port", "sample": "failed: %s" % type(e).__name__,
+                "child_wall_s": round(time.time() - t0, 2)}
 
 
 def pmc_traffic(kernel):
@@ -187,11 +232,11 @@ def main():
     cfg = CONFIGS[args.config]
     B = args.batch or DEFAULT_BATCH[args.config]
     import tmg_ops
-    # default f32 for every configuration.  BASELINE configs[4] names fp16-operand 1x1 mixes; that variant is built, tested
-    # (tests/test_model_parity.py::test_cfg5_stated_batch_with_fp16_mixes) and selectable with --mix f16, but it is NOT faster here: the
-    # stand-alone mixes are bandwidth kernels on fp32 activations (measured round 3: 0.94x).  cfg5 therefore runs the faster fp32
-    # mixes by default and reports the fp16 variant beside it (`mix_f16_variant`).
-    mix = args.mix or "f32"
+    # fp32 mixes everywhere except cfg5: BASELINE configs[4] NAMES fp16-operand 1x1 mixes, so that is what its line measures (tested:
+    # tests/test_model_parity.py::test_cfg5_stated_batch_with_fp16_mixes).  The variant is not faster here - the stand-alone mixes are
+    # bandwidth kernels on fp32 activations (0.94x, round 3) - and the line says so: `mix_f16_speedup` is the fp32-mix step time over
+    # the fp16-mix one on the same workload; `--mix f32` measures the fp32 mixes with the fp16 variant beside it (`mix_f16_variant`).
+    mix = args.mix or ("f16" if args.config == "cfg5" else "f32")
     tmg_ops.set_mix_precision(mix)
     _phase("process group, library load")
     model = build_model(cfg, dev)
@@ -369,6 +414,13 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    allreduce_report = bucket.overlap_report() if bucket is not None else None     # (event pairs: no collective inside)
+    backend = torch.distributed.get_backend() if world > 1 else None
+    if world > 1:
+        # every rank leaves the process group HERE, together: nothing below communicates (round 4: ranks != 0 returned while rank 0
+        # went on for minutes with the group alive)
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     value = B * world * args.steps / dt
@@ -398,6 +450,18 @@ def main():
                                                 "executed_tflops": round(v[2] / max(v[1], 1e-9) / 1e9 * (16.0 / 36.0 if k.startswith("wino") else 1.0), 2)}
                                             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1] / prof_steps[kv[0]])}}
         roof["traffic"] = pmc_traffic(name) if args.config == "M" and B == 64 else None
+        # the second matrix-core class of the step beside the dominant one: the Winograd weight gradients (F(3x3, 2x2)) - or the Winograd
+        # forward / input-gradient class when the weight gradients dominate - with its own executed fraction of the fp32 matrix peak
+        other = [k for k in prof if k.startswith("wino") and k != name]
+        if other:
+            k2 = max(other, key=lambda k: prof[k][1] / prof_steps[k])
+            c2, ms2, fl2 = prof[k2]
+            alg2 = fl2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0
+            roof["second_class"] = {"kernel": k2, "launches_per_step": round(c2 / prof_steps[k2], 1), "ms_per_step": round(ms2 / prof_steps[k2], 3),
+                                    "algorithmic_tflops": round(alg2, 3), "achieved": round(alg2 * 16.0 / 36.0, 3), "peak": PEAK_FP32_MFMA_TF,
+                                    "frac": round(alg2 * 16.0 / 36.0 / PEAK_FP32_MFMA_TF, 4), "traffic": pmc_traffic(k2) if args.config == "M" and B == 64 else None,
+                                    "measured": "HIP events on the launch stream, %d step(s) %s the timed region" % (
+                                        prof_steps[k2], "inside" if prof_steps[k2] == args.steps else "before")}
         if args.config in GFLOP_PER_SAMPLE:
             e2e = value / world * GFLOP_PER_SAMPLE[args.config] / 1e3
             roof["end_to_end_tflops_per_gpu"] = round(e2e, 2)
@@ -412,8 +476,8 @@ def main():
            "config": {"workload": "tmglow %s: %s+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
                args.config, "sample()" if args.direction == "sample" else "forward(x,y)", Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
                "global_batch": B * world, "parallelism": "dp%d" % world, "world_size_observed": world,
-               "backend": (torch.distributed.get_backend() if world > 1 else None), "rank0_device": torch.cuda.get_device_name(dev) + " cuda:%d" % local,
-               "mix_precision": mix, "optimizer": "Adam(amsgrad, wd 1e-8): %s" % opt_name, "allreduce": (bucket.overlap_report() if bucket is not None else None), "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
+               "backend": backend, "rank0_device": torch.cuda.get_device_name(dev) + " cuda:%d" % local,
+               "mix_precision": mix, "optimizer": "Adam(amsgrad, wd 1e-8): %s" % opt_name, "allreduce": allreduce_report, "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
            "peak_mem_gb": round(peak_gb, 2), "roofline": roof}
     if dens is not None:
         out["density_direction"] = dens
@@ -430,7 +494,7 @@ def main():
         tf = mix1[2] / mix1[1] / 1e9
         out["mix_1x1_mfma"] = {"launches_per_step": mix1[0] / 2, "ms_per_step": round(mix1[1] / 2, 3), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TF, 4),
                                "note": "stand-alone 1x1 mixes only (wide levels, LSTM blocks); on the narrow levels the mix runs inside cpl_fwd_kernel"}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args.config)
         _phase("cpu_baseline child (%s)" % args.config)
         if args.config != "cfg1":   # BASELINE configs[0], the reference's own CPU-runnable case, at its stated batch 8

@@ -131,8 +131,16 @@ class TrainFlow(object):
         core = getattr(model, "module", model)
         self.loss = TMGLowLoss(args, model).to(next(core.parameters()).device)
         self._bucket = None
-        self._capture = bool(getattr(args, "capture_window", False)) or os.environ.get("TMG_CAPTURE_WINDOW") == "1"
+        # hipGraph replay of the windows (tmg_dist.CapturedWindow): "on" / "off" when args.capture_window or TMG_CAPTURE_WINDOW (1 / 0)
+        # says so; otherwise "auto" - on HIP devices a window shape is recorded when it comes round the SECOND time (the replay is
+        # worth 5 % on every box measured, round 4) and the trainer falls back to eager windows for a shape whose recording fails
+        env = os.environ.get("TMG_CAPTURE_WINDOW")
+        flag = getattr(args, "capture_window", None)
+        self._capture = ("on" if flag else "off") if flag is not None else ({"1": "on", "0": "off"}.get(env, "auto"))
         self._captured = {}     # window shape -> tmg_dist.CapturedWindow
+        self._seen = {}         # window shape -> eager windows run so far
+        self._capture_failed = {}
+        self.use_hip_adam = not os.environ.get("TMG_NO_HIP_ADAM")
 
     def _window_body(self, core):
         """The forward passes and the loss of one BPTT window (reference trainFlowParallel.py:256-281)."""
@@ -168,6 +176,11 @@ class TrainFlow(object):
         rank, world = self._world()
         split_here = world > 1 and getattr(self.trainingLoader, "world", 1) == 1   # loader not sharded: shard each batch here
         total_loss = 0
+        if self.use_hip_adam and dev.type == "cuda":
+            # main.py:78 constructs torch.optim.Adam(lr, weight_decay=1e-8, amsgrad=True): the same update as ONE launch where its
+            # arguments allow (same object, same state, same state_dict: the scheduler and saveWorkspace keep their references)
+            import tmg_optim
+            tmg_optim.adopt(optimizer)
         optimizer.zero_grad()
         for mbIdx, (input0, target0, lstm_seeds) in enumerate(self.trainingLoader):
             if split_here:
@@ -183,14 +196,30 @@ class TrainFlow(object):
             for i in range(tmax // tback):
                 xin, ytarget = input0[:, i * tback:(i + 1) * tback], target0[:, i * tback:(i + 1) * tback]
                 bucket = self._grad_bucket(core)
-                if self._capture and dev.type == "cuda":
-                    # forward passes + loss + backward of the window as one hipGraph replay (tmg_dist.CapturedWindow; opt-in:
-                    # args.capture_window / TMG_CAPTURE_WINDOW=1); recorded once per window shape
+                cw = None
+                if self._capture != "off" and dev.type == "cuda":
+                    # forward passes + loss + backward of the window as one hipGraph replay (tmg_dist.CapturedWindow), recorded once
+                    # per window shape
                     key = (tuple(xin.shape), tuple(ytarget.shape))
                     cw = self._captured.get(key)
-                    if cw is None:
-                        cw = self._captured[key] = tmg_dist.CapturedWindow(core, self._window_body(core), (xin, ytarget, target0_mean, target0_rms, a0),
-                                                                           bucket=bucket)
+                    if cw is None and key not in self._capture_failed and (self._capture == "on" or (self._seen.get(key, 0) >= 1 and len(self._captured) < 2)):
+                        try:
+                            cw = self._captured[key] = tmg_dist.CapturedWindow(core, self._window_body(core), (xin, ytarget, target0_mean, target0_rms, a0),
+                                                                               bucket=bucket)
+                        except Exception as e:  # noqa: BLE001  (out of memory for the graph's pool, an op that cannot be captured)
+                            if self._capture == "on":
+                                raise
+                            self._capture_failed[key] = repr(e)
+                            for p_ in core.parameters():
+                                p_.grad = None
+                            torch.cuda.synchronize(dev)
+                            torch.cuda.empty_cache()
+                            if bucket is not None:
+                                bucket.paused = False
+                            if self.log is not None:
+                                self.log.warning("window %s stays eager, recording it as a hipGraph failed: %s" % (key, e))
+                    self._seen[key] = self._seen.get(key, 0) + 1
+                if cw is not None:
                     loss, a0 = cw(xin, ytarget, target0_mean, target0_rms, a0)
                 else:
                     # one window = `tback` forward passes on unchanged parameters + ONE backward: parameter-only tensors (folded mixes,

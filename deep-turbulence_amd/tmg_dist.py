@@ -339,8 +339,9 @@ class CapturedWindow:
     weight-gradient launches write their pointer tables with a kernel during capture (tmg_fill_i64), scratch comes from the
     graph's pool, latent draws use torch's graph-safe Philox offsets.  Parameters are read in place: an optimizer step between
     replays is seen by the next one.  The graph keeps the window's activations allocated (its private pool: ~70 GB at the metric
-    shape, batch 64, T = 10).  Construction runs the body twice on the example arguments (eager warm-up, then the recording): BatchNorm
-    running statistics and the random generator advance as for two windows, no gradient is left behind.  bucket: the GradBucket of a
+    shape, batch 64, T = 10).  Construction runs the body twice on the example arguments (eager warm-up, then the recording) and puts
+    the module buffers (BatchNorm running statistics / counters) and the device random generator back afterwards: no gradient, no
+    statistics update and no generator advance is left behind.  bucket: the GradBucket of a
     multi-GPU run - its hooks are switched off for good (the gradient
     exchange then runs after the replay instead of overlapping the backward pass)."""
 
@@ -364,6 +365,13 @@ class CapturedWindow:
             return loss, outs
         # warm-up (lazy initialisation, code objects, cached operand tables) on the stream the capture will use: autograd's
         # AccumulateGrad nodes remember the stream they were created on
+        # Construction must have NO observable side effect: the warm-up and the recording both run the body for real on the example
+        # arguments, and the caller then replays the same window.  Module buffers (BatchNorm running statistics and counters, the mix
+        # layers' `log_s_old`) and the device random generator are put back afterwards, so that the first replayed window starts from
+        # the state an eager first window starts from (round 4 left the statistics updated twice and the Philox offset advanced)
+        buffers = [b for b in model.buffers()]
+        buf_saved = [b.detach().clone() for b in buffers]
+        rng_saved = torch.cuda.get_rng_state(dev)
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):
@@ -377,6 +385,10 @@ class CapturedWindow:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream):
             loss, outs = run()
+        with torch.no_grad():
+            if buffers:
+                torch._foreach_copy_(buffers, buf_saved)
+        torch.cuda.set_rng_state(rng_saved, dev)
         self.loss = loss.detach()
         self.outs = _map_tensors(outs, lambda t: t.detach())
         self._grads = [(p, p.grad) for p in self.params if p.grad is not None]

@@ -168,3 +168,40 @@ class HipAdam(torch.optim.Adam):
         tmg_ops.PARAM_GENERATION[0] += 1
         del grads   # (kept alive until the launch is enqueued)
         return True
+
+
+def adopt(optimizer):
+    """Turns a plain `torch.optim.Adam` (what the reference's main.py:78 constructs) into a HipAdam IN PLACE when its arguments allow:
+    the object, its param_groups and its state stay the ones the caller, the LR scheduler and saveWorkspace hold - only `step()`
+    changes (one launch instead of ~100).  Returns True when the optimizer is (now) a HipAdam.  Not adopted: subclasses, fused /
+    capturable / differentiable / maximize / decoupled-weight-decay groups, parameters that are not fp32 on one HIP device."""
+    import functools
+    import weakref
+    if isinstance(optimizer, HipAdam):
+        return True
+    if type(optimizer) is not torch.optim.Adam:
+        return False
+    for g in optimizer.param_groups:
+        if g.get("fused") or g.get("capturable") or g.get("differentiable") or g.get("maximize") or g.get("decoupled_weight_decay"):
+            return False
+        if torch.is_tensor(g.get("lr")) or not all(p.is_cuda and p.dtype == torch.float32 for p in g["params"]):
+            return False
+    optimizer.__class__ = HipAdam
+    optimizer._chunks, optimizer._fast = {}, {}
+    optimizer._patch_step_function()        # profile / pre- / post-step hooks of torch.optim.Optimizer on the new class
+    w = optimizer.__dict__.get("step")
+    if w is not None and getattr(w, "_wrapped_by_lr_sched", False):
+        # an LR scheduler constructed earlier has wrapped the bound step() of the OLD class (torch/optim/lr_scheduler.py,
+        # patch_track_step_called): the same wrapper around the new one
+        ref = weakref.ref(optimizer)
+        func = HipAdam.step
+
+        @functools.wraps(func)
+        def wrapper(*args, **kwargs):
+            opt = ref()
+            opt._opt_called = True
+            return func.__get__(opt, opt.__class__)(*args, **kwargs)
+
+        wrapper._wrapped_by_lr_sched = True
+        optimizer.step = wrapper
+    return True

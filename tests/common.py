@@ -119,6 +119,7 @@ LOGDET_RTOL = 1e-5
 STATE_ATOL = 1e-5
 GRAD_GLOBAL_REL_L2 = 5e-4
 GRAD_TENSOR_REL_MAX = 1e-2
+KINK_CAP = 3.0      # a tensor's ReLU-kink allowance (KinkProbe) never exceeds this multiple of its base bound
 
 
 def assert_field(a, b, what="field", atol=FIELD_ATOL, rtol=FIELD_RTOL):
@@ -163,11 +164,20 @@ def assert_grads(got, ref, what="grads", global_tol=GRAD_GLOBAL_REL_L2, tensor_t
     worst, worst_k = rels[0] if rels else (0.0, None)
     glob = (num / max(den, 1e-300)) ** 0.5
     assert glob <= global_tol, "%s: global rel-L2 %.3e > %.1e (worst tensor %s %.3e)" % (what, glob, global_tol, worst_k, worst)
-    over = [(v, k, (kink or {}).get(k, 0.0)) for v, k in rels if v > tensor_tol]
+    # a tensor's allowance is capped at KINK_CAP x the base bound: the probe sums what ALL its near-kink ReLUs could move, an fp32
+    # evaluation flips a few of them - a tensor that needs more than the cap fails by name whatever the probe measured for it
+    cap = KINK_CAP * tensor_tol
+    over = [(v, k, min((kink or {}).get(k, 0.0), cap), (kink or {}).get(k, 0.0)) for v, k in rels if v > tensor_tol]
     if report is not None:
-        report["beyond_base_bound"] = [{"tensor": k, "rel_max": v, "base_bound": tensor_tol, "kink_allowance": a} for v, k, a in over]
-    bad = [(v, k, a) for v, k, a in over if v > tensor_tol + a]
-    assert not bad, "%s: %d tensors beyond rel-max %.1e + their own ReLU-kink allowance: %s" % (
+        report["beyond_base_bound"] = [{"tensor": k, "rel_max": v, "base_bound": tensor_tol, "kink_allowance": a, "kink_measured": m}
+                                       for v, k, a, m in over]
+        al = sorted(a for a in (kink or {}).values() if a > 0)
+        report["kink_allowances"] = {"tensors_compared": len(rels), "tensors_with_allowance": len(al), "cap": cap,
+                                     "tensors_at_cap": sum(1 for a in al if a >= cap),
+                                     "min": al[0] if al else 0.0, "median": al[len(al) // 2] if al else 0.0, "max": al[-1] if al else 0.0,
+                                     "tensors_that_needed_it": len(over)}
+    bad = [(v, k, a) for v, k, a, _ in over if v > tensor_tol + a]
+    assert not bad, "%s: %d tensors beyond rel-max %.1e + their own (capped) ReLU-kink allowance: %s" % (
         what, len(bad), tensor_tol, [(k, "%.3e" % v, "kink %.2e" % a) for v, k, a in bad[:4]])
     return glob, worst
 

@@ -686,6 +686,44 @@ def test_zero_pool_hands_out_disjoint_zeroed_buffers():
     assert tmg_ops.zeros_like(bufs[1]).shape == bufs[1].shape
 
 
+def test_adopted_torch_adam_steps_like_torch_adam():
+    """tmg_optim.adopt: the optimizer main.py constructs (torch.optim.Adam, weight decay 1e-8, amsgrad; main.py:78-79 wraps it in an
+    ExponentialLR right away) turned into the one-launch HipAdam IN PLACE: same object, same state schema, the scheduler that was
+    constructed before the adoption still sees the steps and moves the learning rate the kernel uses."""
+    import warnings
+    import tmg_optim
+    from torch.optim.lr_scheduler import ExponentialLR
+    g = torch.Generator().manual_seed(29)
+    shapes = [(3,), (4100,), (16, 8, 3, 3), (1, 1, 1, 1)]
+    pa = [torch.randn(s_, generator=g).to(DEV).requires_grad_(True) for s_ in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = torch.optim.Adam(pa, lr=1e-3, weight_decay=1e-8, amsgrad=True)
+    ob = torch.optim.Adam(pb, lr=1e-3, weight_decay=1e-8, amsgrad=True, foreach=False)
+    sa, sb = ExponentialLR(oa, gamma=0.5), ExponentialLR(ob, gamma=0.5)
+    ident = id(oa)
+    assert tmg_optim.adopt(oa) and isinstance(oa, tmg_optim.HipAdam) and id(oa) == ident and tmg_optim.adopt(oa)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # "lr_scheduler.step() before optimizer.step()" would mean the wrapper lost the steps
+        for it in range(5):
+            for a, b in zip(pa, pb):
+                gr = torch.randn(a.shape, generator=g).to(DEV)
+                a.grad, b.grad = gr.clone(), gr.clone()
+            oa.step()
+            ob.step()
+            if it % 2 == 1:
+                sa.step()
+                sb.step()
+    assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == 1e-3 * 0.25
+    for a, b in zip(pa, pb):
+        _close(a, b.detach().double(), tol=3e-6, what="parameter")
+        for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            _close(oa.state[a][k], ob.state[b][k].double(), tol=3e-6, what=k)
+    ob.load_state_dict(oa.state_dict())
+    # not adopted: another class, fused groups
+    assert not tmg_optim.adopt(torch.optim.SGD(pb, lr=0.1))
+    assert not tmg_optim.adopt(torch.optim.Adam(pb, lr=1e-3, fused=True))
+
+
 def test_hip_adam_cached_path_follows_changes():
     """HipAdam's cached steady-state path (parameter / state pointers kept between steps) against torch.optim.Adam when things change
     under it: a parameter without a gradient in one step, a changed learning rate, and a state dict loaded half-way."""

@@ -530,6 +530,25 @@ def test_cfg5_stated_batch_with_fp16_mixes():
     # 64x64 / batch-2 case of test_fp16_mix_variant_deviation_is_reported_separately); a plan fault in mix16_kernel at these pixel
     # counts would be O(1), like the round-3 1x1 weight-gradient fault was
     assert ge[0] < 0.15, ge
+    # ... and per tensor, so that a dead or garbage tensor cannot hide in the global norm: the deviation of every gradient tensor relative
+    # to max(its own scale, the RMS over ALL gradient elements) - a tensor the fp16 variant left at zero (or filled with noise of the
+    # model's gradient scale) reads >= 1 here whatever its size; tensors whose own gradients nearly cancel are held to the global scale
+    tot = sum(float((b["g"][k].double() ** 2).sum()) for k in live)
+    cnt = sum(b["g"][k].numel() for k in live)
+    rms = (tot / cnt) ** 0.5
+    per = []
+    for k in live:
+        ga, gb = a["g"][k].double(), b["g"][k].double()
+        scale = max(float(gb.abs().max()), rms)
+        per.append((float((ga - gb).abs().max()) / scale, k))
+        assert float(gb.abs().max()) == 0.0 or float(ga.abs().max()) > 0.0, "fp16 variant: dead gradient tensor %s" % k
+    per.sort(reverse=True)
+    rep["per_tensor_rel_to_max_of_scale_and_global_rms"] = {"global_rms": rms, "worst": [{"tensor": k, "rel": v} for v, k in per[:5]],
+                                                            "median": per[len(per) // 2][0]}
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_cfg5_batch64_fp16_mix.json"), "w") as f:
+            json.dump(rep, f, indent=1, default=float)
+    assert per[0][0] < 0.5, per[:3]
 
 
 def test_fp16_mix_variant_deviation_is_reported_separately():
@@ -1037,10 +1056,12 @@ def test_eval_mode_uses_running_statistics():
             assert torch.equal(after[k].cpu(), sd[k]), k
 
 
-def test_trainer_epoch_matches_oracle_loop():
+@pytest.mark.parametrize("mode", ["eager", "captured"])
+def test_trainer_epoch_matches_oracle_loop(mode):
     """Rows F1+F2 together: `TrainFlow.trainParallel` (BPTT window of model.sample steps -> physics-constrained loss ->
     backward -> clip -> optimizer step -> state re-anchoring) on the HIP path against the same loop written with the CPU
-    oracles; latents injected through reconstruct() so that both sides see the same noise."""
+    oracles; latents injected through reconstruct() so that both sides see the same noise.  captured: the window's forward passes,
+    loss and backward recorded as one hipGraph and replayed (args.capture_window; the default for a repeated window shape)."""
     from types import SimpleNamespace
     import sys
     import os
@@ -1063,7 +1084,7 @@ def test_trainer_epoch_matches_oracle_loop():
     x = torch.randn(B, T, cfg["in_features"], h, w, generator=g)
     tgt = torch.randn(B, T, 3, H, W, generator=g)
     seeds = torch.tensor([11, 505])
-    args = SimpleNamespace(beta=20.0, dx=0.05, dy=0.0625, max_grad_norm=0.25)
+    args = SimpleNamespace(beta=20.0, dx=0.05, dy=0.0625, max_grad_norm=0.25, capture_window=(mode == "captured"))
 
     # shapes of the latents are the model's business: take them from one oracle forward instead of trusting the formula above
     P = O.params_from_state_dict(sd)
@@ -1075,8 +1096,10 @@ def test_trainer_epoch_matches_oracle_loop():
     # ---- HIP path through the trainer
     step = {"t": 0}
 
+    eps_dev = [[e.to(DEV) for e in et] for et in eps]      # (resident before any recording: a capture admits no host-to-device copy)
+
     def sample_with_fixed_noise(x_t, states):
-        out = m.reconstruct(x_t, states, [e.to(DEV) for e in eps[step["t"]]])
+        out = m.reconstruct(x_t, states, eps_dev[step["t"] % T])       # (a recording runs the window's T steps more than once)
         step["t"] += 1
         return out
 

@@ -35,7 +35,12 @@ def main():
     ap.add_argument("--capture", action="store_true",
                     help="forward passes + loss + backward of a window as one hipGraph replay (tmg_dist.CapturedWindow); clip, optimizer "
                          "step and state re-anchoring stay eager")
+    ap.add_argument("--eager", action="store_true", help="windows launched eagerly (capture off); neither flag: the trainer's default - a "
+                    "window shape is recorded when it comes round the second time, torch's Adam is adopted as the one-launch HipAdam")
+    ap.add_argument("--no-adopt", action="store_true", help="keep torch.optim.Adam's own step (TMG_NO_HIP_ADAM)")
     a = ap.parse_args()
+    if a.no_adopt:
+        os.environ["TMG_NO_HIP_ADAM"] = "1"
 
     def make_opt(params):
         if a.adam == "hip":
@@ -91,7 +96,9 @@ def main():
         return
     y = torch.randn(B, T * a.windows, 3, 2 * h, 2 * w, generator=g).to(dev)
     seeds = torch.arange(B)
-    args = SimpleNamespace(beta=200.0, dx=2. / 64, dy=2. / 64, max_grad_norm=0.01, capture_window=bool(a.capture))
+    args = SimpleNamespace(beta=200.0, dx=2. / 64, dy=2. / 64, max_grad_norm=0.01)
+    if a.capture or a.eager:
+        args.capture_window = bool(a.capture)      # (absent: the trainer's default)
     opt = make_opt(model.parameters())
     trainer = TrainFlow(args, model, [(x, y, seeds)], None)
     # one call = `windows` BPTT windows of T steps each (trainParallel walks tmax // tback windows of a mini-batch); the first
@@ -114,7 +121,8 @@ def main():
     print(json.dumps({"what": "TrainFlow.trainParallel, %d BPTT window(s) of %d sample() steps, batch %d, 256x256x3 output, L=4, K=16" % (
         a.windows, T, B), "seconds_per_window": round(dt / a.windows, 4), "sample_steps_per_s": round(B * T * a.windows / dt, 2),
         "peak_mem_gb": round(peak, 2), "reserved_mem_gb": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 2), "loss_sum": float(loss), "warmup": "one untimed call of the same shape", "optimizer": a.adam,
-        "captured": bool(a.capture),
+        "captured": bool(trainer._captured), "capture_mode": trainer._capture, "capture_failed": list(trainer._capture_failed.values()),
+        "optimizer_class": type(opt).__name__,
         "lstm_state_init_s_per_minibatch": round(t_init, 4), "lstm_state_host_draw_s_first_use": round(t_cold, 3),
         "note": "window time INCLUDES the per-mini-batch seed states: every distinct seed (the loaders draw them from random_(0, 1000)) is "
                 "drawn once on the host with the reference's CPU generators (tmGlow.py:481-509) and kept in HBM; later mini-batches gather"}))
