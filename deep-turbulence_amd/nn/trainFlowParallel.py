@@ -236,6 +236,8 @@ class TrainFlow(object):
                 # pull the LSTM states half-way back to their seed states (reference :283-287)
                 a0 = [(0.5 * h.detach() + 0.5 * hk, 0.5 * c.detach() + 0.5 * ck) for (h, c), (hk, ck) in zip(a0, aKey)]
                 total_loss = total_loss + loss.detach()
+                loss = None      # (a tensor with a grad_fn keeps the window's autograd nodes - and the parameters' AccumulateGrad nodes, bound
+                                 # to the stream they were created on - alive: the next window may be RECORDED, on another stream)
             if self.log is not None and (mbIdx + 1) % 5 == 0:
                 self.log.log('Train Epoch: {}; Mini-batch: {}/{} ({:.0f}%); \t Current Loss: {:.6f}'.format(
                     epoch, mbIdx, len(self.trainingLoader), 100. * mbIdx / len(self.trainingLoader), float(total_loss)))

@@ -349,6 +349,12 @@ class CapturedWindow:
         import tmg_ops
         if bucket is not None:
             bucket.paused = True     # the exchange follows the replay, un-overlapped (see GradBucket.paused)
+        # graphs of earlier EAGER passes that are still alive (the derived-tensor caches of a window keep theirs until the next
+        # window rebuilds them) pin AccumulateGrad nodes created on the stream those passes ran on; a recording on another stream
+        # would meet them ("AccumulateGrad node's stream does not match": a cross-stream dependency inside the capture)
+        import gc
+        tmg_ops.invalidate_derived(model)
+        gc.collect()
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.static_in = _map_tensors(tuple(example_args), lambda t: t.detach().clone())
         self._in_flat = _flat_tensors(self.static_in)
@@ -374,10 +380,32 @@ class CapturedWindow:
         rng_saved = torch.cuda.get_rng_state(dev)
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self.stream):
-            for _ in range(max(int(warmup), 1)):
-                run()
+        import warnings
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)         # (the autograd engine reports the mismatch below once per process otherwise)
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with torch.cuda.stream(self.stream):
+                    for _ in range(max(int(warmup), 1)):
+                        run()
+        finally:
+            torch.set_warn_always(warn_always)
         torch.cuda.current_stream(dev).wait_stream(self.stream)
+        if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
+            # an autograd graph of an EARLIER pass on another stream is still referenced somewhere (a loss tensor, a state with a
+            # grad_fn): it keeps the parameters' AccumulateGrad nodes alive, and those run on the stream they were created on - inside
+            # a recording that is a dependency on a stream outside the capture (hipStreamEndCapture then crashes the process)
+            for p in self.params:
+                p.grad = None
+            with torch.no_grad():
+                if buffers:
+                    torch._foreach_copy_(buffers, buf_saved)
+            torch.cuda.set_rng_state(rng_saved, dev)
+            for p, g in zip(self.params, saved):
+                p.grad = g
+            raise RuntimeError("CapturedWindow: the autograd graph of an earlier pass (on another stream) is still alive - drop every "
+                               "tensor that carries a grad_fn (loss, states, outputs) before recording a window")
         for p in self.params:
             p.grad = None
         torch.cuda.synchronize(dev)

@@ -97,6 +97,13 @@ class DerivedCache:
             for v in val:
                 yield from DerivedCache._tensors(v)
 
+    def clear(self):
+        """Drops every entry (and the autograd graphs the entries carry)."""
+        for e in self.entries.values():
+            for i_ in e["ids"]:
+                _GradSink.proxy_ids.pop(i_, None)
+        self.entries = {}
+
     def get(self, name, params, extra, build, proxies=False):
         # Sharing a value WITH a graph between forward passes is only right when ONE backward pass follows them all (a second,
         # separate backward would find the shared part of the graph freed): that is the BPTT window, which says so with
@@ -124,6 +131,20 @@ class DerivedCache:
                 del _GradSink.proxy_ids[i_]
         self.entries[name] = {"key": key, "val": val, "stale": stale, "ids": ids}
         return val
+
+
+def invalidate_derived(model=None):
+    """Explicit invalidation of everything derived from parameter values (DerivedCache: folded ActNorm + PLU mixes, zero-padded
+    weights).  The caches key on the parameters' data pointers, torch version counters and PARAM_GENERATION - a write that moves none
+    of them (`p.data.mul_(..)`, weight surgery through `.data` inside a no-grad sampling loop, a kernel launched through ctypes) must
+    be followed by this call.  model: also drop the entries held by its modules (frees the autograd graphs they carry - a hipGraph
+    recording needs the AccumulateGrad nodes of earlier eager passes gone: they remember the stream they were created on)."""
+    PARAM_GENERATION[0] += 1
+    if model is not None:
+        for m in model.modules():
+            c = m.__dict__.get("_derived")
+            if c is not None:
+                c.clear()
 
 
 class _GradSink:
