@@ -393,6 +393,34 @@ def main():
         tmg_ops.set_mix_precision("f32")
         f16_variant = {"what": "the same step with fp16-operand / fp32-accumulate 1x1 mixes (BASELINE configs[4]), 4 steps each after the timed region",
                        "ms_per_step_f16": round(1e3 * t16, 3), "ms_per_step_f32": round(1e3 * t32, 3), "speedup_of_f16": round(t32 / t16, 4)}
+    wino3 = None
+    if args.config in ("M", "cfg4") and graph is None and args.direction == "sample" and not args.no_events:
+        # secondary field: the same step with the wide Winograd contractions (ConvLSTM gate conv, level-wide
+        # conditioning conv, out-conv input gradient) on the bf16 matrix pipe at fp32 accuracy - every fp32 operand split exactly into
+        # three bf16 parts, six of the nine part products, fp32 accumulation; transforms in fp32.  Opt-in
+        # (tmg_ops.set_winograd_precision); the headline above is fp32 MFMA throughout.  A few steps each, alternating, after the
+        # timed region.
+        def few(n=4):
+            step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        ts = {"f32": [], "bf16x3": []}
+        for _ in range(2):
+            for kind in ("f32", "bf16x3"):
+                tmg_ops.set_winograd_precision(kind)
+                ts[kind].append(few())
+        tmg_ops.set_winograd_precision("f32")
+        t32w, t3w = min(ts["f32"]), min(ts["bf16x3"])
+        wino3 = {"what": "the same step with the wide Winograd contractions as six bf16 MFMAs per accumulator tile on a three-way exact split of "
+                         "both fp32 operands (fp32-grade error: tools/micro/wino_bf16x3.hip, tests), 2 x 4 steps each, alternating, after the timed region",
+                 "dtype": "f32 operands, bf16x3 split on the matrix pipe, f32 accumulate", "ms_per_step": round(1e3 * t3w, 3),
+                 "ms_per_step_f32_mfma": round(1e3 * t32w, 3), "value": round(B * world / t3w, 2), "unit": "samples/s",
+                 "speedup": round(t32w / t3w, 4)}
+        _phase("bf16x3 Winograd variant (16 steps)")
     if mix == "f16" and graph is None:
         # the fp16-operand 1x1 mixes against this package's own fp32 mixes on the same workload, a few steps each AFTER the timed
         # region (every rank runs them: the steps contain the gradient exchange).  The stand-alone mixes read and write fp32
@@ -481,6 +509,8 @@ def main():
            "peak_mem_gb": round(peak_gb, 2), "roofline": roof}
     if dens is not None:
         out["density_direction"] = dens
+    if wino3 is not None:
+        out["wino_bf16x3_variant"] = wino3
     if f16_variant is not None:
         out["mix_f16_variant"] = f16_variant
     if mix_speedup is not None:

@@ -437,6 +437,418 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
 }
 
 // =================================================================================================================================
+// OPT-IN VARIANT (round 5): the same wide Winograd contraction with the 16 position GEMMs on the BF16 matrix pipe at fp32 accuracy.
+// An fp32 value splits exactly into three bf16 values by truncation (8 + 8 + 8 significant bits); of the nine bf16 x bf16 products
+// of two split values the six largest - a0 b0, a0 b1, a1 b0, a0 b2, a1 b1, a2 b0 - leave out terms of relative size <= 2^-23, the
+// size of fp32 rounding.  Six v_mfma_f32_16x16x32_bf16 (fp32 accumulation, 16 pipe cycles, K = 32) then replace the 32
+// v_mfma_f32_16x16x4_f32 (32 cycles each) of a position and 32-channel chunk: 96 pipe cycles instead of 1 024 per accumulator tile.
+// Both Winograd transforms stay in fp32; the split happens when V is written to LDS and when U is packed.  Measured against fp64
+// (tools/micro/wino_bf16x3.hip, the gate conv's shape): max-abs 6.7e-7 / rel-L2 2.0e-7, the fp32 kernel above 6.7e-7 / 2.2e-7.
+// Structure, tile, staging, output transform and epilogue are wino_fwd_kernel's; what differs:
+//   V in LDS   [16 pos][3 parts][4 k-quarters][32 tiles][8 bf16]: a B fragment of mfma_f32_16x16x32_bf16 (lane (li, q): tile li,
+//              channels 8 q .. 8 q + 7 of the chunk) is one conflict-free ds_read_b128;
+//   transform  a thread owns (tile, 8-channel group, row xi of the 4x4 position grid): 16 float4 reads of the raw patch, the
+//              row / column passes, 32 values split into 3 parts (5.5 vector instructions per value), 12 ds_write_b128;
+//   U operand  [16 pos][Cin_pad32 / 32][Npad / 16][3 parts][64 lanes][8 bf16] (tmg_conv_wino_pack3): an A fragment (lane (li, q): output
+//              channel li of the tile, input channels 8 q .. 8 q + 7) is one 16-byte load per lane and part.
+// Selected by tmg_ops.set_winograd_precision("bf16x3") / TMG_WINO_BF3=1 (tmg_hip.conv3x3_auto); the default stays the fp32 MFMA kernel.
+// =================================================================================================================================
+typedef __bf16 tmg_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void tmg_split3(float v, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned b0 = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(b0);
+    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b1);
+    p0 = b0 >> 16; p1 = b1 >> 16; p2 = __float_as_uint(r2) >> 16;
+}
+
+// U = G g G^T per (output channel, input channel) in fp32, then split; same modes as wino_pack_kernel.
+// one thread per (chunk, n-tile, lane, j): all 16 positions and 3 parts
+__global__ void wino_pack3_kernel(const float* __restrict__ w, unsigned short* __restrict__ U, int Cout, int Cin, int K, int N, int nch, int ntt, int mode) {
+    const int total = nch * ntt * 64 * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, lane = (i >> 3) & 63;
+        const int r = i >> 9;
+        const int nt = r % ntt, ch = r / ntt;
+        const int n = 16 * nt + (lane & 15), k = 32 * ch + 8 * (lane >> 4) + j;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.f;
+                if (k < K && n < N) v = mode == 0 ? w[((size_t)n * Cin + k) * 9 + a * 3 + b] : w[((size_t)k * Cin + n) * 9 + (2 - a) * 3 + (2 - b)];
+                g[a][b] = v;
+            }
+        float t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                unsigned pr[3];
+                tmg_split3(u[b], pr[0], pr[1], pr[2]);
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    const size_t frag = (((size_t)(a * 4 + b) * nch + ch) * ntt + nt) * 3 + part;
+                    U[(frag * 64 + lane) * 8 + j] = (unsigned short)pr[part];
+                }
+            }
+        }
+    }
+}
+
+// w: torch layout [Cout][Cin][3][3]; U: [16][Kpad32 / 32][Npad / 16][3][64][8] bf16 (= 16 * Kpad32 * Npad * 3 two-byte values).  Modes as
+// tmg_conv_wino_pack.
+extern "C" int tmg_conv_wino_pack3(const void* w, void* U, int64_t Cout, int64_t Cin, int64_t mode, int64_t nvalid, hipStream_t st) {
+    const int K = mode == 0 ? (int)Cin : (int)Cout;
+    const int N = mode == 0 ? (int)Cout : (int)(nvalid > 0 && nvalid < Cin ? nvalid : Cin);
+    const int nch = (K + 31) / 32, ntt = (N + 15) / 16;
+    const int total = nch * ntt * 512;
+    const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    hipLaunchKernelGGL(wino_pack3_kernel, dim3(blocks), dim3(256), 0, st, (const float*)w, (unsigned short*)U, (int)Cout, (int)Cin, K, N, nch, ntt, (int)mode);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+__device__ __forceinline__ unsigned tmg_pack_hi(float hi, float lo) {      // (bf16 trunc(hi) << 16) | bf16 trunc(lo)
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ tmg_bf16x8 tmg_as_bf(uint4 u) {
+    union { uint4 u; tmg_bf16x8 b; } c;
+    c.u = u;
+    return c.b;
+}
+
+template <int NPW>
+__global__ __launch_bounds__(512, 1) void wino_fwd3_kernel(WinoP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 512;
+    constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PP = PH * PW;   // output tile, raw patch (halo 1)
+    constexpr int KC = 32, CS = KC + 8;        // channels per chunk, raw-patch pixel stride (words)
+    constexpr int RAWW = PP * CS;              // words per raw buffer
+    constexpr int VQ = 32 * 16;                // bytes of one [32 tiles][8 bf16] plane
+    constexpr int VPART = 4 * VQ, VPOS = 3 * VPART;   // bytes of one part (4 k-quarters) / one position (3 parts)
+    char* Vb = reinterpret_cast<char*>(lds + 2 * RAWW);    // [16][3][4][32][16 bytes]
+    constexpr int UPI = (PP * (KC / 4) + NT - 1) / NT;   // raw float4 items per thread (3)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    const int ntt = p.Npad >> 4;
+    const int nch = p.nchunks;
+    const int ntile0 = (int)blockIdx.y * (8 * NPW) + NPW * wave;
+    // U addressing (bytes): fragment = 1 KB; [pos][chunk][n-tile][part]
+    const unsigned upart = 1024u, unt = 3u * upart, uch = (unsigned)ntt * unt, upos = (unsigned)nch * uch;
+    unsigned boff[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) boff[n] = (unsigned)min(ntile0 + n, ntt - 1) * unt + (unsigned)lane * 16u;
+    const char* Ub = reinterpret_cast<const char*>(p.U);
+
+    // ---- lean staging state: a thread owns channel quad pc4 of every 64th patch pixel -------------------------------------
+    const int pc4 = tid & 7, ppix0 = tid >> 3;
+    unsigned pyx[UPI];
+#pragma unroll
+    for (int u = 0; u < UPI; ++u) {
+        const int pix = min(ppix0 + u * 64, PP - 1);
+        const int py = pix / PW, px = pix - py * PW;
+        pyx[u] = ((unsigned)py << 16) | (unsigned)px;
+    }
+    float4 pv[UPI];
+
+    // ---- transform mapping: item = (Winograd tile tt, channel octet tc8, row xi of the 4x4 position grid) -------------------------------
+    const int tc8 = tid & 3, tt = (tid >> 2) & 31, txi = tid >> 7;
+    const int tty = tt >> 3, ttx = tt & 7;
+    const int traw = ((2 * tty) * PW + 2 * ttx) * CS + 8 * tc8;   // word offset of patch pixel (0, 0) of the tile in a raw buffer
+    // rows of the patch combined for row xi of B^T d:  xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int tra = (txi == 0) ? 0 : (txi == 2 ? 2 : 1), trb = (txi == 0) ? 2 : (txi == 1 ? 2 : (txi == 2 ? 1 : 3));
+    const float tsb = (txi == 1) ? 1.f : -1.f;
+
+    const int G = gridDim.x;
+    const int nmine = (int)blockIdx.x < p.ntiles ? (p.ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int nst = nmine * nch;
+    int ci = 0, cc = 0, cm = 0;
+    int ti = blockIdx.x, tm = blockIdx.x;
+
+    f32x4 Y[4][2][NPW];   // [output pixel of the 2x2 tile][m-tile][n-tile]
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // U fragments run in STEPS of (position, n-tile) - 32 or 16 per stage, 12 MFMAs each - through a ring of four slots, three steps
+    // ahead of their MFMAs (slot = step & 3: the stage length is a multiple of four, one unrolled body).  [A ring of whole positions
+    // needed 48 registers for ONE position of lead at two n-tiles per wave, 72 for two: spilled.]
+    constexpr int NSTEP = 16 * NPW, LD = 3;
+    uint4 bfr[4][3];
+    for (int k = -2; k < nst; ++k) {
+        // ---- commit stage k+1 --------------------------------------------------------------------------------------------------
+        if (k >= -1 && k + 1 < nst) {
+            float* rb = lds + ((k + 1) & 1) * RAWW;
+#pragma unroll
+            for (int u = 0; u < UPI; ++u) {
+                if (ppix0 + u * 64 < PP) {
+                    float4 v = pv[u];
+                    if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(rb + (ppix0 + u * 64) * CS + 4 * pc4) = v;
+                }
+            }
+            if (++cc == nch) cc = 0;
+        }
+        // ---- issue the loads of stage k+2 -------------------------------------------------------------------------------------
+        if (k + 2 < nst) {
+            int t_ = ti;
+            const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
+            const int ty_ = t_ % p.tiles_y;
+            const int b_ = t_ / p.tiles_y;
+            const int iy0 = ty_ * TH - 1, ix0 = tx_ * TW - 1;
+            const float* tptr = tmg_zero_page;
+            int tss = 0;
+            {
+                int cl = ci * KC + 4 * pc4;
+                if (cl < p.Cin) {
+                    const float* sp = p.in[0].p;
+                    int ss = p.in[0].stride, so = p.in[0].off;
+                    if (cl >= p.in[0].n) {
+                        cl -= p.in[0].n;
+                        sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+                        if (cl >= p.in[1].n) {
+                            cl -= p.in[1].n;
+                            sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+                        }
+                    }
+                    tptr = sp + so + cl;
+                    tss = ss;
+                }
+            }
+            const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win);
+#pragma unroll
+            for (int u = 0; u < UPI; ++u) {
+                const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu);
+                const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);
+                const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);
+                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (size_t)(tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)tss;
+                // streamed once: non-temporal, so that the activations do not push the U operand (re-read by every tile) out of L2
+                {
+                    const f32x4 nt_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_));
+                    pv[u] = make_float4(nt_[0], nt_[1], nt_[2], nt_[3]);
+                }
+            }
+            if (++ci == nch) { ci = 0; ti += G; }
+        }
+        if (k >= 0) {
+            // ---- input transform of stage k: V = B^T d B in fp32, split into three bf16 parts on the way to LDS -----------------------------
+            {
+                const float* rb = lds + (k & 1) * RAWW + traw;
+                float t[4][8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float4 da = *reinterpret_cast<const float4*>(rb + (tra * PW + c) * CS + 4 * e);
+                        const float4 db = *reinterpret_cast<const float4*>(rb + (trb * PW + c) * CS + 4 * e);
+                        t[c][4 * e + 0] = da.x + tsb * db.x; t[c][4 * e + 1] = da.y + tsb * db.y;
+                        t[c][4 * e + 2] = da.z + tsb * db.z; t[c][4 * e + 3] = da.w + tsb * db.w;
+                    }
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    float v[8], r1[8], r2[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = nu == 0 ? t[0][j] - t[2][j] : (nu == 1 ? t[1][j] + t[2][j] : (nu == 2 ? t[2][j] - t[1][j] : t[1][j] - t[3][j]));
+                        r1[j] = v[j] - __uint_as_float(__float_as_uint(v[j]) & 0xffff0000u);
+                        r2[j] = r1[j] - __uint_as_float(__float_as_uint(r1[j]) & 0xffff0000u);
+                    }
+                    char* vp = Vb + (4 * txi + nu) * VPOS + tc8 * VQ + tt * 16;
+                    *reinterpret_cast<uint4*>(vp) = make_uint4(tmg_pack_hi(v[1], v[0]), tmg_pack_hi(v[3], v[2]), tmg_pack_hi(v[5], v[4]), tmg_pack_hi(v[7], v[6]));
+                    *reinterpret_cast<uint4*>(vp + VPART) = make_uint4(tmg_pack_hi(r1[1], r1[0]), tmg_pack_hi(r1[3], r1[2]), tmg_pack_hi(r1[5], r1[4]), tmg_pack_hi(r1[7], r1[6]));
+                    *reinterpret_cast<uint4*>(vp + 2 * VPART) = make_uint4(tmg_pack_hi(r2[1], r2[0]), tmg_pack_hi(r2[3], r2[2]), tmg_pack_hi(r2[5], r2[4]), tmg_pack_hi(r2[7], r2[6]));
+                }
+            }
+            __syncthreads();
+            // ---- 16 position GEMMs over this chunk (6 bf16 MFMAs per accumulator tile), output transform folded in ---------------------
+            {
+                const char* ub = Ub + (size_t)((unsigned)cm * uch);
+                const char* vb = Vb + q * VQ + li * 16;
+#define TMG_W3_LOADB(ST)                                                                                              \
+                {                                                                                                     \
+                    const char* up_ = ((ST) < NSTEP ? ub : ubn) + (unsigned)(((ST) % NSTEP) / NPW) * upos + boff[(ST) % NPW]; \
+                    bfr[(ST) & 3][0] = *reinterpret_cast<const uint4*>(up_);                                          \
+                    bfr[(ST) & 3][1] = *reinterpret_cast<const uint4*>(up_ + 1024);                                   \
+                    bfr[(ST) & 3][2] = *reinterpret_cast<const uint4*>(up_ + 2048);                                   \
+                }
+                // operand of the next stage (the next chunk of this tile, or chunk 0 of the next tile: every tile uses the same U)
+                const char* ubn = Ub + (size_t)((unsigned)((cm + 1 == nch) ? 0 : cm + 1) * uch);
+                if (k == 0) { TMG_W3_LOADB(0) TMG_W3_LOADB(1) TMG_W3_LOADB(2) }
+                // two accumulator sets: the output-transform additions of position p - 1 (vector ALU) sit between the MFMAs of position
+                // p - with six 16-cycle MFMAs per accumulator tile a position is only 24 x 16 pipe cycles, and additions that wait for
+                // their own position's last MFMA (as in the fp32 kernel, where a position is 1 024 cycles) would be a quarter of it
+                f32x4 acc[2][2][NPW];
+#define TMG_W3_YUPD(PPOS, M, N)                                                                                       \
+                {                                                                                                     \
+                    const int xi_ = (PPOS) >> 2, nu_ = (PPOS) & 3;                                                    \
+                    _Pragma("unroll") for (int oy = 0; oy < 2; ++oy) _Pragma("unroll") for (int ox = 0; ox < 2; ++ox) { \
+                        const int ay = oy == 0 ? (xi_ < 3 ? 1 : 0) : (xi_ == 0 ? 0 : (xi_ == 1 ? 1 : -1));            \
+                        const int ax = ox == 0 ? (nu_ < 3 ? 1 : 0) : (nu_ == 0 ? 0 : (nu_ == 1 ? 1 : -1));            \
+                        const int cf = ay * ax;                                                                       \
+                        if (cf != 0) {                                                                                \
+                            f32x4& y_ = Y[oy * 2 + ox][M][N];                                                         \
+                            if (cf > 0) y_ += acc[(PPOS) & 1][M][N];                                                  \
+                            else y_ -= acc[(PPOS) & 1][M][N];                                                         \
+                            /* pin the update HERE (the optimiser sinks the additions below the last position otherwise) */ \
+                            asm volatile("" : "+v"(y_));                                                              \
+                        }                                                                                             \
+                    }                                                                                                 \
+                }
+#pragma unroll
+                for (int pos = 0; pos < 16; ++pos) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint4 af[2][3];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        af[m][0] = *reinterpret_cast<const uint4*>(vb + pos * VPOS + m * 256);
+                        af[m][1] = *reinterpret_cast<const uint4*>(vb + pos * VPOS + VPART + m * 256);
+                        af[m][2] = *reinterpret_cast<const uint4*>(vb + pos * VPOS + 2 * VPART + m * 256);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n) {
+                        const int st_ = pos * NPW + n;
+                        __builtin_amdgcn_sched_barrier(0);
+                        TMG_W3_LOADB(st_ + LD)
+                        __builtin_amdgcn_sched_barrier(0);
+                        const tmg_bf16x8 a0 = tmg_as_bf(bfr[st_ & 3][0]), a1 = tmg_as_bf(bfr[st_ & 3][1]), a2 = tmg_as_bf(bfr[st_ & 3][2]);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const tmg_bf16x8 b0 = tmg_as_bf(af[m][0]), b1 = tmg_as_bf(af[m][1]), b2 = tmg_as_bf(af[m][2]);
+                            f32x4 c_ = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, c_, 0, 0, 0);
+                            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, c_, 0, 0, 0);
+                            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c_, 0, 0, 0);
+                            if (pos > 0) TMG_W3_YUPD(pos > 0 ? pos - 1 : 0, m, n)
+                            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, c_, 0, 0, 0);
+                            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, c_, 0, 0, 0);
+                            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, c_, 0, 0, 0);
+                            acc[pos & 1][m][n] = c_;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n) TMG_W3_YUPD(15, m, n)
+#undef TMG_W3_YUPD
+#undef TMG_W3_LOADB
+            }
+            if (cm + 1 == nch) {
+                // ---- epilogue: lane (li, q) holds channels 4 q .. 4 q + 3 (of each n-tile) of Winograd tile 16 m + li -------------
+                int t_ = tm;
+                const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
+                const int ty_ = t_ % p.tiles_y;
+                const int b_ = t_ / p.tiles_y;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int wt = 16 * m + li;
+                    const int oyb = ty_ * TH + 2 * (wt >> 3), oxb = tx_ * TW + 2 * (wt & 7);
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n) {
+                        const int n0 = (ntile0 + n) * 16 + 4 * q;
+                        if (ntile0 + n < ntt && n0 < p.Cout) {
+                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
+                            int nl = n0;
+                            TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) {
+                                const int oy = oyb + (o >> 1), ox = oxb + (o & 1);
+                                if (oy < p.Hin && ox < p.Win) {
+                                    const unsigned opx = ((unsigned)b_ * (unsigned)p.Hin + (unsigned)oy) * (unsigned)p.Win + (unsigned)ox;
+                                    __builtin_nontemporal_store((f32x4){Y[o][m][n][0] + bv.x, Y[o][m][n][1] + bv.y, Y[o][m][n][2] + bv.z, Y[o][m][n][3] + bv.w},
+                                                                reinterpret_cast<f32x4*>(optr + (size_t)opx * (unsigned)ostride + ooff + nl));
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cm = 0; tm += G;
+            } else {
+                ++cm;
+            }
+        }
+        __syncthreads();   // V and the raw buffer just read are rewritten next round; the raw buffer just written is complete
+    }
+}
+
+// tmg_conv_wino_fwd with the operand of tmg_conv_wino_pack3 (same arguments, same envelope).
+extern "C" int tmg_conv_wino_fwd3(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
+                                  void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, hipStream_t st) {
+    WinoP p;
+    p.nseg = (int)nseg;
+    if (p.nseg < 1 || p.nseg > TMG_MAX_IN_SEG || nout < 1 || nout > TMG_MAX_OUT_SEG) return -3;
+    int csum = 0, osum = 0;
+    bool ok = true;
+    for (int i = 0; i < TMG_MAX_IN_SEG; ++i) p.in[i] = TmgSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < p.nseg; ++i) {
+        p.in[i] = TmgSeg{(const float*)in_ptrs[i], (int)in_desc[3 * i], (int)in_desc[3 * i + 1], (int)in_desc[3 * i + 2]};
+        if (((p.in[i].stride | p.in[i].off | p.in[i].n) & 3) || (((uintptr_t)in_ptrs[i]) & 15)) ok = false;
+        csum += p.in[i].n;
+    }
+    for (int i = 0; i < TMG_MAX_OUT_SEG; ++i) p.out[i] = TmgOSeg{nullptr, 0, 0, 0};
+    for (int i = 0; i < (int)nout; ++i) {
+        p.out[i] = TmgOSeg{(float*)out_ptrs[i], (int)out_desc[3 * i], (int)out_desc[3 * i + 1], (int)out_desc[3 * i + 2]};
+        if (((p.out[i].stride | p.out[i].off | p.out[i].n) & 3) || (((uintptr_t)out_ptrs[i]) & 15)) ok = false;
+        osum += p.out[i].n;
+    }
+    p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.Cout = (int)dims[4];
+    p.relu_in = (int)dims[5]; p.pad_rep = (int)dims[6];
+    if (csum != p.Cin || osum != p.Cout) return -3;
+    if ((p.Cout & 3) || (p.Cin & 3) || p.Cout < 64) ok = false;
+    if (bias && (((uintptr_t)bias) & 15)) ok = false;
+    if (!ok) return -100;
+    p.Cin_pad = (p.Cin + 31) & ~31;
+    p.Npad = (p.Cout + 15) & ~15;
+    p.U = (const float*)U; p.bias = (const float*)bias;
+    p.tiles_x = (p.Win + 15) / 16; p.tiles_y = (p.Hin + 7) / 8;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    p.nchunks = p.Cin_pad / 32;
+    if (p.ntiles <= 0) return 0;
+    if ((long long)p.B * p.Hin * p.Win >= (1LL << 31)) return -100;
+    const int ntt = p.Npad / 16;
+    const int npw = ntt <= 8 ? 1 : 2;
+    const int gy = (ntt + 8 * npw - 1) / (8 * npw);
+    int G = 256 / gy;
+    if (G < 1) G = 1;
+    if (G > p.ntiles) G = p.ntiles;
+    const size_t lds_bytes = (size_t)(2 * 180 * 40) * sizeof(float) + (size_t)16 * 3 * 4 * 512;
+    TmgProf prof(TMG_PROF_WINO, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);   // algorithmic (direct) flops
+    if (npw == 1) {
+        TMG_LDS_OPTIN((&wino_fwd3_kernel<1>));
+        hipLaunchKernelGGL(wino_fwd3_kernel<1>, dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
+    } else {
+        TMG_LDS_OPTIN((&wino_fwd3_kernel<2>));
+        hipLaunchKernelGGL(wino_fwd3_kernel<2>, dim3(G, gy, 1), dim3(512), lds_bytes, st, p);
+    }
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================================================
 // Few output channels (<= 48), many input channels: the input gradients of the contractions above (4R -> Cin gate gradient, 15 C
 // -> Cc conditioning gradient) and the ConvLSTM block's narrow convs.  With only NTN <= 4 output-channel tiles there is no work to
 // give eight waves along N; instead the 16 Winograd positions are dealt to the waves, two each (wave w: xi = w >> 1, nu = 2 (w & 1)

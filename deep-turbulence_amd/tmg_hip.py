@@ -35,7 +35,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3",
 ]
 
 
@@ -318,6 +318,50 @@ def conv_wino_pack(w, mode=0, nvalid=0):
     return U
 
 
+# Arithmetic of the WIDE Winograd contractions (conv3x3_auto): "f32" = fp32 MFMA (the default, the headline's); "bf16x3" = the bf16
+# matrix pipe at fp32 accuracy (three-way exact split of both operands, six part products: tmg_conv_wino_fwd3) - opt-in
+_WINO_PRECISION = ["bf16x3" if os.environ.get("TMG_WINO_BF3") else "f32"]
+
+
+def set_winograd_precision(kind):
+    if kind not in ("f32", "bf16x3"):
+        raise ValueError("Winograd precision must be 'f32' or 'bf16x3', got %r" % (kind,))
+    _WINO_PRECISION[0] = kind
+
+
+def winograd_precision():
+    return _WINO_PRECISION[0]
+
+
+def conv_wino_pack3(w, mode=0, nvalid=0):
+    """bf16x3 Winograd operand of a [Cout, Cin, 3, 3] weight (tmg_conv_wino_pack3): U = G g G^T in fp32, split into three bf16 parts,
+    in A-fragment order of mfma_f32_16x16x32_bf16.  Modes as conv_wino_pack."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    assert w.shape[2] == 3 and w.shape[3] == 3
+    w = w.contiguous()
+    K, N = (Cin, Cout) if mode == 0 else (Cout, nvalid if 0 < nvalid < Cin else Cin)
+    U = torch.empty(16 * ((K + 31) // 32 * 32) * ((N + 15) // 16 * 16) * 3, device=w.device, dtype=torch.int16)
+    _chk(lib().tmg_conv_wino_pack3(_ptr(w), _ptr(U), c_i64(Cout), c_i64(Cin), c_i64(mode), c_i64(nvalid), _stream()), "tmg_conv_wino_pack3")
+    return U
+
+
+def conv_wino_fwd3(inputs, U, Cout, outs, bias=None, relu_in=False, pad_rep=False):
+    """conv_wino_fwd with the bf16x3 operand of conv_wino_pack3; False outside the envelope (nothing was launched)."""
+    if isinstance(outs, torch.Tensor):
+        outs = [outs]
+    B, Hin, Win, _ = inputs[0].shape
+    ip, idesc, n_in = _segs(inputs)
+    op, odesc, n_out = _segs(outs)
+    Cin = sum(t.shape[3] for t in inputs)
+    assert sum(t.shape[3] for t in outs) == Cout and outs[0].shape[1] == Hin and outs[0].shape[2] == Win
+    rc = lib().tmg_conv_wino_fwd3(ip, idesc, c_i64(n_in), _ptr(U), _ptr(bias), op, odesc, c_i64(n_out),
+                                  _i64(B, Hin, Win, Cin, Cout, relu_in, pad_rep), _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_conv_wino_fwd3")
+    return True
+
+
 def conv_wino_narrow(inputs, U, Cout, outs, bias=None, relu_in=False, pad_rep=False, relu_out=False):
     """Few output channels: outs = list of <= 3 NHWC tensors / channel-slice views forming the Cout channels.  False when the
     shape is outside the kernel's envelope (nothing was launched)."""
@@ -360,7 +404,10 @@ def conv3x3_auto(inputs, weight, Cout, outs, bias=None, relu_in=False, pad_rep=F
     Cin = sum(t.shape[3] for t in inputs)
     mode = 1 if dgrad else 0
     if not relu_out and wino_eligible(Cin, Cout, 3, 1):
-        if conv_wino_fwd(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep):
+        if _WINO_PRECISION[0] == "bf16x3":
+            if conv_wino_fwd3(inputs, conv_wino_pack3(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep):
+                return None
+        elif conv_wino_fwd(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep):
             return None
     if wino_narrow_eligible(Cin, Cout):
         if conv_wino_narrow(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep,

@@ -880,6 +880,16 @@ def mix_precision():
     return _MIX_PRECISION
 
 
+def set_winograd_precision(kind):
+    """Arithmetic of the wide Winograd contractions (ConvLSTM gate conv, level-wide conditioning conv, out-conv input gradient):
+    "f32" = fp32 MFMA (default); "bf16x3" = the bf16 matrix pipe at fp32 accuracy (tmg_hip.conv_wino_fwd3; opt-in, round 5)."""
+    H.set_winograd_precision(kind)
+
+
+def winograd_precision():
+    return H.winograd_precision()
+
+
 def _mix16_ok(C):
     return _MIX_PRECISION == "f16" and C % 4 == 0 and C <= 256
 

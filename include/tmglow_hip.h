@@ -72,6 +72,15 @@ int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_desc, int64_t
 int tmg_conv_wino_pack(const void* w, void* U, int64_t Cout, int64_t Cin, int64_t mode, int64_t nvalid, tmg_stream_t st);
 int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
                       void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
+/* OPT-IN variant of the same wide contraction (round 5): the 16 position GEMMs on the bf16 matrix pipe at fp32 accuracy - every fp32
+ * operand split exactly into three bf16 parts (truncation), six of the nine part products (v_mfma_f32_16x16x32_bf16, fp32 accumulate),
+ * both Winograd transforms in fp32 before the split.  tmg_conv_wino_pack3: U = G g G^T split, [16][Kpad32/32][Npad/16][3][64][8] bf16
+ * (16 * Kpad32 * Npad * 3 two-byte values; modes as tmg_conv_wino_pack); tmg_conv_wino_fwd3: tmg_conv_wino_fwd's arguments and envelope.
+ * Replaces nothing of the reference by itself: the same F.conv2d call sites (convLSTM.py:72-74); selected by
+ * tmg_ops.set_winograd_precision("bf16x3") / TMG_WINO_BF3=1, the default stays the fp32 MFMA kernel. */
+int tmg_conv_wino_pack3(const void* w, void* U, int64_t Cout, int64_t Cin, int64_t mode, int64_t nvalid, tmg_stream_t st);
+int tmg_conv_wino_fwd3(const void* const* in_ptrs, const int64_t* in_desc, int64_t nseg, const void* U, const void* bias,
+                       void* const* out_ptrs, const int64_t* out_desc, int64_t nout, const int64_t* dims, tmg_stream_t st);
 /* tmg_conv_wino_pack: mode 0 = forward operand (K = Cin, N = Cout); mode 1 = operand of the input gradient w.r.t. the first
  * `nvalid` input channels (0: all), K = Cout, N = nvalid, taps flipped - what autograd's conv2d backward contracts with.
  * tmg_conv_wino_narrow: the same Winograd contraction for FEW output channels (Cout <= 48, Cin >= 64): the input gradients of the

@@ -488,9 +488,11 @@ def test_mix_f16_kernel(C_, npix, slice_of):
     (2, 12, 16, [48], 112, False, False, True),            # the same at the second level's widths
     (1, 16, 16, [96], 144, False, True, True),             # 9 tiles: back on the two-tiles-per-wave instance
 ])
-def test_winograd_conv_matches_fp64(case):
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_winograd_conv_matches_fp64(case, arith):
     """tmg_conv_wino_fwd (Winograd F(2x2,3x3) on the fp32 matrix cores) against fp64 F.conv2d, at the direct kernel's tolerance,
-    and against the direct kernel itself."""
+    and against the direct kernel itself.  arith "bf16x3": the opt-in tmg_conv_wino_fwd3 (three-way bf16 split of both operands, six
+    part products on the bf16 matrix pipe) - held to the SAME tolerances, and its error against fp64 to at most 1.5x the fp32 kernel's."""
     import tmg_hip as H
     B, Hh, Ww, segs, Cout, relu_in, pad_rep, has_b = case
     g = torch.Generator().manual_seed(sum(segs) + Cout + Hh)
@@ -507,10 +509,35 @@ def test_winograd_conv_matches_fp64(case):
     out = torch.full((B, Hh, Ww, Cout), float("nan"), device=DEV)
     assert H.wino_eligible(sum(segs), Cout, 3, 1)
     assert H.conv_wino_fwd(xd, H.conv_wino_pack(wd), Cout, [out[..., :32], out[..., 32:]], bias=bd, relu_in=relu_in, pad_rep=pad_rep)
+    if arith == "bf16x3":
+        out3 = torch.full((B, Hh, Ww, Cout), float("nan"), device=DEV)
+        assert H.conv_wino_fwd3(xd, H.conv_wino_pack3(wd), Cout, [out3[..., :32], out3[..., 32:]], bias=bd, relu_in=relu_in, pad_rep=pad_rep)
+        e32 = float((out.double().cpu() - ref).abs().max())
+        e3 = float((out3.double().cpu() - ref).abs().max())
+        assert e3 <= 1.5 * e32 + 1e-7 * float(ref.abs().max()), (e3, e32)
+        out = out3
     _close(out, ref, what="winograd conv")
     direct = torch.empty_like(out)
     H.conv_fwd(xd, H.conv_pack(wd, 0), Cout, 3, 1, [direct], bias=bd, relu_in=relu_in, pad_rep=pad_rep)
     _close(out, direct.double(), what="winograd vs direct")
+
+
+def test_winograd_bf16x3_input_gradient_operand():
+    """tmg_conv_wino_pack3 mode 1 (the input-gradient operand: transposed weight, flipped taps, channel prefix) through
+    conv3x3_auto with the bf16x3 switch on, against fp64 conv_transpose2d - the ConvLSTM out-conv's input gradient 40 -> 104."""
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(404)
+    B, Hh, Ww, K, N = 2, 16, 24, 40, 104
+    x = torch.randn(B, Hh, Ww, K, generator=g)
+    w = 0.2 * torch.randn(K, N + 8, 3, 3, generator=g)          # forward conv [Cout = K][Cin = N + 8]; gradient w.r.t. its first N inputs
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1)[:, :N].permute(0, 2, 3, 1)
+    out = torch.full((B, Hh, Ww, N), float("nan"), device=DEV)
+    H.set_winograd_precision("bf16x3")
+    try:
+        assert H.conv3x3_auto([x.to(DEV)], w.to(DEV), N, [out], dgrad=True, nvalid=N) is None      # (None: a Winograd kernel took it)
+    finally:
+        H.set_winograd_precision("f32")
+    _close(out, ref, what="bf16x3 winograd input gradient")
 
 
 @pytest.mark.parametrize("case", [

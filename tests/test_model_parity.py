@@ -1481,6 +1481,45 @@ def test_bptt_window_at_stated_batch_matches_oracle():
                    tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), kink=r64["kink"])
 
 
+@pytest.mark.parametrize("cin,hw,B", [(8, (32, 32), 8), (16, (12, 20), 4)])
+def test_level_with_bf16x3_winograd_matches_fp32_winograd(cin, hw, B):
+    """The opt-in bf16x3 arithmetic of the wide Winograd contractions (tmg_ops.set_winograd_precision: three-way exact bf16 split of
+    both operands, six part products, fp32 accumulation - the ConvLSTM gate conv and the level-wide conditioning conv, forward) against
+    the default fp32-MFMA path on one flow level, generative direction + backward, with the STRICT path-vs-path bounds of
+    test_level_kernels_across_field_and_batch_sizes: the two differ by fp32 rounding only."""
+    import tmg_ops as ops
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+    hs, ws = hw
+    C.seed_all(cin * 11 + B)
+    blk = LSTMFLowBlock(cin, 32, 64, 6, LUdecompose=True, train_sampling=True, do_split=True, squeeze_type=0)
+    C.perturb_(blk, 5, 0.02, 0.05, 0.02)
+    blk.to(DEV)
+    g = torch.Generator().manual_seed(13)
+    z, eps = (torch.randn(B, 2 * cin, hs, ws, generator=g).to(DEV) for _ in range(2))
+    cond = torch.randn(B, 32, hs, ws, generator=g).to(DEV)
+    hst, cst = (torch.randn(B, 64, hs, ws, generator=g).to(DEV) for _ in range(2))
+    res = {}
+    try:
+        for tag in ("f32", "bf16x3"):
+            ops.set_winograd_precision(tag)
+            assert ops.winograd_precision() == tag
+            blk.zero_grad()
+            zi, ci, hi, cc = (t.clone().requires_grad_(True) for t in (z, cond, hst, cst))
+            xr, ldr, st = blk.reverse(zi, ci, (hi, cc), eps=eps)
+            ((xr[:2] ** 2).sum() * 0.5 + ldr[:2].sum() * 0.02 + (st[0][:2] ** 2).sum() * 0.1).backward()
+            gr = {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None}
+            gr.update({"@dz": zi.grad.clone(), "@dcond": ci.grad.clone(), "@dh": hi.grad.clone(), "@dc": cc.grad.clone()})
+            res[tag] = (xr.detach(), ldr.detach(), st[0].detach(), gr)
+    finally:
+        ops.set_winograd_precision("f32")
+    a, b = res["bf16x3"], res["f32"]
+    assert float((a[2] - b[2]).abs().max()) > 0.0, "the bf16x3 kernel must actually run (the gate conv feeds the new state)"
+    C.assert_field(a[0], b[0], "level output", atol=1e-4 * float(b[0].abs().max()), rtol=1e-5)
+    C.assert_field(a[2], b[2], "new hidden state", atol=1e-5)
+    C.assert_logdet(a[1], b[1], rtol=5e-6, atol=1e-3)
+    C.assert_grads(a[3], b[3], "bf16x3 vs fp32 Winograd", global_tol=2e-4, tensor_tol=5e-3)
+
+
 @pytest.mark.parametrize("cin,hw,B", [(4, (64, 64), 64), (8, (17, 33), 32), (16, (16, 16), 128), (16, (9, 23), 64), (32, (8, 16), 64), (3, (30, 30), 64)])
 def test_level_kernels_across_field_and_batch_sizes(cin, hw, B):
     """One flow level (generative direction + backward, recurrent states with gradients, loss on two samples) through the level-fused
