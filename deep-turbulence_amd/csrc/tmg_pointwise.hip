@@ -2117,6 +2117,77 @@ extern "C" int tmg_lu_fold_fwd(const void* tab, const void* sign_s, const void* 
     return 0;
 }
 
+// Inverse of the K folded channel mixes of a level, for the recompute-from-output backward (tmg_ops.LevelCouplingFn, round 5): a
+// coupling layer of the generative direction ends with out = Wm [x1; y2] + bm (glowConv.py:207-222 + actNorm.py:71-85 folded), so its
+// input is rebuilt from its output with Winv = Wm^-1, binv = -Wm^-1 bm.  (The reference's own forward-direction matrix is NOT that
+// inverse: glowConv.py:164-174 adds 0.01 to U's diagonal.)  One block per matrix, Gauss-Jordan with partial pivoting in FP64 on the
+// augmented [C][2C] array in LDS, rounded once on store: an error in a mix matrix is coherent over every pixel it is applied to.
+__global__ __launch_bounds__(256) void mat_inverse_kernel(const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ Winv,
+                                                          float* __restrict__ binv, int C) {
+    extern __shared__ __attribute__((aligned(16))) double aug[];      // [C][2C], then C doubles of pivot-column factors, then 2 + C ints
+    double* fac = aug + 2 * C * C;
+    int* piv = reinterpret_cast<int*>(fac + C);
+    int* dead = piv + 2;              // [C]: channel with an all-zero row and column (zero-padded halves of 3-channel fields, section 3 of
+                                      // DESIGN.md): the mix is block diagonal with a zero block there - inverted on the live block, zero elsewhere
+    const int k = blockIdx.x, tid = threadIdx.x, C2 = 2 * C;
+    const float* Wk = W + (size_t)k * C * C;
+    for (int i = tid; i < C * C2; i += 256) {
+        const int r = i / C2, c = i - r * C2;
+        aug[i] = c < C ? (double)Wk[r * C + c] : (c - C == r ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int col = 0; col < C; ++col) {
+        if (tid == 0) {
+            int best = col;
+            double bv = fabs(aug[col * C2 + col]);
+            for (int r = col + 1; r < C; ++r) {
+                const double v = fabs(aug[r * C2 + col]);
+                if (v > bv) { bv = v; best = r; }
+            }
+            piv[0] = best;
+            dead[col] = bv == 0.0 ? 1 : 0;
+        }
+        __syncthreads();
+        if (dead[col]) continue;      // (block-uniform; rows / columns of a padding channel hold zeros and take no part in the elimination)
+        const int pr = piv[0];
+        if (pr != col)
+            for (int c = tid; c < C2; c += 256) { const double t = aug[col * C2 + c]; aug[col * C2 + c] = aug[pr * C2 + c]; aug[pr * C2 + c] = t; }
+        __syncthreads();
+        const double inv = 1.0 / aug[col * C2 + col];
+        for (int r = tid; r < C; r += 256) fac[r] = aug[r * C2 + col];
+        __syncthreads();
+        for (int c = tid; c < C2; c += 256) aug[col * C2 + c] *= inv;
+        __syncthreads();
+        for (int i = tid; i < C * C2; i += 256) {
+            const int r = i / C2, c = i - r * C2;
+            if (r != col) aug[i] -= fac[r] * aug[col * C2 + c];
+        }
+        __syncthreads();
+    }
+    float* Wo = Winv + (size_t)k * C * C;
+    for (int i = tid; i < C * C; i += 256) {
+        const int r = i / C, c = i - r * C;
+        Wo[i] = dead[r] ? 0.f : (float)aug[r * C2 + C + c];
+    }
+    if (b && binv)
+        for (int r = tid; r < C; r += 256) {
+            double acc = 0.0;
+            for (int c = 0; c < C; ++c) acc += aug[r * C2 + C + c] * (double)b[(size_t)k * C + c];
+            binv[(size_t)k * C + r] = dead[r] ? 0.f : (float)(-acc);
+        }
+}
+
+// Winv[k] = W[k]^-1 (fp64 arithmetic), binv[k] = -Winv[k] b[k] (b / binv may be null).  dims = {K, C}; C <= 64.
+extern "C" int tmg_mat_inverse(const void* W, const void* b, void* Winv, void* binv, const int64_t* dims, hipStream_t st) {
+    const int K = (int)dims[0], C = (int)dims[1];
+    if (K < 1 || C < 1 || C > 64) return -1;
+    const size_t lds = ((size_t)2 * C * C + C) * sizeof(double) + 16 + (size_t)C * sizeof(int);
+    if (lds > 64 * 1024) TMG_LDS_OPTIN((&mat_inverse_kernel));
+    hipLaunchKernelGGL(mat_inverse_kernel, dim3(K), dim3(256), lds, st, (const float*)W, (const float*)b, (float*)Winv, (float*)binv, C);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int tmg_lu_fold_bwd_split(const void* tab, const void* sign_s, const void* perm, const void* iperm, const void* W,
                                      const void* dWm, const void* dbm, const void* dWm_tail, const void* dbm_tail, const void* dld, void* dl,
                                      void* du, void* dlogs, void* da, void* db, const int64_t* dims, const float* fl, hipStream_t st) {

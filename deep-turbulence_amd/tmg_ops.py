@@ -880,6 +880,23 @@ def mix_precision():
     return _MIX_PRECISION
 
 
+# Recompute-from-output ("memory-free") backward of the plain coupling layers (invertibility of the reference's
+# flowAffine.py:85-109 / flowLSTMBlock.py:323-361).  Off by default: it trades time for capacity.
+_RECOMPUTE = [bool(os.environ.get("TMG_RECOMPUTE"))]
+
+
+def set_recompute(on):
+    """True: the level nodes of the narrow flow levels (C <= 32, generative direction) keep NO per-layer activations - backward rebuilds
+    every layer's input from its output (inverse channel mix -> coupling network -> x2 = (y2 + shift) e^{sg}) - so that a 10-step BPTT
+    window's memory is no longer ~2 C + 4 floats per pixel, layer and time-step.  Slower per step (one more forward pass through those
+    layers inside backward); same gradients up to fp32 rounding of the reconstruction."""
+    _RECOMPUTE[0] = bool(on)
+
+
+def recompute():
+    return _RECOMPUTE[0]
+
+
 def set_winograd_precision(kind):
     """Arithmetic of the wide Winograd contractions (ConvLSTM gate conv, level-wide conditioning conv, out-conv input gradient):
     "f32" = fp32 MFMA (default); "bf16x3" = the bf16 matrix pipe at fp32 accuracy (tmg_hip.conv_wino_fwd3; opt-in, round 5)."""
@@ -965,6 +982,24 @@ class LevelCouplingFn(torch.autograd.Function):
     """
 
     @staticmethod
+    def _cond_parts(cond, Wzc, Wdc, NL, NLp, C):
+        """The conditioning map's share of all NL zero convs (Hc) and of the 2 NL growth layers (Dc; dc_of(k) = layer k's two addends)."""
+        B, Hh, Ww, _ = cond.shape
+        dev = cond.device
+        Hc = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)
+        H.conv3x3_auto([cond], Wzc, NL * C, [Hc], relu_in=True, pad_rep=True)
+        Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
+        H.conv_fwd([cond], H.conv_pack(Wdc, 0), 2 * NLp, 3, 1, [Dc], relu_in=True)
+        if B * Hh * Ww >= int(os.environ.get("TMG_LAYER_PLANES_MIN", 1 << 17)):
+            # large images: one float2 plane per layer (every layer reads its addends for every pixel - out of the interleaved
+            # tensor that is a full cache line per pixel, more than the growth kernels' real input)
+            Dc = H.layer_planes(Dc)
+            dc_of = lambda k: (Dc[k][..., 0:1], Dc[k][..., 1:2])  # noqa: E731
+        else:
+            dc_of = lambda k: (Dc[..., 2 * k:2 * k + 1], Dc[..., 2 * k + 1:2 * k + 2])  # noqa: E731
+        return Hc, Dc, dc_of
+
+    @staticmethod
     def forward(ctx, x, cond, Wm, bm, reverse, *wts):
         NL = len(wts) // 5
         x = x if x.stride(3) == 1 else x.contiguous()
@@ -983,17 +1018,7 @@ class LevelCouplingFn(torch.autograd.Function):
         Wdc = zeros((2 * NLp, Cc, 3, 3), dev)
         Wdc.view(NLp, 2, Cc, 3, 3)[:NL, 0] = torch.stack(w1s)[:, 0, ch:cin]
         Wdc.view(NLp, 2, Cc, 3, 3)[:NL, 1] = torch.stack(w2s)[:, 0, ch:cin]
-        Hc = torch.empty((B, Hh, Ww, NL * C), device=dev, dtype=torch.float32)
-        H.conv3x3_auto([cond], Wzc, NL * C, [Hc], relu_in=True, pad_rep=True)
-        Dc = torch.empty((B, Hh, Ww, 2 * NLp), device=dev, dtype=torch.float32)
-        H.conv_fwd([cond], H.conv_pack(Wdc, 0), 2 * NLp, 3, 1, [Dc], relu_in=True)
-        if B * Hh * Ww >= int(os.environ.get("TMG_LAYER_PLANES_MIN", 1 << 17)):
-            # large images: one float2 plane per layer (every layer reads its addends for every pixel - out of the interleaved
-            # tensor that is a full cache line per pixel, more than the growth kernels' real input)
-            Dc = H.layer_planes(Dc)
-            dc_of = lambda k: (Dc[k][..., 0:1], Dc[k][..., 1:2])  # noqa: E731
-        else:
-            dc_of = lambda k: (Dc[..., 2 * k:2 * k + 1], Dc[..., 2 * k + 1:2 * k + 2])  # noqa: E731
+        Hc, Dc, dc_of = LevelCouplingFn._cond_parts(cond, Wzc, Wdc, NL, NLp, C)
         logdet = zeros(B, dev)
         # operand packing of every layer's weights in two launches per level instead of two per layer
         PZ = H.conv_pack_batched(Wz, 0, ch + 4, (ch + 2, ch, Cc))
@@ -1013,6 +1038,9 @@ class LevelCouplingFn(torch.autograd.Function):
         split = fuse and reverse and C in (16, 32) and os.environ.get("TMG_NO_SPLIT_HALVES") is None
         mixaff = (reverse and C in (64, 128) and _MIX_PRECISION == "f32" and Wm.is_contiguous() and bm.is_contiguous()
                   and os.environ.get("TMG_NO_MIX_AFFINE") is None)
+        # Recompute mode (set_recompute; narrow levels, generative direction - where ~80 % of the per-layer activations of the model
+        # live): nothing per layer is kept; backward rebuilds layer k's input from its output (see there)
+        rec = _RECOMPUTE[0] and fuse and reverse and C <= 64
         for k in (range(NL - 1, -1, -1) if reverse else range(NL)):
             xin = cur
             if fuse:
@@ -1031,7 +1059,8 @@ class LevelCouplingFn(torch.autograd.Function):
                 assert ok
                 cur = out
                 # the coupling output y: reverse -> (x1 of the input, y2) as two segments (never materialised), forward -> out
-                saved[k] = (xin, tin, D, r, [t1, y2] if reverse else out)
+                if not rec:
+                    saved[k] = (xin, tin, D, r, [t1, y2] if reverse else out)
                 continue
             tin = cur if reverse else _mix_fwd(cur, Wm[k], bm[k], PM[k])
             x1 = tin[..., :ch]
@@ -1063,6 +1092,7 @@ class LevelCouplingFn(torch.autograd.Function):
         # instead of save_for_backward; the node hands out a VIEW of its last buffer, so the returned tensor (which owns the
         # grad_fn -> ctx reference) is not itself an element of `saved`: no reference cycle when backward never runs
         ctx.saved = saved
+        ctx.rec_out = cur if rec else None      # (recompute mode: the node's own output buffer is all that backward starts from)
         ctx.fuse = fuse
         ctx.split = split
         ctx.meta = (NL, NLp, reverse, ch, Cc)
@@ -1116,9 +1146,33 @@ class LevelCouplingFn(torch.autograd.Function):
         PMt = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 1)
         wg_in = [None] * NL
         mix_wg = [None] * NL if grouped else None   # (input, upstream gradient) of every layer's 1x1 mix
+        rec_out = ctx.rec_out
+        ctx.rec_out = None
+        if rec_out is not None:
+            # Recompute mode: the generative layer k maps tin = [x1 | x2] to out = Wm_k [x1; y2] + bm_k with y2 = x2 e^{-sg} - shift and
+            # (shift, sg) functions of x1 and the conditioning map alone (flowAffine.py:102-109, glowConv.py:207-222).  So from out:
+            #   [x1; y2] = Wm_k^-1 (out - bm_k)                       one 1x1 mix with the inverse (tmg_mat_inverse: fp64, rounded once)
+            #   D        = growth layers of x1                         tmg_c1x2_fwd, as in the forward pass
+            #   x2       = (y2 + shift) e^{sg},  r                     tmg_coupling_fwd in its density-direction form, no trailing mix
+            # and the layer's input is the previous layer's output.  The conditioning shares Hc / Dc of the level are evaluated again.
+            Hc_r, Dc_r, dc_of_r = LevelCouplingFn._cond_parts(cond, Wzc, Wdc, NL, NLp, C)
+            Winv, binv = H.mat_inverse(Wm, bm)
+            ld_dummy = zeros(B, dev)
         for k in (range(NL) if reverse else range(NL - 1, -1, -1)):
-            xin, tin, D, r, y = saved[k]
-            saved[k] = None
+            if rec_out is not None:
+                u = _mix_fwd(rec_out, Winv[k], binv[k])
+                t1 = u[..., :ch]
+                D = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
+                H.c1x2_fwd([t1], w1s[k], w2s[k], D, w_rows=ch, w2_d1_row=ch + Cc, add1=dc_of_r(k)[0], add2=dc_of_r(k)[1])
+                tin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)
+                r = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
+                ok = H.coupling_fwd(u, tin, r, None, D, Hc_r[..., k * C:(k + 1) * C], wzs[k], bzs[k], kps[k], None, None, ld_dummy, False, ch + Cc)
+                assert ok
+                xin, y = tin, [t1, u[..., ch:]]
+                rec_out = tin
+            else:
+                xin, tin, D, r, y = saved[k]
+                saved[k] = None
             if reverse and ctx.fuse and os.environ.get("TMG_NO_FUSED_COUPLING_BWD") is None:
                 # one launch: mix input gradient -> coupling backward -> zero-conv input gradient (exact replicate adjoint)
                 if ctx.split and k != NL - 1:    # gradient w.r.t. a layer input that lives as two halves: the same layout

@@ -321,6 +321,10 @@ int tmg_coupling_bwd_halves(const void* dout1, const void* dout2, const void* x2
  * W^T (the input gradient of the same mix).  C % 4 == 0, C <= 256. */
 int tmg_mix_f16(const void* x, const int64_t* x_d, const void* W, const void* bias, void* y, const int64_t* y_d, const int64_t* dims,
                 tmg_stream_t st);
+/* Inverses of K folded channel mixes [K][C][C] (and binv = -Winv b) in FP64, rounded once: the recompute-from-output backward of the
+ * plain coupling layers rebuilds a layer's input from its output, out = Wm [x1; y2] + bm (glowConv.py:207-222 with actNorm.py:71-85
+ * folded in; the reference's own forward-direction matrix, glowConv.py:164-174, is NOT this inverse).  dims = {K, C}; C <= 64. */
+int tmg_mat_inverse(const void* W, const void* b, void* Winv, void* binv, const int64_t* dims, tmg_stream_t st);
 /* The trainer's optimizer step (main.py:78: Adam, weight decay 1e-8, amsgrad) for all parameters in one launch.  tab: device int64 [n][5] =
  * pointers (param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq); chunks: device int32 [nchunks][3] = (tensor, first element, elements <= 4096);
  * dims = {nchunks, amsgrad}; fl = {lr, beta1, beta2, eps, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t), 1 - beta1, 1 - beta2}.  Arithmetic and order of

@@ -1481,6 +1481,109 @@ def test_bptt_window_at_stated_batch_matches_oracle():
                    tensor_tol=max(C.GRAD_TENSOR_REL_MAX, GRAD_YARDSTICK * fl[1]), kink=r64["kink"])
 
 
+@pytest.mark.parametrize("cin,hw,B", [(4, (64, 64), 8), (8, (17, 33), 4), (3, (30, 30), 4), (16, (16, 16), 8)])
+def test_recompute_backward_matches_stored_activations_level(cin, hw, B):
+    """tmg_ops.set_recompute (round 5): the level node of a narrow flow level keeps NO per-layer activations and its backward rebuilds
+    every layer's input from its output (inverse channel mix -> growth layers -> x2 = (y2 + shift) e^{sg}; flowAffine.py:85-109,
+    flowLSTMBlock.py:323-361) - same forward values bit for bit, gradients within the strict path-vs-path bounds; C = 8, 16, the
+    zero-padded 12 and 32; the 64-channel level (cin = 16 -> C = 64 is not on the fused path) keeps its activations: identical."""
+    import tmg_ops as ops
+    from nn.modules.flowLSTMBlock import LSTMFLowBlock
+    hs, ws = hw
+    C.seed_all(cin * 13 + B)
+    blk = LSTMFLowBlock(cin, 32, 64, 6, LUdecompose=True, train_sampling=True, do_split=True, squeeze_type=0)
+    C.perturb_(blk, 5, 0.02, 0.05, 0.02)
+    blk.to(DEV)
+    g = torch.Generator().manual_seed(21)
+    z, eps = (torch.randn(B, 2 * cin, hs, ws, generator=g).to(DEV) for _ in range(2))
+    cond = torch.randn(B, 32, hs, ws, generator=g).to(DEV)
+    hst, cst = (torch.randn(B, 64, hs, ws, generator=g).to(DEV) for _ in range(2))
+    res = {}
+    try:
+        for tag in ("stored", "recompute"):
+            ops.set_recompute(tag == "recompute")
+            blk.zero_grad()
+            zi, ci, hi, cc = (t.clone().requires_grad_(True) for t in (z, cond, hst, cst))
+            xr, ldr, st = blk.reverse(zi, ci, (hi, cc), eps=eps)
+            ((xr[:2] ** 2).sum() * 0.5 + ldr[:2].sum() * 0.02 + (st[0][:2] ** 2).sum() * 0.1).backward()
+            gr = {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None}
+            gr.update({"@dz": zi.grad.clone(), "@dcond": ci.grad.clone(), "@dh": hi.grad.clone(), "@dc": cc.grad.clone()})
+            res[tag] = (xr.detach(), ldr.detach(), gr)
+    finally:
+        ops.set_recompute(False)
+    a, b = res["recompute"], res["stored"]
+    assert torch.equal(a[0], b[0])          # the forward pass is the same launches (the log-det sums are float atomics: last bits vary)
+    C.assert_logdet(a[1], b[1], rtol=2e-6, atol=1e-3)
+    C.assert_grads(a[2], b[2], "recompute vs stored activations", global_tol=2e-4, tensor_tol=5e-3)
+
+
+@pytest.mark.parametrize("case", ["tiny", "tiny3", "M64"])
+def test_recompute_mode_whole_model(case):
+    """The whole model in recompute mode against the default path: generative direction (reconstruct with fixed latents) + loss +
+    backward; tiny / tiny3 from the reference fixtures, and the metric configuration at its stated batch 64, where the mode's point -
+    the activation memory of a step - is asserted as well."""
+    import tmg_ops as ops
+    from nn.tmGlow import TMGlow
+    if case == "M64":
+        cfg, B = C.CFG_M, 64
+        C.seed_all(12345)
+        m = TMGlow(**C.build_kwargs(cfg))
+        C.perturb_(m, 7, *C.perturb_scales(cfg))
+        m.to(DEV).train()
+        g = torch.Generator().manual_seed(3)
+        Hin, Win = cfg["_in_hw"]
+        x = torch.randn(B, cfg["in_features"], Hin, Win, generator=g).to(DEV)
+        yt = torch.randn(B, cfg["out_features"], Hin * cfg["_up"], Win * cfg["_up"], generator=g).to(DEV)
+        st = m.initLSTMStates(torch.arange(B), [Hin * cfg["_up"], Win * cfg["_up"]])
+        with torch.no_grad():
+            _, _, _, eps = m.forward(x, yt, st, return_eps=True)
+        eps = [e.detach() for e in eps]
+        del yt
+    else:
+        name, cfg = ("tiny_model.npz", C.CFG_TINY) if case == "tiny" else ("tiny3_model.npz", C.CFG_TINY3)
+        d = C.load_npz(name)
+        L = len(cfg["glow_blocks"])
+        m = _model(cfg, {k: torch.from_numpy(v) for k, v in C.sub(d, "sd.").items()})
+        x = torch.from_numpy(d["x"]).to(DEV)
+        st = C.states_from(d, "h_in.", L, DEV)
+        eps = [torch.from_numpy(d["fwd.eps.%d" % i]).to(DEV) for i in range(L + 1)]
+    res, peak = {}, {}
+    try:
+        for tag in ("stored", "recompute"):
+            ops.set_recompute(tag == "recompute")
+            m.zero_grad()
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            y, ld, _ = m.reconstruct(x, st, eps)
+            held = torch.cuda.memory_allocated() - base          # what the forward pass keeps alive for backward
+            C.loss_reverse(y, ld).backward()
+            torch.cuda.synchronize()
+            peak[tag] = (held / 2 ** 30, (torch.cuda.max_memory_allocated() - base) / 2 ** 30)
+            res[tag] = (y.detach(), ld.detach(), {k: v.clone() for k, v in _grads(m).items()})
+            del y, ld
+    finally:
+        ops.set_recompute(False)
+    a, b = res["recompute"], res["stored"]
+    C.assert_field(a[0], b[0], "y", atol=1e-6, rtol=1e-6)       # (same launches; BatchNorm / log-det sums are float atomics)
+    C.assert_logdet(a[1], b[1], rtol=2e-6, atol=1e-3)
+    ge = _grad_err(a[2], b[2])
+    print("\nrecompute mode, %s: gradients vs the stored-activation path global rel-L2 %.2e, worst tensor %.2e; forward keeps %.2f GB (stored: %.2f), "
+          "peak %.2f GB (stored: %.2f)" % (case, ge[0], ge[1], peak["recompute"][0], peak["stored"][0], peak["recompute"][1], peak["stored"][1]))
+    C.assert_grads(a[2], b[2], "recompute vs stored activations (%s)" % case, global_tol=2e-4, tensor_tol=5e-3)
+    if case == "M64":
+        import json
+        import os
+        out = os.path.join(C.ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "recompute_M_batch64.json"), "w") as f:
+                json.dump({"case": "config M, batch 64, one generative step + backward", "grads_vs_stored_global_rel_l2": ge[0],
+                           "grads_vs_stored_worst_tensor_rel_max": ge[1], "forward_keeps_gb": {k: v[0] for k, v in peak.items()},
+                           "peak_gb": {k: v[1] for k, v in peak.items()}}, f, indent=1)
+        # the plain coupling layers of the 16- and 32-channel levels hold ~3.3 of the ~7 GB a step keeps at this configuration
+        assert peak["recompute"][0] < 0.65 * peak["stored"][0], peak
+
+
 @pytest.mark.parametrize("cin,hw,B", [(8, (32, 32), 8), (16, (12, 20), 4)])
 def test_level_with_bf16x3_winograd_matches_fp32_winograd(cin, hw, B):
     """The opt-in bf16x3 arithmetic of the wide Winograd contractions (tmg_ops.set_winograd_precision: three-way exact bf16 split of

@@ -38,7 +38,13 @@ def main():
     ap.add_argument("--eager", action="store_true", help="windows launched eagerly (capture off); neither flag: the trainer's default - a "
                     "window shape is recorded when it comes round the second time, torch's Adam is adopted as the one-launch HipAdam")
     ap.add_argument("--no-adopt", action="store_true", help="keep torch.optim.Adam's own step (TMG_NO_HIP_ADAM)")
+    ap.add_argument("--config", default="M", choices=["M", "cfg5"], help="M: 256x256 output, 4 levels; cfg5 (BASELINE configs[4]): 512x512x4, 5 levels "
+                    "(implies --noc 4: the window runs through tmg_dist.train_window with bench.py's loss)")
+    ap.add_argument("--recompute", action="store_true", help="tmg_ops.set_recompute(True): the narrow levels keep no per-layer activations, "
+                    "backward rebuilds them from the level outputs (capacity mode)")
     a = ap.parse_args()
+    if a.config == "cfg5":
+        a.noc = 4
     if a.no_adopt:
         os.environ["TMG_NO_HIP_ADAM"] = "1"
 
@@ -52,7 +58,10 @@ def main():
     from nn.trainFlowParallel import TrainFlow
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    cfg = dict(C.CFG_M, in_features=4, out_features=a.noc)   # backward-step trainer: nic = 4 (3 fields + inlet velocity), noc = 3
+    cfg = dict(C.CFG5 if a.config == "cfg5" else C.CFG_M, in_features=4, out_features=a.noc)   # backward-step trainer: nic = 4 (3 fields + inlet velocity), noc = 3
+    if a.recompute:
+        import tmg_ops
+        tmg_ops.set_recompute(True)
     C.seed_all(12345)
     with contextlib.redirect_stdout(sys.stderr):
         model = TMGlow(**C.build_kwargs(cfg))
@@ -88,8 +97,10 @@ def main():
         loss = run()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(json.dumps({"what": "tmg_dist.train_window, %d BPTT window(s) of %d sample() steps, batch %d, config M (256x256x4, L=4, K=16), "
-                          "loss of bench.py summed over the steps, clip, Adam(amsgrad), state re-anchoring" % (a.windows, T, B),
+        print(json.dumps({"what": "tmg_dist.train_window, %d BPTT window(s) of %d sample() steps, batch %d, config %s (%dx%dx4, L=%d, K=16), "
+                          "loss of bench.py summed over the steps, clip, Adam(amsgrad), state re-anchoring" % (
+                              a.windows, T, B, a.config, 2 * h, 2 * w, len(cfg["glow_blocks"])), "recompute": bool(a.recompute),
+                          "reserved_mem_gb": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 2),
                           "seconds_per_window": round(dt / a.windows, 4), "sample_steps_per_s": round(B * T * a.windows / dt, 2),
                           "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2), "loss_sum": float(loss),
                           "warmup": "one untimed call of the same shape", "captured": bool(a.capture)}))
