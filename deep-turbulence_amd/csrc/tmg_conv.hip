@@ -438,6 +438,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
             if (cm + 1 == nchunks) {
                 // epilogue: transposed C/D map: col = lane & 15 (pixel of the m-tile), row = (lane >> 4) * 4 + r (channel)
                 const int b_ = tm_b, oy0_ = tm_y * TH, ox0_ = tm_x * TW;
+                // (opaque copy per epilogue: the channel offsets n0 / nl below are tile-invariant; hoisted out of the stage loop they are
+                // one register per n-tile that the widest instance <4,4,*> - 256 registers - spilled: 8 bytes of scratch per lane)
+                int qe = q;
+                asm volatile("" : "+v"(qe));
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int oy = oy0_ + (mrc[i] >> 16), ox = ox0_ + (mrc[i] & 0xffff);
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                         const unsigned opx = (unsigned)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);  // host: B*H < 2^24, W < 2^24
 #pragma unroll
                         for (int j = 0; j < NTW; ++j) {
-                            const int n0 = (ntile0 + j) * 16 + 4 * q;
+                            const int n0 = (ntile0 + j) * 16 + 4 * qe;
                             if (n0 < p.Cout) {
                                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                                 if (HB) {

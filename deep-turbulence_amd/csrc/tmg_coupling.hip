@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
         TMG_CPL_ORIGIN(TILE)                                                                                        \
         const unsigned img_ = (unsigned)b_ * (unsigned)(p.H * p.W);                                                 \
         _Pragma("unroll") for (int u = 0; u < NPI; ++u) {                                                           \
-            const int i = min(tid + u * 256, NIT - 1);                                                              \
+            const int i = min(tidl + u * 256, NIT - 1);                                                             \
             const int pp = i / K4, s_ = i - pp * K4;                                                                \
             const int py = pp / PW, px = pp - py * PW;                                                              \
             /* replicate padding: clamp the coordinates (flowUtils.py:246) */                                       \
@@ -148,10 +148,17 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
     // image stay in registers until the range moves on to the next image: one atomic per wave and image, not per tile)
     const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t0 = tmg_xcd_block((int)blockIdx.x, (int)gridDim.x, p.xmap) * per, t1 = min(t0 + per, p.ntiles);
+    // The staging items' patch coordinates (i / K4, / PW) depend on the thread alone: left to the compiler they are hoisted out of the
+    // tile loop - NPI items x (LDS offsets, patch row / column) - and, at C = 32 where the weight fragments already hold 114 registers,
+    // spilled (152 bytes per lane, reloaded in every tile's commit).  An opaque copy of the thread index per tile keeps them where
+    // they are used: ~10 integer instructions per item and tile.
+    int tidl = tid;
     if (t0 < t1) TMG_CPL_ISSUE(t0)
     int par = 0, ldb = -1;
     float ldacc = 0.f;
     for (int tile = t0; tile < t1; ++tile, par ^= 1) {
+        // (C <= 16: no spill to cure, and the recomputed arithmetic measured +3.5 % on the first level's launch - not applied there)
+        if (CT == 2) asm volatile("" : "+v"(tidl));
         TMG_CPL_ORIGIN(tile)
         const int b = b_, oy0 = oy0_, ox0 = ox0_;
         const unsigned img = (unsigned)b * (unsigned)(p.H * p.W);
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void cpl_fwd_kernel(CplFP p) 
         // ---- commit the staged registers: relu(x1 | d1, d2) on the patch, raw x1 of the tile -------------------------------
 #pragma unroll
         for (int u = 0; u < NPI; ++u) {
-            const int i = tid + u * 256;
+            const int i = tidl + u * 256;
             if (i < NIT) {
                 const int pp = i / K4, s = i - pp * K4;
                 const int py = pp / PW, px = pp - py * PW;
@@ -454,6 +461,12 @@ __global__ __launch_bounds__(256, CT == 1 ? 2 : 2) void cpl_bwd_kernel(CplBP p) 
     const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t0 = tmg_xcd_block((int)blockIdx.x, (int)gridDim.x, p.xmap) * per, t1 = min(t0 + per, p.ntiles);
     for (int tile = t0; tile < t1; ++tile) {
+        // lane coordinates re-derived from an opaque copy of the thread index per tile: the index arithmetic built on them is
+        // tile-invariant, the compiler hoists it out of the loop and - at C = 32, where the weight fragments hold 160 registers - spills
+        // it (40 bytes per lane, reloaded in every tile); recomputing it costs a handful of integer instructions per tile
+        int tidl = tid;
+        asm volatile("" : "+v"(tidl));
+        const int lane = tidl & 63, wave = tidl >> 6, li = lane & 15, q = lane >> 4;
         int t_ = tile;
         const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
         const int ty = t_ % p.tiles_y;

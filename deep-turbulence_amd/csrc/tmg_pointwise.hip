@@ -1254,6 +1254,10 @@ __global__ __launch_bounds__(256, NQ <= 2 ? 4 : 3) void dense2_bwd_lean_kernel(D
         const int ty = t % p.tiles_y;
         const int b = t / p.tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
+        // (an opaque copy of the thread index per tile: the staging items' patch coordinates i / QW, i / PW are tile-invariant, hoisted
+        // out of the loop and - with four blocks per CU, 128 registers - one of them spilled: 8 bytes of scratch per lane)
+        int tidl = tid;
+        asm volatile("" : "+v"(tidl));
         __syncthreads();
         const int oy = oy0 + row, ox = ox0 + col;
         const bool own = oy < p.Hin && ox < p.Win;
@@ -1263,7 +1267,7 @@ __global__ __launch_bounds__(256, NQ <= 2 ? 4 : 3) void dense2_bwd_lean_kernel(D
         bool a2in[2], a1in[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * 256;
+            const int i = tidl + u * 256;
             {
                 const int py = i / QW, px = i - py * QW;
                 const int y = oy0 - 2 + py, x = ox0 - 2 + px;
@@ -1291,13 +1295,13 @@ __global__ __launch_bounds__(256, NQ <= 2 ? 4 : 3) void dense2_bwd_lean_kernel(D
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * 256;
+            const int i = tidl + u * 256;
             if (i < QH * QW) A2[i] = (a2in[u] && a2d[u] > 0.f) ? a2g[u] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * 256;
+            const int i = tidl + u * 256;
             if (i < PH * PW) {
                 const int py = i / PW, px = i - py * PW;
                 float v = 0.f;

@@ -756,13 +756,17 @@ __global__ __launch_bounds__(512, 1) void wino_fwd3_kernel(WinoP p) {
                 const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
                 const int ty_ = t_ % p.tiles_y;
                 const int b_ = t_ / p.tiles_y;
+                // (opaque copies per epilogue: the tile-invariant output offsets built on them are otherwise hoisted out of the stage loop
+                // and spilled at two n-tiles per wave)
+                int lie = li, qe = q;
+                asm volatile("" : "+v"(lie), "+v"(qe));
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int wt = 16 * m + li;
+                    const int wt = 16 * m + lie;
                     const int oyb = ty_ * TH + 2 * (wt >> 3), oxb = tx_ * TW + 2 * (wt & 7);
 #pragma unroll
                     for (int n = 0; n < NPW; ++n) {
-                        const int n0 = (ntile0 + n) * 16 + 4 * q;
+                        const int n0 = (ntile0 + n) * 16 + 4 * qe;
                         if (ntile0 + n < ntt && n0 < p.Cout) {
                             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
