@@ -822,6 +822,8 @@ extern "C" int tmg_conv_wino_fwd3(const void* const* in_ptrs, const int64_t* in_
     p.B = (int)dims[0]; p.Hin = (int)dims[1]; p.Win = (int)dims[2]; p.Cin = (int)dims[3]; p.Cout = (int)dims[4];
     p.relu_in = (int)dims[5]; p.pad_rep = (int)dims[6];
     if (csum != p.Cin || osum != p.Cout) return -3;
+    // (FEW output channels - the input-gradient shapes 256 -> 40, 240 -> 32 .. of wino_nn_kernel - were measured on this kernel with
+    // three of eight waves live: 0.47-0.69x of wino_nn_kernel, the per-chunk transform / staging / barriers of 8-60 chunks dominate)
     if ((p.Cout & 3) || (p.Cin & 3) || p.Cout < 64) ok = false;
     if (bias && (((uintptr_t)bias) & 15)) ok = false;
     if (!ok) return -100;

@@ -64,9 +64,15 @@ for B, Hh, Ww, K, N in [(64, 128, 128, 256, 40), (64, 128, 128, 240, 32), (64, 6
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / n
-    tw = t(lambda: H.conv_wino_narrow([x], U, N, [out]))
+    U3 = H.conv_wino_pack3(w, 1)
+    tws, t3s = [], []
+    for _ in range(3):
+        tws.append(t(lambda: H.conv_wino_narrow([x], U, N, [out])))
+        t3s.append(t(lambda: H.conv_wino_fwd3([x], U3, N, [out])) if N >= 64 else float("nan"))
+    tw, t3 = sorted(tws)[1], sorted(t3s)[1]
     td = t(lambda: H.conv_fwd([x], Wp, N, 3, 1, [out]))
-    print("%4dx%-4d %4d -> %4d   winograd %7.3f ms (%6.1f TF)   direct %7.3f ms (%6.1f TF)" % (Hh, Ww, K, N, tw, fl / tw / 1e9, td, fl / td / 1e9))
+    print("%4dx%-4d %4d -> %4d   winograd (few-output kernel, fp32) %7.3f ms (%6.1f TF)   bf16x3 wide kernel %7.3f ms (%6.1f TF, %.2fx)   direct %7.3f ms (%6.1f TF)" % (
+        Hh, Ww, K, N, tw, fl / tw / 1e9, t3, fl / t3 / 1e9, tw / t3, td, fl / td / 1e9))
 
 print("weight gradients:")
 for B, Hh, Ww, segs, Cout in [(64, 128, 128, [8, 32, 64], 256), (64, 128, 128, [32], 240), (64, 64, 64, [16, 32, 64], 256), (64, 64, 64, [32], 480),
