@@ -153,6 +153,27 @@ __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int i
 // Zero-filled global memory: lanes of a load batch that have nothing to read point here, so the batch has no control flow.
 static __device__ float tmg_zero_page[64];
 
+// Loads through pointers the compiler cannot prove global - pointers that arrive as integers in a device table (the grouped launches'
+// segment tables), and everything selected against them - are emitted as flat_load: those tick the LDS counter as well as the memory
+// counter, and since LDS and memory return out of order every later wait for an LDS read becomes lgkmcnt(0) INCLUDING the outstanding
+// flat loads - a prefetched tile is then waited for at the first fragment read of the current one (round 5: found in every
+// wino_wgrad_kernel and conv_wgrad_kernel<..,true> instance).  These helpers state the address space.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef TMG_FLAT_LOADS      // (A/B builds only: the generic loads of rounds 1-4)
+#define TMG_GAS
+#else
+#define TMG_GAS __attribute__((address_space(1)))
+#endif
+__device__ __forceinline__ float4 tmg_ldg4(const float* p) {
+    const f32x4 v = *(const TMG_GAS f32x4*)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float2 tmg_ldg2(const float* p) {
+    const f32x2 v = *(const TMG_GAS f32x2*)p;
+    return make_float2(v[0], v[1]);
+}
+__device__ __forceinline__ float tmg_ldg1(const float* p) { return *(const TMG_GAS float*)p; }
+
 // ---- XCD-aware tile order (speed only, never correctness) --------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2: MI355X_MICROARCH.md, Workgroup dispatch), so with
 // tile = blockIdx.x neighbouring tiles of an image always sit on DIFFERENT L2s and every halo line is fetched from the fabric

@@ -782,7 +782,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
             const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);                                              \
             const int elem = (int)__umul24(__umul24(iyc, p.Win) + ixc, tss) + tbv_;                               \
             const float* a_ = (oob || !pcv || ppix0 + u * pstep >= PHPW) ? g_tmg_zero_page : tptr + elem;             \
-            pv[u] = *reinterpret_cast<const float4*>(a_);                                                         \
+            pv[u] = tmg_ldg4(a_);   /* (table-derived pointers: see tmg_ldg4) */                                  \
             if (p.in_scale) oobm |= (oob ? 1u : 0u) << u;                                                         \
         }                                                                                                         \
         const int tbd_ = b_ * p.Hout * p.Wout * dss;                                                              \
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(WgradP p) {
             const bool inb = oy < p.Hout && ox < p.Wout && m < MPIX;                                              \
             const int elem = (int)__umul24(__umul24(oy, p.Wout) + ox, dss) + tbd_;                                \
             const float* a_ = inb ? dptr + elem : g_tmg_zero_page;                                                    \
-            dv[u] = *reinterpret_cast<const float4*>(a_);                                                         \
+            dv[u] = tmg_ldg4(a_);                                                                                 \
         }                                                                                                         \
     }
 #define TMG_WG_COMMIT_F(BW)                                                                                       \

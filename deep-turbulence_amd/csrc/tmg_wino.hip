@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
             const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1);                             \
             const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);                                                  \
             const float* a_ = (oob || xpix0 + u * xstep >= PP) ? tmg_zero_page : xptr + (size_t)(ib + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)xss; \
-            xv[u] = *reinterpret_cast<const float4*>(a_);                                                             \
+            xv[u] = tmg_ldg4(a_);      /* (the pointer may come from the grouped launch's table: see tmg_ldg4) */        \
         }                                                                                                             \
         _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                              \
             const int m = dpix0 + u * dstep;                                                                          \
