@@ -1119,7 +1119,8 @@ struct PackJob {
     const float* w; float* wpk;
     int Cout, Cin, ntaps, Kpad, Npad, mode, cvalid, csplit, cgap;
 };
-struct PackJobs { PackJob j[16]; };
+constexpr int TMG_PACK_JOBS = 48;     // 56 bytes each: 2.7 KB of kernel arguments
+struct PackJobs { PackJob j[TMG_PACK_JOBS]; };
 
 __global__ void conv_pack_many_kernel(PackJobs J) {
     const PackJob& jb = J.j[blockIdx.y];
@@ -1636,10 +1637,10 @@ extern "C" int tmg_conv_pack_batched(const void* w, void* wpk, int64_t nbatch, i
 // {Cout, Cin, cin_eff, ksize, mode, cvalid, csplit, cgap} with the meaning of tmg_conv_pack_map (cvalid = Cin, csplit = INT_MAX, cgap = 0:
 // the identity map of tmg_conv_pack).
 extern "C" int tmg_conv_pack_many(const void* const* w, void* const* wpk, const int64_t* jobs, int64_t njobs, hipStream_t st) {
-    if (njobs < 1 || njobs > 16) return -3;
+    if (njobs < 1 || njobs > TMG_PACK_JOBS) return -3;
     PackJobs J;
     size_t maxtot = 0;
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < TMG_PACK_JOBS; ++i) {
         const int s_ = i < (int)njobs ? i : 0;     // unused slots repeat job 0 (never selected: gridDim.y = njobs)
         const int64_t* d = jobs + 8 * s_;
         const int Cout = (int)d[0], Cin = (int)d[1], ce = (int)d[2], ks = (int)d[3], mode = (int)d[4];

@@ -11,6 +11,7 @@ descriptor the library expects.
 """
 import ctypes
 import os
+import weakref
 import subprocess
 
 import torch
@@ -207,10 +208,62 @@ def _i64(*v):
 # ------------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------------
+# Bumped by code that rewrites parameter memory behind torch's version counters (tmg_optim.HipAdam, tmg_dist.broadcast_parameters,
+# tmg_ops.invalidate_derived); tmg_ops.PARAM_GENERATION is this list.
+PARAM_GENERATION = [0]
+
+
+class _PackPlan:
+    """The packed MFMA operands of the model's PARAMETERS, all re-packed by a few launches per parameter update instead of one
+    launch per conv and pass (round 5: 67 tmg_conv_pack launches of ~4.6 us per training step, 670 per eager BPTT window).  The plan
+    learns which (parameter, mode, cin_eff, cmap) operands the model asks for; the first request that finds its operand stale - the
+    parameter's memory, torch version counter or PARAM_GENERATION moved - re-packs EVERY known operand whose parameter moved
+    (tmg_conv_pack_many, 48 jobs per launch), later requests of the same parameter state are dictionary look-ups.  Only nn.Parameter
+    objects take part (identity + weak reference): temporaries derived from parameters have no version to check and are packed per call
+    as before.  While a hipGraph is being recorded the plan is bypassed (the recorded pass must re-pack at every replay)."""
+
+    def __init__(self):
+        self.jobs = {}
+
+    @staticmethod
+    def _state(w):
+        return (w.data_ptr(), w._version, PARAM_GENERATION[0], w.device)
+
+    def get(self, w, mode, cin_eff, cmap):
+        key = (id(w), int(mode), int(cin_eff), cmap)
+        e = self.jobs.get(key)
+        st = self._state(w)
+        if e is not None and e["ref"]() is w and e["state"] == st:
+            return e["out"]
+        self.jobs[key] = {"ref": weakref.ref(w), "state": None, "out": None, "spec": (int(mode), int(cin_eff), cmap)}
+        self._repack(w.device)
+        return self.jobs[key]["out"]
+
+    def _repack(self, device):
+        todo = []
+        for k in list(self.jobs):
+            e = self.jobs[k]
+            w = e["ref"]()
+            if w is None:
+                del self.jobs[k]
+            elif w.device == device and e["state"] != self._state(w):
+                todo.append((e, w))
+        outs = conv_pack_many([(w,) + e["spec"] for e, w in todo])
+        for (e, w), o in zip(todo, outs):
+            e["out"], e["state"] = o, self._state(w)
+
+
+_PACK_PLAN = _PackPlan()
+
+
 def conv_pack(w, mode, cin_eff=0, cmap=None):
     """w: torch layout [Cout, Cin, k, k] -> packed MFMA operand (see tmg_conv_pack); cin_eff > Cin zero-extends the
-    input-channel dimension.  cmap = (cvalid, csplit, cgap) selects / re-maps source channels (tmg_conv_pack_map)."""
+    input-channel dimension.  cmap = (cvalid, csplit, cgap) selects / re-maps source channels (tmg_conv_pack_map).  Parameters go
+    through the pack plan (_PackPlan: the returned tensor is shared by every request of the same parameter state - read-only)."""
     check_act(w)
+    if (isinstance(w, torch.nn.Parameter) and w.is_contiguous() and os.environ.get("TMG_NO_PACK_PLAN") is None
+            and not torch.cuda.is_current_stream_capturing()):
+        return _PACK_PLAN.get(w, mode, cin_eff, tuple(int(v) for v in cmap) if cmap is not None else None)
     w = w.contiguous()
     Cout, Cin, k, _ = w.shape
     if cmap is not None:
@@ -230,11 +283,11 @@ def conv_pack(w, mode, cin_eff=0, cmap=None):
 
 
 def conv_pack_many(jobs):
-    """jobs: list of (w, mode) or (w, mode, cin_eff, cmap) as conv_pack takes them -> list of packed operands, <= 16 jobs per launch
-    (tmg_conv_pack_many).  All operands of a call live in one allocation."""
+    """jobs: list of (w, mode) or (w, mode, cin_eff, cmap) as conv_pack takes them -> list of packed operands, <= 48 jobs per launch
+    (tmg_conv_pack_many).  All operands of a launch live in one allocation."""
     outs = []
-    for g0 in range(0, len(jobs), 16):
-        grp = [tuple(j) + (0, None)[len(j) - 2:] for j in jobs[g0:g0 + 16]]
+    for g0 in range(0, len(jobs), 48):
+        grp = [tuple(j) + (0, None)[len(j) - 2:] for j in jobs[g0:g0 + 48]]
         desc, sizes, ws = [], [], []
         for w, mode, cin_eff, cmap in grp:
             check_act(w)

@@ -71,7 +71,7 @@ def zeros_like(t):
 
 # Bumped by every writer of parameter memory that torch's version counters do not see (tmg_optim.HipAdam updates the parameters
 # from a kernel launched through ctypes): part of the key of every value derived from parameters (DerivedCache).
-PARAM_GENERATION = [0]
+PARAM_GENERATION = H.PARAM_GENERATION      # (one list object: tmg_hip's pack plan keys on it too)
 
 
 class DerivedCache:

@@ -254,7 +254,7 @@ int tmg_dkappa(const void* w, const void* dw, int64_t nw, const void* b, const v
 int tmg_conv_pack_batched(const void* w, void* wpk, int64_t nbatch, int64_t Cout, int64_t Cin, int64_t cin_eff, int64_t ksize,
                           int64_t mode, const int64_t* map, tmg_stream_t st);
 
-/* njobs <= 16 independent packing jobs (different tensors, shapes, modes) in one launch: w[i] / wpk[i] = source / destination of job
+/* njobs <= 48 independent packing jobs (different tensors, shapes, modes) in one launch: w[i] / wpk[i] = source / destination of job
  * i, jobs = njobs x {Cout, Cin, cin_eff, ksize, mode, cvalid, csplit, cgap} as tmg_conv_pack_map (identity map: cvalid = Cin,
  * csplit = INT_MAX, cgap = 0).  The forward and input-gradient operands of all layers of a dense block (denseBlock.py:69-100). */
 int tmg_conv_pack_many(const void* const* w, void* const* wpk, const int64_t* jobs, int64_t njobs, tmg_stream_t st);

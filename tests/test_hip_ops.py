@@ -820,6 +820,74 @@ def test_thin_grouped_weight_gradient(shape):
         _close(res["thin"][k], w.grad, tol=2e-5, what="group %d vs fp64" % k)
 
 
+def test_pack_plan_repacks_every_parameter_operand_once_per_update():
+    """tmg_hip._PackPlan (round 5): the packed operands of PARAMETERS are re-packed by one tmg_conv_pack_many launch per parameter
+    update instead of one launch per request - values identical to the per-call pack, stale after an in-place update (torch version
+    counter), after a write behind torch's back that bumps PARAM_GENERATION, after the storage moved; temporaries and hipGraph
+    recording are not cached; dead parameters are dropped."""
+    import gc
+    import tmg_hip as H
+    plan = H._PACK_PLAN
+    plan.jobs.clear()
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.nn.Parameter(torch.randn(co, ci, k, k, generator=g).to(DEV)) for co, ci, k in ((16, 8, 3), (40, 20, 3), (32, 32, 1), (7, 10, 3))]
+    specs = [(0, 0, None), (1, 0, None), (0, 24, None), (1, 12, (6, 4, 4))]      # (the last: 4 leading + 2 trailing of 10 source channels)
+    calls = {"many": 0}
+    real_many = H.conv_pack_many
+
+    def counting_many(jobs):
+        calls["many"] += 1
+        return real_many(jobs)
+    H.conv_pack_many = counting_many
+    try:
+        def request_all():
+            return [H.conv_pack(w, m, ce, cm) for w, (m, ce, cm) in zip(ws, specs)]
+
+        def plain_all():
+            return [H.conv_pack(w.detach().clone(), m, ce, cm) for w, (m, ce, cm) in zip(ws, specs)]     # (temporaries: never cached)
+        first = request_all()
+        n_learn = calls["many"]
+        assert n_learn == len(ws) and len(plan.jobs) == len(ws)          # learning pass: one launch per new operand
+        for a, b in zip(first, plain_all()):
+            assert torch.equal(a, b)
+        again = request_all()
+        assert calls["many"] == n_learn and all(a is b for a, b in zip(first, again))       # unchanged parameters: look-ups
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5)                                              # what torch.optim does: version counters move
+        upd = request_all()
+        assert calls["many"] == n_learn + 1, "one launch re-packs every stale operand"
+        for a, b, old in zip(upd, plain_all(), first):
+            assert torch.equal(a, b) and not torch.equal(a, old)
+        ws[1].data.mul_(2.0)                                             # behind torch's back: needs the generation bump
+        assert H.conv_pack(ws[1], *specs[1]) is upd[1]
+        H.PARAM_GENERATION[0] += 1
+        upd2 = request_all()
+        assert calls["many"] == n_learn + 2
+        for a, b in zip(upd2, plain_all()):
+            assert torch.equal(a, b)
+        ws[0].data = ws[0].data.clone()                                  # storage moved
+        assert torch.equal(H.conv_pack(ws[0], *specs[0]), upd2[0]) and calls["many"] == n_learn + 3
+        # a hipGraph recording bypasses the plan
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            rec = H.conv_pack(ws[2], *specs[2])
+        assert rec is not upd2[2]
+        gph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rec, upd2[2])
+        # dead parameters leave the plan at the next re-pack
+        del ws[3], first, again, upd, upd2, w
+        gc.collect()
+        with torch.no_grad():
+            ws[0].add_(1.0)
+        H.conv_pack(ws[0], *specs[0])
+        assert len(plan.jobs) == 3
+    finally:
+        H.conv_pack_many = real_many
+        plan.jobs.clear()
+
+
 @pytest.mark.parametrize("shape", [(3, 2, 16, 16, 8, False), (15, 1, 20, 35, 8, True), (4, 2, 33, 17, 8, True), (5, 1, 16, 32, 8, False),
                                    (2, 3, 8, 16, 8, True), (2, 1, 7, 5, 8, False), (16, 2, 24, 48, 8, True)])
 def test_level_weight_gradients_in_one_launch(shape):
