@@ -231,7 +231,9 @@ class bptt_window:
 
 class fused_grad_accumulation:
     """Context for ONE backward pass (wrap `loss.backward()`): see _GradSink.  Not re-entrant; gradients reach `p.grad` on exit, i.e.
-    before the gradient exchange / clipping / optimizer step.  Post-accumulate-grad hooks of the deferred parameters do not fire."""
+    before the gradient exchange / clipping / optimizer step.  Post-accumulate-grad hooks of the deferred parameters do not fire.
+    The sink is process-wide (autograd evaluates the nodes on its own device thread, so a thread-local would not reach them): one
+    training loop per process - the design's one process per GPU."""
 
     def __enter__(self):
         if _GradSink.active is not None:
