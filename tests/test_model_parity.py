@@ -418,6 +418,18 @@ def test_stated_batches_match_oracle_with_gradients(name, cfg, B, n):
     _stated_batch_case(name, cfg, B, n=n, density=(name == "M"))
 
 
+def test_metric_configuration_with_bf16x3_winograd_matches_oracle():
+    """The metric configuration at its stated batch (64) with the opt-in bf16x3 arithmetic of the wide Winograd contractions
+    (tmg_ops.set_winograd_precision: six bf16 MFMAs per accumulator tile on an exact three-way split of both fp32 operands) against the
+    fp64 oracle with every parameter gradient - _stated_batch_case with the bounds of the fp32-MFMA path, unchanged."""
+    import tmg_ops as ops
+    try:
+        ops.set_winograd_precision("bf16x3")
+        _stated_batch_case("M_wino_bf16x3", C.CFG_M, 64, n=2, density=False)
+    finally:
+        ops.set_winograd_precision("f32")
+
+
 def test_cfg5_full_size_properties():
     """BASELINE configs[4] at its full field (512x512x4 output, five flow levels, default widths), batch 1, with the fp16-input
     1x1 mixes that configuration names AND with the fp32 mixes: (i) forward -> reconstruct is the identity, (ii) forward
