@@ -216,6 +216,11 @@ def main():
     ap.add_argument("--mix", default=None, choices=["f32", "f16"],
                     help="arithmetic of the 1x1 channel mixes: f32 MFMA (default) or fp16 operands / fp32 accumulation (the variant "
                          "BASELINE.json configs[4] names; not faster here - cfg5 reports it beside the fp32 line)")
+    ap.add_argument("--wino", default="f32", choices=["f32", "bf16x3"],
+                    help="arithmetic of the wide Winograd contractions in the TIMED region: fp32 MFMA (default, the headline) or the opt-in "
+                         "bf16x3 form (exact three-way bf16 split of both fp32 operands, six MFMAs per accumulator tile, fp32 accumulate: "
+                         "fp32-grade error, tests/test_model_parity.py::test_metric_configuration_with_bf16x3_winograd_matches_oracle); "
+                         "`dtype` names it")
     args = ap.parse_args()
 
     _phase("imports (torch, tests/common)")
@@ -238,6 +243,7 @@ def main():
     # the fp16-mix one on the same workload; `--mix f32` measures the fp32 mixes with the fp16 variant beside it (`mix_f16_variant`).
     mix = args.mix or ("f16" if args.config == "cfg5" else "f32")
     tmg_ops.set_mix_precision(mix)
+    tmg_ops.set_winograd_precision(args.wino)
     _phase("process group, library load")
     model = build_model(cfg, dev)
     _phase("model construction + upload")
@@ -394,7 +400,7 @@ def main():
         f16_variant = {"what": "the same step with fp16-operand / fp32-accumulate 1x1 mixes (BASELINE configs[4]), 4 steps each after the timed region",
                        "ms_per_step_f16": round(1e3 * t16, 3), "ms_per_step_f32": round(1e3 * t32, 3), "speedup_of_f16": round(t32 / t16, 4)}
     wino3 = None
-    if args.config in ("M", "cfg4") and graph is None and args.direction == "sample" and not args.no_events:
+    if args.config in ("M", "cfg4") and graph is None and args.direction == "sample" and not args.no_events and args.wino == "f32":
         # secondary field: the same step with the wide Winograd contractions (ConvLSTM gate conv, level-wide
         # conditioning conv, out-conv input gradient) on the bf16 matrix pipe at fp32 accuracy - every fp32 operand split exactly into
         # three bf16 parts, six of the nine part products, fp32 accumulation; transforms in fp32.  Opt-in
@@ -500,13 +506,18 @@ def main():
                      + "; optimizer step: " + opt_name,
            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if mix == "f32" else "f32 (1x1 mixes: fp16 operands, fp32 accumulate)", "data": "synthetic",
+           "dtype": ("f32" if mix == "f32" else "f32 (1x1 mixes: fp16 operands, fp32 accumulate)")
+                    + ("" if args.wino == "f32" else " (wide Winograd contractions: f32 operands split into three bf16 parts on the matrix pipe, f32 accumulate)"),
+           "data": "synthetic",
            "config": {"workload": "tmglow %s: %s+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
                args.config, "sample()" if args.direction == "sample" else "forward(x,y)", Hin * up, Win * up, cfg["out_features"], len(cfg["glow_blocks"]), cfg["glow_blocks"][0], B),
                "global_batch": B * world, "parallelism": "dp%d" % world, "world_size_observed": world,
                "backend": backend, "rank0_device": torch.cuda.get_device_name(dev) + " cuda:%d" % local,
                "mix_precision": mix, "optimizer": "Adam(amsgrad, wd 1e-8): %s" % opt_name, "allreduce": allreduce_report, "loss_last": float(loss.detach()), "launch": "hipGraph replay" if graph is not None else "eager"},
            "peak_mem_gb": round(peak_gb, 2), "roofline": roof}
+    if args.wino != "f32" and isinstance(roof, dict):
+        roof["note_wino_bf16x3"] = ("--wino bf16x3: the wide launches of this class ran six bf16 MFMAs per accumulator tile (bf16 pipe, 2.5 PF dense); "
+                                    "`peak` / `frac` above are still priced against the fp32 MFMA peak and the fp32 algorithm's 16 / 36 products")
     if dens is not None:
         out["density_direction"] = dens
     if wino3 is not None:
