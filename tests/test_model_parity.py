@@ -939,8 +939,8 @@ def test_fused_grad_accumulation_matches_autograd_accumulation(cfg_name):
     assert ops._GradSink.active is None
 
 
-@pytest.mark.parametrize("cfg_name", ["tiny", "tiny3"])
-def test_captured_window_matches_eager_window(cfg_name):
+@pytest.mark.parametrize("cfg_name,recompute", [("tiny", False), ("tiny3", False), ("tiny", True)])
+def test_captured_window_matches_eager_window(cfg_name, recompute, request):
     """tmg_dist.CapturedWindow (forward passes + loss + backward of a BPTT window as one hipGraph replay; the loop it serves is
     trainFlowParallel.py:256-281): three windows of three time-steps with recurrent states, an optimizer step between them (the
     replay must read the updated parameters in place) and new inputs per window (copied into the graph's input tensors) give the
@@ -967,6 +967,9 @@ def test_captured_window_matches_eager_window(cfg_name):
         return body
 
     inputs = lambda w: [x * (1.0 + 0.1 * t + 0.05 * w) for t in range(3)]  # noqa: E731
+    if recompute:      # (round 5) the recompute-from-output backward inside the recorded window, against eager windows in the same mode
+        ops.set_recompute(True)
+        request.addfinalizer(lambda: ops.set_recompute(False))
     cw = tmg_dist.CapturedWindow(mc, body_of(mc), (inputs(0), h_in))
     assert all(p.grad is None for p in mc.parameters())      # recording leaves no gradient behind
     oe, oc = torch.optim.SGD(me.parameters(), lr=1e-3), torch.optim.SGD(mc.parameters(), lr=1e-3)
