@@ -271,7 +271,10 @@ def test_baseline_configs_match_fp64_oracle(name, cfg, B):
                 json.dump({"config": name, "batch": B, "yardstick": YARDSTICK, "quantities": rep}, f, indent=1, default=float)
 
 
-def _stated_batch_case(name, cfg, B, n=2, density=True):
+_ORACLE_RESULTS = {}      # (configuration, B, n) -> the CPU oracle's fp64 / fp32 evaluation (shared by the arithmetic variants of one case)
+
+
+def _stated_batch_case(name, cfg, B, n=2, density=True, oracle_key=None):
     """One BASELINE configuration at its STATED batch size on the HIP path - generative direction, loss on the first `n` samples,
     backward - against the CPU oracle with gradients.  Samples are independent through the flow and coupled only by the encoder's
     BatchNorm batch statistics, so the oracle runs its encoder on the FULL batch (< 1 % of the work; its gradient flows through the
@@ -316,8 +319,9 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
     yr, ld, ho, gr = hip_step(x.to(DEV), st, eps, slice(0, n))
     assert float((yr - y.to(DEV)).abs().max()) < 2e-3          # forward -> reconstruct round trip over the WHOLE batch
     import contextlib
-    res = {}
-    for dt in (torch.float64, torch.float32):
+    okey = (oracle_key or name, B, n)
+    res = _ORACLE_RESULTS.get(okey, {})
+    for dt in ((torch.float64, torch.float32) if not res else ()):
         P = O.params_from_state_dict(sd, dtype=dt)
         kp = C.KinkProbe() if dt == torch.float64 else contextlib.nullcontext()
         with kp:
@@ -334,6 +338,7 @@ def _stated_batch_case(name, cfg, B, n=2, density=True):
             res[dt]["nk"] = kp.n_elements
             res[dt]["kink"] = kp.allowances(O.trainable(P), res[dt]["g"])
         del yo, ldo, hoo, z, z_out, c_out
+    _ORACLE_RESULTS[okey] = res
     r64, r32 = res[torch.float64], res[torch.float32]
     rep = {"config": name, "batch": B, "loss_samples": n}
     try:
@@ -425,7 +430,7 @@ def test_metric_configuration_with_bf16x3_winograd_matches_oracle():
     import tmg_ops as ops
     try:
         ops.set_winograd_precision("bf16x3")
-        _stated_batch_case("M_wino_bf16x3", C.CFG_M, 64, n=2, density=False)
+        _stated_batch_case("M_wino_bf16x3", C.CFG_M, 64, n=2, density=False, oracle_key="M")      # (the oracle results of the M case, if it ran)
     finally:
         ops.set_winograd_precision("f32")
 
