@@ -153,6 +153,15 @@ __device__ __forceinline__ void stage_patch(const P& p, float* lds, int b, int i
 // Zero-filled global memory: lanes of a load batch that have nothing to read point here, so the batch has no control flow.
 static __device__ float tmg_zero_page[64];
 
+// The matrix-core source files are built without the packed-fp32 vector instructions (tmg_hip.NO_PACKED_F32: beside MFMAs a
+// v_pk_add_f32 costs more than the two scalar additions it replaces); a kernel in such a file that is vector-ALU work, or that was
+// tuned with them, keeps them with this attribute.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TMG_PACKED_F32 __attribute__((target("packed-fp32-ops")))
+#else
+#define TMG_PACKED_F32
+#endif
+
 // Loads through pointers the compiler cannot prove global - pointers that arrive as integers in a device table (the grouped launches'
 // segment tables), and everything selected against them - are emitted as flat_load: those tick the LDS counter as well as the memory
 // counter, and since LDS and memory return out of order every later wait for an LDS read becomes lgkmcnt(0) INCLUDING the outstanding

@@ -529,7 +529,7 @@ __device__ __forceinline__ tmg_bf16x8 tmg_as_bf(uint4 u) {
 }
 
 template <int NPW>
-__global__ __launch_bounds__(512, 1) void wino_fwd3_kernel(WinoP p) {
+__global__ __launch_bounds__(512, 1) TMG_PACKED_F32 void wino_fwd3_kernel(WinoP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = 512;
     constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PP = PH * PW;   // output tile, raw patch (halo 1)
@@ -1406,7 +1406,8 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
 // per launch; with only gy gz CIT NCO = 24..64 blocks per launch the walk of gx / NG slabs per thread is a chain of exposed load
 // latencies: NG = 8 for the launches with many slabs.)
 template <int NG>
-__global__ __launch_bounds__(64 * NG) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
+// (a vector-ALU kernel in a file built without the packed-fp32 instructions: it keeps them - without, the 16-group instance spills)
+__global__ __launch_bounds__(64 * NG) TMG_PACKED_F32 void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, float* __restrict__ dbias,
                                                                    int gx, int gy, int gz, int CIT, int NCO, int Cin, int Cout, int cin_dst,
                                                                    int cin_valid, int ci_split, int ci_off0, int ci_off1, int bpg,
                                                                    long long dw_gstride, int db_gstride) {
