@@ -13,6 +13,7 @@ import ctypes
 import os
 import weakref
 import subprocess
+import sys
 
 import torch
 
@@ -80,7 +81,13 @@ def build(force=False, verbose=False):
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        # (hipcc hands -target-feature to its HOST pass as well, which prints one "not a recognized feature" line per kernel: dropped)
+        err = "\n".join(ln for ln in r.stderr.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in ln)
+        if err.strip():
+            print(err, file=sys.stderr, flush=True)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
