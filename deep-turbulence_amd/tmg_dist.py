@@ -382,49 +382,57 @@ class CapturedWindow:
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         import warnings
         warn_always = torch.is_warn_always_enabled()
-        torch.set_warn_always(True)         # (the autograd engine reports the mismatch below once per process otherwise)
+        # EVERY exit - success, the stream-mismatch refusal below, an allocation failure on the graph pool, an op that cannot be
+        # captured, an exception out of `body` - goes through the `finally` at the end: module buffers, the device generator and the
+        # caller's gradients are put back, so that a caller that falls back to eager windows (TrainFlow) continues on exactly the
+        # trajectory an eager run would have taken (only two of the exits restored them)
+        ok = False
         try:
-            with warnings.catch_warnings(record=True) as caught:
-                warnings.simplefilter("always")
-                with torch.cuda.stream(self.stream):
-                    for _ in range(max(int(warmup), 1)):
-                        run()
-        finally:
-            torch.set_warn_always(warn_always)
-        torch.cuda.current_stream(dev).wait_stream(self.stream)
-        if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
-            # an autograd graph of an EARLIER pass on another stream is still referenced somewhere (a loss tensor, a state with a
-            # grad_fn): it keeps the parameters' AccumulateGrad nodes alive, and those run on the stream they were created on - inside
-            # a recording that is a dependency on a stream outside the capture (hipStreamEndCapture then crashes the process)
+            torch.set_warn_always(True)         # (the autograd engine reports the mismatch below once per process otherwise)
+            try:
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    with torch.cuda.stream(self.stream):
+                        for _ in range(max(int(warmup), 1)):
+                            run()
+            finally:
+                torch.set_warn_always(warn_always)
+                torch.cuda.current_stream(dev).wait_stream(self.stream)
+            if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
+                # an autograd graph of an EARLIER pass on another stream is still referenced somewhere (a loss tensor, a state with a
+                # grad_fn): it keeps the parameters' AccumulateGrad nodes alive, and those run on the stream they were created on -
+                # inside a recording that is a dependency on a stream outside the capture (hipStreamEndCapture then crashes the process)
+                raise RuntimeError("CapturedWindow: the autograd graph of an earlier pass (on another stream) is still alive - drop "
+                                   "every tensor that carries a grad_fn (loss, states, outputs) before recording a window")
             for p in self.params:
                 p.grad = None
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()            # the warm-up's activations go back to the device: the graph's pool is a separate one
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                loss, outs = self._record(run)
+            self.loss = loss.detach()
+            self.outs = _map_tensors(outs, lambda t: t.detach())
+            self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
+            ok = True
+        finally:
+            if not ok:
+                self.graph = None
+                tmg_ops.invalidate_derived(model)      # graphs / cached tensors of the failed pass (they may live in the graph's pool)
             with torch.no_grad():
                 if buffers:
                     torch._foreach_copy_(buffers, buf_saved)
             torch.cuda.set_rng_state(rng_saved, dev)
             for p, g in zip(self.params, saved):
                 p.grad = g
-            raise RuntimeError("CapturedWindow: the autograd graph of an earlier pass (on another stream) is still alive - drop every "
-                               "tensor that carries a grad_fn (loss, states, outputs) before recording a window")
-        for p in self.params:
-            p.grad = None
-        torch.cuda.synchronize(dev)
-        torch.cuda.empty_cache()            # the warm-up's activations go back to the device: the graph's pool is a separate one
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            loss, outs = run()
-        with torch.no_grad():
-            if buffers:
-                torch._foreach_copy_(buffers, buf_saved)
-        torch.cuda.set_rng_state(rng_saved, dev)
-        self.loss = loss.detach()
-        self.outs = _map_tensors(outs, lambda t: t.detach())
-        self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
-        for p, g in zip(self.params, saved):
-            p.grad = g
         self.replays = 0
         # the graph reads the parameters in place: their storage must still be where it was recorded
         self._param_ptrs = [p.data_ptr() for p in self.params]
+
+    @staticmethod
+    def _record(run):
+        """The recording pass itself (a seam for the failure-path tests: tests/test_model_parity.py makes it raise)."""
+        return run()
 
     def __call__(self, *args):
         new = _flat_tensors(tuple(args))

@@ -1220,6 +1220,99 @@ def test_trainer_default_records_a_repeated_window_shape():
         assert float((out["default"][1][k] - v).abs().max()) <= 2e-2 * step_size, k
 
 
+def test_trainer_failed_recording_leaves_the_eager_trajectory(monkeypatch):
+    """the default trainer records a repeated window shape and falls back to eager windows when the recording fails - the
+    failed construction must leave NOTHING behind.  The recording pass is made to raise after it has run the window's body for real
+    (BatchNorm statistics advanced, device generator advanced, gradients bound): afterwards buffers, generator state and gradients are
+    what they were, the trainer notes the failure, and four mini-batches end on the parameters and BatchNorm buffers of a trainer that
+    never tried (same optimizer on both sides)."""
+    from types import SimpleNamespace
+    import copy
+    import tmg_dist
+    from nn.tmGlow import TMGlow
+    from nn.trainFlowParallel import TrainFlow
+    cfg = C.CFG_TINY3
+    B, T, (h, w) = 2, 3, cfg["_in_hw"]
+    H, W = h * cfg["_up"], w * cfg["_up"]
+    C.seed_all(1357)
+    m0 = TMGlow(**C.build_kwargs(cfg))
+    C.perturb_(m0, 7, 0.03, 0.05, 0.03)
+    m0.out_std, m0.out_mu = torch.tensor([1.3, 0.7, 2.1]), torch.tensor([0.2, -0.1, 0.4])
+    g = torch.Generator().manual_seed(78)
+    loader = [(torch.randn(B, T, cfg["in_features"], h, w, generator=g), torch.randn(B, T, 3, H, W, generator=g), torch.tensor([3 + i, 40 + i]))
+              for i in range(4)]
+
+    # ---- the constructor on its own: state before == state after a failed recording
+    m = copy.deepcopy(m0).to(DEV)
+    x0 = loader[0][0][:, 0].to(DEV)
+    st = m.initLSTMStates(loader[0][2], [H, W])
+    marks = [torch.full_like(p, 0.5) for p in m.parameters()]
+    for p, mk in zip(m.parameters(), marks):
+        p.grad = mk
+    buf0 = {k: v.detach().clone() for k, v in m.named_buffers()}
+    rng0 = torch.cuda.get_rng_state(DEV)
+    ran = {"n": 0}
+
+    def failing_record(run):
+        out = run()                      # the body really runs inside the capture: statistics / generator / gradients all move
+        ran["n"] += 1
+        raise RuntimeError("forced recording failure")
+
+    monkeypatch.setattr(tmg_dist.CapturedWindow, "_record", staticmethod(failing_record))
+
+    def body(x, states):
+        y, ld, states = m.sample(x, states)             # device-drawn latents: advances the Philox offset
+        return C.loss_reverse(y, ld), (states,)
+
+    with pytest.raises(RuntimeError, match="forced recording failure"):
+        tmg_dist.CapturedWindow(m, body, (x0, st))
+    torch.cuda.synchronize()
+    assert ran["n"] == 1
+    assert torch.equal(torch.cuda.get_rng_state(DEV), rng0)
+    for k, v in m.named_buffers():
+        assert torch.equal(v, buf0[k]), k
+    for p, mk in zip(m.parameters(), marks):
+        assert p.grad is mk
+
+    # ---- through the trainer: the fallback continues on the eager trajectory
+    e_model = copy.deepcopy(m0).to(DEV)
+    with torch.no_grad():
+        _, _, _, e_ref = e_model.forward(loader[0][0][:, 0].to(DEV), loader[0][1][:, 0].to(DEV), None, return_eps=True)
+    eps_dev = [[torch.randn(v.shape, generator=g).to(DEV) for v in e_ref] for _ in range(T)]
+    out = {}
+    for mode in ("default", "off"):
+        m = copy.deepcopy(m0).to(DEV)
+        step = {"t": 0}
+
+        def sample_with_fixed_noise(x_t, states, m=m, step=step):
+            r = m.reconstruct(x_t, states, eps_dev[step["t"] % T])
+            step["t"] += 1
+            return r
+
+        m.sample = sample_with_fixed_noise
+        args = SimpleNamespace(beta=20.0, dx=0.05, dy=0.0625, max_grad_norm=0.25)
+        if mode == "off":
+            args.capture_window = False
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-8, amsgrad=True)
+        tr = TrainFlow(args, m, loader, None)
+        tr.use_hip_adam = False
+        total = tr.trainParallel(m, opt, epoch=0)
+        out[mode] = (float(total), {k: v.detach().clone() for k, v in m.state_dict().items()}, tr)
+    trd = out["default"][2]
+    assert trd._capture == "auto" and not trd._captured and len(trd._capture_failed) == 1
+    assert "forced recording failure" in next(iter(trd._capture_failed.values()))
+    assert ran["n"] == 2                                  # tried once for the shape, never again
+    assert abs(out["default"][0] - out["off"][0]) <= 1e-5 * abs(out["off"][0]) + 1e-5, (out["default"][0], out["off"][0])
+    for k, v in out["off"][1].items():
+        got = out["default"][1][k]
+        if k.endswith("num_batches_tracked"):
+            assert torch.equal(got, v), k                 # a leaked statistics update would count twice
+        elif "running_" in k:
+            assert float((got - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-7, k
+        elif v.dtype.is_floating_point and "log_s_old" not in k:
+            assert float((got - v).abs().max()) <= 2e-2 * 4e-3, k
+
+
 def test_trainer_test_loop_error_measure():
     """`TrainFlow.test` (reference trainFlowParallel.py:313-382): un-normalisation with out_std / out_mu, sample mean over the
     roll-outs, squared error summed over time-steps 1..tmax (step 0 excluded) and divided by ntest * tmax * H * W - checked

@@ -40,7 +40,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 cnt, tim = collections.Counter(), collections.Counter()
 for e in prof.events():
-    if not e.name.startswith("aten::") or e.device_time_total <= 0 or e.device_time_total >= 12:
+    if not e.name.startswith("aten::") or e.device_time_total <= 0 or e.device_time_total >= float(os.environ.get("TMG_GLUE_MAX_US", "12")):
         continue
     if any(c.device_time_total > 0 and c.name.startswith("aten::") for c in (e.cpu_children or [])):
         continue            # count the leaf op that launched
@@ -55,3 +55,25 @@ for e in prof.events():
 print("small torch-native launches: %d, %.1f us" % (sum(cnt.values()), sum(tim.values())))
 for k, n in cnt.most_common(60):
     print("%4d %7.1f us  %-18s %s" % (n, tim[k], k[0], k[1]))
+
+# ---- second census: every device-side copy / fill (hipMemcpyAsync -> __amd_rocclr_copyBuffer, Memcpy HtoD / DtoD records) by the op
+# and Python line that issued it
+ccnt, ctim = collections.Counter(), collections.Counter()
+for e in prof.events():
+    ks = [k for k in (e.kernels or []) if ("Memcpy" in k.name or "rocclr" in k.name or "Memset" in k.name)]
+    if not ks:
+        continue
+    if any((c.kernels or []) for c in (e.cpu_children or [])):
+        continue
+    st = [s for s in (e.stack or []) if "deep-turbulence_amd" in s or "common.py" in s or "bench" in s]
+    par, q = [], e.cpu_parent
+    while q is not None and len(par) < 4:
+        par.append(q.name[:40])
+        q = q.cpu_parent
+    for k in ks:
+        key = (k.name[:40], e.name[:30], st[0].split("/")[-1][:70] if st else " < ".join(par))
+        ccnt[key] += 1
+        ctim[key] += k.duration
+print("device copies / fills: %d, %.1f us" % (sum(ccnt.values()), sum(ctim.values())))
+for k, n in ccnt.most_common(60):
+    print("%4d %7.1f us  %-40s %-30s %s" % (n, ctim[k], k[0], k[1], k[2]))
