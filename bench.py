@@ -275,7 +275,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         if y_fwd is None:
             y, ld, _ = model.sample(x, states)
-            loss = C.loss_reverse(y, ld)
+            loss = tmg_ops.reverse_loss(y, ld)      # = tests/common.py::loss_reverse (mean(y^2) + mean(logdet) / (noc H W)), two launches
         else:
             _, logp, _, _ = model.forward(x, y_fwd, states)
             loss = C.loss_forward(logp, y_fwd)
@@ -297,7 +297,7 @@ def main():
         def body(x_, st_):
             if y_fwd is None:
                 y_, ld_, _ = model.sample(x_, st_)
-                return C.loss_reverse(y_, ld_), ()
+                return tmg_ops.reverse_loss(y_, ld_), ()
             _, logp_, _, _ = model.forward(x_, y_fwd, st_)
             return C.loss_forward(logp_, y_fwd), ()
         graph = tmg_dist.CapturedWindow(model, body, (x, states))

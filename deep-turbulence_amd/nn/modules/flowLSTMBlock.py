@@ -70,12 +70,12 @@ class AffineCouplingBlock(_BlockBase):
         layers in one batched pass and also accounts for their log-dets); None -> fold here and add the log-det."""
         if not isinstance(self.conv, InvertibleConv1x1LU):
             return _run_unfused(self, xn, condn, None, reverse)[:2]
-        extra = self._mix_logdet(xn) if mix is None else 0.
+        extra = self._mix_logdet(xn) if mix is None else None      # (None: the caller accounts for the mix log-dets of the level)
         if reverse:
             t, ld = self.coupling.run(xn, condn, True)
-            return self._mix(t, True, mix), ld + extra
+            return self._mix(t, True, mix), (ld if extra is None else ld + extra)
         y, ld = self.coupling.run(self._mix(xn, False, mix), condn, False)
-        return y, ld + extra
+        return y, (ld if extra is None else ld + extra)
 
     def forward(self, x, cond):
         y, ld = self.run(H.nhwc(x), H.nhwc(cond), False)
@@ -110,12 +110,12 @@ class LSTMCouplingBlock(_BlockBase):
         """pad > 0: xn and mix are in the zero-padded channel layout of LSTMFLowBlock._pad_x (then mix is given)."""
         if not isinstance(self.conv, InvertibleConv1x1LU):
             return _run_unfused(self, xn, condn, state, reverse)
-        extra = self._mix_logdet(xn) if mix is None else 0.
+        extra = self._mix_logdet(xn) if mix is None else None      # (None: the caller accounts for the mix log-dets of the level)
         if reverse:
             t, ld, st = self.coupling.run(xn, condn, state, True, pad=pad)
-            return self._mix(t, True, mix), ld + extra, st
+            return self._mix(t, True, mix), (ld if extra is None else ld + extra), st
         y, ld, st = self.coupling.run(self._mix(xn, False, mix), condn, state, False, pad=pad)
-        return y, ld + extra, st
+        return y, (ld if extra is None else ld + extra), st
 
     def _call(self, x, cond, rec_states, reverse):
         st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
@@ -380,7 +380,7 @@ class LSTMFLowBlock(nn.Module):
         ch = xn.shape[3] // 2
         pad = (-ch) % 4 if (self._all_lu() and xn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
         lm, Wm, bm = self._level_mix_cached(False, xn.shape[1] * xn.shape[2], ch, pad)
-        logdet = 0. if lm is None else lm[2]
+        lds = [] if lm is None else [lm[2]]          # log-det terms of the level, summed by ONE launch at the end (ops.sum_logdet)
         out_states = []
         fused = self._fusable(lm, xn)
         if pad:
@@ -389,7 +389,7 @@ class LSTMFLowBlock(nn.Module):
         if fused:
             Wh, bh = (sp[0], sp[1]) if sp else (Wm[:-1], bm[:-1])
             xn, dld = self._level_call(xn, condn, Wh, bh, layers[:-1], False, ch, pad)
-            logdet = logdet + dld
+            lds.append(dld)
         for i, layer in enumerate(layers):
             if fused and i < self.n_layers - 1:
                 continue
@@ -399,20 +399,22 @@ class LSTMFLowBlock(nn.Module):
                 out_states = (H.nchw(so[0]), H.nchw(so[1]))
             else:
                 xn, dld = layer.run(xn, condn, False, mix)
-            logdet = logdet + dld
+            lds.append(dld)
         if pad:
             xn = self._unpad_x(xn, ch, pad)
+        B, dev = xn.shape[0], xn.device
         if self.do_split:
             z1, lp, eps = self.split(H.nchw(xn), return_eps=return_eps)
-            return z1, logdet + lp, out_states, eps
-        return H.nchw(xn), logdet, out_states, None
+            return z1, ops.sum_logdet(lds + [lp], B, dev), out_states, eps
+        return H.nchw(xn), ops.sum_logdet(lds, B, dev), out_states, None
 
-    def reverse(self, y, cond, rec_states, eps=None):
-        logdet = 0.
+    def reverse(self, y, cond, rec_states, eps=None, rng=None):
+        """rng: (nonce, site) of the in-kernel latent draw when eps is None (TMGlow.sample hands one nonce to all levels)."""
+        lds = []                                     # log-det terms of the level, summed by ONE launch at the end (ops.sum_logdet)
         out_states = []
         if self.do_split:
-            y, lp = self.split.reverse(y, eps)
-            logdet = logdet + lp
+            y, lp = self.split.reverse(y, eps, rng=rng)
+            lds.append(lp)
         yn, condn = H.nhwc(y), H.nhwc(cond)
         st = None if rec_states is None else (H.nhwc(rec_states[0]), H.nhwc(rec_states[1]))
         layers = list(self.revlayers._modules.values())
@@ -420,7 +422,7 @@ class LSTMFLowBlock(nn.Module):
         pad = (-ch) % 4 if (self._all_lu() and yn.shape[3] % 2 == 0 and not os.environ.get("TMG_NO_LEVEL_FUSION")) else 0
         lm, Wm, bm = self._level_mix_cached(True, yn.shape[1] * yn.shape[2], ch, pad)
         if lm is not None:
-            logdet = logdet + lm[2]
+            lds.append(lm[2])
         fused = self._fusable(lm, yn)
         if pad:
             yn = self._pad_x(yn, ch, pad)
@@ -433,11 +435,11 @@ class LSTMFLowBlock(nn.Module):
             elif fused:
                 Wh, bh = (sp[0], sp[1]) if sp else (Wm[:-1], bm[:-1])
                 yn, dld = self._level_call(yn, condn, Wh, bh, layers[:-1], True, ch, pad)
-                logdet = logdet + dld
+                lds.append(dld)
                 break
             else:
                 yn, dld = layers[i].run(yn, condn, True, mix)
-            logdet = logdet + dld
+            lds.append(dld)
         if pad:
             yn = self._unpad_x(yn, ch, pad)
-        return H.nchw(self._squeeze_nhwc(yn, False)), logdet, out_states
+        return H.nchw(self._squeeze_nhwc(yn, False)), ops.sum_logdet(lds, yn.shape[0], yn.device), out_states

@@ -58,16 +58,37 @@ class CheckerSqueeze(nn.Module):
 
 
 class GaussianDiag(object):
-    """Diagonal Gaussian over a feature map (reference :147-209).  The log-std is clamped to
-    [-10, ln 5] at construction (the reference clamps in place, :163)."""
+    """Diagonal Gaussian over a feature map (reference :147-209).  The log-std is clamped to [-10, ln 5] (the reference clamps in
+    place at construction, :163).  On the HIP path the two maps usually arrive as ONE [B,h,w,2C] tensor (the encoder's output,
+    tmGlow.py:399-403: `hz=`): the kernels read (mean | log-std) from it in place and apply the clamp themselves, so neither the
+    chunk, nor the clamp, nor the re-concatenation of the two halves is ever launched; `mean` / `log_stddev` are evaluated on demand."""
     Log2PI = float(np.log(2 * np.pi))
 
-    def __init__(self, mean, log_stddev):
-        self.mean = mean
-        self.log_stddev = log_stddev.clamp(min=-10., max=math.log(5.))
+    def __init__(self, mean=None, log_stddev=None, hz=None):
+        if hz is not None:
+            self._hz_map = hz                    # NHWC [B,h,w,2C], un-clamped
+            self._mean = self._lsd = None
+        else:
+            self._hz_map = None
+            self._mean = mean
+            self._lsd = log_stddev.clamp(min=-10., max=math.log(5.))
+
+    @property
+    def mean(self):
+        if self._mean is None:
+            self._mean = H.nchw(self._hz_map[..., :self._hz_map.shape[3] // 2])
+        return self._mean
+
+    @property
+    def log_stddev(self):
+        if self._lsd is None:
+            self._lsd = H.nchw(self._hz_map[..., self._hz_map.shape[3] // 2:]).clamp(min=-10., max=math.log(5.))
+        return self._lsd
 
     def _hz(self):
-        return torch.cat([H.nhwc(self.mean), H.nhwc(self.log_stddev)], 3)
+        if self._hz_map is not None:
+            return self._hz_map
+        return torch.cat([H.nhwc(self._mean), H.nhwc(self._lsd)], 3)
 
     def likelihood(self, x):
         # element-wise map; only used for inspection in the reference (:167-179)
@@ -78,10 +99,11 @@ class GaussianDiag(object):
         logp, eps = ops.GaussLogpFn.apply(self._hz(), H.nhwc(x), 0, ops.TOP_LIMITS, bool(return_eps))
         return (logp, H.nchw(eps)) if return_eps else logp
 
-    def sample(self, eps=None):
-        if eps is None:
-            eps = torch.randn_like(self.log_stddev)
-        z, _ = ops.GaussSampleFn.apply(self._hz(), H.nhwc(eps), 0, ops.TOP_LIMITS)
+    def sample(self, eps=None, rng=None):
+        """mean + exp(log_stddev) eps; eps None: drawn inside the kernel (rng = (nonce, site) of the model call, or a fresh nonce)."""
+        if eps is None and rng is None:
+            rng = (ops.latent_nonce(self._hz().device), 0)
+        z, _ = ops.GaussDrawFn.apply(self._hz(), None, None if eps is None else H.nhwc(eps), rng, 0, ops.TOP_LIMITS)
         return H.nchw(z)
 
 
@@ -140,12 +162,12 @@ class Split(nn.Module):
         logp, eps = ops.GaussLogpFn.apply(hz, z2, 1, ops.SPLIT_LIMITS, bool(return_eps))
         return H.nchw(z1.contiguous()), logp, (H.nchw(eps) if return_eps else None)
 
-    def reverse(self, z1, eps=None):
+    def reverse(self, z1, eps=None, rng=None):
+        """cat(z1, z2 = mean + exp(log-std) eps) and its log-prob; the sample is written into the second half of the result by the
+        kernel (no torch.cat), eps None: drawn inside it (rng = (nonce, site) of the model call, default a fresh nonce)."""
         z1n = H.nhwc(z1)
         hz = self.latent_encoder.raw(z1n)
-        if eps is None:
-            eps_n = torch.randn(z1n.shape, device=z1n.device, dtype=z1n.dtype)
-        else:
-            eps_n = H.nhwc(eps)
-        z2, logp = ops.GaussSampleFn.apply(hz, eps_n, 1, ops.SPLIT_LIMITS)
-        return H.nchw(torch.cat([z1n, z2], 3)), logp
+        if eps is None and rng is None:
+            rng = (ops.latent_nonce(z1n.device), 0)
+        out, logp = ops.GaussDrawFn.apply(hz, z1n, None if eps is None else H.nhwc(eps), rng, 1, ops.SPLIT_LIMITS)
+        return H.nchw(out), logp

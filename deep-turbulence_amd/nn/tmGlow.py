@@ -106,22 +106,24 @@ class LSTMCFlowDecoder(nn.Module):
 
     def forward(self, x, c_in, h_in, return_eps=False):
         assert (len(c_in) == len(self.flow_blocks)), 'List of conditions need to be same length as flow blocks.'
-        z, log_det, eps, s_out = x, 0, [], []
+        z, lds, eps, s_out = x, [], [], []
         for i, flow_block in enumerate(self.flow_blocks):
             z, ld, s0, eps0 = flow_block.forward(z, c_in[i], None if h_in is None else h_in[i], return_eps)
-            log_det = log_det + ld
+            lds.append(ld)
             eps.append(eps0)
             s_out.append(s0)
-        return z, log_det, s_out, eps
+        return z, ops.sum_logdet(lds, z.shape[0], z.device), s_out, eps
 
-    def reverse(self, z, c_in, h_in, eps):
+    def reverse(self, z, c_in, h_in, eps, nonce=None):
+        """nonce: key of the in-kernel latent draws of this call (TMGlow.sample); None: every split draws its own."""
         assert (len(c_in) == len(self.flow_blocks)), 'List of conditions need to be same length as flow blocks.'
-        x, log_det, s_out = z, 0, []
+        x, lds, s_out = z, [], []
         for i in range(len(self.flow_blocks) - 1, -1, -1):
-            x, ld, s0 = self.flow_blocks[i].reverse(x, c_in[i], None if h_in is None else h_in[i], eps[i])
-            log_det = log_det + ld
+            rng = (nonce, i) if (nonce is not None and eps[i] is None) else None
+            x, ld, s0 = self.flow_blocks[i].reverse(x, c_in[i], None if h_in is None else h_in[i], eps[i], rng=rng)
+            lds.append(ld)
             s_out.insert(0, s0)
-        return x, log_det, s_out
+        return x, ops.sum_logdet(lds, x.shape[0], x.device), s_out
 
 
 class TMGlow(nn.Module):
@@ -144,9 +146,10 @@ class TMGlow(nn.Module):
         print('Total number of parameters: {}'.format(self._num_parameters()))
 
     def _prior(self, x):
-        z_out, c_out = self.encoder.forward(x)
-        cmean, clog_stddev = z_out.chunk(2, 1)
-        return GaussianDiag(cmean, clog_stddev), c_out
+        """(deepest-level prior, conditioning maps): the encoder's [mean | log-std] map goes to the Gaussian kernels as it is
+        (reference :399-403 chunks it; the clamp of flowUtils.py:163 is applied inside the kernels)."""
+        z, c_out = self.encoder.run(H.nhwc(x))
+        return GaussianDiag(hz=z), [H.nchw(c) for c in c_out]
 
     @_on_input_device
     def forward(self, x, y, h_in=None, return_eps=False):
@@ -165,9 +168,11 @@ class TMGlow(nn.Module):
     def sample(self, x, h_in=None):
         """Conditional generation with freshly drawn latents; no top-prior term in the log-det (reference :417-440)."""
         cprior, c_out = self._prior(x)
-        z_samp = cprior.sample()
-        eps = [None for _ in range(len(self.glow_blocks))]
-        return self.glow.reverse(z_samp, c_out, h_in, eps)
+        L = len(self.glow_blocks)
+        nonce = ops.latent_nonce(x.device)       # one draw from torch's generator keys the in-kernel draws of all L + 1 latents
+        z_samp = cprior.sample(rng=(nonce, L))
+        eps = [None for _ in range(L)]
+        return self.glow.reverse(z_samp, c_out, h_in, eps, nonce=nonce)
 
     @_on_input_device
     def reconstruct(self, x, h_in, eps):

@@ -20,7 +20,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtmglow_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip", "tmg_coupling.hip", "tmg_wino.hip", "tmg_thin.hip"]
+SOURCES = ["tmg_conv.hip", "tmg_pointwise.hip", "tmg_physics.hip", "tmg_mix16.hip", "tmg_coupling.hip", "tmg_wino.hip", "tmg_thin.hip", "tmg_glue.hip"]
 # Sources compiled WITHOUT the packed-fp32 vector instructions (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32): beside MFMAs a packed
 # f32 instruction costs ~13 cycles more than the two scalar ones it replaces (MI355X_MICROARCH.md, cycle constants, 'price of one
 # filler beside MFMAs'), and the compiler SLP-packs adjacent scalar adds / multiplies by itself under -O3.  The matrix-core kernels'
@@ -39,7 +39,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_level_wgrad_merged",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_level_wgrad_merged", "tmg_gauss_sample", "tmg_reverse_loss_fwd", "tmg_reverse_loss_bwd", "tmg_sum_terms", "tmg_vec_sum", "tmg_level_pack",
 ]
 
 
@@ -964,6 +964,45 @@ def gauss_bwd(hz, zin, dzin, g, dzout, dhz, mode, clip_mean, limits):
     do = _d2(dzout) if dzout is not None else _i64(0, 0)
     _chk(lib().tmg_gauss_bwd(_ptr(hz), _d2(hz), _ptr(zin), _d2(zin), _ptr(dzin), di, _ptr(g), _ptr(dzout), do, _ptr(dhz), _d2(dhz),
                              _i64(B, H * W, Ch, mode, clip_mean), _fl(limits), _stream()), "tmg_gauss_bwd")
+
+
+def gauss_sample(hz, eps, z1, out, logp, clip_mean, limits, eps_out=None, nonce=None, site=0):
+    """out[..., C - Ch:] = mean + exp(log-std) eps, out[..., :Ch] = z1 (when given): the Gaussian sample written straight into the
+    level's activation (tmg_gauss_sample).  eps None: drawn in the kernel from (nonce, site) and stored to eps_out."""
+    B, Hh, Ww, Co = out.shape
+    Ch = hz.shape[3] // 2
+    off = Co - Ch
+    zd = lambda t: _d2(t) if t is not None else _i64(0, 0)  # noqa: E731
+    od = seg(out)
+    _chk(lib().tmg_gauss_sample(_ptr(hz), _d2(hz), _ptr(eps), zd(eps), _ptr(z1), zd(z1), _ptr(out), _i64(od[1], off), c_i64(0), _ptr(eps_out),
+                                _ptr(logp), _ptr(nonce), _i64(B, Hh * Ww, Ch, clip_mean, site), _fl(limits), _stream()), "tmg_gauss_sample")
+
+
+def reverse_loss_fwd(y, ld, loss, s1, s2):
+    _chk(lib().tmg_reverse_loss_fwd(_ptr(y), _ptr(ld), _ptr(loss), _i64(y.numel(), ld.numel()), _flts([s1, s2]), _stream()), "tmg_reverse_loss_fwd")
+
+
+def reverse_loss_bwd(y, g, dy, dld, s1, s2):
+    _chk(lib().tmg_reverse_loss_bwd(_ptr(y), _ptr(g), _ptr(dy), _ptr(dld), _i64(y.numel(), dld.numel()), _flts([s1, s2]), _stream()), "tmg_reverse_loss_bwd")
+
+
+SUM_TERMS_MAX = 8
+
+
+def sum_terms(terms, out):
+    """out[b] = sum of the terms (fp32 vectors of out's length, or one-element tensors: broadcast) in one launch (tmg_sum_terms)."""
+    n = len(terms)
+    ptrs = (c_vp * n)(*[t.data_ptr() for t in terms])
+    _chk(lib().tmg_sum_terms(ptrs, _i64(*[t.numel() for t in terms]), c_i64(n), _ptr(out), c_i64(out.numel()), _stream()), "tmg_sum_terms")
+
+
+def vec_sum(g, out):
+    _chk(lib().tmg_vec_sum(_ptr(g), c_i64(g.numel()), _ptr(out), _stream()), "tmg_vec_sum")
+
+
+def level_pack(tab, Wz, Wcat, Bz, Kp, NL, NLp, C, ch, Cc):
+    """Stacked / sliced parameter operands of a level node from the modules' own tensors (tmg_level_pack; tab from _segment_table)."""
+    _chk(lib().tmg_level_pack(_ptr(tab), _ptr(Wz), _ptr(Wcat), _ptr(Bz), _ptr(Kp), _i64(NL, NLp, C, ch, Cc), _stream()), "tmg_level_pack")
 
 
 def checker(src, dst, to_small):

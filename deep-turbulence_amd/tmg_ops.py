@@ -709,6 +709,139 @@ class GaussSampleFn(torch.autograd.Function):
         return dhz, None, None, None
 
 
+def latent_nonce(device):
+    """Two int64 on `device` drawn from torch's generator of that device (ONE launch per model call): the key of the in-kernel Philox
+    draws of every latent of the call (tmg_gauss_sample).  The latents therefore follow torch.manual_seed / get_rng_state /
+    set_rng_state like torch.randn's would, and a hipGraph replay draws fresh ones (the generator's offset is graph-safe) - without a
+    randn launch, an eps write and an eps read per level."""
+    return torch.empty(2, dtype=torch.int64, device=device).random_()
+
+
+class GaussDrawFn(torch.autograd.Function):
+    """Split.reverse / GaussianDiag.sample on the HIP path as ONE launch: z2 = mean + exp(log-std) eps, written into the second half
+    of the [B,h,w,2 Ch] tensor whose first half is z1 (the reference's torch.cat((z1, z2), 1), flowUtils.py:334; z1 None: the
+    deepest prior, output [B,h,w,Ch]), with the log-prob per sample (:331-333).  eps given (reconstruct) or drawn in the kernel from
+    (nonce, site) (sample, :206 / :328).  Gradients: d(hz) by tmg_gauss_bwd (mode 1), d(z1) = the first half of the output's
+    gradient (a channel-slice view: no copy), none for eps."""
+
+    @staticmethod
+    def forward(ctx, hz, z1, eps, rng, clip_mean, limits):
+        hz = hz if hz.stride(3) == 1 else hz.contiguous()
+        B, Hh, Ww, C2 = hz.shape
+        Ch = C2 // 2
+        dev = hz.device
+        if z1 is not None and z1.stride(3) != 1:
+            z1 = z1.contiguous()
+        out = torch.empty((B, Hh, Ww, 2 * Ch if z1 is not None else Ch), device=dev, dtype=torch.float32)
+        logp = zeros(B, dev)
+        if eps is not None:
+            eps = eps if eps.stride(3) == 1 else eps.contiguous()
+            H.gauss_sample(hz, eps, z1, out, logp, clip_mean, limits)
+        else:
+            nonce, site = rng
+            eps = torch.empty((B, Hh, Ww, Ch), device=dev, dtype=torch.float32)
+            H.gauss_sample(hz, None, z1, out, logp, clip_mean, limits, eps_out=eps, nonce=nonce, site=site)
+        ctx.cfg = (clip_mean, limits, Ch, z1 is not None)
+        ctx.save_for_backward(hz, eps)
+        ctx.set_materialize_grads(False)
+        return out, logp
+
+    @staticmethod
+    def backward(ctx, dout, g):
+        hz, eps = ctx.saved_tensors
+        clip_mean, limits, Ch, has_z1 = ctx.cfg
+        dhz = torch.empty_like(hz)
+        dz2 = dz1 = None
+        if dout is not None:
+            dout = dout if dout.stride(3) == 1 else dout.contiguous()
+            dz2 = dout[..., Ch:] if has_z1 else dout
+            dz1 = dout[..., :Ch] if has_z1 else None
+        H.gauss_bwd(hz, eps, dz2, g.contiguous() if g is not None else None, None, dhz, 1, clip_mean, limits)
+        return dhz, dz1, None, None, None, None
+
+
+class ReverseLossFn(torch.autograd.Function):
+    """The benchmark loss of SURVEY 8-D, generative direction: mean(y^2) + mean(logdet) / (noc H W) as one reduction launch, its gradient
+    as one element-wise launch (tmg_reverse_loss_*); y is the model's NCHW-shaped, channels-last output (any layout is accepted)."""
+
+    @staticmethod
+    def forward(ctx, y, logdet):
+        H.check_act(y)
+        yn = y.permute(0, 2, 3, 1)
+        yn = yn if yn.is_contiguous() else yn.contiguous()
+        ld = logdet.contiguous()
+        n = yn.numel()
+        loss = zeros(1, y.device)
+        H.reverse_loss_fwd(yn, ld, loss, 1.0 / n, 1.0 / n)     # mean(ld) / (noc H W) = sum(ld) / (B noc H W) = sum(ld) / numel(y)
+        ctx.save_for_backward(yn)
+        ctx.B = ld.numel()
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        yn, = ctx.saved_tensors
+        n = yn.numel()
+        dyn = torch.empty_like(yn)
+        dld = torch.empty(ctx.B, device=yn.device, dtype=torch.float32)
+        H.reverse_loss_bwd(yn, g.contiguous(), dyn, dld, 1.0 / n, 1.0 / n)
+        return dyn.permute(0, 3, 1, 2), dld
+
+
+def reverse_loss(y, logdet):
+    """mean(y^2) + mean(logdet) / (noc H W) (SURVEY 8-D) on the HIP path; tests/common.py::loss_reverse is the torch statement of it."""
+    return ReverseLossFn.apply(y, logdet)
+
+
+class SumTermsFn(torch.autograd.Function):
+    """Sum of per-sample log-det terms ([B] vectors; one-element tensors are broadcast) in ONE launch - the reference adds them one `+`
+    at a time (flowLSTMBlock.py:314-318, :345-359; tmGlow.py:438-440), ~25 one-block launches per step here.  Backward: the upstream
+    gradient itself for a [B] term, its sum (one tiny launch, shared by all scalar terms of the node) for a broadcast one."""
+
+    @staticmethod
+    def forward(ctx, B, *terms):
+        ts = [t.reshape(-1) if t.is_contiguous() else t.contiguous().reshape(-1) for t in terms]
+        out = torch.empty(B, device=ts[0].device, dtype=torch.float32)
+        H.sum_terms(ts, out)
+        ctx.meta = [(t.numel(), t.shape) for t in terms]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gs = None
+        outs = []
+        for n, shape in ctx.meta:
+            if n == g.numel() and len(shape) == 1:
+                outs.append(g)
+            elif n == 1:
+                if gs is None:
+                    gs = torch.empty(1, device=g.device, dtype=torch.float32)
+                    H.vec_sum(g, gs)
+                outs.append(gs.view(shape))
+            else:
+                outs.append(g.view(shape))
+        return (None,) + tuple(outs)
+
+
+def sum_logdet(terms, B, device):
+    """Sum of log-det contributions: python numbers and None are dropped (0), tensors of B elements or one element are summed by one
+    launch per SUM_TERMS_MAX terms.  Returns 0. when nothing is left (the callers add it to a tensor or return it as is)."""
+    ts = [t for t in terms if torch.is_tensor(t)]
+    const = sum(float(t) for t in terms if t is not None and not torch.is_tensor(t))
+    if const != 0.0:
+        ts.append(torch.full((1,), const, device=device, dtype=torch.float32))
+    if not ts:
+        return 0.
+    if len(ts) == 1 and ts[0].numel() == B and ts[0].dim() == 1:
+        return ts[0]
+    while len(ts) > 1 or ts[0].numel() != B:
+        head, ts = ts[:H.SUM_TERMS_MAX], ts[H.SUM_TERMS_MAX:]
+        ts.insert(0, SumTermsFn.apply(B, *head))
+        if len(ts) == 1:
+            break
+    return ts[0]
+
+
 class CheckerFn(torch.autograd.Function):
     """Checker squeeze (to_small) / un-squeeze (flowUtils.py:99-145)."""
 
@@ -1002,6 +1135,32 @@ class LevelCouplingFn(torch.autograd.Function):
         return Hc, Dc, dc_of
 
     @staticmethod
+    def _level_operands(wts, NL, NLp, C, ch, Cc, dev):
+        """(Wz [NL,C,cin+2,3,3] = stack of the zero-conv weights, Wcat = [Wzc ; Wdc] with Wzc [NL C,Cc,3,3] the conditioning columns
+        of all zero convs and Wdc [2 NLp,Cc,3,3] those of the growth layers - output channel 2k / 2k+1 = growth layer 1 / 2 of coupling
+        layer k: a layer's two addends share one cache line of Dc -, Bz [NL,C], Kp [NL]) through tmg_level_pack: one launch reading the
+        modules' tensors through a device pointer table (round 5: ~10 stack / slice-copy / cat launches per level and direction)."""
+        cin = ch + Cc
+        w1s, w2s, wzs, bzs, kps = wts[0::5], wts[1::5], wts[2::5], wts[3::5], wts[4::5]
+        Wz = torch.empty((NL, C, cin + 2, 3, 3), device=dev, dtype=torch.float32)
+        Wcat = torch.empty((NL * C + 2 * NLp, Cc, 3, 3), device=dev, dtype=torch.float32)
+        Bz = torch.empty((NL, C), device=dev, dtype=torch.float32)
+        Kp = torch.empty(NL, device=dev, dtype=torch.float32)
+        if all(w.is_contiguous() and w.dtype == torch.float32 for w in wts) and os.environ.get("TMG_NO_LEVEL_PACK") is None:
+            tab = H._segment_table([[w.data_ptr() for w in wts[5 * k:5 * k + 5]] for k in range(NL)], dev)
+            H.level_pack(tab, Wz, Wcat, Bz, Kp, NL, NLp, C, ch, Cc)
+            return Wz, Wcat, Bz, Kp
+        torch.stack(wzs, out=Wz)
+        Wcat[:NL * C] = Wz[:, :, ch:cin].reshape(NL * C, Cc, 3, 3)
+        Wdc = Wcat[NL * C:].view(NLp, 2, Cc, 3, 3)
+        Wdc[NL:].zero_()
+        Wdc[:NL, 0] = torch.stack(w1s)[:, 0, ch:cin]
+        Wdc[:NL, 1] = torch.stack(w2s)[:, 0, ch:cin]
+        torch.stack(bzs, out=Bz)
+        torch.stack([kp.reshape(()) for kp in kps], out=Kp)
+        return Wz, Wcat, Bz, Kp
+
+    @staticmethod
     def forward(ctx, x, cond, Wm, bm, reverse, *wts):
         NL = len(wts) // 5
         x = x if x.stride(3) == 1 else x.contiguous()
@@ -1013,13 +1172,9 @@ class LevelCouplingFn(torch.autograd.Function):
         dev = x.device
         NLp = (NL + 3) // 4 * 4
         w1s, w2s, wzs, bzs, kps = wts[0::5], wts[1::5], wts[2::5], wts[3::5], wts[4::5]
-        # cond-side operands of the whole level (parameter-sized copies, no autograd inside a Function)
-        Wz = torch.stack(wzs)                                              # [NL, C, cin+2, 3, 3]
-        Wzc = Wz[:, :, ch:cin].reshape(NL * C, Cc, 3, 3).contiguous()
-        # output channel 2k / 2k+1 = growth layer 1 / 2 of coupling layer k: a layer's two addends share one cache line of Dc
-        Wdc = zeros((2 * NLp, Cc, 3, 3), dev)
-        Wdc.view(NLp, 2, Cc, 3, 3)[:NL, 0] = torch.stack(w1s)[:, 0, ch:cin]
-        Wdc.view(NLp, 2, Cc, 3, 3)[:NL, 1] = torch.stack(w2s)[:, 0, ch:cin]
+        # parameter-side operands of the whole level (parameter-sized copies, no autograd inside a Function): ONE gather launch
+        Wz, Wcat, Bz, Kp = LevelCouplingFn._level_operands(wts, NL, NLp, C, ch, Cc, dev)
+        Wzc, Wdc = Wcat[:NL * C], Wcat[NL * C:]
         Hc, Dc, dc_of = LevelCouplingFn._cond_parts(cond, Wzc, Wdc, NL, NLp, C)
         logdet = zeros(B, dev)
         # operand packing of every layer's weights in two launches per level instead of two per layer
@@ -1098,14 +1253,14 @@ class LevelCouplingFn(torch.autograd.Function):
         ctx.fuse = fuse
         ctx.split = split
         ctx.meta = (NL, NLp, reverse, ch, Cc)
-        ctx.save_for_backward(cond, Wm, bm, Wzc, Wdc, *wts)
+        ctx.save_for_backward(cond, Wm, bm, Wz, Wcat, Bz, Kp, *wts)
         return cur.view(cur.shape), logdet
 
     @staticmethod
     def backward(ctx, dy, dld):
         NL, NLp, reverse, ch, Cc = ctx.meta
-        cond, Wm, bm, Wzc, Wdc = ctx.saved_tensors[:5]
-        wts = ctx.saved_tensors[5:]
+        cond, Wm, bm, Wz, Wcat, Bz, Kp = ctx.saved_tensors[:7]
+        wts = ctx.saved_tensors[7:]
         w1s, w2s, wzs, bzs, kps = wts[0::5], wts[1::5], wts[2::5], wts[3::5], wts[4::5]
         saved = ctx.saved
         if saved is None:
@@ -1116,6 +1271,7 @@ class LevelCouplingFn(torch.autograd.Function):
         B, Hh, Ww, C = dy.shape
         cin = ch + Cc
         dev = dy.device
+        Wzc, Wdc = Wcat[:NL * C], Wcat[NL * C:]
         g = dld.contiguous() if dld is not None else None
         # stacked native-layout parameter gradients of the whole level, one zero fill
         n1, n2, nz = cin * 9, (cin + 1) * 9, C * (cin + 2) * 9
@@ -1143,7 +1299,6 @@ class LevelCouplingFn(torch.autograd.Function):
         # exp(kappa)*dhh: they run as ONE grouped launch after the loop (a few microseconds of MFMA work each otherwise,
         # dominated by launch / pipeline-fill).  Their inputs stay alive until then (NL * C floats per pixel).
         grouped = NL > 1 and ch + 4 <= 132 and os.environ.get("TMG_NO_GROUPED_WGRAD") is None
-        Wz = torch.stack(wzs)
         PZt = H.conv_pack_batched(Wz, 1, ch + 4, (ch + 2, ch, Cc))          # input-gradient operands of all layers: one launch
         PMt = H.conv_pack_batched(Wm.reshape(NL, C, C, 1, 1), 1)
         wg_in = [None] * NL
@@ -1297,7 +1452,7 @@ class LevelCouplingFn(torch.autograd.Function):
         # zero-conv part (dy = DH) and growth-layer part (dy = DD) of d(cond) as ONE contraction over [DH | DD] (K = NL (C + 4)): the
         # padding mode of the forward convs does not enter the interior of an input gradient, the replicate fold below adds the ring
         # terms of the zero convs alone (operand of Wzc by itself)
-        Wcat = torch.cat([Wzc, Wdc], 0)                  # rows NL C + 2k / + 2k+1: cond columns of w1_k / w2_k (Wdc's own layout)
+        # (Wcat = [Wzc ; Wdc]: rows NL C + 2k / + 2k+1 are the cond columns of w1_k / w2_k - Wdc's own layout)
         H.conv3x3_auto([DH, DD], Wcat, Cc, [Gc], dgrad=True)
         H.conv_rep_border_fix(DH, H.conv_pack(Wzc, 1), [Gc])
         H.masked_add(Gc, src=Gc, ref=cond)
@@ -1306,9 +1461,8 @@ class LevelCouplingFn(torch.autograd.Function):
         H.conv_wgrad([cond], DD, tmpC.view(2 * NLp, Cc, 3, 3), None, 3, 1, relu_in=True)
         # one launch: rows of tmpX / tmpC -> dW1 / dW2, and d(kappa_k) = <wz_k, dwz_k> + <bz_k, dbz_k> inside the clamp range
         # (homogeneity of the zero conv in (W, b); the two inner products nearly cancel for small kappa gradients: fp64 sums)
-        Kp = torch.stack([kp.reshape(()) for kp in kps])
         dK = torch.empty(NL, device=dev, dtype=torch.float32)
-        H.level_finish(Wz, dWz, torch.stack(bzs), dBz, Kp, tmpX, tmpC, dW1, dW2, dK, zeros(4 * NL, dev), ch, Cc)
+        H.level_finish(Wz, dWz, Bz, dBz, Kp, tmpX, tmpC, dW1, dW2, dK, zeros(4 * NL, dev), ch, Cc)
         grads = []
         for k in range(NL):
             grads += [dW1[k], dW2[k], dWz[k], dBz[k], dK[k].reshape(kps[k].shape)]

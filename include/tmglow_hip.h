@@ -409,6 +409,42 @@ int tmg_mix_f32_affine_bwd(const void* dy, const int64_t* dy_d, const void* W, c
                            const void* g, const void* kappa, void* dto1, void* dtin2, const int64_t* dtin2_d, void* dhh,
                            const int64_t* dhh_d, const int64_t* dims, tmg_stream_t st);
 
+/* ---- round 6: the glue around the flow kernels as launches of this library (tmg_glue.hip) ------------------------- */
+
+#define TMG_SUM_TERMS_MAX 8
+
+/* Split.reverse / GaussianDiag.sample (flowUtils.py:194-209, :325-335): z2 = mean + exp(log-std) eps with (mean | log-std) = hz
+ * [npix][2 Ch] clipped as in tmg_gauss_fwd, written to out + o_d[1] at pixel stride o_d[0] - i.e. straight into the second half of
+ * the [.., 2 Ch] tensor the reference builds with torch.cat((z1, z2), 1) (:334); pass (optional, [npix][Ch] at stride p_d[0]) is
+ * copied to out + pass_off beside it.  eps_in given: reconstruct's latents; NULL: eps ~ N(0, 1) is drawn in the kernel
+ * (Philox4x32-10, counter = (element quad, site), key = the two int64 at `nonce`, device memory - the host draws the nonce with
+ * torch's generator once per model call, so the latents follow torch.manual_seed and stay fresh under hipGraph replay) and stored to
+ * eps_out [npix][Ch] (optional) for the backward pass (tmg_gauss_bwd, mode 1).  logp[image] += sum -0.5 (ln 2 pi + 2 lsd + eps^2).
+ * dims = {B, pixels per image, Ch, clip_mean, site}; fl = {mean_lo, mean_hi, logstd_lo, logstd_hi}. */
+int tmg_gauss_sample(const void* hz, const int64_t* hz_d, const void* eps_in, const int64_t* ei_d, const void* pass,
+                     const int64_t* p_d, void* out, const int64_t* o_d, int64_t pass_off, void* eps_out, void* logp, const void* nonce,
+                     const int64_t* dims, const float* fl, tmg_stream_t st);
+
+/* The benchmark loss of SURVEY 8-D, generative direction: *loss += fl[0] sum(y^2) + fl[1] sum(logdet) (the caller zeroes *loss;
+ * fl = {1 / numel(y), 1 / (B noc H W)}), and its gradient dy = 2 fl[0] *g y, dld[b] = fl[1] *g with the upstream gradient read from
+ * device memory.  y, dy: n contiguous floats, 16-byte aligned.  dims = {n, B}.  Replaces the pow / mean / div / add chain the
+ * reference-side harness would build from torch ops (main.py trains through TMGLowLoss, trainFlowParallel.py:104-177 - tmg_phys_*). */
+int tmg_reverse_loss_fwd(const void* y, const void* ld, void* loss, const int64_t* dims, const float* fl, tmg_stream_t st);
+int tmg_reverse_loss_bwd(const void* y, const void* g, void* dy, void* dld, const int64_t* dims, const float* fl, tmg_stream_t st);
+
+/* Log-det bookkeeping (tmGlow.py:412-414, :438-440; flowLSTMBlock.py:314-318, :345-359 sum the per-layer / per-level terms with one
+ * `+` each): out[b] = sum_k terms[k][lens[k] == 1 ? 0 : b], n <= TMG_SUM_TERMS_MAX terms of length B or 1 (a broadcast scalar).
+ * tmg_vec_sum: out[0] = sum_b g[b] - the gradient of a broadcast term. */
+int tmg_sum_terms(const void* const* terms, const int64_t* lens, int64_t n, void* out, int64_t B, tmg_stream_t st);
+int tmg_vec_sum(const void* g, int64_t B, void* out, tmg_stream_t st);
+
+/* Parameter-side operands of a level's NL plain coupling layers gathered through a device table tab[NL][5] of the modules' own
+ * tensors (w1 [1][ch+Cc][3][3], w2 [1][ch+Cc+1][3][3], wz [C][ch+Cc+2][3][3], bz [C], kappa [1]; denseBlock.py:135-152,
+ * flowUtils.py:211-247): Wz [NL][C][ch+Cc+2][3][3] (stack), Wcat [NL C + 2 NLp][Cc][3][3] (rows k C + o: conditioning columns of
+ * wz_k; rows NL C + 2k / + 2k+1: conditioning columns of w1_k / w2_k, zero for the NLp - NL padding layers), Bz [NL][C], Kp [NL].
+ * dims = {NL, NLp, C, ch, Cc}. */
+int tmg_level_pack(const void* tab, void* Wz, void* Wcat, void* Bz, void* Kp, const int64_t* dims, tmg_stream_t st);
+
 /* ---- physics-constrained reverse-KL loss (tmg_physics.hip) ------------------------------ */
 
 /* Residual sums of TMGLowLoss (trainFlowParallel.py:121-177 / physicsConstrained.py:42-94): y, target = [N,3,H,W]

@@ -239,6 +239,152 @@ def test_gauss_logp_and_sample(clip):
     _close(_back(hd2.grad), hr2.grad, what="sample dhz")
 
 
+@pytest.mark.parametrize("clip,Ch,with_z1", [(1, 5, True), (0, 8, False), (1, 6, True), (0, 64, True)])
+def test_gauss_draw_node_given_latents(clip, Ch, with_z1):
+    """Round 6: Split.reverse / GaussianDiag.sample as ONE launch (tmg_gauss_sample via ops.GaussDrawFn) - the sample written into the
+    second half of the [.., 2 Ch] result beside the pass-through half - against the fp64 statement of flowUtils.py:194-209, :325-335
+    (cat(z1, mean + exp(log-std) eps), its log-prob) with gradients for hz and z1; channel counts that are not multiples of 4 and
+    inputs that are channel-slice views included."""
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(19)
+    B, Hh, Ww = 3, 5, 7
+    hz = 1.5 * torch.randn(B, 2 * Ch, Hh, Ww, generator=g)
+    e = torch.randn(B, Ch, Hh, Ww, generator=g)
+    z1 = torch.randn(B, Ch, Hh, Ww, generator=g)
+    limits = ops.SPLIT_LIMITS if clip else ops.TOP_LIMITS
+    hr, z1r = hz.double().requires_grad_(True), z1.double().requires_grad_(True)
+    h = F.hardtanh(hr, -2.0, math.log(5.0)) if clip else hr
+    m, sd = h.chunk(2, 1)
+    sd = sd.clamp(-10.0, math.log(5.0))
+    z2 = m + torch.exp(sd) * e.double()
+    out_r = torch.cat([z1r, z2], 1) if with_z1 else z2
+    lp_r = (-0.5 * (math.log(2 * math.pi) + 2 * sd + e.double() ** 2)).reshape(B, -1).sum(1)
+    go = torch.randn(out_r.shape, generator=g).double()
+    gl = torch.randn(B, generator=g).double()
+    ((out_r * go).sum() + (lp_r * gl).sum()).backward()
+    # HIP: hz / z1 / eps as channel-slice views of wider buffers (the kernels address them in place)
+    wide = torch.zeros(B, Hh, Ww, 2 * Ch + 3, device=DEV)
+    wide[..., :2 * Ch] = _nhwc(hz)
+    hd = wide[..., :2 * Ch].detach().requires_grad_(True)
+    z1d = _nhwc(z1).requires_grad_(True) if with_z1 else None
+    out, lp = ops.GaussDrawFn.apply(hd, z1d, _nhwc(e), None, clip, limits)
+    _close(_back(out), out_r, what="out")
+    _close(lp, lp_r, what="logp")
+    ((out * _nhwc(go.float())).sum() + (lp * gl.float().to(DEV)).sum()).backward()
+    _close(_back(hd.grad), hr.grad, what="dhz")
+    if with_z1:
+        _close(_back(z1d.grad), z1r.grad, what="dz1")
+
+
+def test_gauss_draw_node_in_kernel_latents():
+    """The latents tmg_gauss_sample draws itself (Philox4x32-10 keyed by a nonce from torch's generator + Box-Muller): the stored eps
+    reproduces the written sample exactly, the same (nonce, site) gives the same numbers, another site / nonce independent ones, the
+    moments are those of N(0, 1) (mean, variance, skewness, kurtosis, tails) and neighbouring elements / quads are uncorrelated; the
+    nonce follows torch.manual_seed."""
+    import tmg_ops as ops
+    B, Hh, Ww, Ch = 4, 64, 64, 16
+    hz = torch.zeros(B, Hh, Ww, 2 * Ch, device=DEV)
+    hz[..., :Ch] = 0.25
+    hz[..., Ch:] = math.log(2.0)
+    torch.manual_seed(1234)
+    nonce = ops.latent_nonce(torch.device(DEV))
+    torch.manual_seed(1234)
+    assert torch.equal(ops.latent_nonce(torch.device(DEV)), nonce)         # follows torch's generator
+    assert not torch.equal(ops.latent_nonce(torch.device(DEV)), nonce)     # ... and advances it
+
+    def draw(nonce, site):
+        ctx_out, lp = ops.GaussDrawFn.apply(hz.clone().requires_grad_(True), None, None, (nonce, site), 0, ops.TOP_LIMITS)
+        eps = ctx_out.grad_fn.saved_tensors[1]
+        return ctx_out.detach(), lp.detach(), eps
+
+    z, lp, eps = draw(nonce, 2)
+    assert torch.allclose(z, 0.25 + 2.0 * eps, rtol=0, atol=1e-6)
+    ref_lp = (-0.5 * (math.log(2 * math.pi) + 2 * math.log(2.0) + eps.double() ** 2)).reshape(B, -1).sum(1)
+    _close(lp, ref_lp, what="logp of drawn latents")
+    z_b, _, eps_b = draw(nonce, 2)
+    assert torch.equal(eps_b, eps)
+    _, _, eps_c = draw(nonce, 3)
+    _, _, eps_d = draw(ops.latent_nonce(torch.device(DEV)), 2)
+    e = eps.double().reshape(-1)
+    n = e.numel()                                                         # 262 144 draws: standard errors ~ 2e-3 (mean) .. 1e-2 (kurtosis)
+    assert abs(float(e.mean())) < 1e-2 and abs(float(e.var()) - 1.0) < 1.5e-2
+    assert abs(float((e ** 3).mean())) < 3e-2 and abs(float((e ** 4).mean()) - 3.0) < 8e-2
+    assert abs(float((e.abs() > 2.0).double().mean()) - 0.0455) < 3e-3 and float(e.abs().max()) > 3.8
+    for other in (eps_c, eps_d, torch.roll(eps, 1, 3), torch.roll(eps, 4, 3), torch.roll(eps, 1, 2), torch.roll(eps, 1, 0)):
+        c = float((e * other.double().reshape(-1)).mean())
+        assert abs(c) < 1e-2, c                                            # uncorrelated: |corr| ~ 1 / sqrt(n) = 2e-3
+    assert n == B * Hh * Ww * Ch
+
+
+def test_reverse_loss_node_matches_torch():
+    """ops.reverse_loss (tmg_reverse_loss_fwd / _bwd: one reduction launch, one gradient launch) against the torch statement of the
+    benchmark loss, tests/common.py::loss_reverse, values and gradients; a size that is not a multiple of 4 included."""
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(5)
+    for shape in ((4, 3, 10, 14), (3, 3, 5, 7), (8, 4, 32, 32)):
+        y = torch.randn(shape, generator=g)
+        ld = 100.0 * torch.randn(shape[0], generator=g)
+        yr, lr = y.double().requires_grad_(True), ld.double().requires_grad_(True)
+        ref = C.loss_reverse(yr, lr)
+        (ref * 1.7).backward()
+        yd = y.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ldd = ld.to(DEV).requires_grad_(True)
+        got = ops.reverse_loss(yd, ldd)
+        assert got.shape == ()
+        _close(got, ref, tol=2e-6, what="loss")
+        (got * 1.7).backward()
+        _close(yd.grad, yr.grad, tol=2e-6, what="dy")
+        _close(ldd.grad, lr.grad, tol=2e-6, what="dlogdet")
+        yc = y.to(DEV).requires_grad_(True)                       # an NCHW-contiguous input takes the converting path
+        _close(ops.reverse_loss(yc, ldd.detach()), ref, tol=2e-6, what="loss, NCHW input")
+
+
+def test_sum_logdet_one_launch():
+    """ops.sum_logdet: [B] vectors, broadcast scalars (0-d and 1-element tensors), python numbers and None, more terms than one launch
+    takes; gradients are the upstream vector / its sum."""
+    import tmg_ops as ops
+    B = 7
+    g = torch.Generator().manual_seed(3)
+    vec = [torch.randn(B, generator=g) for _ in range(11)]
+    sc = [torch.randn((), generator=g), torch.randn(1, generator=g)]
+    terms_r = [v.double().requires_grad_(True) for v in vec] + [s_.double().requires_grad_(True) for s_ in sc]
+    ref = sum(terms_r[:11]) + terms_r[11] + terms_r[12] + 2.5
+    gl = torch.randn(B, generator=g)
+    (ref * gl.double()).sum().backward()
+    terms_d = [t.float().to(DEV).requires_grad_(True) for t in vec + sc]
+    got = ops.sum_logdet(terms_d[:5] + [None, 2.5, 0.0] + terms_d[5:], B, torch.device(DEV))
+    _close(got, ref.detach(), what="sum")
+    (got * gl.to(DEV)).sum().backward()
+    for td, tr in zip(terms_d, terms_r):
+        _close(td.grad, tr.grad, what="grad")
+    assert ops.sum_logdet([None, 0.0], B, torch.device(DEV)) == 0.
+    one = terms_d[0].detach()
+    assert ops.sum_logdet([one], B, torch.device(DEV)) is one
+
+
+def test_level_pack_matches_torch_stacks(monkeypatch):
+    """tmg_level_pack (the stacked / sliced parameter operands of a level node from the modules' own tensors, one launch) against the
+    torch stack / slice / cat statement it replaces (kept behind TMG_NO_LEVEL_PACK), for a level with one padding layer (NL = 15) and
+    one with three (NL = 5)."""
+    import tmg_ops as ops
+    g = torch.Generator().manual_seed(8)
+    for NL, C, Cc in ((15, 16, 32), (5, 8, 12), (3, 64, 32)):
+        ch = C // 2
+        cin = ch + Cc
+        NLp = (NL + 3) // 4 * 4
+        wts = []
+        for _ in range(NL):
+            wts += [torch.randn(1, cin, 3, 3, generator=g).to(DEV), torch.randn(1, cin + 1, 3, 3, generator=g).to(DEV),
+                    torch.randn(C, cin + 2, 3, 3, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV), torch.randn(1, 1, 1, 1, generator=g).to(DEV)]
+        got = ops.LevelCouplingFn._level_operands(wts, NL, NLp, C, ch, Cc, torch.device(DEV))
+        monkeypatch.setenv("TMG_NO_LEVEL_PACK", "1")
+        ref = ops.LevelCouplingFn._level_operands(wts, NL, NLp, C, ch, Cc, torch.device(DEV))
+        monkeypatch.delenv("TMG_NO_LEVEL_PACK")
+        for a, b, what in zip(got, ref, ("Wz", "Wcat", "Bz", "Kp")):
+            assert torch.equal(a, b), (NL, C, what)
+        assert float(got[1][NL * C + 2 * NL:].abs().max()) == 0.0 if NLp > NL else True
+
+
 def test_checker_and_upsample():
     import tmg_ops as ops
     from oracle import tmglow_oracle as O

@@ -13,6 +13,7 @@ for p in (ROOT, os.path.join(ROOT, "deep-turbulence_amd"), os.path.join(ROOT, "t
     sys.path.insert(0, p)
 import common as C  # noqa: E402
 from tmg_optim import HipAdam  # noqa: E402
+import tmg_ops  # noqa: E402
 cfg = bench.CONFIGS["M"]
 dev = torch.device("cuda")
 model = bench.build_model(cfg, dev)
@@ -27,7 +28,7 @@ states = [(a.contiguous(memory_format=torch.channels_last), b.contiguous(memory_
 def step():
     opt.zero_grad(set_to_none=True)
     y, ld, _ = model.sample(x, states)
-    C.loss_reverse(y, ld).backward()
+    tmg_ops.reverse_loss(y, ld).backward()
     opt.step()
 
 
