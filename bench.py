@@ -221,7 +221,12 @@ def main():
                          "bf16x3 form (exact three-way bf16 split of both fp32 operands, six MFMAs per accumulator tile, fp32 accumulate: "
                          "fp32-grade error, tests/test_model_parity.py::test_metric_configuration_with_bf16x3_winograd_matches_oracle); "
                          "`dtype` names it")
+    ap.add_argument("--force-bucket", action="store_true",
+                    help="N = 1 only: a process group of ONE rank on the real collective backend (RCCL) with the gradient buckets, their hooks "
+                         "and the all-reduce in the step - what a multi-GPU rank runs, minus the peers; config.allreduce / backend report it")
     args = ap.parse_args()
+    if args.force_bucket and args.gpus == 1:
+        os.environ["TMG_FORCE_DIST"] = "1"
 
     _phase("imports (torch, tests/common)")
     import tmg_dist
@@ -247,8 +252,9 @@ def main():
     _phase("process group, library load")
     model = build_model(cfg, dev)
     _phase("model construction + upload")
-    tmg_dist.broadcast_parameters(model)
-    bucket = tmg_dist.GradBucket(model.parameters(), measure=True) if world > 1 else None
+    forced = bool(args.force_bucket and world == 1)
+    tmg_dist.broadcast_parameters(model, force=forced)
+    bucket = tmg_dist.GradBucket(model.parameters(), measure=True, force=forced) if (world > 1 or forced) else None
     use_graph = args.graph and world == 1
     # the reference's optimizer (main.py:78: Adam, weight decay 1e-8, amsgrad); `fused` = torch's single-kernel multi-tensor
     # implementation of the same update (about 100 launches per step fewer than the default foreach one)
@@ -449,8 +455,8 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     allreduce_report = bucket.overlap_report() if bucket is not None else None     # (event pairs: no collective inside)
-    backend = torch.distributed.get_backend() if world > 1 else None
-    if world > 1:
+    backend = torch.distributed.get_backend() if (world > 1 or forced) else None
+    if world > 1 or forced:
         # every rank leaves the process group HERE, together: nothing below communicates (round 4: ranks != 0 returned while rank 0
         # went on for minutes with the group alive)
         torch.distributed.barrier()

@@ -380,6 +380,238 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same contraction with PRODUCER waves.  wino_fwd_kernel's eight waves stage, transform and multiply in lock step: the
+// matrix pipe idles through commit + issue + input transform + two barriers per chunk (24 % of a wave's life, round-3 stamps).  Here
+// the block has twelve waves: waves 0-7 only multiply (the position loop, the output transform and the epilogue of wino_fwd_kernel,
+// unchanged), waves 8-11 only produce: a producer thread owns (Winograd tile, channel quad) of a chunk, loads its 4x4 input patch
+// straight from global memory into registers (16 float4; the overlapping tiles share their pixels through L1 / L2: no raw patch in
+// LDS), applies padding rule / ReLU, transforms (B^T d B) in registers and writes the 16 position values into the OTHER of two V
+// buffers (2 x 80 KB = all of the CU's LDS).  ONE barrier per chunk: after it the multipliers read the buffer the producers have just
+// filled and the producers refill the one the multipliers have just left.  A chunk is 16 positions x 32 MFMAs x 32 cycles x 2 waves per
+// SIMD = 33 k cycles of matrix work; a producer needs a few thousand for its loads and ~100 vector instructions, so it always waits
+// at the barrier and the multipliers never wait for data after the first stage.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NPW>
+__global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TH = 8, TW = 16;
+    constexpr int KC = 32;
+    constexpr int VS = KC + 8;                 // V row stride (words): a fragment read is a float4 per lane at li * VS + 4 q
+    constexpr int VPL = 32 * VS;               // words per V position plane (32 Winograd tiles)
+    constexpr int VBUF = 16 * VPL;             // words per V buffer
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int nmine = (int)blockIdx.x < p.ntiles ? (p.ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int nchunks = p.nchunks, nst = nmine * nchunks;
+    if (wave >= 8) {
+        // ================================================= producers =================================================
+        const int ptid = tid - 512;
+        const int tc4 = ptid & 7, tt = ptid >> 3;
+        const int tty = tt >> 3, ttx = tt & 7;
+        const int tv = tt * VS + 4 * tc4;
+        int ci = 0, ti = blockIdx.x;
+        for (int k = 0; k < nst; ++k) {
+            int t_ = ti;
+            const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
+            const int ty_ = t_ % p.tiles_y;
+            const int b_ = t_ / p.tiles_y;
+            const int iy0 = ty_ * TH - 1 + 2 * tty, ix0 = tx_ * TW - 1 + 2 * ttx;
+            const float* tptr = tmg_zero_page;
+            int tss = 0;
+            {
+                int cl = ci * KC + 4 * tc4;
+                if (cl < p.Cin) {
+                    const float* sp = p.in[0].p;
+                    int ss = p.in[0].stride, so = p.in[0].off;
+                    if (cl >= p.in[0].n) {
+                        cl -= p.in[0].n;
+                        sp = p.in[1].p; ss = p.in[1].stride; so = p.in[1].off;
+                        if (cl >= p.in[1].n) {
+                            cl -= p.in[1].n;
+                            sp = p.in[2].p; ss = p.in[2].stride; so = p.in[2].off;
+                        }
+                    }
+                    tptr = sp + so + cl;
+                    tss = ss;
+                }
+            }
+            const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win);
+            float4 d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int iy = iy0 + r;
+                const int iyc = min(max(iy, 0), p.Hin - 1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ix = ix0 + c;
+                    const int ixc = min(max(ix, 0), p.Win - 1);
+                    const bool oob = !p.pad_rep && (iy != iyc || ix != ixc);
+                    const float* a_ = oob ? tmg_zero_page : tptr + (size_t)(tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)tss;
+                    d[r][c] = *reinterpret_cast<const float4*>(a_);
+                }
+            }
+            if (p.relu_in) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        d[r][c].x = fmaxf(d[r][c].x, 0.f); d[r][c].y = fmaxf(d[r][c].y, 0.f);
+                        d[r][c].z = fmaxf(d[r][c].z, 0.f); d[r][c].w = fmaxf(d[r][c].w, 0.f);
+                    }
+            }
+#define TMG_W4(OP, A_, B_) make_float4(A_.x OP B_.x, A_.y OP B_.y, A_.z OP B_.z, A_.w OP B_.w)
+            float* vbuf = lds + (k & 1) * VBUF + tv;
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                float4 t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (xi == 0) t[c] = TMG_W4(-, d[0][c], d[2][c]);
+                    else if (xi == 1) t[c] = TMG_W4(+, d[1][c], d[2][c]);
+                    else if (xi == 2) t[c] = TMG_W4(-, d[2][c], d[1][c]);
+                    else t[c] = TMG_W4(-, d[1][c], d[3][c]);
+                }
+                float* vb = vbuf + (xi * 4) * VPL;
+                *reinterpret_cast<float4*>(vb) = TMG_W4(-, t[0], t[2]);
+                *reinterpret_cast<float4*>(vb + VPL) = TMG_W4(+, t[1], t[2]);
+                *reinterpret_cast<float4*>(vb + 2 * VPL) = TMG_W4(-, t[2], t[1]);
+                *reinterpret_cast<float4*>(vb + 3 * VPL) = TMG_W4(-, t[1], t[3]);
+            }
+#undef TMG_W4
+            if (++ci == nchunks) { ci = 0; ti += G; }
+            __syncthreads();       // stage k is in V[k & 1]; the multipliers have left V[(k + 1) & 1]
+        }
+        return;
+    }
+    // ===================================================== multipliers =====================================================
+    const int li = lane & 15, q = lane >> 4;
+    const int KB = p.Cin_pad >> 4;
+    const int ntt = p.Npad >> 4;
+    const int ntile0 = (int)blockIdx.y * (8 * NPW) + NPW * wave;
+    const size_t kb_stride = (size_t)p.Npad * 16, pos_stride = (size_t)KB * p.Npad * 16;
+    int boff[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) boff[n] = li * 16 + 4 * q + min(ntile0 + n, ntt - 1) * 256;
+    int cm = 0, tm = blockIdx.x;
+    f32x4 Y[4][2][NPW];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 bfr[4][2][NPW];
+    for (int k = 0; k < nst; ++k) {
+        const int c0 = cm * KC;
+        const int kgn = min(KC, p.Cin_pad - c0) >> 4;
+        const float* ub = p.U + (size_t)(c0 >> 4) * kb_stride;
+#define TMG_WN_LOADB(R, UB, KGN, POS)                                                                                 \
+        {                                                                                                             \
+            const float* up_ = (UB) + (size_t)(POS) * pos_stride;                                                     \
+            _Pragma("unroll") for (int n = 0; n < NPW; ++n) {                                                         \
+                bfr[R][0][n] = *reinterpret_cast<const float4*>(up_ + boff[n]);                                       \
+                bfr[R][1][n] = *reinterpret_cast<const float4*>(up_ + (size_t)((KGN) - 1) * kb_stride + boff[n]);     \
+            }                                                                                                         \
+        }
+        if (k == 0) { TMG_WN_LOADB(0, ub, kgn, 0) TMG_WN_LOADB(1, ub, kgn, 1) TMG_WN_LOADB(2, ub, kgn, 2) }
+        __syncthreads();           // stage k has been produced
+        {
+            const float4* v4 = reinterpret_cast<const float4*>(lds + (k & 1) * VBUF) + (li * VS + 4 * q) / 4;
+            const int c0n = (cm + 1 == nchunks) ? 0 : c0 + KC;
+            const int kgn_n = min(KC, p.Cin_pad - c0n) >> 4;
+            const float* ubn = p.U + (size_t)(c0n >> 4) * kb_stride;
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) {
+                const int R = pos & 3;
+                __builtin_amdgcn_sched_barrier(0);
+                if (pos + 3 < 16) TMG_WN_LOADB((pos + 3) & 3, ub, kgn, pos + 3)
+                else TMG_WN_LOADB((pos + 3) & 3, ubn, kgn_n, pos + 3 - 16)
+                float4 af[2][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    af[0][m] = v4[(pos * VPL + m * 16 * VS) / 4];
+                    af[1][m] = v4[(pos * VPL + m * 16 * VS + 16) / 4];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[2][NPW];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define TMG_WN_STEP(KG, E)                                                                                            \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n)           \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[R][KG][n].E, af[KG][m].E, acc[m][n], 0, 0, 0);
+                TMG_WN_STEP(0, x) TMG_WN_STEP(0, y) TMG_WN_STEP(0, z) TMG_WN_STEP(0, w)
+                if (kgn == 2) { TMG_WN_STEP(1, x) TMG_WN_STEP(1, y) TMG_WN_STEP(1, z) TMG_WN_STEP(1, w) }
+#undef TMG_WN_STEP
+                const int xi = pos >> 2, nu = pos & 3;
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox) {
+                        const int ay = oy == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : (xi == 1 ? 1 : -1));
+                        const int ax = ox == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : (nu == 1 ? 1 : -1));
+                        const int cf = ay * ax;
+                        if (cf != 0) {
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                                for (int n = 0; n < NPW; ++n) {
+                                    f32x4& y_ = Y[oy * 2 + ox][m][n];
+                                    if (cf > 0) y_ += acc[m][n];
+                                    else y_ -= acc[m][n];
+                                }
+                            if constexpr (NPW == 2) asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][0][1]), "+v"(Y[oy * 2 + ox][1][0]), "+v"(Y[oy * 2 + ox][1][1]));
+                            else asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][1][0]));
+                        }
+                    }
+            }
+        }
+#undef TMG_WN_LOADB
+        if (cm + 1 == nchunks) {
+            int t_ = tm;
+            const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
+            const int ty_ = t_ % p.tiles_y;
+            const int b_ = t_ / p.tiles_y;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int wt = 16 * m + li;
+                const int oyb = ty_ * TH + 2 * (wt >> 3), oxb = tx_ * TW + 2 * (wt & 7);
+#pragma unroll
+                for (int n = 0; n < NPW; ++n) {
+                    const int n0 = (ntile0 + n) * 16 + 4 * q;
+                    if (ntile0 + n < ntt && n0 < p.Cout) {
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
+                        int nl = n0;
+                        TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const int oy = oyb + (o >> 1), ox = oxb + (o & 1);
+                            if (oy < p.Hin && ox < p.Win) {
+                                const unsigned opx = ((unsigned)b_ * (unsigned)p.Hin + (unsigned)oy) * (unsigned)p.Win + (unsigned)ox;
+                                *reinterpret_cast<float4*>(optr + (size_t)opx * (unsigned)ostride + ooff + nl) =
+                                    make_float4(Y[o][m][n][0] + bv.x, Y[o][m][n][1] + bv.y, Y[o][m][n][2] + bv.z, Y[o][m][n][3] + bv.w);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cm = 0; tm += G;
+        } else {
+            ++cm;
+        }
+    }
+}
+
 // out = conv3x3_stride1(pad(act(in))) + bias with the Winograd operand of tmg_conv_wino_pack.
 // dims = {B, H, W, Cin, Cout, relu_in, pad_replicate}; in_desc / out_desc = {stride, off, n} per segment (<= 3 each).
 // Envelope: float4-addressable segments, Cin % 4 == 0, Cout % 4 == 0, Cout >= 64; returns -100 outside it (the caller
@@ -425,6 +657,19 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
     if (G > p.ntiles) G = p.ntiles;
     const size_t lds_bytes = (size_t)(2 * 180 * 40 + 16 * 32 * 40) * sizeof(float);
     TmgProf prof(TMG_PROF_WINO, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);   // algorithmic (direct) flops
+    static const int pc = getenv("TMG_WINO_PC") ? atoi(getenv("TMG_WINO_PC")) : 0;            // A / B switch: producer-wave form
+    if (pc) {
+        const size_t ldsp = (size_t)(2 * 16 * 32 * 40) * sizeof(float);      // two V buffers: all 160 KB of the CU
+        // (twelve waves = three per SIMD = 168 registers: the two-tiles-per-wave form needs 221, so a block covers 128 output channels)
+        const int gyp = (ntt + 7) / 8;
+        int Gp = 256 / gyp;
+        if (Gp < 1) Gp = 1;
+        if (Gp > p.ntiles) Gp = p.ntiles;
+        TMG_LDS_OPTIN((&wino_fwdp_kernel<1>));
+        hipLaunchKernelGGL(wino_fwdp_kernel<1>, dim3(Gp, gyp, 1), dim3(768), ldsp, st, p);
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     if (npw == 1) {
         TMG_LDS_OPTIN((&wino_fwd_kernel<1>));
         hipLaunchKernelGGL(wino_fwd_kernel<1>, dim3(G, gy, 1), dim3(512), lds_bytes, st, p);

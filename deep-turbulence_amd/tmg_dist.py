@@ -19,7 +19,9 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available() and not os.environ.get("TMG_SINGLE_DEVICE"):
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))   # kernels launch on the current device's stream
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("TMG_FORCE_DIST")) and not dist.is_initialized():
+        # (TMG_FORCE_DIST=1: a process group of ONE rank - legal with RCCL on one device - so that the collective path runs through the
+        # real backend on a one-GPU box: bench.py --force-bucket, tests/test_dist_gpu.py)
         if backend is None:
             backend = os.environ.get("TMG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -28,11 +30,11 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def broadcast_parameters(module, src=0):
+def broadcast_parameters(module, src=0, force=False):
     """One-time parameter / buffer broadcast so every replica starts identical: ONE collective per dtype over a flat copy of all
     tensors of that dtype (fp32 parameters + buffers, the int64 BatchNorm counters) instead of one per tensor (~1 000 at the metric
     configuration: each a launch + a rendezvous on the RCCL stream)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return
     groups = {}
     for t in list(module.parameters()) + list(module.buffers()):
@@ -57,7 +59,9 @@ class GradBucket:
 
     Layout (static, identical on every rank by construction): ALL parameters that require a gradient, in reverse registration
     order, cut into buckets of <= `bucket_mb`; a bucket owns ONE persistent flat buffer [gradients | one has-gradient flag per
-    parameter].  The collectives of a step are ALWAYS bucket 0, 1, .., n-1 in that order, then ONE small control vector, then -
+    parameter]; the LAST bucket's buffer ends with the n + 2 floats of the control vector.  The collectives of a step are ALWAYS
+    bucket 0, 1, .., n-1 in that order (the last one - the first-registered parameters, whose gradients arrive last anyway - always from
+    allreduce_mean(), with the control values in its tail: no collective of their own, staged through a pinned buffer), then -
     only when the REDUCED control vector says so - a second pass of the buckets it names, in order.  No rank-local decision changes
     the sequence or the sizes of the collectives, so ranks whose live sets differ (or change at different times) can neither
     dead-lock each other nor bind different gradient sets.
@@ -66,8 +70,8 @@ class GradBucket:
     dead `norm2`, SURVEY fact 8, never does).  From then on every parameter carries a post-accumulate-grad hook and a bucket is
     handed to the collective (RCCL over xGMI with backend "nccl", async) the moment its expected gradients exist and every
     earlier bucket has gone - while backward is still running on the earlier layers.  `allreduce_mean()` then issues what is
-    left, all-reduces the control vector `[late[0..n-1] | changed | aliased]` and reads its n + 2 reduced values on the host (the one
-    host read of a steady step):
+    left, the last bucket with the control vector `[late[0..n-1] | changed | aliased]` in its tail, and reads the n + 2 reduced values
+    on the host (the one host read of a steady step):
       * late[b] > 0: on SOME rank a gradient arrived for bucket b after it had gone (a parameter's first-ever gradient: the live set
         grew) - EVERY rank sends bucket b again with all its gradients (round 4 re-sent it on the rank that saw it only: one collective
         more than its peers);
@@ -86,7 +90,9 @@ class GradBucket:
 
     `measure=True`: event pairs around the exchange (see `overlap_report`)."""
 
-    def __init__(self, params, bucket_mb=32, measure=False):
+    def __init__(self, params, bucket_mb=32, measure=False, force=False):
+        """force: run the collectives also in a process group of ONE rank (the real backend on a one-GPU box)."""
+        self.force = bool(force)
         self.params = [p for p in params if p.requires_grad]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self.buckets = None        # list of parameter lists (built on first use: the parameters may still move device)
@@ -128,9 +134,11 @@ class GradBucket:
             n += p.numel()
         if cur:
             self.buckets.append(cur)
+        nctrl = len(self.buckets) + 2
         for bi, bk in enumerate(self.buckets):
             ng = sum(p.numel() for p in bk)
-            flat = torch.zeros(ng + len(bk), device=bk[0].device, dtype=bk[0].dtype)
+            last = bi == len(self.buckets) - 1
+            flat = torch.zeros(ng + len(bk) + (nctrl if last else 0), device=bk[0].device, dtype=bk[0].dtype)
             views, o = [], 0
             for k, p in enumerate(bk):
                 views.append(flat[o:o + p.numel()].view_as(p))
@@ -139,8 +147,12 @@ class GradBucket:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             self._flat.append(flat)
             self._views.append(views)
-            self._flags.append(flat[ng:])
-        self._ctrl = torch.zeros(len(self.buckets) + 2, device=self.buckets[0][0].device, dtype=torch.float32)
+            self._flags.append(flat[ng:ng + len(bk)])
+            if last:
+                self._ctrl = flat[ng + len(bk):]              # rides on the last bucket's collective
+        self._ctrl_host = torch.zeros(nctrl, dtype=self._ctrl.dtype)
+        if self._ctrl.is_cuda:
+            self._ctrl_host = self._ctrl_host.pin_memory()    # (a pageable source makes the copy a synchronising one)
         self._reset()
 
     def _reset(self):
@@ -193,14 +205,15 @@ class GradBucket:
         elif bi in self._launched:
             self._late.add(bi)          # a first-ever gradient for a bucket that has gone: reported in the control vector, every rank
                                         # sends the bucket again in allreduce_mean()
-        while self._next < len(self.buckets) and self._ready(self._next) and self._next not in self._launched:
+        # (the last bucket never goes from a hook: it carries the control vector, which is known only after backward)
+        while self._next < len(self.buckets) - 1 and self._ready(self._next) and self._next not in self._launched:
             self._launch(self._next)
             self._next += 1
             self.launched_during_backward += 1
 
     # ---- called between backward and the optimizer step ---------------------------------------------------------------
     def allreduce_mean(self):
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not (dist.is_initialized() and (dist.get_world_size() > 1 or self.force)):
             return 0
         world = dist.get_world_size()
         if self.buckets is None:
@@ -210,12 +223,12 @@ class GradBucket:
         if self.measure and self.params and self.params[0].is_cuda:
             ev_done = torch.cuda.Event(enable_timing=True)
             ev_done.record()                       # backward has been issued up to here on the compute stream
-        for bi in range(nbk):                      # what the hooks did not hand over, in the fixed order
+        for bi in range(nbk - 1):                  # what the hooks did not hand over, in the fixed order
             if bi not in self._launched:
                 self._launch(bi)
         # gradients bound after backward (tmg_ops.fused_grad_accumulation) never pass a hook: a bucket that went from a hook without one
         # of them is late too - compare every bucket's has-gradient pattern now with the one it was sent with
-        for bi in range(nbk):
+        for bi in range(nbk - 1):
             if self._sent_pat.get(bi) != tuple(p.grad is not None for p in self.buckets[bi]):
                 self._late.add(bi)
         local = {id(p) for p in self.params if p.grad is not None}
@@ -223,11 +236,13 @@ class GradBucket:
                       for views, bk in zip(self._views, self.buckets) for v, p in zip(views, bk))
         ctrl = [1.0 if bi in self._late else 0.0 for bi in range(nbk)]
         ctrl += [1.0 if (self._live_local is None or local != self._live_local) else 0.0, 1.0 if aliased else 0.0]
-        self._ctrl.copy_(torch.tensor(ctrl, dtype=torch.float32))
-        cwork = dist.all_reduce(self._ctrl, op=dist.ReduceOp.SUM, async_op=True)
+        # the control values ride in the tail of the last bucket's flat buffer (round 5 sent them as a collective of their own, from a
+        # pageable host tensor: a synchronising copy and a rendezvous more per step)
+        self._ctrl_host.copy_(torch.tensor(ctrl, dtype=self._ctrl_host.dtype))
+        self._ctrl.copy_(self._ctrl_host, non_blocking=True)
+        self._launch(nbk - 1)
         for bi, work in self._work:
             work.wait()
-        cwork.wait()
         red = self._ctrl.tolist()                  # the one host read of a steady step (n + 2 floats; identical on every rank)
         late_any = [bi for bi in range(nbk) if red[bi] > 0.0]
         if late_any:

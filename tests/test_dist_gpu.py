@@ -115,3 +115,50 @@ def test_bench_two_rank_path_on_one_device():
     ar = cfg["allreduce"]
     assert ar is not None and ar["buckets"] >= 1 and ar["bytes"] > 20e6 and ar["exchange_ms"] > 0 and ar["exposed_ms"] >= 0
     assert cfg["loss_last"] == cfg["loss_last"]            # not NaN
+
+
+def test_rccl_world_size_one_buckets_and_broadcast(tmp_path):
+    """the REAL collective backend without a second GPU.  tests/dist_rccl1_worker.py joins a process group of one
+    rank with backend "nccl" (RCCL) and runs the flat parameter broadcast, two BPTT windows (buckets issued after the fused gradient
+    accumulation) and three single steps (buckets handed to RCCL from the post-accumulate hooks while backward is running; the control
+    vector in the last bucket's tail) - against the same steps on an identical model with no bucket at all.  A one-rank all-reduce /
+    broadcast is the identity, so losses, gradient norms and parameters must agree to the noise of the float atomics; what the test
+    adds over the gloo ones is RCCL's asynchronous handles and its stream ordering against the compute stream."""
+    out = str(tmp_path / "rccl1.pt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(30400 + (os.getpid() % 1500)),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("TMG_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(C.ROOT, "tests", "dist_rccl1_worker.py"), out], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = torch.load(out)
+    assert res["backend"] == "nccl" and res["broadcast_exact"]
+    a, b = res["rccl"], res["plain"]
+    assert a["nbuckets"] > 1 and a["hooked_single_step"] >= 3 and a["second_passes"] == 0
+    assert a["overlap"] is not None and a["overlap"]["exchange_ms"] > 0
+    for la, lb in zip(a["loss"], b["loss"]):
+        assert abs(la - lb) <= 2e-5 * abs(lb) + 2e-5, (a["loss"], b["loss"])
+    for ga, gb in zip(a["gn"], b["gn"]):
+        assert abs(ga - gb) <= 5e-4 * gb
+    for k, v in b["params"].items():
+        assert float((a["params"][k] - v).abs().max()) <= 2e-2 * 5e-3, k          # Adam: |update| <= lr per step, five steps
+
+
+def test_bench_forced_bucket_reports_rccl():
+    """`bench.py --gpus 1 --force-bucket`: the single-GPU bench step with the gradient buckets and the all-reduce of a multi-GPU rank on
+    a one-rank RCCL group; the JSON line names the backend and carries the event-pair measurement of the exchange."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(32700 + (os.getpid() % 1500)))
+    env.pop("TMG_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(C.ROOT, "bench.py"), "--gpus", "1", "--force-bucket", "--config", "cfg4", "--batch", "4", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline", "--no-events"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and cfg["backend"] == "nccl" and cfg["world_size_observed"] == 1
+    ar = cfg["allreduce"]
+    assert ar is not None and ar["buckets"] >= 1 and ar["bytes"] > 20e6 and ar["exchange_ms"] > 0
+    assert cfg["loss_last"] == cfg["loss_last"]

@@ -668,6 +668,52 @@ def test_winograd_conv_matches_fp64(case, arith):
     _close(out, direct.double(), what="winograd vs direct")
 
 
+@pytest.mark.parametrize("kind", ["wide_exponents", "cancellation", "tiny_beside_unit", "all_tiny"])
+def test_winograd_bf16x3_adversarial_operands(kind):
+    """The bf16x3 arithmetic (three-way bf16 split of both transformed operands, six part products) on operands chosen against it,
+    with the fp32-MFMA Winograd kernel's own error against fp64 as the yardstick (same data, same transforms):
+      wide_exponents    per-channel scales 2^-30 .. 2^+30 on the activations, the inverse on the weights: every product is O(1) but the
+                        operands of one contraction span 60 binades;
+      cancellation      channel pairs with equal activations and negated weights (their exact sum is zero) beside one small live
+                        channel: the result is 1e-4 of the terms that cancel;
+      tiny_beside_unit  activations of 2^-112 (their third bf16 part is an fp32 denormal) beside O(1) channels;
+      all_tiny          every activation at 2^-112 .. 2^-108: the third parts are denormal and the matrix pipe flushes them - the
+                        documented envelope of the switch: the result keeps >= 15 bits (the first two parts), not 24.
+    """
+    import tmg_hip as H
+    g = torch.Generator().manual_seed(31)
+    B, Hh, Ww, Cin, Cout = 2, 16, 16, 64, 256
+    x = torch.randn(B, Hh, Ww, Cin, generator=g)
+    w = 0.2 * torch.randn(Cout, Cin, 3, 3, generator=g)
+    if kind == "wide_exponents":
+        e = torch.linspace(-30, 30, Cin).round()
+        x = x * torch.exp2(e)
+        w = w * torch.exp2(-e).view(1, Cin, 1, 1)
+    elif kind == "cancellation":
+        x[..., 1:Cin - 1:2] = x[..., 0:Cin - 2:2]
+        w[:, 1:Cin - 1:2] = -w[:, 0:Cin - 2:2]
+        x[..., Cin - 2:] *= 1e-4
+    elif kind == "tiny_beside_unit":
+        x[..., ::2] *= 2.0 ** -112
+    else:
+        x = x * torch.exp2(torch.randint(-112, -107, (Cin,), generator=g).float())
+    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2).double(), (1, 1, 1, 1)), w.double()).permute(0, 2, 3, 1)
+    xd, wd = x.to(DEV), w.to(DEV)
+    out = torch.empty((B, Hh, Ww, Cout), device=DEV)
+    out3 = torch.empty((B, Hh, Ww, Cout), device=DEV)
+    assert H.conv_wino_fwd([xd], H.conv_wino_pack(wd), Cout, [out])
+    assert H.conv_wino_fwd3([xd], H.conv_wino_pack3(wd), Cout, [out3])
+    scale = float(ref.abs().max())
+    e32 = float((out.double().cpu() - ref).abs().max()) / scale
+    e3 = float((out3.double().cpu() - ref).abs().max()) / scale
+    print("\nbf16x3 adversarial %-18s scale %.3e  fp32-MFMA err %.3e  bf16x3 err %.3e (relative to the largest output)" % (kind, scale, e32, e3))
+    assert torch.isfinite(out3).all()
+    if kind == "all_tiny":
+        assert e3 <= 2.0 ** -15, (e3, e32)
+    else:
+        assert e3 <= 1.5 * e32 + 1e-7, (e3, e32)
+
+
 def test_winograd_bf16x3_input_gradient_operand():
     """tmg_conv_wino_pack3 mode 1 (the input-gradient operand: transposed weight, flipped taps, channel prefix) through
     conv3x3_auto with the bf16x3 switch on, against fp64 conv_transpose2d - the ConvLSTM out-conv's input gradient 40 -> 104."""
