@@ -657,10 +657,14 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
     if (G > p.ntiles) G = p.ntiles;
     const size_t lds_bytes = (size_t)(2 * 180 * 40 + 16 * 32 * 40) * sizeof(float);
     TmgProf prof(TMG_PROF_WINO, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);   // algorithmic (direct) flops
-    static const int pc = getenv("TMG_WINO_PC") ? atoi(getenv("TMG_WINO_PC")) : 0;            // A / B switch: producer-wave form
-    if (pc) {
+    // Producer-wave form (round 6) for the contractions with <= 128 output channels (one n-tile per wave: 100 registers, twelve waves
+    // fit): 0.592 -> 0.551 ms (40 -> 104 at 128^2), 0.157 -> 0.146, 0.051 -> 0.049 (profiles/r6_ab_wino_producer_waves.txt).  Two
+    // n-tiles per wave need 221 registers with the four-deep U ring; at the 168 that twelve waves leave, a two-deep ring measured 2.375 ms
+    // against 2.294 for the gate conv and a three-deep one spills: the wide shapes stay on wino_fwd_kernel<2>.  TMG_WINO_PC=0: off,
+    // =2: the one-tile producer form for every shape (two blocks per pixel tile above 128 channels: 2.355 ms).
+    static const int pc = getenv("TMG_WINO_PC") ? atoi(getenv("TMG_WINO_PC")) : 1;
+    if ((pc == 1 && npw == 1) || pc == 2) {
         const size_t ldsp = (size_t)(2 * 16 * 32 * 40) * sizeof(float);      // two V buffers: all 160 KB of the CU
-        // (twelve waves = three per SIMD = 168 registers: the two-tiles-per-wave form needs 221, so a block covers 128 output channels)
         const int gyp = (ntt + 7) / 8;
         int Gp = 256 / gyp;
         if (Gp < 1) Gp = 1;
