@@ -377,6 +377,18 @@ struct TmgProf {
 enum { TMG_PROF_CPL = 32, TMG_PROF_C1X2 = 33, TMG_PROF_D2B = 34, TMG_PROF_AFF = 35, TMG_PROF_AFFB = 36, TMG_PROF_LSTMF = 37,
        TMG_PROF_LSTMB = 38, TMG_PROF_GAUSS = 39, TMG_PROF_RESAMPLE = 40, TMG_PROF_MIX16 = 41, TMG_PROF_CPLB = 42, TMG_PROF_WINO = 43, TMG_PROF_WINO_WG = 44 };
 
+// Compute units of the current device (queried once per process: one process per GPU).  The persistent kernels size their grids as
+// multiples of it - one 512-thread block per CU, or the measured 2x / 3x / 4x of the narrow-level tile kernels - instead of the
+// literal 256 of an MI355X (a silent mis-tuning on any other part).
+static inline int tmg_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
 #define TMG_CHECK_LAUNCH()                          \
     do {                                            \
         hipError_t e__ = hipGetLastError();         \

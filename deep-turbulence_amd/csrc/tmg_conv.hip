@@ -1560,7 +1560,7 @@ static int conv_fwd_lean(ConvP p, hipStream_t st) {
         p.ntiles = p.B * p.tiles_x * p.tiles_y;
         p.KCH = kch;
         p.nchunks = (p.Cin_pad + kch - 1) / kch;
-        int G = 256 / gy;
+        int G = tmg_num_cus() / gy;
         if (fp[4] > 0 && p.ksize == 3) G *= fp[4];
         if (G < 1) G = 1;
         if (G > p.ntiles) G = p.ntiles;
@@ -1794,7 +1794,7 @@ struct WgradPlan {
     size_t lds_bytes, ws_floats;
 };
 
-static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin, int Cout, WgradPlan* pl) {
+static int plan_wgrad_impl(int B, int Hout, int Wout, int ksize, int stride, int Cin, int Cout, WgradPlan* pl, bool allow4) {
     int twl = ilog2_ceil(Wout);
     if (twl > 5) twl = 5;
     if (twl < 1) twl = 1;
@@ -1831,7 +1831,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
             if (cit <= 2 && cot >= 8 && nc < 4 && ntaps == 9) continue;
             cg = cit;
         }
-        if (nc > cot) continue;
+        if (nc > cot || (nc == 4 && !allow4)) continue;
         while (cg > 1 && !fits(cg, nc)) --cg;
         if (!fits(cg, nc)) continue;
         const int g = ((cit + cg - 1) / cg) * ((cot + nc - 1) / nc);
@@ -1872,7 +1872,7 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
             const int th = mp >> twl, ph = th + 2 * halo;
             const int tiles = B * ((Wout + TW - 1) / TW) * ((Hout + th - 1) / th);
             if (ph * PW * k4p <= 7 * 512 && 2 * ((size_t)(ph * PW * 16 + 16) * pl->CITG + (size_t)(mp * 16 + 16) * NCO) * 4 <= 160 * 1024 &&
-                tiles >= 4 * 256 / (pl->gy * pl->gz)) {
+                tiles >= 4 * tmg_num_cus() / (pl->gy * pl->gz)) {
                 pl->MPIX = mp; pl->TH = th;
                 pl->tiles_y = (Hout + th - 1) / th;
                 pl->ntiles = tiles;
@@ -1885,12 +1885,20 @@ static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin,
     if (pl->lds_bytes < 8192) pl->lds_bytes = 8192;  // the dbias fold reuses the first 8 KB
     if (pl->lds_bytes < (size_t)4 * pl->NP * NCO * 1024) pl->lds_bytes = (size_t)4 * pl->NP * NCO * 1024;  // cross-wave fold of the partial sums
     // pixel shares: one 512-thread block per CU, but >= 4 tiles per block (two rounds fill the pipeline)
-    int gx = 256 / (pl->gy * ngroups);
+    int gx = tmg_num_cus() / (pl->gy * ngroups);
     if (gx > pl->ntiles / 4) gx = pl->ntiles / 4;
     if (gx < 1) gx = 1;
     pl->gx = gx;
     pl->ws_floats = (size_t)gx * pl->gy * pl->gz * (pl->ksplit ? 1 : 4) * pl->NP * NCO * 256 + (size_t)gx * pl->gy * 64;
     return 0;
+}
+
+// (NP, NCO) = (5, 4) needs 21 registers more than the file has (84 B of scratch per lane, rounds 3-5; outside config M's step): such a
+// plan is made again without the four-output-tile register tiles.
+static int plan_wgrad(int B, int Hout, int Wout, int ksize, int stride, int Cin, int Cout, WgradPlan* pl) {
+    const int rc = plan_wgrad_impl(B, Hout, Wout, ksize, stride, Cin, Cout, pl, true);
+    if (rc == 0 && pl->NP == 5 && pl->NCO == 4) return plan_wgrad_impl(B, Hout, Wout, ksize, stride, Cin, Cout, pl, false);
+    return rc;
 }
 
 // Number of floats of scratch the slab path of tmg_conv_wgrad wants for these dims (same layout as tmg_conv_wgrad's dims).
@@ -1938,8 +1946,8 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
         // blockIdx.y walks (group, output-channel block)
         // (blockIdx.z still walks the input-channel blocks of a group wider than one block)
         pl.gy = bpg * ngroups;
-        int gx = 256 / (pl.gy * pl.gz);
-        if (tmg_wg_plan(1) > 1) gx = tmg_wg_plan(1) * 256 / (pl.gy * pl.gz);
+        int gx = tmg_num_cus() / (pl.gy * pl.gz);
+        if (tmg_wg_plan(1) > 1) gx = tmg_wg_plan(1) * tmg_num_cus() / (pl.gy * pl.gz);
         if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
         if (gx < 1) gx = 1;
         pl.gx = gx;
@@ -1964,7 +1972,7 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
     if (pl.NP == NP_ && pl.NCO == NCO_)                                                           \
         lrc = p.fstage ? launch_wgrad<NP_, NCO_, true>(p, grid, pl.lds_bytes, st) : launch_wgrad<NP_, NCO_, false>(p, grid, pl.lds_bytes, st);
     TMG_WG_CASE(3, 1) TMG_WG_CASE(3, 2) TMG_WG_CASE(3, 4)
-    TMG_WG_CASE(5, 1) TMG_WG_CASE(5, 2) TMG_WG_CASE(5, 4)
+    TMG_WG_CASE(5, 1) TMG_WG_CASE(5, 2)
     TMG_WG_CASE(7, 1) TMG_WG_CASE(7, 2)
     TMG_WG_CASE(8, 1) TMG_WG_CASE(8, 2)
     TMG_WG_CASE(9, 1) TMG_WG_CASE(9, 2)
@@ -2006,8 +2014,8 @@ extern "C" int64_t tmg_conv_wgrad_grouped_ws_floats(const int64_t* dims, int64_t
     WgradPlan pl;
     if (plan_wgrad((int)dims[0], (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7], (int)dims[8], &pl) != 0) return 0;
     const int gy = pl.gy * (int)ngroups;
-    int gx = 256 / (gy * pl.gz);
-    if (tmg_wg_plan(1) > 1) gx = tmg_wg_plan(1) * 256 / (gy * pl.gz);
+    int gx = tmg_num_cus() / (gy * pl.gz);
+    if (tmg_wg_plan(1) > 1) gx = tmg_wg_plan(1) * tmg_num_cus() / (gy * pl.gz);
     if (gx > pl.ntiles / 4) gx = pl.ntiles / 4;
     if (gx < 1) gx = 1;
     return (int64_t)((size_t)gx * gy * pl.gz * (pl.ksplit ? 1 : 4) * pl.NP * pl.NCO * 256 + (size_t)gx * gy * 64);

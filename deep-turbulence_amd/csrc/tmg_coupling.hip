@@ -313,7 +313,7 @@ static int launch_cpl_fwd(const CplFP& p, hipStream_t st) {
     if (lds > 64 * 1024) TMG_LDS_OPTIN((&cpl_fwd_kernel<CT, K4>));
     // blocks: one resident wave (3 per CU at C <= 16, 2 above), every block with the same number of tiles (measured at 64 x 128 x 128 and
     // 64 x 64 x 64: 768 / 512; an uneven 5-or-6 split or a second wave of blocks costs 10-20 %)
-    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : (CT == 1 ? 768 : 512);
+    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : (CT == 1 ? 3 : 2) * tmg_num_cus();   // 768 / 512 on an MI355X
     const int per_blk = (p.ntiles + gcap - 1) / gcap;
     const int grid = (p.ntiles + per_blk - 1) / per_blk;
     // algorithmic HBM bytes: x (C), D (4), hc (C) read; out (C), r (C/2), y2 (C/2) written
@@ -663,7 +663,7 @@ static int launch_cpl_bwd(const CplBP& p, hipStream_t st) {
     if (lds > 64 * 1024) TMG_LDS_OPTIN((&cpl_bwd_kernel<CT, MT, KS>));
     // blocks: measured at 64 x 128 x 128 (C = 16: 4 096 tiles) 256: 193 us, 512: 140, 768: 139, 1 024: 119, 2 048: 124, 4 096: 136 - two
     // resident blocks per CU, twice as many blocks as that with an even tile count each; at C = 32 (1 024 tiles) 512: 87, 768: 90, 1 024: 100
-    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : (CT == 1 ? 1024 : 512);
+    static const int gcap = getenv("TMG_CPL_GRID") ? atoi(getenv("TMG_CPL_GRID")) : (CT == 1 ? 4 : 2) * tmg_num_cus();   // 1 024 / 512 on an MI355X
     const int per_blk = (p.ntiles + gcap - 1) / gcap;
     const int grid = (p.ntiles + per_blk - 1) / per_blk;
     // algorithmic HBM bytes: dout (C), r (C/2), tin2 (C/2) read; DH (C), dtin (C), G0 (C/2), GD (4) written

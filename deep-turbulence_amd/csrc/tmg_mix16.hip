@@ -61,13 +61,53 @@ __global__ __launch_bounds__(256) void mix16_kernel(Mix16P p) {
 #pragma unroll
             for (int ks = 0; ks < NT; ++ks) Areg[mt * NT + ks] = Wl[(ks * 4 + lq) * CP + mt * 16 + l16];
     }
+    const long group = 16L * NP;
+    if constexpr (NT > 8) {
+        // Wide mixes (C > 128: the 256-channel level of BASELINE configs[4]).  Round 5's form kept NT bias quads, NT fp32 B quads, their
+        // fp16 conversions and - hoisted by the scheduler - most of a tile row's A fragments live at once: 564 B of scratch per lane at
+        // NT = 16.  Here the B quads are converted as they arrive (the fp32 copies die at once), the bias quad is read per output tile
+        // (L1-resident) and a scheduling fence per output tile keeps the A-fragment reads of later tiles from being hoisted.
+        for (long g0 = ((long)blockIdx.x * 4 + wave) * group; g0 < p.npix; g0 += (long)gridDim.x * 4 * group) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np) {
+                const long px = g0 + np * 16 + l16;
+                h16x4 Bf[NT];
+                {
+                    float4 xv[NT];
+#pragma unroll
+                    for (int ks = 0; ks < NT; ++ks) {
+                        const int c = ks * 16 + 4 * lq;
+                        const float* a = (px < p.npix && c < C) ? p.x + (size_t)px * p.xs + c : tmg_zero_page;
+                        xv[ks] = *reinterpret_cast<const float4*>(a);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < NT; ++ks) {
+                        Bf[ks][0] = (_Float16)xv[ks].x; Bf[ks][1] = (_Float16)xv[ks].y;
+                        Bf[ks][2] = (_Float16)xv[ks].z; Bf[ks][3] = (_Float16)xv[ks].w;
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int c = mt * 16 + 4 * lq;
+                    const float4 bq = (p.bias && c < C) ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    f32x4 acc = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                    for (int ks = 0; ks < NT; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(Wl[(ks * 4 + lq) * CP + mt * 16 + l16], Bf[ks], acc, 0, 0, 0);
+                    if (px < p.npix && c < C)
+                        *reinterpret_cast<float4*>(p.y + (size_t)px * p.ys + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+        }
+        return;
+    }
     float4 bv[NT];
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         const int c = mt * 16 + 4 * lq;
         bv[mt] = (p.bias && c < C) ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const long group = 16L * NP;
     for (long g0 = ((long)blockIdx.x * 4 + wave) * group; g0 < p.npix; g0 += (long)gridDim.x * 4 * group) {
         float4 xv[NP][NT];
 #pragma unroll

@@ -618,7 +618,7 @@ static int launch_level_wgrad(LvlWgP p, int G, hipStream_t st) {
     // CU ran as a full round plus a quarter-filled one of the same length
     int per_cu = 160 * 1024 / lds_bytes;
     per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
-    int P = per_cu * 256 / G;
+    int P = per_cu * tmg_num_cus() / G;
     P = P > p.ntiles ? p.ntiles : (P < 1 ? 1 : P);
     if (P >= 8) P &= ~7;
     p.G = G; p.P = P;

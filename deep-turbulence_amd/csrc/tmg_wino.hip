@@ -652,7 +652,7 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
     const int ntt = p.Npad / 16;
     const int npw = ntt <= 8 ? 1 : 2;           // output-channel tiles per wave (see the kernel)
     const int gy = (ntt + 8 * npw - 1) / (8 * npw);
-    int G = 256 / gy;
+    int G = tmg_num_cus() / gy;
     if (G < 1) G = 1;
     if (G > p.ntiles) G = p.ntiles;
     const size_t lds_bytes = (size_t)(2 * 180 * 40 + 16 * 32 * 40) * sizeof(float);
@@ -666,7 +666,7 @@ extern "C" int tmg_conv_wino_fwd(const void* const* in_ptrs, const int64_t* in_d
     if ((pc == 1 && npw == 1) || pc == 2) {
         const size_t ldsp = (size_t)(2 * 16 * 32 * 40) * sizeof(float);      // two V buffers: all 160 KB of the CU
         const int gyp = (ntt + 7) / 8;
-        int Gp = 256 / gyp;
+        int Gp = tmg_num_cus() / gyp;
         if (Gp < 1) Gp = 1;
         if (Gp > p.ntiles) Gp = p.ntiles;
         TMG_LDS_OPTIN((&wino_fwdp_kernel<1>));
@@ -1087,7 +1087,7 @@ extern "C" int tmg_conv_wino_fwd3(const void* const* in_ptrs, const int64_t* in_
     const int ntt = p.Npad / 16;
     const int npw = ntt <= 8 ? 1 : 2;
     const int gy = (ntt + 8 * npw - 1) / (8 * npw);
-    int G = 256 / gy;
+    int G = tmg_num_cus() / gy;
     if (G < 1) G = 1;
     if (G > p.ntiles) G = p.ntiles;
     const size_t lds_bytes = (size_t)(2 * 180 * 40) * sizeof(float) + (size_t)16 * 3 * 4 * 512;
@@ -1417,7 +1417,7 @@ extern "C" int tmg_conv_wino_narrow(const void* const* in_ptrs, const int64_t* i
     p.nchunks = (p.Cin_pad + 31) / 32;
     if (p.ntiles <= 0) return 0;
     if ((long long)p.B * p.Hin * p.Win >= (1LL << 31)) return -100;      // 32-bit pixel indices in the kernels
-    const int G = p.ntiles < 256 ? p.ntiles : 256;
+    const int G = p.ntiles < tmg_num_cus() ? p.ntiles : tmg_num_cus();
     switch (p.Npad >> 4) {
         case 1: return launch_wino_nn<1>(p, G, st);
         case 2: return launch_wino_nn<2>(p, G, st);
@@ -1756,7 +1756,7 @@ static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, int ngroups, 
     pl->NCO = cotg <= 2 ? 2 : (cotg == 3 ? 3 : 4);
     pl->gy *= ngroups;     // block row = (group, output-channel block)
     const int ntiles = B * ((W + 15) / 16) * ((H + 7) / 8);
-    int gx = 256 / (pl->gy * pl->gz);
+    int gx = tmg_num_cus() / (pl->gy * pl->gz);
     if (gx > ntiles / 2) gx = ntiles / 2;
     if (gx < 1) gx = 1;
     pl->gx = gx;

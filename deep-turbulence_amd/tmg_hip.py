@@ -466,10 +466,12 @@ def conv3x3_auto(inputs, weight, Cout, outs, bias=None, relu_in=False, pad_rep=F
     Cin = sum(t.shape[3] for t in inputs)
     mode = 1 if dgrad else 0
     if not relu_out and wino_eligible(Cin, Cout, 3, 1):
-        if _WINO_PRECISION[0] == "bf16x3":
-            if conv_wino_fwd3(inputs, conv_wino_pack3(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep):
-                return None
-        elif conv_wino_fwd(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep):
+        # bf16x3 (opt-in): when its kernel declines the shape, the fp32 wide Winograd kernel is next - not the narrow / direct ones
+        # (a silent slowdown)
+        if (_WINO_PRECISION[0] == "bf16x3"
+                and conv_wino_fwd3(inputs, conv_wino_pack3(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep)):
+            return None
+        if conv_wino_fwd(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep):
             return None
     if wino_narrow_eligible(Cin, Cout):
         if conv_wino_narrow(inputs, conv_wino_pack(weight, mode, nvalid), Cout, outs, bias=bias, relu_in=relu_in, pad_rep=pad_rep,
