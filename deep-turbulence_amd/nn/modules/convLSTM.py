@@ -1,7 +1,5 @@
 """Convolutional LSTM on the HIP path.  API mirror of the reference's nn/modules/convLSTM.py
 (ConvLSTMCell :16-104, ResidLSTMBlock :107-152)."""
-import os
-
 import torch
 import torch.nn as nn
 
@@ -63,17 +61,8 @@ class ResidLSTMBlock(nn.Module):
 
     def run(self, inputs, state, out_grad_premasked=False):
         """out_grad_premasked: see tmg_ops.conv (the LSTM coupling layer's tail masks the gradient it sends back by [out > 0])."""
-        cell, oc = self.convLSTM, self.out_seq.LSTM_out_conv
-        if (cell.conv.bias is not None and tuple(cell.kernel_size) == (3, 3) and oc.bias is not None
-                and os.environ.get("TMG_NO_RESID_LSTM_NODE") is None):
-            # cell + out conv as one node: the inputs they share get ONE summed gradient from one contraction (ops.ResidLSTMFn)
-            if state is None:
-                t = inputs[0]
-                h_cur, c_cur = torch.zeros(t.shape[:3] + (cell.hidden_dim,), device=t.device, dtype=t.dtype), None
-            else:
-                h_cur, c_cur = state
-            return ops.ResidLSTMFn.apply(cell.conv.weight, cell.conv.bias, oc.weight, oc.bias, h_cur, c_cur, bool(out_grad_premasked), *inputs)
         h_next, c_next = self.convLSTM.run(inputs, state)
+        oc = self.out_seq.LSTM_out_conv
         out = ops.conv(list(inputs) + [h_next], oc.weight, oc.bias, relu_out=True, _grad_premasked=out_grad_premasked)
         return out, h_next, c_next
 

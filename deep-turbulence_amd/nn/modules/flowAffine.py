@@ -105,7 +105,8 @@ class LSTMAffineCouplingLayer(nn.Module):
             h_cur, c_cur = z(*xn.shape[:3], cell.hidden_dim), None
         else:
             h_cur, c_cur = state
-        out, h_next, c_next = ops.ResidLSTMFn.apply(gw, cell.conv.bias, ow, ob, h_cur, c_cur, True, x1, condn)
+        h_next, c_next = ops.ConvLSTMCellFn.apply(gw, cell.conv.bias, h_cur, c_cur, x1, condn)
+        out = ops.conv([x1, condn, h_next], ow, ob, relu_out=True, _grad_premasked=True)
         y, ld = ops.CouplingTailFn.apply(xn, out, w1, w2, wz, bz, zc.scale, reverse, 1)
         return y, ld, (h_next, c_next)
 

@@ -658,114 +658,6 @@ class ConvLSTMCellFn(torch.autograd.Function):
         return _defer((weight, bias), (dW, db)) + (dins[-1], dc_prev if ctx.has_c else None) + tuple(dins[:-1])
 
 
-class ResidLSTMFn(torch.autograd.Function):
-    """ResidLSTMBlock as ONE node (reference convLSTM.py:137-152): the ConvLSTM cell of ConvLSTMCellFn followed by
-    out = relu(conv3x3(cat(inputs, h_next)) + b_o).  Round 6: as two nodes (cell, out conv) the block's inputs - the pass-through half
-    x1 and the level's conditioning map, 134 MB at the first level - received one gradient from each node and autograd added them
-    with a full-tensor launch per pair (8 of the step's 24 gradient-accumulation launches, the two largest among them).  A conv is
-    linear in its input channels, so here ONE input-gradient contraction produces the summed gradient of the shared inputs:
-
-        d(inputs) = [W_o[:, :n] ; W_g[:, :n]]^T (*) [dout ; dgates]          (K = C_o + 4R channels -> n = the inputs' channels)
-
-    after the out conv's gradient w.r.t. h_next alone (K = C_o -> R) has gone through the cell's pointwise backward.  The same flops as
-    the two separate input gradients, no addition, no second write of the shared tensors.
-
-    premasked: the only consumer of `out` masks the gradient it sends back by [out > 0] (see `conv`): the ReLU mask pass is skipped.
-    Single backward pass only (the gate buffer is overwritten in place by the pre-activation gradients)."""
-
-    @staticmethod
-    def forward(ctx, wg, bg, wo, bo, h_cur, c_cur, premasked, *inputs):
-        inputs = tuple(t if t.stride(3) == 1 else t.contiguous() for t in inputs)
-        h_cur = h_cur if h_cur.stride(3) == 1 else h_cur.contiguous()
-        if c_cur is not None and c_cur.stride(3) != 1:
-            c_cur = c_cur.contiguous()
-        B, Hh, Ww, _ = inputs[0].shape
-        R4 = wg.shape[0]
-        R = R4 // 4
-        Co = wo.shape[0]
-        dev = wg.device
-        gates = torch.empty((B, Hh, Ww, R4), device=dev, dtype=torch.float32)
-        H.conv3x3_auto(list(inputs) + [h_cur], wg, R4, [gates], bias=bg)
-        c_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
-        h_next = torch.empty((B, Hh, Ww, R), device=dev, dtype=torch.float32)
-        H.lstm_pointwise_fwd(gates, c_cur, c_next, h_next)
-        out = torch.empty((B, Hh, Ww, Co), device=dev, dtype=torch.float32)
-        H.conv3x3_auto(list(inputs) + [h_next], wo, Co, [out], bias=bo, relu_out=True)
-        ctx.n_in = len(inputs)
-        ctx.has_c = c_cur is not None
-        ctx.premasked = bool(premasked)
-        ctx.consumed = False
-        ctx.save_for_backward(wg, bg, wo, bo, h_cur, c_cur, gates, c_next, h_next, out, *inputs)
-        ctx.set_materialize_grads(False)
-        return out, h_next, c_next
-
-    @staticmethod
-    def backward(ctx, dout, dh_ext, dc_ext):
-        if ctx.consumed:
-            raise RuntimeError("ResidLSTMFn: the gate buffer was consumed by a previous backward pass")
-        ctx.consumed = True
-        wg, bg, wo, bo, h_cur, c_cur, acts, c_next, h_next, out = ctx.saved_tensors[:10]
-        inputs = list(ctx.saved_tensors[10:])
-        dev = wg.device
-        nrest = sum(t.shape[3] for t in inputs)
-        R = h_next.shape[3]
-        dWg, dbg = zeros_like(wg), zeros_like(bg)
-        dWo, dbo = zeros_like(wo), zeros_like(bo)
-        # (wg, bg, wo, bo, h_cur, c_cur, premasked, *inputs)
-        need_in = any(ctx.needs_input_grad[7:7 + ctx.n_in])
-        need_h = ctx.needs_input_grad[4]
-        dins = [None] * ctx.n_in
-        dh_cur = dc_prev = None
-        if dout is None:
-            # the block's feature map took no part in the loss: only the states carry gradients (a stand-alone use of the block)
-            dy = None
-            dh = dh_ext.contiguous() if dh_ext is not None else None
-        else:
-            if ctx.premasked:
-                dy = dout.contiguous()
-                if os.environ.get("TMG_CHECK_PREMASK"):
-                    leak = float((dy * (out <= 0)).abs().max())
-                    if leak != 0.0:
-                        raise RuntimeError("ResidLSTMFn: premasked contract violated (%.3e): `out` has a consumer that does not mask its gradient" % leak)
-            else:
-                dy = torch.empty_like(out)
-                H.masked_add(dy, src=dout.contiguous(), ref=out)
-            H.conv_wgrad(inputs + [h_next], dy, dWo, dbo, 3, 1)
-            # gradient of the out conv w.r.t. h_next alone (its last R input channels)
-            dh = torch.empty(h_next.shape, device=dev, dtype=torch.float32)
-            H.conv3x3_auto([dy], wo[:, nrest:].contiguous(), R, [dh], dgrad=True)
-            if dh_ext is not None:
-                H.masked_add(dh, src=dh, add=dh_ext.contiguous())
-        if dh is not None or dc_ext is not None:
-            dc_prev = torch.empty_like(c_next) if (ctx.has_c and ctx.needs_input_grad[5]) else None
-            H.lstm_pointwise_bwd(acts, c_cur, c_next, dh, dc_ext.contiguous() if dc_ext is not None else None, dc_prev)
-            dg = acts        # now the pre-activation gate gradients
-            segs = inputs + [h_cur]
-            if R == 64 and 32 < nrest <= 48 and nrest % 4 == 0 and H.wino_wgrad_eligible(nrest, wg.shape[0]):
-                # (two launches writing disjoint column ranges of dW: see ConvLSTMCellFn.backward)
-                Cin = nrest + 64
-                H.conv_wgrad(inputs, dg, dWg, dbg, 3, 1, cin_dst=Cin, cin_valid=nrest, ci_off0=0)
-                H.conv_wgrad([h_cur], dg, dWg, None, 3, 1, cin_dst=Cin, cin_valid=64, ci_off0=nrest)
-            else:
-                H.conv_wgrad(segs, dg, dWg, dbg, 3, 1)
-            if need_h:
-                dh_cur = torch.empty(h_cur.shape, device=dev, dtype=torch.float32)
-                H.conv3x3_auto([dg], wg[:, nrest:].contiguous(), R, [dh_cur], dgrad=True)
-        else:
-            dg = None
-        if need_in and (dy is not None or dg is not None):
-            dins = [torch.empty(t.shape, device=dev, dtype=torch.float32) for t in inputs]
-            if dy is not None and dg is not None:
-                # the summed gradient of the shared inputs as ONE contraction over [dout ; dgates]
-                wcomb = torch.cat([wo[:, :nrest], wg[:, :nrest]], 0)
-                H.conv3x3_auto([dy, dg], wcomb, nrest, dins, dgrad=True)
-            elif dg is not None:
-                H.conv3x3_auto([dg], wg, nrest, dins, dgrad=True, nvalid=nrest)
-            else:
-                H.conv3x3_auto([dy], wo, nrest, dins, dgrad=True, nvalid=nrest)
-        return _defer((wg, bg, wo, bo), (dWg, dbg, dWo, dbo)) + (dh_cur, dc_prev if ctx.has_c else None, None) + tuple(dins)
-
-
 class GaussLogpFn(torch.autograd.Function):
     """log N(z2; mean, exp(lsd)) summed per sample, and eps = (z2-mean)/exp(lsd)  (flowUtils.py:176-192, :311)."""
 

@@ -1270,72 +1270,6 @@ def test_conv_lstm_cell_node_matches_fp64(case):
     _close(bd.grad, br.grad, tol=tol, what="db")
 
 
-@pytest.mark.parametrize("case", [(2, 16, 16, [8, 32], True, True), (1, 9, 20, [16, 32], True, False), (2, 8, 8, [32, 32], False, True),
-                                  (2, 16, 8, [64, 32], True, True), (1, 12, 12, [4, 32], False, False)])
-@pytest.mark.parametrize("state_grads", [True, False])
-def test_resid_lstm_node_matches_fp64(case, state_grads):
-    """ResidLSTMFn (round 6; reference convLSTM.py:137-152: ConvLSTM cell, then out = relu(conv3x3(cat(t0, h')) + b_o)) at the model's
-    widths: the three outputs and every gradient against fp64 autograd.  The node computes the gradient of the inputs the two convs
-    share as ONE contraction over [dout ; dgates] and the out conv's gradient w.r.t. h' on its own; state_grads: gradients also arrive
-    on h' and c' from outside (the next time-step of a BPTT window); h_grad False: the incoming hidden state carries none (first
-    time-step); premasked: the consumer of `out` has already masked its gradient by [out > 0]."""
-    import tmg_ops as ops
-    B, Hh, Ww, segs, h_grad, premasked = case
-    R = 64
-    g = torch.Generator().manual_seed(sum(segs) + Hh + 7)
-    xs = [torch.randn(B, Hh, Ww, c, generator=g) for c in segs]
-    h0 = torch.randn(B, Hh, Ww, R, generator=g)
-    c0 = torch.randn(B, Hh, Ww, R, generator=g)
-    n = sum(segs)
-    wg = 0.15 * torch.randn(4 * R, n + R, 3, 3, generator=g)
-    bg = 0.2 * torch.randn(4 * R, generator=g)
-    wo = 0.15 * torch.randn(n, n + R, 3, 3, generator=g)
-    bo = 0.2 * torch.randn(n, generator=g)
-    go = torch.randn(B, Hh, Ww, n, generator=g)
-    gh, gc = torch.randn(B, Hh, Ww, R, generator=g), torch.randn(B, Hh, Ww, R, generator=g)
-    # fp64 reference
-    xr = [t.double().requires_grad_(True) for t in xs]
-    hr, cr = h0.double().requires_grad_(h_grad), c0.double().requires_grad_(True)
-    pr = [t.double().requires_grad_(True) for t in (wg, bg, wo, bo)]
-    t = torch.cat(xr + [hr], 3).permute(0, 3, 1, 2)
-    gates = F.conv2d(t, pr[0], pr[1], padding=1).permute(0, 2, 3, 1)
-    i_, f_, o_, g_ = torch.split(gates, R, 3)
-    cn = torch.sigmoid(f_) * cr + torch.sigmoid(i_) * torch.tanh(g_)
-    hn = torch.sigmoid(o_) * torch.tanh(cn)
-    t2 = torch.cat(xr + [hn], 3).permute(0, 3, 1, 2)
-    out = F.relu(F.conv2d(t2, pr[2], pr[3], padding=1).permute(0, 2, 3, 1))
-    # (a premasked upstream gradient is zero wherever out is: the same loss either way)
-    loss = (out * go.double()).sum()
-    if state_grads:
-        loss = loss + (hn * gh.double()).sum() + (cn * gc.double()).sum()
-    loss.backward()
-    # HIP
-    xd = [t.to(DEV).requires_grad_(True) for t in xs]
-    hd, cd = h0.to(DEV).requires_grad_(h_grad), c0.to(DEV).requires_grad_(True)
-    pd = [t.to(DEV).requires_grad_(True) for t in (wg, bg, wo, bo)]
-    o2, h2, c2 = ops.ResidLSTMFn.apply(pd[0], pd[1], pd[2], pd[3], hd, cd, premasked, *xd)
-    _close(o2, out, what="out")
-    _close(h2, hn, what="h'")
-    _close(c2, cn, what="c'")
-    god = go.to(DEV)
-    if premasked:
-        god = god * (o2.detach() > 0)
-    loss = (o2 * god).sum()
-    if state_grads:
-        loss = loss + (h2 * gh.to(DEV)).sum() + (c2 * gc.to(DEV)).sum()
-    loss.backward()
-    tol = 3e-5
-    for a, r, what in zip(xd, xr, ["dx%d" % k for k in range(len(xs))]):
-        _close(a.grad, r.grad, tol=tol, what=what)
-    _close(cd.grad, cr.grad, tol=tol, what="dc")
-    if h_grad:
-        _close(hd.grad, hr.grad, tol=tol, what="dh")
-    else:
-        assert hd.grad is None
-    for a, r, what in zip(pd, pr, ("dWg", "dbg", "dWo", "dbo")):
-        _close(a.grad, r.grad, tol=tol, what=what)
-
-
 @pytest.mark.parametrize("training", [True, False])
 def test_dense_block_node_matches_per_layer_path(training):
     """tmg_ops.DenseBlockFn (all layers of an encoder dense block on one pre-sized buffer, gradient accumulated in place) against
