@@ -1702,8 +1702,7 @@ extern "C" int tmg_conv_fwd_add(const void* const* in_ptrs, const int64_t* in_de
     }
     if (osum != p.Cout) return -4;
 
-    static const int fwd_old = getenv("TMG_FWD_OLD") ? 1 : 0;
-    if (!fwd_old) {
+    {
         const int rc = conv_fwd_lean(p, st);
         if (rc != -100) return rc;
     }
@@ -1962,10 +1961,7 @@ static int wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, int64_
     for (int i = 0; i < p.nseg; ++i)
         if (p.in[i].stride >= (1 << 24) || (long)p.B * p.Hin * p.Win * p.in[i].stride >= (1L << 31)) p.fstage = 0;
     if (p.dy.stride >= (1 << 24) || (long)p.B * p.Hout * p.Wout * p.dy.stride >= (1L << 31)) p.fstage = 0;
-    static const int no_fstage = getenv("TMG_WG_NOFSTAGE") ? 1 : 0;
-    if (no_fstage) p.fstage = 0;
-    static const int wg_dbg = getenv("TMG_WG_DBG") ? atoi(getenv("TMG_WG_DBG")) : 0;
-    p.dbg = wg_dbg;
+    p.dbg = 0;
     if (ngroups > 1 && (!p.fstage || !p.ws)) return -100;  // grouped launches exist only on the lean, slab-reduced path
     int lrc = -7;
 #define TMG_WG_CASE(NP_, NCO_)                                                                    \
@@ -2044,8 +2040,7 @@ extern "C" int tmg_conv_rep_border_fix(const void* dy, const int64_t* dy_desc, c
               (p.Cx & 3) == 0 && p.Npad <= 128;
     for (int i = 0; i < (int)nout; ++i)
         if (((p.out[i].stride | p.out[i].off | p.out[i].n) & 3) || (((uintptr_t)p.out[i].p) & 15)) mf = false;
-    static const int no_mf = getenv("TMG_BORDER_SCALAR") ? 1 : 0;
-    if (mf && !no_mf) {
+    if (mf) {
         BorderMP m;
         m.b = p;
         const int cnt[8] = {p.H - 2, p.H - 2, p.W - 2, p.W - 2, 1, 1, 1, 1};

@@ -668,9 +668,8 @@ static int launch_cpl_bwd(const CplBP& p, hipStream_t st) {
     const int grid = (p.ntiles + per_blk - 1) / per_blk;
     // algorithmic HBM bytes: dout (C), r (C/2), tin2 (C/2) read; DH (C), dtin (C), G0 (C/2), GD (4) written
     TmgProf prof(TMG_PROF_CPLB, 4.0 * p.B * (double)p.H * p.W * (4.5 * p.C + 4), st);
-    static const int noperm = getenv("TMG_CPLB_NOPERM") ? 1 : 0;       // A / B switch
     if constexpr (CT == 1) {
-        if (!p.fwd && !noperm) {
+        if (!p.fwd) {
             hipLaunchKernelGGL((cpl_bwd_kernel<CT, MT, KS, true>), dim3(grid), dim3(256), lds, st, p);
             TMG_CHECK_LAUNCH();
             return 0;

@@ -1845,8 +1845,7 @@ extern "C" int tmg_dense2_bwd(const void* const* in_ptrs, const int64_t* in_desc
         gx = (p.ntiles + per_blk - 1) / per_blk;
     }
     TmgProf prof(TMG_PROF_D2B, 4.0 * p.B * (double)p.Hin * p.Win * (3.0 * p.cin_nn + 4 + 4 + 4 + 2), st);   // x, G0 read, dx written; D, GD; add0 ~ included in 3 cin
-    static const bool no_lean = getenv("TMG_D2_NO_LEAN") != nullptr;
-    if (!no_lean && !p.dW1 && !p.dW2 && p.vec4 && ng == 1 && p.nseg == 2 && p.in[0].n == p.cin_nn && p.in[1].n == 4 && (p.cin_nn & 3) == 0 &&
+    if (!p.dW1 && !p.dW2 && p.vec4 && ng == 1 && p.nseg == 2 && p.in[0].n == p.cin_nn && p.in[1].n == 4 && (p.cin_nn & 3) == 0 &&
         p.g0[0].n == p.cin_nn && p.dd1_out &&
         (p.dd_quad || (p.dd2_out == p.dd1_out + 1 && !(p.dd_stride & 1) && !(((uintptr_t)p.dd1_out) & 7))) &&
         (double)p.B * p.Hin * p.Win * 4.0 * (double)std::max(std::max(std::max(p.in[0].stride, p.g0[0].stride), std::max(p.out[0].stride, p.add0_stride)),

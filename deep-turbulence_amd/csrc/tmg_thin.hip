@@ -317,340 +317,6 @@ extern "C" int tmg_mix_wgrad_grouped(const void* gtab, int64_t G, void* dW, void
 }
 
 // =================================================================================================================================
-// ALL THREE per-layer weight gradients of a narrow level's coupling layers in one launch (round 5; generative direction):
-//   zero conv      dWz[g][co][ci][tap] += sum_px DH_g[px][co] relu(X_g)[px + tap - 1][ci]      replicate padding, C outputs, + bias sums
-//   growth layers  dWx[g][co][ci][tap] += sum_px DD_g[px][co] relu(X_g)[px + tap - 1][ci]      zero padding, 2 outputs
-//   channel mix    dWm[g][o][i]        += sum_px dout_g[px][o] y_g[px][i],  y = (x1 | y2)      + bias sums
-// with X = (x1 | D) - flowUtils.py:246-247 (Conv2dZeros), denseBlock.py:135-152, glowConv.py:207-222 under autograd.  The three
-// launches it replaces (conv_wgrad_kernel<9,1>, wgrad_thin_kernel, mix_wgrad_kernel) read x1 | D twice and x1 a third time; here a
-// block stages the RAW (x1 | D) patch of a tile once (replicate padded), the tile's DH / DD / dout slices and y2, and runs every
-// contraction on v_mfma_f32_4x4x1 blocks (see wgrad_thin_kernel): per pixel and slot of 16 (tap, channel quad) blocks ONE read of the
-// ReLU'd patch value feeds 1 + C / 4 instructions (the DD quad and the C / 4 column quads of DH), and the mix is (C / 4)^2 blocks of
-// (y quad) x (dout quad) - 1 instruction per pixel at C = 16, 4 at C = 32.  The growth layers' zero padding against the zero conv's
-// replicate padding: the patch is replicate padded and, in tiles that touch the image border, the DD instruction's operand is masked
-// where pixel + tap leaves the image (interior tiles take a path without the test).
-// =================================================================================================================================
-struct LvlWgP {
-    const long long* gtab;   // [G][16]: {x1, stride, 0, ch} {D, stride, 0, 4} {y2, stride, 0, ch} {dout half 1, stride, dout half 2, stride}
-    const float* DH; int dhs;   // shared [npix][>= G C]: layer g at channels [C g, C g + C)
-    const float* DD; int dds;   // shared compact [npix][>= 2 G]: layer g at channels 2 g, 2 g + 1
-    float* dWz; int cin_dst, ci_off1;   // [G][C][cin_dst][9]; patch channel ci < ch -> row ci, the two D channels -> rows ch + ci_off1 + {0, 1}
-    float* dBz;              // [G][C]
-    float* dWx;              // [G][4][ch + 4][9] (rows 2, 3 untouched)
-    float* dWm;              // [G][C][C]
-    float* dbm;              // [G][C]
-    int B, H, W;
-    int tiles_x, tiles_y, ntiles, G, P;
-    int dbg;                 // TMG_LW_DBG (timing experiments, wrong results): 1 = no MFMA phase, 2 = no global loads
-};
-
-// TMG_LW_EXP (compile-time ablations, wrong results): 1 = no ReLU / padding mask / bias additions in the MFMA loop, 2 = and no LDS reads
-#ifndef TMG_LW_EXP
-#define TMG_LW_EXP 0
-#endif
-template <int CH>
-__global__ __launch_bounds__(256, 3) void level_wgrad_kernel(LvlWgP p) {
-    constexpr int C = 2 * CH, NQ = C / 4, HQ = CH / 4;
-    constexpr int CS = CH + 4, Q = CS / 4, NB = 9 * Q, SL = (NB + 15) / 16;
-    constexpr int NM = NQ * NQ / 16;                         // mix instructions per pixel
-    constexpr int TH = 8, PWp = 19, PH = TH + 2, PW = 18, NPX = TH * 16;
-    constexpr int XW = PH * PWp * CS;
-    // (the y2 tile uses the patch's pixel and row strides: the mix's A operand then differs between lanes by its base alone)
-    constexpr int O_DD = XW, O_DH = O_DD + NPX * 4, O_DC = O_DH + NPX * C, O_Y2 = O_DC + NPX * C, LW = O_Y2 + TH * PWp * CS;
-    constexpr int NA = SL + SL * NQ + NM;                    // accumulators (f32x4) per lane
-    constexpr int RR = LW / 1024;                            // accumulators per reduction round (4 waves x 256 floats each)
-    static_assert(RR >= 1, "reduction area");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l3 = lane & 3, lb = lane >> 2;
-    int g, part;
-    if ((p.P & 7) == 0) {       // the G blocks of a partition walk the same tiles and share the DH / DD lines: one XCD (see wgrad_thin_kernel)
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        g = slot % p.G;
-        part = xcd + 8 * (slot / p.G);
-    } else {
-        g = blockIdx.x % p.G;
-        part = blockIdx.x / p.G;
-    }
-    const long long* gt = p.gtab + (size_t)g * 16;
-    const float* x1p = reinterpret_cast<const float*>(gt[0]);
-    const float* Dp = reinterpret_cast<const float*>(gt[4]);
-    const float* y2p = reinterpret_cast<const float*>(gt[8]);
-    const float* dc1 = reinterpret_cast<const float*>(gt[12]);
-    const float* dc2 = reinterpret_cast<const float*>(gt[14]);
-    const int x1s = (int)gt[1], Ds = (int)gt[5], y2s = (int)gt[9], dc1s = (int)gt[13], dc2s = (int)gt[15];
-    const float* dhb = p.DH + C * g;
-    const float* ddb = p.DD + 2 * g;
-
-    // per slot: this lane's block (tap, channel quad) -> offset of its A element in the patch, tap offsets for the zero-padding mask
-    int aoff[SL], kyo[SL], kxo[SL];
-#pragma unroll
-    for (int t = 0; t < SL; ++t) {
-        const int beta = min(16 * t + lb, NB - 1);
-        const int u = beta / Q, s = beta - u * Q;
-        const int ky = u / 3, kx = u - ky * 3;
-        aoff[t] = (ky * PWp + kx) * CS + 4 * s + l3;
-        kyo[t] = ky - 1; kxo[t] = kx - 1;
-    }
-    // mix: block beta = 16 m + lane / 4 = (y quad i) * NQ + (dout quad j); y quads below HQ are x1 (patch centre), the others y2
-    int moff[NM], mb[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-        const int beta = 16 * m + lb;
-        const int i = beta / NQ, j = beta - i * NQ;
-        moff[m] = i < HQ ? (PWp + 1) * CS + 4 * i + l3 : O_Y2 + 4 * (i - HQ) + l3;
-        mb[m] = O_DC + 4 * j + l3;
-    }
-    f32x4 acc[NA];
-#pragma unroll
-    for (int a = 0; a < NA; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 bH[NQ / 4];          // bias sums of the zero conv: component e of bH[v] = channel 4 (4 v + e) + l3
-#pragma unroll
-    for (int v = 0; v < NQ / 4; ++v) bH[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bM = 0.f;            // bias sum of the mix: dout channel 4 j + l3 of this lane's block in instruction 0
-
-    // ---- staging in two halves: ISSUE loads a tile's operands into registers (branch-free: items past the end and pixels outside the
-    // image read a zero page), COMMIT writes them to LDS.  With PF the next tile's loads are in flight during the MFMA phase of the
-    // current one: the co-resident blocks of a CU otherwise fall into step - all of them loading (HBM-bound), then all of them
-    // multiplying - and the launch takes the SUM of its memory time and its matrix time (measured: 54 + 38 us per layer at C = 16).
-    constexpr bool PF = true;
-    constexpr int NXI = PH * PW * Q, NX = (NXI + 255) / 256, NH = NPX * NQ / 256, NY = (NPX * HQ + 255) / 256;
-    float4 rx[NX], rh[NH], rd[NH], ry[NY];
-    float2 rdd = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < NX; ++u) rx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < NH; ++u) { rh[u] = make_float4(0.f, 0.f, 0.f, 0.f); rd[u] = rh[u]; }
-#pragma unroll
-    for (int u = 0; u < NY; ++u) ry[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#define TMG_LW_ISSUE(TILE)                                                                                                        \
-    if (p.dbg != 2) {                                                                                                             \
-        int t_ = (TILE);                                                                                                          \
-        const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;                                                                          \
-        const int ty_ = t_ % p.tiles_y;                                                                                           \
-        const int iy0 = ty_ * TH, ix0 = tx_ * 16;                                                                                 \
-        const size_t img = (size_t)(t_ / p.tiles_y) * p.H * p.W;                                                                  \
-        /* (an opaque copy of the thread index: the items' coordinates are tile-invariant, and left to the compiler they are */   \
-        /* hoisted out of the tile loop and spilled next to the accumulators) */                                                  \
-        int tidl = tid;                                                                                                           \
-        asm volatile("" : "+v"(tidl));                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < NX; ++u) {                                                                          \
-            const int it = tidl + u * 256, itc = min(it, NXI - 1);                                                                \
-            const int pp = itc / Q, qd = itc - pp * Q;                                                                            \
-            const int row = pp / PW, col = pp - row * PW;                                                                         \
-            const int iy = min(max(iy0 - 1 + row, 0), p.H - 1), ix = min(max(ix0 - 1 + col, 0), p.W - 1);                         \
-            const size_t pix = img + (size_t)iy * p.W + ix;                                                                       \
-            const float* a_ = qd < HQ ? x1p + pix * x1s + 4 * qd : Dp + pix * Ds;                                                 \
-            rx[u] = tmg_ldg4(it < NXI ? a_ : tmg_zero_page);                                              \
-        }                                                                                                                         \
-        {                                                                                                                         \
-            const int it = tidl & (NPX - 1);                                                                                      \
-            const int oy = iy0 + (it >> 4), ox = ix0 + (it & 15);                                                                 \
-            const float* a_ = ddb + (img + (size_t)min(oy, p.H - 1) * p.W + min(ox, p.W - 1)) * p.dds;                            \
-            rdd = tmg_ldg2((oy < p.H && ox < p.W) ? a_ : tmg_zero_page);                                  \
-        }                                                                                                                         \
-        _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                          \
-            const int it = tidl + u * 256;                                                                                        \
-            const int px = it / NQ, j = it - px * NQ;                                                                             \
-            const int oy = iy0 + (px >> 4), ox = ix0 + (px & 15);                                                                 \
-            const bool ok = oy < p.H && ox < p.W;                                                                                 \
-            const size_t pix = img + (size_t)min(oy, p.H - 1) * p.W + min(ox, p.W - 1);                                           \
-            rh[u] = tmg_ldg4(ok ? dhb + pix * p.dhs + 4 * j : tmg_zero_page);                             \
-            const float* d_ = j < HQ ? dc1 + pix * dc1s + 4 * j : dc2 + pix * dc2s + 4 * (j - HQ);                                \
-            rd[u] = tmg_ldg4(ok ? d_ : tmg_zero_page);                                                    \
-        }                                                                                                                         \
-        _Pragma("unroll") for (int u = 0; u < NY; ++u) {                                                                          \
-            const int it = min(tidl + u * 256, NPX * HQ - 1);                                                                     \
-            const int px = it / HQ, j = it - px * HQ;                                                                             \
-            const int oy = min(iy0 + (px >> 4), p.H - 1), ox = min(ix0 + (px & 15), p.W - 1);      /* (dout is zero there) */     \
-            ry[u] = tmg_ldg4(y2p + (img + (size_t)oy * p.W + ox) * y2s + 4 * j);                          \
-        }                                                                                                                         \
-    }
-    if (part < p.ntiles) { TMG_LW_ISSUE(part) }
-    for (int tile = part; tile < p.ntiles; tile += p.P) {
-        int t_ = tile;
-        const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
-        const int ty = t_ % p.tiles_y;
-        const int oy0 = ty * TH, ox0 = tx * 16;
-        __syncthreads();   // the previous tile's readers are done
-        {
-            int tidl = tid;
-            asm volatile("" : "+v"(tidl));
-            // raw (x1 | D) patch, replicate padded
-#pragma unroll
-            for (int u = 0; u < NX; ++u) {
-                const int it = tidl + u * 256;
-                const int pp = it / Q, qd = it - pp * Q;
-                const int row = pp / PW, col = pp - row * PW;
-                if (it < NXI) *reinterpret_cast<float4*>(lds + (row * PWp + col) * CS + 4 * qd) = rx[u];
-            }
-            // the tile's DD pair, DH (transposed: [px][channel % 4][channel / 4]), dout and y2 (with the patch's pixel / row strides)
-            if (tidl < NPX) *reinterpret_cast<float4*>(lds + O_DD + tidl * 4) = make_float4(rdd.x, rdd.y, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < NH; ++u) {
-                const int it = tidl + u * 256;
-                const int px = it / NQ, j = it - px * NQ;
-                float* ht = lds + O_DH + px * C + j;
-                ht[0] = rh[u].x; ht[NQ] = rh[u].y; ht[2 * NQ] = rh[u].z; ht[3 * NQ] = rh[u].w;
-                *reinterpret_cast<float4*>(lds + O_DC + px * C + 4 * j) = rd[u];
-            }
-#pragma unroll
-            for (int u = 0; u < NY; ++u) {
-                const int it = tidl + u * 256;
-                const int px = it / HQ, j = it - px * HQ;
-                if (it < NPX * HQ) *reinterpret_cast<float4*>(lds + O_Y2 + ((px >> 4) * PWp + (px & 15)) * CS + 4 * j) = ry[u];
-            }
-        }
-        __syncthreads();
-        if (PF && tile + p.P < p.ntiles) { TMG_LW_ISSUE(tile + p.P) }
-        if (p.dbg == 1) continue;
-        // One code path (a border / interior pair of loops made the register allocator keep two copies of the accumulators), and the
-        // LDS operands of pixel i + 1 are read BEFORE the instructions of pixel i are issued: reading them right before their use left
-        // the matrix pipe 58 % idle (every wave waits one LDS latency per pixel pair; measured without any global load in the kernel).
-        static_assert(TH == 8, "two rows per wave");
-        float bdv[2], av[2][SL], yav[2][NM], ybv[2][NM];
-        f32x4 bhv[2][NQ / 4];
-#define TMG_LW_READ(I, S)                                                                                                         \
-        {                                                                                                                         \
-            const int r_ = wave + 4 * ((I) >> 4), px_ = (I) & 15;                                                                 \
-            const float* xr_ = lds + r_ * PWp * CS + px_ * CS;                                                                    \
-            bdv[S] = lds[O_DD + (r_ * 16 + px_) * 4 + l3];                                                                        \
-            _Pragma("unroll") for (int v = 0; v < NQ / 4; ++v)                                                                    \
-                bhv[S][v] = *reinterpret_cast<const f32x4*>(lds + O_DH + (r_ * 16 + px_) * C + l3 * NQ + 4 * v);                  \
-            _Pragma("unroll") for (int t = 0; t < SL; ++t) av[S][t] = xr_[aoff[t]];                                               \
-            _Pragma("unroll") for (int m = 0; m < NM; ++m) { yav[S][m] = xr_[moff[m]]; ybv[S][m] = lds[mb[m] + (r_ * 16 + px_) * C]; } \
-        }
-        TMG_LW_READ(0, 0)
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int r = wave + 4 * (i >> 4), px = i & 15, sl = i & 1;
-#if TMG_LW_EXP >= 2
-            if (i == 0) TMG_LW_READ(1, 1)
-#else
-            if (i + 1 < 32) TMG_LW_READ(i + 1, (i + 1) & 1)
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#if TMG_LW_EXP < 1
-#pragma unroll
-            for (int v = 0; v < NQ / 4; ++v) bH[v] += bhv[sl][v];
-#endif
-#pragma unroll
-            for (int t = 0; t < SL; ++t) {
-#if TMG_LW_EXP >= 1
-                const float a = av[sl][t];
-                const bool in = true;
-#else
-                const float a = fmaxf(av[sl][t], 0.f);
-                const bool in = (unsigned)(oy0 + r + kyo[t]) < (unsigned)p.H && (unsigned)(ox0 + px + kxo[t]) < (unsigned)p.W;
-#endif
-                acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(in ? a : 0.f, bdv[sl], acc[t], 0, 0, 0);      // zero padding of the growth convs
-#pragma unroll
-                for (int j = 0; j < NQ; ++j)
-                    acc[SL + t * NQ + j] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bhv[sl][j >> 2][j & 3], acc[SL + t * NQ + j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                if (m == 0) bM += ybv[sl][m];
-                acc[SL + SL * NQ + m] = __builtin_amdgcn_mfma_f32_4x4x1f32(yav[sl][m], ybv[sl][m], acc[SL + SL * NQ + m], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef TMG_LW_READ
-        if (!PF && tile + p.P < p.ntiles) { TMG_LW_ISSUE(tile + p.P) }
-    }
-#undef TMG_LW_ISSUE
-    // ---- the four waves' partial sums meet in LDS (RR accumulators per round), one atomic per (block, element) ----------------------
-    float* dWzg = p.dWz + (size_t)g * C * p.cin_dst * 9;
-    float* dWxg = p.dWx + (size_t)g * 4 * CS * 9;
-    float* dWmg = p.dWm + (size_t)g * C * C;
-#pragma unroll
-    for (int a0 = 0; a0 < NA; a0 += RR) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RR; ++i)
-            if (a0 + i < NA) *reinterpret_cast<f32x4*>(lds + ((i * 4 + wave) * 64 + lane) * 4) = acc[a0 + i];
-        __syncthreads();
-        for (int e = tid; e < RR * 256; e += 256) {
-            const int i = e >> 8, l = (e >> 2) & 63, r = e & 3;
-            const int a = a0 + i;
-            if (a >= NA) break;
-            const float* src = lds + (i * 4 * 64 + l) * 4 + r;
-            const float v = src[0] + src[256] + src[512] + src[768];
-            if (a < SL + SL * NQ) {
-                const int t = a < SL ? a : (a - SL) / NQ;
-                const int beta = 16 * t + (l >> 2);
-                if (beta < NB) {
-                    const int u = beta / Q, s = beta - u * Q;
-                    const int ci = 4 * s + r;
-                    if (a < SL) {
-                        if ((l & 3) < 2) unsafeAtomicAdd(dWxg + ((size_t)(l & 3) * CS + ci) * 9 + u, v);
-                    } else if (ci < CH + 2) {
-                        const int co = 4 * ((a - SL) - t * NQ) + (l & 3);
-                        unsafeAtomicAdd(dWzg + ((size_t)co * p.cin_dst + (ci < CH ? ci : ci + p.ci_off1)) * 9 + u, v);
-                    }
-                }
-            } else {
-                const int beta = 16 * (a - SL - SL * NQ) + (l >> 2);
-                const int yi = beta / NQ, j = beta - yi * NQ;
-                unsafeAtomicAdd(dWmg + (size_t)(4 * j + (l & 3)) * C + 4 * yi + r, v);
-            }
-        }
-    }
-    // bias sums: every lane with the same lane % 4 holds the same bH; the mix's dout quads j = 0 .. NQ - 1 sit in blocks 0 .. NQ - 1 of
-    // instruction 0 (y quad 0)
-    if (lb == 0) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) unsafeAtomicAdd(p.dBz + (size_t)g * C + 4 * j + l3, bH[j >> 2][j & 3]);
-    }
-    if (lb < NQ) unsafeAtomicAdd(p.dbm + (size_t)g * C + 4 * lb + l3, bM);
-}
-
-template <int CH>
-static int launch_level_wgrad(LvlWgP p, int G, hipStream_t st) {
-    constexpr int C = 2 * CH, CS = CH + 4, TH = 8;
-    constexpr int lds_bytes = ((TH + 2) * 19 * CS + TH * 16 * (4 + 2 * C) + TH * 19 * CS) * 4;
-    static_assert(lds_bytes <= 64 * 1024, "above 64 KB the kernel would need the per-device LDS opt-in (TMG_LDS_OPTIN)");
-    p.tiles_x = (p.W + 15) / 16;
-    p.tiles_y = (p.H + TH - 1) / TH;
-    p.ntiles = p.B * p.tiles_x * p.tiles_y;
-    // ONE round of blocks: 3 per CU (the register budget of __launch_bounds__(256, 3); LDS would allow 4) - a grid of 3.75 blocks per
-    // CU ran as a full round plus a quarter-filled one of the same length
-    int per_cu = 160 * 1024 / lds_bytes;
-    per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
-    int P = per_cu * tmg_num_cus() / G;
-    P = P > p.ntiles ? p.ntiles : (P < 1 ? 1 : P);
-    if (P >= 8) P &= ~7;
-    p.G = G; p.P = P;
-    static const int dbg = getenv("TMG_LW_DBG") ? atoi(getenv("TMG_LW_DBG")) : 0;
-    p.dbg = dbg;
-    hipLaunchKernelGGL((level_wgrad_kernel<CH>), dim3(P * G), dim3(256), lds_bytes, st, p);
-    TMG_CHECK_LAUNCH();
-    return 0;
-}
-
-// gtab: device int64 [G][16], row g = {x1 pointer, pixel stride, 0, ch} {D pointer, pixel stride, 0, 4} {y2 pointer, pixel stride, 0, ch}
-// {dout half-1 pointer, pixel stride, dout half-2 pointer, pixel stride} of layer g (all NHWC, 16-byte aligned pixels; x1 is BOTH the
-// zero conv's input half and the first half of the mix input).  DH [npix][dh_stride] (layer g at channels [C g, C g + C)), DD
-// [npix][dd_stride] (compact: layer g at channels 2 g, 2 g + 1).  dims = {B, H, W, ch, cin_dst, ci_off1}.  dWz [G][C][cin_dst][3][3],
-// dBz [G][C], dWx [G][4][ch + 4][3][3] (rows 0, 1), dWm [G][C][C], dbm [G][C] are ACCUMULATED into (float atomics: zero them first).
-// ch = 8 (the 16-channel level); otherwise -100 (nothing launched: use the three grouped entry points).
-extern "C" int tmg_level_wgrad_merged(const void* gtab, int64_t G, const void* DH, int64_t dh_stride, const void* DD, int64_t dd_stride,
-                                      void* dWz, void* dBz, void* dWx, void* dWm, void* dbm, const int64_t* dims, hipStream_t st) {
-    LvlWgP p;
-    p.gtab = (const long long*)gtab; p.DH = (const float*)DH; p.dhs = (int)dh_stride; p.DD = (const float*)DD; p.dds = (int)dd_stride;
-    p.dWz = (float*)dWz; p.dBz = (float*)dBz; p.dWx = (float*)dWx; p.dWm = (float*)dWm; p.dbm = (float*)dbm;
-    p.B = (int)dims[0]; p.H = (int)dims[1]; p.W = (int)dims[2]; p.cin_dst = (int)dims[4]; p.ci_off1 = (int)dims[5];
-    const int ch = (int)dims[3];
-    if (G < 1 || !gtab || !DH || !DD || !dWz || !dBz || !dWx || !dWm || !dbm) return -100;
-    if ((dh_stride & 3) || (dd_stride & 1) || ((uintptr_t)DH & 15) || ((uintptr_t)DD & 7)) return -100;
-    if (ch == 8) return launch_level_wgrad<8>(p, (int)G, st);
-    // (ch = 16 was built and measured: 87 us per layer against 57 for the three launches - at 32 channels the mix is 4 instructions with 8
-    // ds_read_b32 per pixel and the LDS array, not the matrix pipe, bounds the MFMA phase: 55 us per layer - and is not instantiated)
-    return -100;
-}
-
-// =================================================================================================================================
 // [npix][2 K] -> [K][npix][2]: the level-wide conditioning addends of the growth-1 convs (one conv over cond for all layers of a level,
 // channel 2k / 2k+1 = layer k) re-laid as one pixel-contiguous float2 plane per layer.  Every layer's c1x2_fwd launch reads its two
 // addends for every pixel: out of the [npix][2K] tensor that is a full 128-byte line per pixel for 8 useful bytes (134 MB per launch at

@@ -1369,13 +1369,6 @@ static int launch_wino_nn(const WinoNP& p, int G, hipStream_t st) {
     const size_t lds_bytes = (size_t)(2 * 180 * 40 + 16 * 32 * (NTN * 16 + (NTN < 3 ? 4 : 0))) * sizeof(float);
     TMG_LDS_OPTIN((&wino_nn_kernel<NTN>));
     TmgProf prof(TMG_PROF_WINO, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);
-    static const int noskew = getenv("TMG_WN_NOSKEW") ? atoi(getenv("TMG_WN_NOSKEW")) : 0;       // A / B switch
-    if (noskew == 1) {
-        TMG_LDS_OPTIN((&wino_nn_kernel<NTN, 0>));
-        hipLaunchKernelGGL((wino_nn_kernel<NTN, 0>), dim3(G), dim3(512), lds_bytes, st, p);
-        TMG_CHECK_LAUNCH();
-        return 0;
-    }
     hipLaunchKernelGGL((wino_nn_kernel<NTN>), dim3(G), dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;
@@ -1820,8 +1813,7 @@ static int wino_wgrad_impl(const void* const* in_ptrs, const int64_t* in_desc, i
     TMG_WW_CASE(4, 4)
 #undef TMG_WW_CASE
     if (rc != 0) return rc;
-    static const int ng_env = getenv("TMG_WW_REDUCE_NG") ? atoi(getenv("TMG_WW_REDUCE_NG")) : 0;
-    const int ng = ng_env ? ng_env : (pl.gx >= 64 ? 16 : (pl.gx >= 32 ? 8 : 4));
+    const int ng = pl.gx >= 64 ? 16 : (pl.gx >= 32 ? 8 : 4);
     if (ng == 16) {
         TMG_LDS_OPTIN((&wino_wgrad_reduce_kernel<16>));
         hipLaunchKernelGGL(wino_wgrad_reduce_kernel<16>, dim3(pl.gy * pl.gz * pl.CIT * pl.NCO), dim3(1024), 15 * 64 * 37 * sizeof(float), st,

@@ -39,7 +39,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_level_wgrad_merged", "tmg_gauss_sample", "tmg_reverse_loss_fwd", "tmg_reverse_loss_bwd", "tmg_sum_terms", "tmg_vec_sum", "tmg_level_pack",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_gauss_sample", "tmg_reverse_loss_fwd", "tmg_reverse_loss_bwd", "tmg_sum_terms", "tmg_vec_sum", "tmg_level_pack",
 ]
 
 
@@ -482,54 +482,6 @@ def conv3x3_auto(inputs, weight, Cout, outs, bias=None, relu_in=False, pad_rep=F
     return wpk
 
 
-_SIDE = {}
-
-
-class side_stream:
-    """Context manager: run the enclosed launches on a per-device side HIP stream, ordered after everything already
-    enqueued on the current stream, and make the current stream wait for them on exit of `join()`.
-
-        with H.side_stream(dev, keep=(tensors read on the side stream)) as ss:
-            ... launches ...          # run concurrently with what the main stream enqueues afterwards
-        ... main-stream work ...
-        ss.join()                     # main stream waits for the side work (no host sync)
-
-    Used to overlap weight-gradient kernels (off the critical path of back-propagation) with the input-gradient chain.
-    Measured on MI355X at config M: the step is GPU-bound and the overlapped kernels only contend (568 vs 584 samples/s),
-    so it is opt-in (TMG_SIDE=1) and the default runs everything on the current stream.
-    """
-
-    def __init__(self, device, keep=()):
-        self.main = torch.cuda.current_stream(device)
-        key = device.index if device.index is not None else torch.cuda.current_device()
-        if key not in _SIDE:
-            _SIDE[key] = torch.cuda.Stream(device=device)
-        self.side = _SIDE[key]
-        self.keep = keep
-        self.ctx = None
-
-    def __enter__(self):
-        self.inline = torch.cuda.is_current_stream_capturing() or not os.environ.get('TMG_SIDE')  # capture, or not opted in: single stream
-        if self.inline:
-            return self
-        self.side.wait_stream(self.main)
-        for t in self.keep:
-            if t is not None:
-                t.record_stream(self.side)   # the caching allocator must not recycle these while the side stream reads them
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *a):
-        if not self.inline:
-            self.ctx.__exit__(*a)
-        return False
-
-    def join(self):
-        if not self.inline:
-            self.main.wait_stream(self.side)
-
-
 _WS = {}
 
 
@@ -716,43 +668,6 @@ def conv_wgrad_grouped(group_inputs, dy, dy_group_channels, dW, dbias, ksize, st
     if rc == -100:
         return False
     _chk(rc, "tmg_conv_wgrad_grouped")
-    return True
-
-
-def level_wgrad_merged(wg_in, mix_wg, DH, DD, C, dWz, dBz, dWx, dWm, dbm, ci_off1):
-    """The zero-conv, growth-layer and channel-mix weight gradients of all layers of a narrow level in ONE launch
-    (tmg_level_wgrad_merged).  wg_in[k] = [x1, D]; mix_wg[k] = ([x1, y2], upstream gradient as a tensor or a pair of halves) with the
-    SAME x1; DH [B,H,W,>= G C], DD [B,H,W,>= 2 G] (compact pairs).  Returns False when the level is outside the kernel's envelope
-    (nothing was launched: the three grouped launches take over).  Measured SLOWER than the three launches at the metric shape (132
-    against 110 us per layer): LevelCouplingFn calls it only under TMG_MERGED_WGRAD=1."""
-    if C != 16:
-        return False
-    ch = C // 2
-    G = len(wg_in)
-    rows = []
-    for k in range(G):
-        x1, D = wg_in[k]
-        y, dout = mix_wg[k]
-        if not (isinstance(y, (list, tuple)) and len(y) == 2):
-            return False
-        y1, y2 = y
-        d1, d2 = _halves(dout)
-        ts = (x1, D, y2, d1, d2)
-        if not (x1.shape[3] == ch and D.shape[3] == 4 and y2.shape[3] == ch and y1.data_ptr() == x1.data_ptr() and y1.stride() == x1.stride()
-                and all(_pixel_linear(t) and t.stride(2) % 4 == 0 and t.data_ptr() % 16 == 0 and t.dtype == torch.float32 for t in ts)):
-            return False
-        rows.append(list(seg(x1)) + list(seg(D)) + list(seg(y2)) + [seg(d1)[0], seg(d1)[1], seg(d2)[0], seg(d2)[1]])
-    B, Hh, Ww, _ = wg_in[0][0].shape
-    if not (_pixel_linear(DH) and _pixel_linear(DD) and DH.shape[3] >= G * C and DD.shape[3] >= 2 * G and dWz.is_contiguous()
-            and dBz.is_contiguous() and dWx.is_contiguous() and dWm.is_contiguous() and dbm.is_contiguous()
-            and tuple(dWx.shape[:3]) == (G, 4, ch + 4) and tuple(dWz.shape[:2]) == (G, C)):
-        return False
-    gtab = _segment_table(rows, DH.device)
-    rc = lib().tmg_level_wgrad_merged(_ptr(gtab), c_i64(G), _ptr(DH), c_i64(DH.stride(2)), _ptr(DD), c_i64(DD.stride(2)), _ptr(dWz), _ptr(dBz),
-                                      _ptr(dWx), _ptr(dWm), _ptr(dbm), _i64(B, Hh, Ww, ch, dWz.shape[2], ci_off1), _stream())
-    if rc == -100:
-        return False
-    _chk(rc, "tmg_level_wgrad_merged")
     return True
 
 

@@ -313,18 +313,16 @@ class ConvFn(torch.autograd.Function):
                     raise RuntimeError("ConvFn: _grad_premasked contract violated - the output gradient is non-zero (%.3e) where the "
                                        "ReLU output is zero: `out` has a consumer that does not mask its gradient" % leak)
         dW = db = dk = None
-        ss = None
         if ctx.needs_input_grad[0] or ctx.has_kappa:
             dW = zeros_like(weight)
             db = zeros_like(bias) if ctx.has_bias else None
             if ctx.has_kappa:
                 dk = zeros_like(kappa)
-            # weight gradients run on the side stream, concurrently with the input-gradient kernels below
-            ss = H.side_stream(dy.device, keep=(dy, dW, db, dk, weight, bias, kappa) + tuple(inputs))
-            with ss:
-                H.conv_wgrad(list(inputs), dy, dW, db, ksize, stride, kappa=kappa, relu_in=relu_in, pad_rep=pad_rep)
-                if ctx.has_kappa:
-                    H.dkappa(weight, dW, bias if ctx.has_bias else weight[:0], db if ctx.has_bias else dW[:0], kappa, dk)
+            # (weight gradients on a second stream beside the input-gradient kernels: measured three times - every weight gradient,
+            # rounds 1 / 2; the wide levels' only, round 6, profiles/r6_ab_side_stream_wide_levels.txt - and slower each time)
+            H.conv_wgrad(list(inputs), dy, dW, db, ksize, stride, kappa=kappa, relu_in=relu_in, pad_rep=pad_rep)
+            if ctx.has_kappa:
+                H.dkappa(weight, dW, bias if ctx.has_bias else weight[:0], db if ctx.has_bias else dW[:0], kappa, dk)
         dins = [None] * ctx.n_in
         if any(ctx.needs_input_grad[4:]):
             dins = [torch.empty(t.shape, device=t.device, dtype=torch.float32) for t in inputs]
@@ -353,8 +351,6 @@ class ConvFn(torch.autograd.Function):
             if relu_in:
                 for d, t in zip(dins, inputs):
                     H.masked_add(d, src=d, ref=t)
-        if ss is not None:
-            ss.join()
         return _defer((weight, bias, kappa), (dW, db, dk)) + (None,) + tuple(dins)
 
 
@@ -487,8 +483,7 @@ class DenseBlockFn(torch.autograd.Function):
 
 
 def bn_batch_stats(x, bn):
-    """Training-mode statistics of nn.BatchNorm2d `bn` on an NHWC tensor / channel-slice view: one-pass fp64 moments (round 3; the
-    centred two-pass form is kept behind TMG_BN_TWO_PASS), then ONE kernel for mean, var, rstd, the folded affine and the momentum update of the running
+    """Training-mode statistics of nn.BatchNorm2d `bn` on an NHWC tensor / channel-slice view: one-pass fp64 moments, then ONE kernel for mean, var, rstd, the folded affine and the momentum update of the running
     statistics (the ~15 element-wise torch ops this replaces were ~40 % of the step's small launches).
     -> (mean, rstd, a, bsh), each [C]."""
     B, Hh, Ww, C = x.shape
@@ -497,21 +492,14 @@ def bn_batch_stats(x, bn):
     track = bn.track_running_stats
     mom = bn.momentum if bn.momentum is not None else 0.1
     with torch.no_grad():
-        if os.environ.get("TMG_BN_TWO_PASS") is None:
-            # one pass: sum and sum of squares in fp64 (no cancellation error in E[x^2] - E[x]^2), the activation is read once
-            acc64 = zeros((4 * C,), x.device).view(torch.float64)     # [2][C] doubles out of the pooled zero buffer (256-byte aligned)
-            H.chan_moments(x, acc64)
-            nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None and bn.num_batches_tracked.device == x.device) else None
-            H.bn_finalize64(acc64, bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
-                            bn.running_var if track else None, out, n, bn.eps, mom, counter=nbt)
-            if nbt is not None:
-                track = False        # counted by the launch above
-        else:
-            acc = zeros((4, C), x.device)
-            H.chan_reduce(x, None, None, None, None, None, acc[0], acc[1], 0)
-            H.chan_reduce(x, None, acc[0], None, None, None, acc[2], acc[3], 0, divisor=n)
-            H.bn_finalize(acc[0], acc[3], bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
-                          bn.running_var if track else None, out, n, bn.eps, mom)
+        # one pass: sum and sum of squares in fp64 (no cancellation error in E[x^2] - E[x]^2), the activation is read once
+        acc64 = zeros((4 * C,), x.device).view(torch.float64)     # [2][C] doubles out of the pooled zero buffer (256-byte aligned)
+        H.chan_moments(x, acc64)
+        nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None and bn.num_batches_tracked.device == x.device) else None
+        H.bn_finalize64(acc64, bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
+                        bn.running_var if track else None, out, n, bn.eps, mom, counter=nbt)
+        if nbt is not None:
+            track = False        # counted by the launch above
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
     return out[0], out[2], out[3], out[4]
@@ -974,11 +962,9 @@ class CouplingTailFn(torch.autograd.Function):
         dwz = flat[n1 + n2:n1 + n2 + nz].view(C, cin + 2, 3, 3)
         dbz = flat[n1 + n2 + nz:n1 + n2 + nz + C]
         dk = flat[n1 + n2 + nz + C:].view(kappa.shape)
-        # 2. zero-conv weight / bias / scale gradients on the side stream: they are off the critical path and overlap
-        #    with the input-gradient chain below
-        with H.side_stream(dev, keep=(dhh, x, aux, D, flat, wz, bz, kappa)) as ss:
-            H.conv_wgrad(nn_in + [D], dhh, dwz, dbz, 3, 1, kappa=kappa, relu_in=True, pad_rep=True, cin_dst=cin + 2)
-            H.dkappa(wz, dwz, bz, dbz, kappa, dk)
+        # 2. zero-conv weight / bias / scale gradients
+        H.conv_wgrad(nn_in + [D], dhh, dwz, dbz, 3, 1, kappa=kappa, relu_in=True, pad_rep=True, cin_dst=cin + 2)
+        H.dkappa(wz, dwz, bz, dbz, kappa, dk)
         G = [torch.empty(t.shape, device=dev, dtype=torch.float32) for t in nn_in]
         GD = torch.empty((B, Hh, Ww, 4), device=dev, dtype=torch.float32)
         wz_t = H.conv_pack(wz, 1, cin + 4)
@@ -992,7 +978,6 @@ class CouplingTailFn(torch.autograd.Function):
             H.dense2_bwd(nn_in + [D], w1, w2, dw1, dw2, GD, D, G, [G[0]], cin, rows1=cin, rows2=cin + 1)
             H.masked_add(dx[..., :ch], src=dy[..., :ch])
             daux = G[0]
-        ss.join()
         return (dx, daux) + _defer((w1, w2, wz, bz, kappa), (dw1, dw2, dwz, dbz, dk)) + (None, None)
 
 
@@ -1415,16 +1400,7 @@ class LevelCouplingFn(torch.autograd.Function):
                 mix_wg[k] = mdef[0]
             del xin, tin, D, r, y
         tmpX = None
-        merged = False
-        if grouped and reverse and ctx.fuse and os.environ.get("TMG_MERGED_WGRAD") is not None and all(m is not None for m in mix_wg):
-            # round 5, opt-in: the three per-layer weight gradients of every layer (zero conv, growth layers, channel mix) from ONE read
-            # of x1 | D, y2, the upstream gradient and the DH / DD slices (tmg_level_wgrad_merged).  Parity-green and 1.8 GB less traffic
-            # per step, but 132 us per layer against 110 for the three grouped launches it replaces: not the default
-            tmpX = zeros((NL, 4, ch + 4, 3, 3), dev)
-            merged = H.level_wgrad_merged(wg_in, mix_wg, DH, DD, C, dWz, dBz, tmpX, dWm, dbm, Cc)
-            if merged:
-                wg_in = mix_wg = None
-        if grouped and not merged:
+        if grouped:
             if not H.conv_wgrad_grouped(wg_in, DH, C, dWz, dBz, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2,
                                         ci_split=ch, ci_off0=0, ci_off1=Cc):
                 for k in range(NL):

@@ -365,20 +365,6 @@ int tmg_conv_wgrad_thin_grouped(const void* gtab, int64_t G, const int64_t* seg_
  * otherwise -100.  dW [G][C][C], db [G][C] (nullable) are accumulated into. */
 int tmg_mix_wgrad_grouped(const void* gtab, int64_t G, void* dW, void* db, const int64_t* dims, tmg_stream_t st);
 
-/* All three per-layer weight gradients of a narrow level's coupling layers in ONE launch (generative direction; round 5): the zero conv's
- * (flowUtils.py:100-108 / :246-247 under autograd: replicate padding, C outputs, bias), the two growth-1 layers' (denseBlock.py:135-152:
- * zero padding, 2 outputs) and the channel mix's (glowConv.py:207-222 + actNorm.py:71-85 w.r.t. the folded matrix and bias) - the three
- * grouped launches tmg_conv_wgrad_grouped / tmg_conv_wgrad_thin_grouped / tmg_mix_wgrad_grouped read x1 | D twice and x1 a third time.
- * gtab: device int64 [G][16], row g = {x1 pointer, pixel stride, 0, ch} {D pointer, pixel stride, 0, 4} {y2 pointer, pixel stride, 0, ch}
- * {upstream-gradient half 1 pointer, pixel stride, half 2 pointer, pixel stride}: x1 is the zero conv's / growth layers' input half AND the
- * first half of the mix input (x1 | y2).  DH [npix][dh_stride]: layer g's exp(kappa) dhh at channels [C g, C g + C); DD [npix][dd_stride]:
- * layer g's (dd1, dd2) at channels 2 g, 2 g + 1.  dims = {B, H, W, ch, cin_dst, ci_off1}: dWz [G][C][cin_dst][3][3] receives patch channel
- * ci < ch at row ci and the two growth channels at rows ch + ci_off1 + {0, 1}.  dBz [G][C], dWx [G][4][ch + 4][3][3] (rows 0, 1: the layout
- * of tmg_conv_wgrad_thin_grouped), dWm [G][C][C], dbm [G][C].  Everything is ACCUMULATED into (float atomics: zero first).  ch = 8 (the
- * 16-channel level; at 32 channels the three launches measured faster), otherwise -100 (nothing launched). */
-int tmg_level_wgrad_merged(const void* gtab, int64_t G, const void* DH, int64_t dh_stride, const void* DD, int64_t dd_stride, void* dWz,
-                           void* dBz, void* dWx, void* dWm, void* dbm, const int64_t* dims, tmg_stream_t st);
-
 /* [npix][CP] -> [CP/2][npix][2]: the level-wide conditioning addends of the growth-1 convs (channel 2k / 2k+1 = coupling layer k,
  * flowAffine.py:73-75 with the conditioning part of the dense block's input split off) as one pixel-contiguous float2 plane per layer, so
  * that each layer's launch reads 8 bytes per pixel instead of a whole line of the interleaved tensor.  CP a multiple of 4. */

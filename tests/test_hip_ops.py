@@ -1080,68 +1080,6 @@ def test_pack_plan_repacks_every_parameter_operand_once_per_update():
         plan.jobs.clear()
 
 
-@pytest.mark.parametrize("shape", [(3, 2, 16, 16, 8, False), (15, 1, 20, 35, 8, True), (4, 2, 33, 17, 8, True), (5, 1, 16, 32, 8, False),
-                                   (2, 3, 8, 16, 8, True), (2, 1, 7, 5, 8, False), (16, 2, 24, 48, 8, True)])
-def test_level_weight_gradients_in_one_launch(shape):
-    """tmg_level_wgrad_merged (round 5: zero-conv, growth-layer and channel-mix weight gradients of all layers of a narrow level from one
-    read of x1 | D, y2, the upstream gradient and the DH / DD slices) against the three grouped launches it replaces and against fp64
-    autograd: replicate padding for the zero conv and zero padding for the growth layers out of ONE staged patch, ragged tiles, images
-    smaller than a tile, upstream gradients as one tensor or as two halves, the conditioning gap in the zero conv's
-    weight layout, the compact (dd1, dd2) stash with a padding layer."""
-    import tmg_hip as H
-    G, B, Hh, Ww, ch, split = shape
-    C_, Cc = 2 * ch, 5
-    cin = ch + Cc
-    g = torch.Generator().manual_seed(G * 100 + ch + Hh)
-    rnd = lambda *s_: torch.randn(*s_, generator=g).to(DEV)  # noqa: E731
-    if split:
-        x1s = [rnd(B, Hh, Ww, ch) for _ in range(G)]
-    else:
-        x1s = [rnd(B, Hh, Ww, C_)[..., :ch] for _ in range(G)]            # channel-slice views of [.., C] tensors
-    Ds = [rnd(B, Hh, Ww, 4) for _ in range(G)]
-    for d in Ds:
-        d[..., 2:] = 0                                                    # (d1, d2, 0, 0)
-    y2s = [rnd(B, Hh, Ww, ch) for _ in range(G)]
-    douts = [(rnd(B, Hh, Ww, ch), rnd(B, Hh, Ww, ch)) if split else rnd(B, Hh, Ww, C_) for _ in range(G)]
-    NLp = (G + 3) // 4 * 4
-    DH = rnd(B, Hh, Ww, G * C_)
-    DD = rnd(B, Hh, Ww, 2 * NLp)
-    wg_in = [[x1, d] for x1, d in zip(x1s, Ds)]
-    mix_wg = [([x1, y2], dout) for x1, y2, dout in zip(x1s, y2s, douts)]
-
-    def buffers():
-        return (torch.zeros(G, C_, cin + 2, 3, 3, device=DEV), torch.zeros(G, C_, device=DEV), torch.zeros(G, 4, ch + 4, 3, 3, device=DEV),
-                torch.zeros(G, C_, C_, device=DEV), torch.zeros(G, C_, device=DEV))
-    dWz, dBz, dWx, dWm, dbm = buffers()
-    assert H.level_wgrad_merged(wg_in, mix_wg, DH, DD, C_, dWz, dBz, dWx, dWm, dbm, Cc)
-    rWz, rBz, rWx, rWm, rbm = buffers()
-    assert H.conv_wgrad_grouped(wg_in, DH, C_, rWz, rBz, 3, 1, relu_in=True, pad_rep=True, cin_dst=cin + 2, cin_valid=ch + 2, ci_split=ch,
-                                ci_off0=0, ci_off1=Cc)
-    assert H.conv_wgrad_grouped(wg_in, DD, 2, rWx, None, 3, 1, relu_in=True)
-    gdy = [H._halves(d) for d in douts] if split else douts
-    assert H.conv_wgrad_grouped([a for a, _ in mix_wg], None, C_, rWm.view(G, C_, C_, 1, 1), rbm, 1, 1, group_dy=gdy)
-    for a, b, what in ((dWz, rWz, "zero conv dW"), (dBz, rBz, "zero conv dbias"), (dWx, rWx, "growth layers dW"), (dWm, rWm, "mix dW"),
-                       (dbm, rbm, "mix dbias")):
-        _close(a, b, tol=2e-5, what="%s: one launch vs the grouped launch it replaces" % what)
-    assert float(dWz[:, :, ch:cin].abs().max()) == 0.0 and float(dWx[:, 2:].abs().max()) == 0.0      # conditioning rows / unused rows untouched
-    for k in range(G):
-        xin = torch.cat([x1s[k], Ds[k]], 3).permute(0, 3, 1, 2).double().relu()
-        wz = torch.zeros(C_, ch + 4, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
-        bz = torch.zeros(C_, dtype=torch.float64, device=DEV, requires_grad=True)
-        yz = F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="replicate"), wz, bz)
-        (yz * DH[..., k * C_:(k + 1) * C_].permute(0, 3, 1, 2).double()).sum().backward()
-        _close(dWz[k][:, :ch], wz.grad[:, :ch], tol=2e-5, what="layer %d zero conv, x1 rows vs fp64" % k)
-        _close(dWz[k][:, cin:], wz.grad[:, ch:ch + 2], tol=2e-5, what="layer %d zero conv, growth rows vs fp64" % k)
-        _close(dBz[k], bz.grad, tol=2e-5, what="layer %d zero conv bias vs fp64" % k)
-        wx = torch.zeros(2, ch + 4, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
-        (F.conv2d(xin, wx, padding=1) * DD[..., 2 * k:2 * k + 2].permute(0, 3, 1, 2).double()).sum().backward()
-        _close(dWx[k][:2], wx.grad, tol=2e-5, what="layer %d growth layers vs fp64" % k)
-        y = torch.cat([x1s[k], y2s[k]], 3).double().reshape(-1, C_)
-        do = (torch.cat(list(douts[k]), 3) if split else douts[k]).double().reshape(-1, C_)
-        _close(dWm[k], do.t() @ y, tol=2e-5, what="layer %d mix vs fp64" % k)
-        _close(dbm[k], do.sum(0), tol=2e-5, what="layer %d mix bias vs fp64" % k)
-
-
 @pytest.mark.parametrize("shape", [(3, 2, 16, 16, 16), (15, 1, 20, 35, 16), (4, 3, 17, 9, 32), (2, 1, 64, 64, 32)])
 def test_mix_weight_gradient_grouped_kernel(shape):
     """tmg_mix_wgrad_grouped (weight / bias gradients of the 1x1 mixes of all layers of a level, streaming GEMM over the pixels)

@@ -1861,49 +1861,6 @@ def test_level_with_bf16x3_winograd_matches_fp32_winograd(cin, hw, B):
     C.assert_grads(a[3], b[3], "bf16x3 vs fp32 Winograd", global_tol=2e-4, tensor_tol=5e-3)
 
 
-@pytest.mark.parametrize("cin,hw,B", [(4, (32, 48), 8), (4, (17, 33), 3)])
-def test_level_with_merged_weight_gradients_matches_three_launches(cin, hw, B):
-    """The opt-in single-launch form of a 16-channel level's per-layer weight gradients (TMG_MERGED_WGRAD=1: zero conv, growth layers and
-    channel mix of all layers from one read of their operands, tmg_level_wgrad_merged) inside the level's autograd node against the
-    default three grouped launches: every parameter gradient of the level, path against path."""
-    import os
-    import tmg_hip as H
-    from nn.modules.flowLSTMBlock import LSTMFLowBlock
-    hs, ws = hw
-    C.seed_all(cin * 7 + B)
-    blk = LSTMFLowBlock(cin, 32, 64, 6, LUdecompose=True, train_sampling=True, do_split=True, squeeze_type=0)
-    C.perturb_(blk, 5, 0.02, 0.05, 0.02)
-    blk.to(DEV)
-    g = torch.Generator().manual_seed(17)
-    z, eps = (torch.randn(B, 2 * cin, hs, ws, generator=g).to(DEV) for _ in range(2))
-    cond = torch.randn(B, 32, hs, ws, generator=g).to(DEV)
-    hst, cst = (torch.randn(B, 64, hs, ws, generator=g).to(DEV) for _ in range(2))
-    res, calls = {}, []
-    real = H.level_wgrad_merged
-
-    def spy(*a, **k):
-        calls.append(real(*a, **k))
-        return calls[-1]
-    H.level_wgrad_merged = spy
-    try:
-        for tag in ("three", "merged"):
-            os.environ.pop("TMG_MERGED_WGRAD", None)
-            if tag == "merged":
-                os.environ["TMG_MERGED_WGRAD"] = "1"
-            blk.zero_grad()
-            zi, ci, hi, cc = (t.clone().requires_grad_(True) for t in (z, cond, hst, cst))
-            xr, ldr, st = blk.reverse(zi, ci, (hi, cc), eps=eps)
-            ((xr[:2] ** 2).sum() * 0.5 + ldr[:2].sum() * 0.02 + (st[0][:2] ** 2).sum() * 0.1).backward()
-            gr = {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None}
-            gr.update({"@dz": zi.grad.clone(), "@dcond": ci.grad.clone()})
-            res[tag] = gr
-    finally:
-        os.environ.pop("TMG_MERGED_WGRAD", None)
-        H.level_wgrad_merged = real
-    assert calls == [True], "the single-launch kernel must have run exactly once, under the switch: %s" % calls
-    C.assert_grads(res["merged"], res["three"], "one launch vs three grouped launches", global_tol=3e-6, tensor_tol=1e-4)
-
-
 @pytest.mark.parametrize("cin,hw,B", [(4, (64, 64), 64), (8, (17, 33), 32), (16, (16, 16), 128), (16, (9, 23), 64), (32, (8, 16), 64), (3, (30, 30), 64)])
 def test_level_kernels_across_field_and_batch_sizes(cin, hw, B):
     """One flow level (generative direction + backward, recurrent states with gradients, loss on two samples) through the level-fused
