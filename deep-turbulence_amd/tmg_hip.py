@@ -545,23 +545,26 @@ _GTAB = {}
 
 
 def _segment_table(rows, device):
-    """Device copy of a grouped launch's segment table.  The table holds raw pointers of activations; in a steady training loop the
-    caching allocator hands out the same blocks step after step, so the same table recurs and its device copy is reused - no
-    pageable host-to-device copy (a synchronising one) per grouped launch.  The cache is bounded; a miss just copies."""
+    """Device copy of a pointer table (the grouped launches' segment tables, tmg_level_pack's parameter table).  The values travel as
+    the ARGUMENTS of a fill kernel (tmg_fill_i64, 256 int64 per launch): asynchronous, in stream order, legal during hipGraph capture.
+    Round 5 copied the table from pageable host memory on a cache miss - a synchronising copy: one per grouped launch whenever the
+    activations' addresses changed, i.e. on every time-step of an eager BPTT window (its T sets of activations are all alive), and with
+    round 6's parameter tables in the FORWARD pass it cost the host-bound eager window its run-ahead (0.49 -> 0.53 s per window).
+    In a steady single-step loop the caching allocator hands out the same blocks step after step: the table recurs and its device copy
+    is reused (no launch at all).  The cache is bounded; a miss is one or two 3-us launches."""
+    flat = [int(v) for r in rows for v in r]
     if torch.cuda.is_current_stream_capturing():
-        # hipGraph capture: no host-to-device copy can be recorded - the table is written by a kernel that carries the values as its
-        # arguments (tmg_fill_i64).  The pointers come from the graph's private pool and are the same at every replay.  Not cached:
-        # the table lives in the graph's pool like every other tensor of the capture.
-        flat = [int(v) for r in rows for v in r]
+        # not cached: the table lives in the graph's pool like every other tensor of the capture
         t = torch.empty((len(rows), len(rows[0])), dtype=torch.int64, device=device)
         _chk(lib().tmg_fill_i64(_ptr(t), _i64(*flat), c_i64(len(flat)), _stream()), "tmg_fill_i64")
         return t
-    key = (device.index, tuple(tuple(r) for r in rows))
+    key = (device.index, len(rows), tuple(flat))
     t = _GTAB.get(key)
     if t is None:
-        if len(_GTAB) > 256:
+        if len(_GTAB) > 1024:
             _GTAB.clear()
-        t = torch.tensor(rows, dtype=torch.int64).to(device)
+        t = torch.empty((len(rows), len(rows[0])), dtype=torch.int64, device=device)
+        _chk(lib().tmg_fill_i64(_ptr(t), _i64(*flat), c_i64(len(flat)), _stream()), "tmg_fill_i64")
         _GTAB[key] = t
     return t
 
