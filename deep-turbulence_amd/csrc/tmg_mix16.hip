@@ -38,17 +38,38 @@ __global__ __launch_bounds__(256) void mix16_kernel(Mix16P p) {
     h16x4* Wl = reinterpret_cast<h16x4*>(smem_raw);  // [NT*4][CP]: (ci quad, co) -> 4 halfs
     constexpr int CP = NT * 16;
     const int C = p.C;
-    for (int i = threadIdx.x; i < NT * 4 * CP; i += 256) {
-        const int kq = i / CP, co = i - kq * CP;
-        h16x4 v;
+    // W -> fp16 tiles in LDS.  Eight items per thread are loaded before any is converted (round 6: one item at a time was a chain of
+    // 64 exposed L2 latencies per thread at C = 256 - 30 us of a 60-us launch on the 16 x 16 maps of cfg5's deepest level); the plain
+    // orientation reads its four input channels as ONE float4 (C % 4 == 0: the entry point checks it)
+    constexpr int WU = 8;
+    for (int i0 = threadIdx.x; i0 < NT * 4 * CP; i0 += 256 * WU) {
+        float4 wv[WU];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ci = 4 * kq + e;
-            float f = 0.f;
-            if (co < C && ci < C) f = p.transposed ? p.W[(size_t)ci * C + co] : p.W[(size_t)co * C + ci];
-            v[e] = (_Float16)f;
+        for (int u = 0; u < WU; ++u) {
+            const int i = i0 + u * 256;
+            const int kq = i / CP, co = i - kq * CP;
+            const int ci = 4 * kq;
+            wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NT * 4 * CP && co < C && ci < C) {
+                if (!p.transposed) {
+                    wv[u] = *reinterpret_cast<const float4*>(p.W + (size_t)co * C + ci);
+                } else {
+                    wv[u].x = p.W[(size_t)ci * C + co];
+                    wv[u].y = p.W[(size_t)(ci + 1) * C + co];
+                    wv[u].z = p.W[(size_t)(ci + 2) * C + co];
+                    wv[u].w = p.W[(size_t)(ci + 3) * C + co];
+                }
+            }
         }
-        Wl[i] = v;
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int i = i0 + u * 256;
+            if (i < NT * 4 * CP) {
+                h16x4 v;
+                v[0] = (_Float16)wv[u].x; v[1] = (_Float16)wv[u].y; v[2] = (_Float16)wv[u].z; v[3] = (_Float16)wv[u].w;
+                Wl[i] = v;
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

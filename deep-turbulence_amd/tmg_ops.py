@@ -982,10 +982,15 @@ class CouplingTailFn(torch.autograd.Function):
 
 
 # Arithmetic of the 1x1 channel mixes (ActNorm folded into the invertible 1x1 conv, glowConv.py:193-194 / :219-220):
-# "f32" (default) = fp32 MFMA through tmg_conv_fwd; "f16" = fp16 operands, fp32 accumulation (tmg_mix_f16), forward and input
-# gradient - the variant BASELINE.json configs[4] names.  Explicit opt-in: set_mix_precision("f16") or TMG_MIX_F16=1.  Weight
-# gradients stay fp32 in both modes.  The deviation of "f16" from "f32" is reported by tests/test_model_parity.py, separately
-# from the fp32 parity tolerances.
+# "f32" (default) = fp32 MFMA; "f16" = fp16 operands, fp32 accumulation (tmg_mix_f16), forward and input gradient - the variant
+# BASELINE.json configs[4] names.  Explicit opt-in: set_mix_precision("f16") or TMG_MIX_F16=1.  Round 6: "f16" applies wherever the
+# mix is a LAUNCH OF ITS OWN - the LSTM coupling block of every level, every layer of a level wider than 128 channels (cfg5's 256),
+# the density direction's per-layer mixes.  Inside the fused coupling kernels of the generative direction (cpl_fwd / cpl_bwd at
+# 16 / 32 channels, mix32<AFF> at 64 / 128) the mix is a second MFMA contraction on the coupling's accumulator registers and stays
+# fp32: rounds 2-5 switched those kernels OFF under "f16" and ran the per-op chain instead, which is why the fp16 line was SLOWER
+# (0.89-0.94x).  The kernels are bandwidth-bound on fp32 activations either way (8 C bytes per pixel): 2-byte operands cannot buy more
+# than the conversion costs (profiles/r6_mix_f16_vs_f32.txt).  Weight gradients stay fp32 in both modes.  The
+# deviation of "f16" from "f32" is reported by tests/test_model_parity.py, separately from the fp32 parity tolerances.
 _MIX_PRECISION = "f16" if os.environ.get("TMG_MIX_F16") else "f32"
 
 
@@ -1169,7 +1174,7 @@ class LevelCouplingFn(torch.autograd.Function):
         cur = x
         # narrow levels: zero conv, coupling, log-det and - in the generative direction - the following channel mix are ONE launch
         # (tmg_coupling_fwd) after the growth layers' launch; wide levels keep one launch per op
-        fuse = (8 <= C <= 32 and ch % 4 == 0 and _MIX_PRECISION == "f32" and os.environ.get("TMG_NO_FUSED_COUPLING") is None
+        fuse = (8 <= C <= 32 and ch % 4 == 0 and os.environ.get("TMG_NO_FUSED_COUPLING") is None
                 and all(w.is_contiguous() for w in wts))
         # Split-halves layout (round 4; generative direction on the levels whose per-layer kernels are bandwidth-bound): between
         # the layers of the node an activation lives as TWO [B,h,w,C/2] tensors (x1, x2) instead of one [B,h,w,C].  The kernels
@@ -1178,7 +1183,7 @@ class LevelCouplingFn(torch.autograd.Function):
         # coupling kernel's x1 patch loads and x2 epilogue loads no longer pull each other's half-used lines through L2 twice.
         # The node's input and output stay single tensors (addressed as two channel-slice views).
         split = fuse and reverse and C in (16, 32) and os.environ.get("TMG_NO_SPLIT_HALVES") is None
-        mixaff = (reverse and C in (64, 128) and _MIX_PRECISION == "f32" and Wm.is_contiguous() and bm.is_contiguous()
+        mixaff = (reverse and C in (64, 128) and Wm.is_contiguous() and bm.is_contiguous()
                   and os.environ.get("TMG_NO_MIX_AFFINE") is None)
         # Recompute mode (set_recompute; narrow levels, generative direction - where ~80 % of the per-layer activations of the model
         # live): nothing per layer is kept; backward rebuilds layer k's input from its output (see there)
@@ -1368,7 +1373,7 @@ class LevelCouplingFn(torch.autograd.Function):
             dtin = torch.empty((B, Hh, Ww, C), device=dev, dtype=torch.float32)        # grad w.r.t. the tail input
             dhh = DH[..., k * C:(k + 1) * C]
             add0 = None
-            if reverse and isinstance(y, list) and C in (64, 128) and _MIX_PRECISION == "f32":
+            if reverse and isinstance(y, list) and C in (64, 128):
                 # the forward pass took the fused coupling + mix launch: its backward in one launch too (mix input gradient with the
                 # coupling's backward on the way out); dto1 = the pass-through half of the gradient, completed by dense2_bwd below
                 dto1 = torch.empty((B, Hh, Ww, ch), device=dev, dtype=torch.float32)
