@@ -244,7 +244,7 @@ def main():
     import tmg_ops
     # fp32 mixes everywhere except cfg5: BASELINE configs[4] NAMES fp16-operand 1x1 mixes, so that is what its line measures (tested:
     # tests/test_model_parity.py::test_cfg5_stated_batch_with_fp16_mixes).  The variant is not faster here - the stand-alone mixes are
-    # bandwidth kernels on fp32 activations (0.94x, round 3) - and the line says so: `mix_f16_speedup` is the fp32-mix step time over
+    # bandwidth kernels on fp32 activations up to 32 channels (1.00x since round 6: profiles/r6_mix_f16_vs_f32.txt) - and the line says so: `mix_f16_speedup` is the fp32-mix step time over
     # the fp16-mix one on the same workload; `--mix f32` measures the fp32 mixes with the fp16 variant beside it (`mix_f16_variant`).
     mix = args.mix or ("f16" if args.config == "cfg5" else "f32")
     tmg_ops.set_mix_precision(mix)
@@ -512,7 +512,7 @@ def main():
                      + "; optimizer step: " + opt_name,
            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": ("f32" if mix == "f32" else "f32 (1x1 mixes: fp16 operands, fp32 accumulate)")
+           "dtype": ("f32" if mix == "f32" else "f32 (stand-alone 1x1 mixes: fp16 operands, fp32 accumulate; the mixes inside the fused coupling kernels: fp32 MFMA)")
                     + ("" if args.wino == "f32" else " (wide Winograd contractions: f32 operands split into three bf16 parts on the matrix pipe, f32 accumulate)"),
            "data": "synthetic",
            "config": {"workload": "tmglow %s: %s+logdet+backward+Adam, out %dx%dx%d, L=%d, K=%d, batch %d/GPU" % (
