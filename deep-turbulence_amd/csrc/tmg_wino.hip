@@ -1448,13 +1448,18 @@ struct WinoWP {
     int tiles_x, tiles_y, ntiles;
 };
 
-template <int CIT, int NCO>
+// DB (round 6): TWO tile buffers where they fit the CU's 160 KB (every instance except 4 x 3 and 4 x 4).  The single-buffered form commits
+// the prefetched tile, meets at a barrier, multiplies, meets again: commit + issue + two barriers are 16 % of a launch during which no wave
+// feeds the matrix pipe (round-4 ablation).  With two buffers the next tile is committed into the idle buffer BETWEEN k-steps 3 and 4 of
+// the current one - LDS writes and the next global loads beside the other waves' MFMAs - and a tile costs one barrier.
+template <int CIT, int NCO, bool DB>
 __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = 512;
     constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PP = PH * PW;
     constexpr int CSX = CIT * 16 + 8, CSD = NCO * 16 + 8;   // pixel strides (words): 2 CS = 16 (mod 32) -> the two tile columns a
                                                             // half-wave reads fall on disjoint bank halves
+    constexpr int BUFW = PP * CSX + 128 * CSD;              // words per tile buffer
     float* XR = lds;                // [PP][CSX] raw (activated) input patch
     float* DR = lds + PP * CSX;     // [128][CSD] raw dy tile
     constexpr int KX = CIT <= 1 ? 4 : (CIT <= 2 ? 8 : 16), KXL = CIT <= 1 ? 2 : (CIT <= 2 ? 3 : 4);   // float4 slots per pixel (2^n)
@@ -1563,58 +1568,84 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(WinoWP p) {
             for (int n = 0; n < NCO; ++n) acc[e][i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int G = gridDim.x;
-    if ((int)blockIdx.x < p.ntiles) TMG_WW_ISSUE((int)blockIdx.x)
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += G) {
-        // ---- commit the prefetched tile, then put the next one in flight ---------------------------------------------------------
-#pragma unroll
-        for (int u = 0; u < UX; ++u) {
-            if (xc4 < CIT * 4 && xpix0 + u * xstep < PP) {
-                float4 v = xv[u];
-                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(XR + (xpix0 + u * xstep) * CSX + 4 * xc4) = v;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UD; ++u) {
-            if (dc4 < NCO * 4 && dpix0 + u * dstep < 128) {
-                *reinterpret_cast<float4*>(DR + (dpix0 + u * dstep) * CSD + 4 * dc4) = dv[u];
-                bacc.x += dv[u].x; bacc.y += dv[u].y; bacc.z += dv[u].z; bacc.w += dv[u].w;
-            }
-        }
-        __syncthreads();
-        if (tile + G < p.ntiles) TMG_WW_ISSUE(tile + G)
-        // ---- 8 k-steps of 4 Winograd tiles: tile index 4 s + q -> tile row s >> 1, tile column 4 (s & 1) + q -------------------
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int sx = ((2 * (s >> 1)) * PW + 8 * (s & 1)) * CSX;          // patch offset of the k-step's first tile
-            const int sd = ((2 * (s >> 1)) * 16 + 8 * (s & 1)) * CSD;
-            float xa[2][CIT], dh[2][NCO];
-#pragma unroll
-            for (int i = 0; i < CIT; ++i) {
-                const float u0 = fmaf(XR[oxb0 + sx + 16 * i], sg, XR[oxa0 + sx + 16 * i]);
-                const float u1 = fmaf(XR[oxb1 + sx + 16 * i], sg, XR[oxa1 + sx + 16 * i]);
-                const float u2 = fmaf(XR[oxb2 + sx + 16 * i], sg, XR[oxa2 + sx + 16 * i]);
-                xa[0][i] = u0 - u2;
-                xa[1][i] = fmaf(u1, s1, u2);
-            }
-#pragma unroll
-            for (int n = 0; n < NCO; ++n) {
-                const float* dp_ = DR + od + sd + 16 * n;
-                const f2 d_ = k00 * dp_[0] + k01 * dp_[CSD] + k10 * dp_[16 * CSD] + k11 * dp_[17 * CSD];
-                dh[0][n] = d_.x; dh[1][n] = d_.y;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < CIT; ++i)
-#pragma unroll
-                for (int n = 0; n < NCO; ++n) {
-                    acc[0][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][i], dh[0][n], acc[0][i][n], 0, 0, 0);
-                    acc[1][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][i], dh[1][n], acc[1][i][n], 0, 0, 0);
-                }
-        }
-        __syncthreads();
+#define TMG_WW_COMMIT(XRB, DRB)                                                                                        \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < UX; ++u) {                                                               \
+            if (xc4 < CIT * 4 && xpix0 + u * xstep < PP) {                                                             \
+                float4 v = xv[u];                                                                                      \
+                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
+                *reinterpret_cast<float4*>((XRB) + (xpix0 + u * xstep) * CSX + 4 * xc4) = v;                           \
+            }                                                                                                          \
+        }                                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < UD; ++u) {                                                               \
+            if (dc4 < NCO * 4 && dpix0 + u * dstep < 128) {                                                            \
+                *reinterpret_cast<float4*>((DRB) + (dpix0 + u * dstep) * CSD + 4 * dc4) = dv[u];                       \
+                bacc.x += dv[u].x; bacc.y += dv[u].y; bacc.z += dv[u].z; bacc.w += dv[u].w;                            \
+            }                                                                                                          \
+        }                                                                                                              \
     }
+    // 8 k-steps of 4 Winograd tiles: tile index 4 s + q -> tile row s >> 1, tile column 4 (s & 1) + q
+#define TMG_WW_KSTEPS(S0, S1, XRB, DRB)                                                                                \
+    _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const int sx = ((2 * (s >> 1)) * PW + 8 * (s & 1)) * CSX;          /* patch offset of the k-step's first tile */ \
+        const int sd = ((2 * (s >> 1)) * 16 + 8 * (s & 1)) * CSD;                                                      \
+        float xa[2][CIT], dh[2][NCO];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < CIT; ++i) {                                                              \
+            const float u0 = fmaf((XRB)[oxb0 + sx + 16 * i], sg, (XRB)[oxa0 + sx + 16 * i]);                           \
+            const float u1 = fmaf((XRB)[oxb1 + sx + 16 * i], sg, (XRB)[oxa1 + sx + 16 * i]);                           \
+            const float u2 = fmaf((XRB)[oxb2 + sx + 16 * i], sg, (XRB)[oxa2 + sx + 16 * i]);                           \
+            xa[0][i] = u0 - u2;                                                                                        \
+            xa[1][i] = fmaf(u1, s1, u2);                                                                               \
+        }                                                                                                              \
+        _Pragma("unroll") for (int n = 0; n < NCO; ++n) {                                                              \
+            const float* dp_ = (DRB) + od + sd + 16 * n;                                                               \
+            const f2 d_ = k00 * dp_[0] + k01 * dp_[CSD] + k10 * dp_[16 * CSD] + k11 * dp_[17 * CSD];                   \
+            dh[0][n] = d_.x; dh[1][n] = d_.y;                                                                          \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < CIT; ++i)                                                                \
+            _Pragma("unroll") for (int n = 0; n < NCO; ++n) {                                                          \
+                acc[0][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][i], dh[0][n], acc[0][i][n], 0, 0, 0);         \
+                acc[1][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1][i], dh[1][n], acc[1][i][n], 0, 0, 0);         \
+            }                                                                                                          \
+    }
+    if constexpr (DB) {
+        int cur = 0;
+        if ((int)blockIdx.x < p.ntiles) {
+            TMG_WW_ISSUE((int)blockIdx.x)
+            TMG_WW_COMMIT(XR, DR)
+            if ((int)blockIdx.x + G < p.ntiles) TMG_WW_ISSUE((int)blockIdx.x + G)
+        }
+        __syncthreads();
+        for (int tile = blockIdx.x; tile < p.ntiles; tile += G) {
+            const float* xrb = XR + cur * BUFW;
+            const float* drb = DR + cur * BUFW;
+            TMG_WW_KSTEPS(0, 4, xrb, drb)
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + G < p.ntiles) {
+                // the next tile (in flight since the previous round) -> the idle buffer; the one after it -> the registers
+                TMG_WW_COMMIT(XR + (cur ^ 1) * BUFW, DR + (cur ^ 1) * BUFW)
+                if (tile + 2 * G < p.ntiles) TMG_WW_ISSUE(tile + 2 * G)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TMG_WW_KSTEPS(4, 8, xrb, drb)
+            __syncthreads();      // the idle buffer is complete, this one has been read by every wave
+            cur ^= 1;
+        }
+    } else {
+        if ((int)blockIdx.x < p.ntiles) TMG_WW_ISSUE((int)blockIdx.x)
+        for (int tile = blockIdx.x; tile < p.ntiles; tile += G) {
+            // ---- commit the prefetched tile, then put the next one in flight -----------------------------------------------------
+            TMG_WW_COMMIT(XR, DR)
+            __syncthreads();
+            if (tile + G < p.ntiles) TMG_WW_ISSUE(tile + G)
+            TMG_WW_KSTEPS(0, 8, XR, DR)
+            __syncthreads();
+        }
+    }
+#undef TMG_WW_COMMIT
+#undef TMG_WW_KSTEPS
 #undef TMG_WW_ISSUE
     // ---- partial sums -> this block's slab (accumulator order, coalesced float4 stores) ---------------------------------------------
     const size_t bl = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
@@ -1745,6 +1776,7 @@ static int plan_wino_wgrad(int B, int H, int W, int Cin, int Cout, int ngroups, 
     const int citg = (cit + pl->gz - 1) / pl->gz;
     pl->CIT = citg <= 2 ? 2 : (citg == 3 ? 3 : 4);
     pl->gy = (cot + 3) / 4;
+    // (4 x 3 register tiles - double-buffered - in place of 4 x 4 for the 64-channel blocks: 3.39 against 2.77 ms at 104 -> 256, round 6)
     const int cotg = (cot + pl->gy - 1) / pl->gy;
     pl->NCO = cotg <= 2 ? 2 : (cotg == 3 ? 3 : 4);
     pl->gy *= ngroups;     // block row = (group, output-channel block)
@@ -1766,10 +1798,17 @@ extern "C" int64_t tmg_conv_wino_wgrad_ws_floats(const int64_t* dims) {
 
 template <int CIT, int NCO>
 static int launch_wino_wgrad(const WinoWP& p, const WinoWPlan& pl, hipStream_t st) {
-    const size_t lds_bytes = (size_t)(180 * (CIT * 16 + 8) + 128 * (NCO * 16 + 8)) * sizeof(float);
-    TMG_LDS_OPTIN((&wino_wgrad_kernel<CIT, NCO>));
+    constexpr size_t one = (size_t)(180 * (CIT * 16 + 8) + 128 * (NCO * 16 + 8)) * sizeof(float);
+    constexpr bool DB = 2 * one <= 160 * 1024;       // two tile buffers where they fit (see the kernel)
+    static const int nodb = getenv("TMG_WW_NO_DB") ? 1 : 0;      // A / B switch
     TmgProf prof(TMG_PROF_WINO_WG, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);
-    hipLaunchKernelGGL((wino_wgrad_kernel<CIT, NCO>), dim3(pl.gx, pl.gy, pl.gz), dim3(512), lds_bytes < 8192 ? 8192 : lds_bytes, st, p);
+    if (DB && !nodb) {
+        TMG_LDS_OPTIN((&wino_wgrad_kernel<CIT, NCO, DB>));
+        hipLaunchKernelGGL((wino_wgrad_kernel<CIT, NCO, DB>), dim3(pl.gx, pl.gy, pl.gz), dim3(512), 2 * one, st, p);
+    } else {
+        TMG_LDS_OPTIN((&wino_wgrad_kernel<CIT, NCO, false>));
+        hipLaunchKernelGGL((wino_wgrad_kernel<CIT, NCO, false>), dim3(pl.gx, pl.gy, pl.gz), dim3(512), one < 8192 ? 8192 : one, st, p);
+    }
     TMG_CHECK_LAUNCH();
     return 0;
 }
