@@ -85,14 +85,24 @@ class GradBucket:
     `p.grad = None`, exactly as in a single-process run (the optimizer skips them: no moment decay, no weight decay).  A parameter
     that is live somewhere but has no gradient on this rank contributes zeros.  Works unchanged with gloo on CPU.
 
+    Host synchronisation: the reduced control vector is read on the host (a synchronisation) only in the first steps, until the live
+    set has been quiet for SYNC_STEPS consecutive steps; from then on it is examined one step late (see allreduce_mean): a steady
+    step contains NO host synchronisation.  TMG_BUCKET_SYNC=1 reads it in every step.
+
     Contract: ONE backward per `allreduce_mean()` (no gradient accumulation, no retain_graph second pass) - a second gradient for
     the same parameter raises.
 
     `measure=True`: event pairs around the exchange (see `overlap_report`)."""
 
+    SYNC_STEPS = 3
+
     def __init__(self, params, bucket_mb=32, measure=False, force=False):
         """force: run the collectives also in a process group of ONE rank (the real backend on a one-GPU box)."""
         self.force = bool(force)
+        self.always_sync = bool(os.environ.get("TMG_BUCKET_SYNC"))   # A / B switch: read the control vector on the host in every step
+        self._sync_left = self.SYNC_STEPS      # steps of the synchronous protocol still to run (see allreduce_mean)
+        self._pending = None                   # event behind the asynchronous copy of the previous step's reduced control vector
+        self.deferred_steps = 0                # diagnostics: steps whose control vector was examined one step later
         self.params = [p for p in params if p.requires_grad]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self.buckets = None        # list of parameter lists (built on first use: the parameters may still move device)
@@ -151,8 +161,10 @@ class GradBucket:
             if last:
                 self._ctrl = flat[ng + len(bk):]              # rides on the last bucket's collective
         self._ctrl_host = torch.zeros(nctrl, dtype=self._ctrl.dtype)
+        self._ctrl_read = torch.zeros(nctrl, dtype=self._ctrl.dtype)
         if self._ctrl.is_cuda:
             self._ctrl_host = self._ctrl_host.pin_memory()    # (a pageable source makes the copy a synchronising one)
+            self._ctrl_read = self._ctrl_read.pin_memory()
         self._reset()
 
     def _reset(self):
@@ -243,7 +255,39 @@ class GradBucket:
         self._launch(nbk - 1)
         for bi, work in self._work:
             work.wait()
-        red = self._ctrl.tolist()                  # the one host read of a steady step (n + 2 floats; identical on every rank)
+        # Reading the reduced control vector is a HOST SYNCHRONISATION: the host cannot run ahead into the next step while the GPU
+        # finishes this one, and the next step's ~300 short launches (encoder, deepest levels: 10-20 us of GPU time each, ~20 us of
+        # host time each) then reach an empty queue - measured on a one-rank RCCL group: 43.1 -> 49.7 ms per step at config M with the
+        # collective itself patched OUT (tools/bucket_cost.py).  So the synchronous protocol runs only while the live set is still
+        # settling (SYNC_STEPS consecutive quiet steps); afterwards the vector of step N is copied to pinned memory asynchronously and
+        # examined at step N + 1 - by every rank alike, it is the REDUCED vector - where a non-zero entry (the live set changed after
+        # all: never in TM-Glow, whose live set is static from the first step) sends all ranks back to the synchronous protocol.  The one
+        # step in between went without the second pass: the late gradient of the newly live parameter is missing from that step's sum
+        # on every rank alike (replicas stay identical), and a warning says so.
+        deferred = self._sync_left <= 0 and self._ctrl.is_cuda and not self.always_sync
+        if deferred:
+            if self._pending is not None:
+                self._pending.synchronize()        # recorded a whole step ago: complete unless the host is more than a step ahead
+                prev = self._ctrl_read.tolist()
+                if any(v > 0.0 for v in prev):
+                    import warnings
+                    warnings.warn("GradBucket: the set of parameters with gradients changed after it had settled (reduced control "
+                                  "vector %s of the previous step); the previous step's exchange ran without a second pass, the "
+                                  "synchronous protocol is back on for %d steps" % (prev, self.SYNC_STEPS))
+                    self._sync_left = self.SYNC_STEPS
+                    deferred = False
+                    self._pending = None
+        if deferred:
+            self._ctrl_read.copy_(self._ctrl, non_blocking=True)
+            self._pending = torch.cuda.Event()
+            self._pending.record()
+            red = [0.0] * (nbk + 2)
+            self.deferred_steps += 1
+        else:
+            red = self._ctrl.tolist()              # the one host read of a settling step (n + 2 floats; identical on every rank)
+            self._pending = None
+            quiet = not any(v > 0.0 for v in red)
+            self._sync_left = self._sync_left - 1 if (quiet and self._live_any is not None) else self.SYNC_STEPS
         late_any = [bi for bi in range(nbk) if red[bi] > 0.0]
         if late_any:
             # the live set grew behind a bucket that had gone - on some rank.  p.grad still holds every rank's OWN gradient (re-binding

@@ -59,7 +59,7 @@ def main(out_path):
             rec["gn"].append(float(gn))
         # (b) the benchmark's unit: single steps with plain backward - the hooks hand complete buckets to RCCL while backward runs
         h0 = bucket.launched_during_backward if bk is not None else 0
-        for _ in range(3):
+        for _ in range(6):
             opt.zero_grad(set_to_none=True)
             y, lp, _ = m.reconstruct(xs[0], states, eps[0])
             loss = C.loss_reverse(y, lp)
@@ -73,6 +73,7 @@ def main(out_path):
             rec["nbuckets"] = len(bucket.buckets)
             rec["overlap"] = bucket.overlap_report()
             rec["second_passes"] = bucket.second_passes
+            rec["deferred_steps"] = bucket.deferred_steps
         rec["params"] = {k: v.detach().cpu().clone() for k, v in m.named_parameters()}
         out[tag] = rec
     res.update(out)

@@ -120,7 +120,7 @@ def test_bench_two_rank_path_on_one_device():
 def test_rccl_world_size_one_buckets_and_broadcast(tmp_path):
     """the REAL collective backend without a second GPU.  tests/dist_rccl1_worker.py joins a process group of one
     rank with backend "nccl" (RCCL) and runs the flat parameter broadcast, two BPTT windows (buckets issued after the fused gradient
-    accumulation) and three single steps (buckets handed to RCCL from the post-accumulate hooks while backward is running; the control
+    accumulation) and six single steps (buckets handed to RCCL from the post-accumulate hooks while backward is running; the control
     vector in the last bucket's tail) - against the same steps on an identical model with no bucket at all.  A one-rank all-reduce /
     broadcast is the identity, so losses, gradient norms and parameters must agree to the noise of the float atomics; what the test
     adds over the gloo ones is RCCL's asynchronous handles and its stream ordering against the compute stream."""
@@ -134,14 +134,15 @@ def test_rccl_world_size_one_buckets_and_broadcast(tmp_path):
     res = torch.load(out)
     assert res["backend"] == "nccl" and res["broadcast_exact"]
     a, b = res["rccl"], res["plain"]
-    assert a["nbuckets"] > 1 and a["hooked_single_step"] >= 3 and a["second_passes"] == 0
+    assert a["nbuckets"] > 1 and a["hooked_single_step"] >= 6 and a["second_passes"] == 0
+    assert a["deferred_steps"] >= 2          # the live set settled: the later steps ran without a host synchronisation
     assert a["overlap"] is not None and a["overlap"]["exchange_ms"] > 0
     for la, lb in zip(a["loss"], b["loss"]):
         assert abs(la - lb) <= 2e-5 * abs(lb) + 2e-5, (a["loss"], b["loss"])
     for ga, gb in zip(a["gn"], b["gn"]):
         assert abs(ga - gb) <= 5e-4 * gb
     for k, v in b["params"].items():
-        assert float((a["params"][k] - v).abs().max()) <= 2e-2 * 5e-3, k          # Adam: |update| <= lr per step, five steps
+        assert float((a["params"][k] - v).abs().max()) <= 2e-2 * 8e-3, k          # Adam: |update| <= lr per step, eight steps
 
 
 def test_bench_forced_bucket_reports_rccl():
