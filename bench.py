@@ -253,7 +253,19 @@ def main():
     model = build_model(cfg, dev)
     _phase("model construction + upload")
     forced = bool(args.force_bucket and world == 1)
-    tmg_dist.broadcast_parameters(model, force=forced)
+    # RCCL prints a start-up banner (version, host, library path) to the C-level stdout when its communicator is created - at the first
+    # collective.  The contract is ONE JSON line on rank 0's stdout: the first collective runs with file descriptor 1 pointing at stderr.
+    sys.stdout.flush()
+    fd1 = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        tmg_dist.broadcast_parameters(model, force=forced)
+        if world > 1 or forced:
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(fd1, 1)
+        os.close(fd1)
     bucket = tmg_dist.GradBucket(model.parameters(), measure=True, force=forced) if (world > 1 or forced) else None
     use_graph = args.graph and world == 1
     # the reference's optimizer (main.py:78: Adam, weight decay 1e-8, amsgrad); `fused` = torch's single-kernel multi-tensor

@@ -1772,7 +1772,10 @@ static int launch_wgrad(const WgradP& p, dim3 grid, size_t lds_bytes, hipStream_
     TMG_LDS_OPTIN((&conv_wgrad_kernel<NP, NCO, LEAN>));
     const int nco_i = NCO == 1 ? 0 : (NCO == 2 ? 1 : 2);
     const int kid = NP == 3 ? 8 + nco_i : (NP == 8 ? 28 + nco_i : 19 + ((NP - 5) / 2) * 3 + nco_i);
-    ProfScope prof(kid, 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
+    // (a grouped launch does the work of grid.y / bpg identically shaped contractions: rounds 2-5 booked ONE group's flops - the
+    // '6.4 TFLOP/s' of conv_wgrad_kernel<9,1> in their bench lines was 1/15 of the first level's 0.87-ms launch)
+    const double ngr = p.gtab ? (double)(grid.y / (p.bpg > 0 ? p.bpg : 1)) : 1.0;
+    ProfScope prof(kid, ngr * 2.0 * p.B * p.Hout * p.Wout * (double)p.Cout * p.Cin * p.ksize * p.ksize, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<NP, NCO, LEAN>), grid, dim3(512), lds_bytes, st, p);
     TMG_CHECK_LAUNCH();
     return 0;

@@ -1801,7 +1801,8 @@ static int launch_wino_wgrad(const WinoWP& p, const WinoWPlan& pl, hipStream_t s
     constexpr size_t one = (size_t)(180 * (CIT * 16 + 8) + 128 * (NCO * 16 + 8)) * sizeof(float);
     constexpr bool DB = 2 * one <= 160 * 1024;       // two tile buffers where they fit (see the kernel)
     static const int nodb = getenv("TMG_WW_NO_DB") ? 1 : 0;      // A / B switch
-    TmgProf prof(TMG_PROF_WINO_WG, 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);
+    const double ngr = p.gtab ? (double)(pl.gy / (p.bpg > 0 ? p.bpg : 1)) : 1.0;      // (a grouped launch: every group's flops)
+    TmgProf prof(TMG_PROF_WINO_WG, ngr * 2.0 * p.B * p.Hin * p.Win * (double)p.Cout * p.Cin * 9, st);
     if (DB && !nodb) {
         TMG_LDS_OPTIN((&wino_wgrad_kernel<CIT, NCO, DB>));
         hipLaunchKernelGGL((wino_wgrad_kernel<CIT, NCO, DB>), dim3(pl.gx, pl.gy, pl.gz), dim3(512), 2 * one, st, p);

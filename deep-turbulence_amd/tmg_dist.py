@@ -96,9 +96,11 @@ class GradBucket:
 
     SYNC_STEPS = 3
 
-    def __init__(self, params, bucket_mb=32, measure=False, force=False):
-        """force: run the collectives also in a process group of ONE rank (the real backend on a one-GPU box)."""
+    def __init__(self, params, bucket_mb=32, measure=False, force=False, defer_on_cpu=False):
+        """force: run the collectives also in a process group of ONE rank (the real backend on a one-GPU box).  defer_on_cpu: the
+        one-step-late examination of the control vector also for CPU tensors (where there is nothing to gain: the protocol's tests)."""
         self.force = bool(force)
+        self.defer_on_cpu = bool(defer_on_cpu)
         self.always_sync = bool(os.environ.get("TMG_BUCKET_SYNC"))   # A / B switch: read the control vector on the host in every step
         self._sync_left = self.SYNC_STEPS      # steps of the synchronous protocol still to run (see allreduce_mean)
         self._pending = None                   # event behind the asynchronous copy of the previous step's reduced control vector
@@ -264,10 +266,11 @@ class GradBucket:
         # all: never in TM-Glow, whose live set is static from the first step) sends all ranks back to the synchronous protocol.  The one
         # step in between went without the second pass: the late gradient of the newly live parameter is missing from that step's sum
         # on every rank alike (replicas stay identical), and a warning says so.
-        deferred = self._sync_left <= 0 and self._ctrl.is_cuda and not self.always_sync
+        deferred = self._sync_left <= 0 and (self._ctrl.is_cuda or self.defer_on_cpu) and not self.always_sync
         if deferred:
             if self._pending is not None:
-                self._pending.synchronize()        # recorded a whole step ago: complete unless the host is more than a step ahead
+                if self._ctrl.is_cuda:
+                    self._pending.synchronize()    # recorded a whole step ago: complete unless the host is more than a step ahead
                 prev = self._ctrl_read.tolist()
                 if any(v > 0.0 for v in prev):
                     import warnings
@@ -275,12 +278,16 @@ class GradBucket:
                                   "vector %s of the previous step); the previous step's exchange ran without a second pass, the "
                                   "synchronous protocol is back on for %d steps" % (prev, self.SYNC_STEPS))
                     self._sync_left = self.SYNC_STEPS
+                    self._live_any = None          # the flags of THIS step are read below: the live set is learned again
                     deferred = False
                     self._pending = None
         if deferred:
             self._ctrl_read.copy_(self._ctrl, non_blocking=True)
-            self._pending = torch.cuda.Event()
-            self._pending.record()
+            if self._ctrl.is_cuda:
+                self._pending = torch.cuda.Event()
+                self._pending.record()
+            else:
+                self._pending = True
             red = [0.0] * (nbk + 2)
             self.deferred_steps += 1
         else:

@@ -317,6 +317,65 @@ def test_live_set_grows_on_one_rank_only():
     assert r0["reads"] == r1["reads"]
 
 
+def _run_change_after_settling(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, C.PKG)
+    import warnings
+    import tmg_dist
+    torch.set_num_threads(1)
+    tmg_dist.init_from_env("gloo")
+    torch.manual_seed(5)
+    prm = [torch.nn.Parameter(torch.randn(7, 3)) for _ in range(4)]      # a, b, c, d -> buckets [d, c], [b, a]
+    x = torch.randn(4, 3) + rank
+    bucket = tmg_dist.GradBucket(prm, bucket_mb=2.1 * 21 * 4 / 2 ** 20, defer_on_cpu=True)
+    opt = torch.optim.SGD(prm, lr=1e-2)
+    out, warned = [], []
+    for step in range(10):
+        use = {1, 3} | ({0} if rank == 1 and step >= 6 else set())          # from step 6 on rank 1 ALONE also uses a
+        opt.zero_grad(set_to_none=True)
+        loss = 0.0
+        for i in sorted(use, reverse=True):
+            loss = loss + ((prm[i] @ x.t()) ** 2).sum() * (i + 1)
+        loss.backward()
+        own = {i: p.grad.clone() for i, p in enumerate(prm) if p.grad is not None}
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            bucket.allreduce_mean()
+        warned.append(any("changed after it had settled" in str(m.message) for m in w))
+        out.append({"own": own, "mean": {i: p.grad.clone() for i, p in enumerate(prm) if p.grad is not None}, "deferred": bucket.deferred_steps})
+        opt.step()
+    ret[rank] = {"steps": out, "warned": warned, "params": [p.detach().clone() for p in prm], "second": bucket.second_passes}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_live_set_change_after_settling_is_caught_one_step_late_on_every_rank():
+    """Round 6: once the live set has been quiet for SYNC_STEPS steps the reduced control vector is examined ONE STEP LATE (no host
+    synchronisation in a steady step).  Here rank 1 alone starts using parameter `a` at step 6, long after settling: step 6 runs without
+    the flag re-read (a's gradient is dropped - on BOTH ranks alike: the replicas stay identical), step 7 finds the previous step's
+    reduced vector non-zero on both ranks (a warning each), returns to the synchronous protocol and binds a's mean gradient from then
+    on.  No rank-local decision, no deadlock, no divergence."""
+    world = 2
+    port = 36500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_change_after_settling, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["steps"][5]["deferred"] >= 2 and r1["steps"][5]["deferred"] >= 2          # steps 4 and 5 ran without the host read
+    for k in range(10):
+        s0, s1 = r0["steps"][k], r1["steps"][k]
+        want_keys = {1, 3} if k <= 6 else {0, 1, 3}
+        assert set(s0["mean"]) == want_keys and set(s1["mean"]) == want_keys, (k, set(s0["mean"]), set(s1["mean"]))
+        for i in want_keys:
+            want = 0.5 * (s0["own"].get(i, 0.0) + s1["own"].get(i, 0.0))
+            assert torch.allclose(s0["mean"][i], want, rtol=1e-6, atol=1e-6), (k, i)
+            assert torch.equal(s0["mean"][i], s1["mean"][i]), (k, i)
+    assert r0["warned"] == r1["warned"] and r0["warned"][7] and sum(r0["warned"]) == 1   # caught at step 7, by both ranks, once
+    for p0, p1 in zip(r0["params"], r1["params"]):
+        assert torch.equal(p0, p1)
+    assert r0["second"] == r1["second"]
+
+
 def _run_flat_broadcast(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     sys.path.insert(0, C.PKG)
