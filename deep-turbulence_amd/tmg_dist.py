@@ -57,9 +57,14 @@ def broadcast_parameters(module, src=0, force=False):
 class GradBucket:
     """Bucketed gradient all-reduce (mean over ranks), overlapped with backward.
 
-    Layout (static, identical on every rank by construction): ALL parameters that require a gradient, in reverse registration
-    order, cut into buckets of <= `bucket_mb`; a bucket owns ONE persistent flat buffer [gradients | one has-gradient flag per
-    parameter]; the LAST bucket's buffer ends with the n + 2 floats of the control vector.  The collectives of a step are ALWAYS
+    Layout (static, identical on every rank by construction): ALL parameters that require a gradient, in the order in which the
+    FIRST backward pass delivered their gradients (rank 0's order, broadcast; `order="reverse"`: reverse registration order), cut into
+    buckets of <= `bucket_mb` (4 MB: six buckets at the metric configuration); a bucket owns ONE persistent flat buffer [gradients |
+    one has-gradient flag per parameter]; the LAST bucket's buffer ends with the n + 2 floats of the control vector.  TM-Glow's
+    generative direction runs the flow levels deepest-first, so its backward delivers the first level's gradients first and the
+    large deep levels' late - the opposite of reverse registration order, with which no bucket could leave before the end of backward
+    (one-rank RCCL group, config M, 4-MB buckets: first bucket ready 7.1 ms before the last all-reduce completes with the arrival
+    order, 2.6 ms with reverse registration order; 0.1 ms of the exchange exposed either way on one rank, tools/bucket_cost.py).  The collectives of a step are ALWAYS
     bucket 0, 1, .., n-1 in that order (the last one - the first-registered parameters, whose gradients arrive last anyway - always from
     allreduce_mean(), with the control values in its tail: no collective of their own, staged through a pinned buffer), then -
     only when the REDUCED control vector says so - a second pass of the buckets it names, in order.  No rank-local decision changes
@@ -96,7 +101,7 @@ class GradBucket:
 
     SYNC_STEPS = 3
 
-    def __init__(self, params, bucket_mb=32, measure=False, force=False, defer_on_cpu=False):
+    def __init__(self, params, bucket_mb=4, measure=False, force=False, defer_on_cpu=False, order="arrival"):
         """force: run the collectives also in a process group of ONE rank (the real backend on a one-GPU box).  defer_on_cpu: the
         one-step-late examination of the control vector also for CPU tensors (where there is nothing to gain: the protocol's tests)."""
         self.force = bool(force)
@@ -106,6 +111,9 @@ class GradBucket:
         self._pending = None                   # event behind the asynchronous copy of the previous step's reduced control vector
         self.deferred_steps = 0                # diagnostics: steps whose control vector was examined one step later
         self.params = [p for p in params if p.requires_grad]
+        self.order = order
+        self._arrival, self._arrival_seen = [], set()
+        self._order_hooks = [p.register_post_accumulate_grad_hook(self._record_arrival) for p in self.params] if order == "arrival" else []
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self.buckets = None        # list of parameter lists (built on first use: the parameters may still move device)
         self._flat = []            # persistent flat buffer per bucket: gradients, then one flag per parameter
@@ -135,8 +143,35 @@ class GradBucket:
         self._ev_first = None
 
     # ---- static layout ------------------------------------------------------------------------------------------------------
+    def _record_arrival(self, p):
+        """Order-recording hook of the FIRST backward pass (registered at construction): the bucket layout follows it."""
+        if self.buckets is None and p.grad is not None and id(p) not in self._arrival_seen:
+            self._arrival_seen.add(id(p))
+            self._arrival.append(p)
+
+    def _layout_order(self):
+        """The parameters in the order the buckets are cut from.  "reverse": reverse registration order (what a feed-forward net's
+        backward produces, roughly).  "arrival" (default): the order in which the FIRST backward pass delivered the gradients - TM-Glow's
+        generative direction runs the flow levels deepest-first, so its backward delivers level 1 first and the big deep levels late,
+        the opposite of reverse registration order: with that layout NO bucket could go before the end of backward - followed by the
+        parameters that delivered none (reverse registration order).  Rank 0's order is broadcast (indices into the registration
+        order): the layout is identical on every rank by construction."""
+        if self.order != "arrival" or not self._arrival:
+            return list(reversed(self.params))
+        seen = self._arrival_seen
+        order = list(self._arrival) + [p for p in reversed(self.params) if id(p) not in seen]
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            pos = {id(p): i for i, p in enumerate(self.params)}
+            idx = torch.tensor([pos[id(p)] for p in order], dtype=torch.int64, device=self.params[0].device)
+            dist.broadcast(idx, 0)
+            order = [self.params[i] for i in idx.tolist()]
+        return order
+
     def _build(self):
-        order = list(reversed(self.params))   # backward produces the last-registered parameters' gradients first (roughly)
+        order = self._layout_order()
+        for h in self._order_hooks:
+            h.remove()
+        self._order_hooks = []
         self.buckets, cur, n = [], [], 0
         for p in order:
             if cur and n + p.numel() > self.bucket_elems:

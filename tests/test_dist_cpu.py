@@ -148,7 +148,7 @@ def _run_bucket_edges(rank, world, port, ret):
     torch.manual_seed(5)
     a, b, c = (torch.nn.Parameter(torch.randn(7, 3)) for _ in range(3))
     x = torch.randn(4, 3) + rank
-    bucket = tmg_dist.GradBucket([a, b, c], bucket_mb=1e-4)      # one parameter per bucket
+    bucket = tmg_dist.GradBucket([a, b, c], bucket_mb=1e-4, order="reverse")      # one parameter per bucket
     out = {}
 
     def step(use):
@@ -214,7 +214,7 @@ def _run_divergent_live_sets(rank, world, port, ret):
     torch.manual_seed(5)
     a, b, c = (torch.nn.Parameter(torch.randn(7, 3)) for _ in range(3))
     x = torch.randn(4, 3) + rank
-    bucket = tmg_dist.GradBucket([a, b, c], bucket_mb=1e-4)
+    bucket = tmg_dist.GradBucket([a, b, c], bucket_mb=1e-4, order="reverse")
     out = []
     # ranks DISAGREE about which parameters have gradients (rank 0: a, b; rank 1: a, c), then swap: the fixed collective sequence
     # must neither hang nor mis-pair buffers; a parameter live on one rank is reduced with zeros from the other
@@ -265,7 +265,7 @@ def _run_one_sided_growth(rank, world, port, ret):
     torch.manual_seed(5)
     prm = [torch.nn.Parameter(torch.randn(7, 3)) for _ in range(4)]      # a, b, c, d -> buckets [d, c], [b, a]
     x = torch.randn(4, 3) + rank
-    bucket = tmg_dist.GradBucket(prm, bucket_mb=2.1 * 21 * 4 / 2 ** 20)
+    bucket = tmg_dist.GradBucket(prm, bucket_mb=2.1 * 21 * 4 / 2 ** 20, order="reverse")
     opt = torch.optim.Adam(prm, lr=1e-2, weight_decay=1e-3, amsgrad=True)
     out = []
     # both ranks: b and d live.  From step 2 on rank 1 ALONE also uses c - its gradient is bound after backward (deferred node), i.e.
@@ -327,7 +327,7 @@ def _run_change_after_settling(rank, world, port, ret):
     torch.manual_seed(5)
     prm = [torch.nn.Parameter(torch.randn(7, 3)) for _ in range(4)]      # a, b, c, d -> buckets [d, c], [b, a]
     x = torch.randn(4, 3) + rank
-    bucket = tmg_dist.GradBucket(prm, bucket_mb=2.1 * 21 * 4 / 2 ** 20, defer_on_cpu=True)
+    bucket = tmg_dist.GradBucket(prm, bucket_mb=2.1 * 21 * 4 / 2 ** 20, defer_on_cpu=True, order="reverse")
     opt = torch.optim.SGD(prm, lr=1e-2)
     out, warned = [], []
     for step in range(10):
@@ -436,7 +436,7 @@ def _run_deferred_grads(rank, world, port, ret):
     torch.manual_seed(3)
     a, b = (torch.nn.Parameter(torch.randn(5, 3)) for _ in range(2))
     x = torch.randn(4, 3) + rank
-    bucket = tmg_dist.GradBucket([a, b], bucket_mb=1e-4)
+    bucket = tmg_dist.GradBucket([a, b], bucket_mb=1e-4, order="reverse")
     out = []
     for step in range(3):
         for p in (a, b):

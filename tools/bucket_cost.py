@@ -39,9 +39,11 @@ def run(bucket, n=15):
         if bucket is not None:
             bucket.allreduce_mean()
         opt.step()
-    for _ in range(4):
+    for _ in range(6):
         step()
     torch.cuda.synchronize()
+    if bucket is not None:
+        bucket.overlap_report()      # (drop the warm-up steps' event pairs: the first collective creates the communicator)
     t0 = time.perf_counter()
     for _ in range(n):
         step()
@@ -50,8 +52,10 @@ def run(bucket, n=15):
 
 
 print("no bucket                      %.2f ms per step" % run(None))
-bk = tmg_dist.GradBucket(model.parameters(), measure=True, force=True)
-print("bucket, RCCL one-rank group    %.2f ms per step   %s" % (run(bk), bk.overlap_report()))
+bk = tmg_dist.GradBucket(model.parameters(), measure=True, force=True, bucket_mb=float(os.environ.get("TMG_BUCKET_MB", "32")),
+                         order=os.environ.get("TMG_BUCKET_ORDER", "arrival"))
+t_ = run(bk)
+print("bucket, RCCL one-rank group    %.2f ms per step   %d buckets, %d launched from hooks, report of the timed steps: %s" % (t_, len(bk.buckets), bk.launched_during_backward, bk.overlap_report()))
 real = dist.all_reduce
 
 
