@@ -295,3 +295,35 @@ extern "C" int tmg_level_pack(const void* tab, void* Wz, void* Wcat, void* Bz, v
     TMG_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// up[b][y][x][c] = (y, x both even) ? dy[b][y / 2][x / 2][c] : 0 - the operand of the stride-2 input gradient on the matrix cores
+// (tmg_ops.ConvFn.backward: dx = stride-1 correlation of the flipped taps with dy spread onto the even positions of a zero grid).
+// One launch writes the whole grid (round 5: a zero fill of the grid + a strided torch copy).  float4 over channels (C % 4 == 0).
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void spread2_kernel(const float* __restrict__ dy, int dys, float* __restrict__ up, int B, int H, int W, int h, int w, int C4) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(x & 1) && !(y & 1) && (y >> 1) < h && (x >> 1) < w)
+            v = *reinterpret_cast<const float4*>(dy + (((size_t)b * h + (y >> 1)) * w + (x >> 1)) * dys + 4 * c4);
+        reinterpret_cast<float4*>(up)[i] = v;
+    }
+}
+
+// dims = {B, H, W (of the grid), h, w (of dy), C}; dy_d = {pixel stride, channel offset}; up: contiguous [B][H][W][C]
+extern "C" int tmg_spread2(const void* dy, const int64_t* dy_d, void* up, const int64_t* dims, hipStream_t st) {
+    const int C = (int)dims[5];
+    if ((C & 3) || (dy_d[0] & 3) || (dy_d[1] & 3) || ((((uintptr_t)dy) | ((uintptr_t)up)) & 15)) return -100;
+    const size_t total = (size_t)dims[0] * dims[1] * dims[2] * (C / 4);
+    hipLaunchKernelGGL(spread2_kernel, dim3(glue_grid(total)), dim3(256), 0, st, (const float*)dy + dy_d[1], (int)dy_d[0], (float*)up, (int)dims[0],
+                       (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], C / 4);
+    TMG_CHECK_LAUNCH();
+    return 0;
+}

@@ -39,7 +39,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_gauss_sample", "tmg_reverse_loss_fwd", "tmg_reverse_loss_bwd", "tmg_sum_terms", "tmg_vec_sum", "tmg_level_pack",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_gauss_sample", "tmg_reverse_loss_fwd", "tmg_reverse_loss_bwd", "tmg_sum_terms", "tmg_vec_sum", "tmg_level_pack", "tmg_spread2",
 ]
 
 
@@ -918,6 +918,16 @@ def sum_terms(terms, out):
 
 def vec_sum(g, out):
     _chk(lib().tmg_vec_sum(_ptr(g), c_i64(g.numel()), _ptr(out), _stream()), "tmg_vec_sum")
+
+
+def spread2(dy, up):
+    """up (contiguous [B,H,W,C]) = dy on the even positions, zeros elsewhere, in one launch (tmg_spread2); False outside the envelope."""
+    B, Hh, Ww, C = up.shape
+    rc = lib().tmg_spread2(_ptr(dy), _d2(dy), _ptr(up), _i64(B, Hh, Ww, dy.shape[1], dy.shape[2], C), _stream())
+    if rc == -100:
+        return False
+    _chk(rc, "tmg_spread2")
+    return True
 
 
 def level_pack(tab, Wz, Wcat, Bz, Kp, NL, NLp, C, ch, Cc):

@@ -301,7 +301,8 @@ class ConvFn(torch.autograd.Function):
         premasked = len(ctx.opts) > 5 and ctx.opts[5]
         weight, bias, kappa, out = ctx.saved_tensors[:4]
         inputs = ctx.saved_tensors[4:]
-        dout = dout.contiguous()
+        if not H._pixel_linear(dout):       # (a channel slice of a wider gradient is addressed in place: pixel stride + offset)
+            dout = dout.contiguous()
         if relu_out and not premasked:
             dy = torch.empty_like(dout)
             H.masked_add(dy, src=dout, ref=out)
@@ -343,8 +344,10 @@ class ConvFn(torch.autograd.Function):
                     # = a stride-1 correlation with the flipped taps over dy spread onto the even positions of a zero grid
                     # (4x the minimal MFMA work, but these encoder convs have 8-32 channels: the scalar direct kernel spent
                     # 260 us per call at 0.12 TB/s on them)
-                    up = zeros((dy.shape[0], Hin_, Win_, dy.shape[3]), dy.device)
-                    up[:, ::2, ::2] = dy
+                    up = torch.empty((dy.shape[0], Hin_, Win_, dy.shape[3]), device=dy.device, dtype=torch.float32)
+                    if not H.spread2(dy, up):
+                        up.zero_()
+                        up[:, ::2, ::2] = dy
                     H.conv_fwd([up], H.conv_pack(weight, 1), inputs[0].shape[3], ksize, 1, dins)
                 else:
                     H.conv_dgrad_direct(dy, weight, dins[0], ksize, stride)

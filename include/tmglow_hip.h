@@ -431,6 +431,11 @@ int tmg_vec_sum(const void* g, int64_t B, void* out, tmg_stream_t st);
  * dims = {NL, NLp, C, ch, Cc}. */
 int tmg_level_pack(const void* tab, void* Wz, void* Wcat, void* Bz, void* Kp, const int64_t* dims, tmg_stream_t st);
 
+/* up[b][y][x][c] = dy[b][y/2][x/2][c] where y and x are even, 0 elsewhere: the operand of the stride-2 input gradient of the encoder's
+ * down-sampling convs (tmGlow.py:75-77, :177-181: conv3x3 stride 2) as a stride-1 contraction on the matrix cores.  up: contiguous
+ * [B][H][W][C]; dims = {B, H, W, h, w, C}; dy_d = {pixel stride, channel offset}; C % 4 == 0, else -100 (nothing launched). */
+int tmg_spread2(const void* dy, const int64_t* dy_d, void* up, const int64_t* dims, tmg_stream_t st);
+
 /* ---- physics-constrained reverse-KL loss (tmg_physics.hip) ------------------------------ */
 
 /* Residual sums of TMGLowLoss (trainFlowParallel.py:121-177 / physicsConstrained.py:42-94): y, target = [N,3,H,W]
