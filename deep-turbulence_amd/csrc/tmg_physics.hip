@@ -274,6 +274,109 @@ extern "C" int tmg_phys_fwd(const void* y, const void* target, void* sums, void*
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The two residual fields for ANY stencil pair of the reference (3x3 or 5x5 first- and second-derivative stencils,
+// pc/grad1Filter.py:37-57, pc/grad2Filter.py:28-49) and with or without the cell-size scaling (physicsConstrained.py:58-59, :90-91):
+// the stand-alone API of PhysConstrainedLES.  The trainer's loss uses the 3x3 / scaled form through phys_fwd_kernel; this one is a
+// plain one-thread-per-pixel kernel over global memory (fields of a few hundred KB).
+//   ustar [N][H][W + 2] = clamp(sd * (d/dy v + d/dx u)) on the field with its first / last column replicated (:54), zero padding beyond
+//   pstar [N][H][W]     = clamp(sp * ((p_xx + p_yy) / rho + u_x^2 + 2 u_y v_x + v_y^2)), zero padding
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float g1w5(int a, int b) {   // d/dx, 5x5 (rows a, columns b) before the / (9 * 12)
+    const float col[5] = {1.f, -8.f, 0.f, 8.f, -1.f};
+    const float row[5] = {1.f, 2.f, 3.f, 2.f, 1.f};
+    return row[a] * col[b];
+}
+__device__ __forceinline__ float g2w5(int a, int b) {   // d2/dx2, 5x5: the reference's last column is -1 in EVERY row (grad2Filter.py:33-37)
+    const float col[5] = {-1.f, 16.f, -30.f, 16.f, -1.f};
+    const float row[5] = {1.f, 2.f, 3.f, 2.f, 1.f};
+    return b == 4 ? -1.f : row[a] * col[b];
+}
+
+template <int K1, int K2>
+__global__ void phys_fields_kernel(const float* __restrict__ u, const float* __restrict__ pr, float* __restrict__ ustar,
+                                   float* __restrict__ pstar, int N, int H, int W, float dx, float dy, float rho, float sd, float sp) {
+    constexpr int R1 = K1 / 2, R2 = K2 / 2;
+    const size_t plane = (size_t)H * W;
+    const size_t total = (size_t)N * H * (W + 2);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int jw = (int)(idx % (W + 2));
+        size_t r = idx / (W + 2);
+        const int i = (int)(r % H);
+        const int n = (int)(r / H);
+        const float* U = u + (size_t)n * 2 * plane;
+        const float* V = U + plane;
+        auto w1 = [&](int a, int b) { return K1 == 3 ? g1w(a, b) : g1w5(a, b) / 108.f; };
+        auto w2 = [&](int a, int b) { return K2 == 3 ? g2w(a, b) : g2w5(a, b) / 108.f; };
+        if (ustar) {
+            // widened field: column jw of [0, W + 2) reads column clamp(jw - 1) of the original; zero outside the widened field
+            float dux = 0.f, dvy = 0.f;
+#pragma unroll
+            for (int a = 0; a < K1; ++a)
+#pragma unroll
+                for (int b = 0; b < K1; ++b) {
+                    const int ii = i + a - R1, jj = jw + b - R1;
+                    if (ii < 0 || ii >= H || jj < 0 || jj >= W + 2) continue;
+                    const int jc = min(max(jj - 1, 0), W - 1);
+                    dux += w1(a, b) * U[(size_t)ii * W + jc];
+                    dvy += w1(b, a) * V[(size_t)ii * W + jc];
+                }
+            const float raw = sd * (dvy / dy + dux / dx);
+            ustar[idx] = fminf(fmaxf(raw, -1.f), 1.f);
+        }
+        if (pstar && jw < W) {
+            const int j = jw;
+            const float* P = pr + (size_t)n * plane;
+            float ux_x = 0.f, ux_y = 0.f, uy_x = 0.f, uy_y = 0.f, pxx = 0.f, pyy = 0.f;
+#pragma unroll
+            for (int a = 0; a < K1; ++a)
+#pragma unroll
+                for (int b = 0; b < K1; ++b) {
+                    const int ii = i + a - R1, jj = j + b - R1;
+                    if (ii < 0 || ii >= H || jj < 0 || jj >= W) continue;
+                    const float uu = U[(size_t)ii * W + jj], vv = V[(size_t)ii * W + jj];
+                    ux_x += w1(a, b) * uu; ux_y += w1(b, a) * uu;
+                    uy_x += w1(a, b) * vv; uy_y += w1(b, a) * vv;
+                }
+#pragma unroll
+            for (int a = 0; a < K2; ++a)
+#pragma unroll
+                for (int b = 0; b < K2; ++b) {
+                    const int ii = i + a - R2, jj = j + b - R2;
+                    if (ii < 0 || ii >= H || jj < 0 || jj >= W) continue;
+                    const float pp = P[(size_t)ii * W + jj];
+                    pxx += w2(a, b) * pp; pyy += w2(b, a) * pp;
+                }
+            ux_x /= dx; uy_x /= dx; ux_y /= dy; uy_y /= dy;
+            const float raw = sp * ((pxx / (dx * dx) + pyy / (dy * dy)) / rho + ux_x * ux_x + 2.f * ux_y * uy_x + uy_y * uy_y);
+            pstar[((size_t)n * H + i) * W + j] = fminf(fmaxf(raw, -1.f), 1.f);
+        }
+    }
+}
+
+// u: [N][2][H][W] planar velocity, p: [N][1][H][W] pressure (may be null when pstar is null); ustar [N][1][H][W + 2] / pstar [N][1][H][W]
+// (either may be null).  dims = {N, H, W, k1, k2, scale}; k1, k2 in {3, 5} (else -100, nothing launched: the reference raises
+// ValueError for other sizes); fl = {dx, dy, rho}.
+extern "C" int tmg_phys_fields(const void* u, const void* p, void* ustar, void* pstar, const int64_t* dims, const float* fl, hipStream_t st) {
+    const int N = (int)dims[0], H = (int)dims[1], W = (int)dims[2], k1 = (int)dims[3], k2 = (int)dims[4], scale = (int)dims[5];
+    if ((k1 != 3 && k1 != 5) || (k2 != 3 && k2 != 5)) return -100;
+    if (pstar && !p) return -3;
+    const float dx = fl[0], dy = fl[1], rho = fl[2];
+    const float sd = scale ? dx : 1.f, sp = scale ? dx * dy : 1.f;
+    const size_t total = (size_t)N * H * (W + 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+#define TMG_PF(K1_, K2_) hipLaunchKernelGGL((phys_fields_kernel<K1_, K2_>), dim3(blocks), dim3(256), 0, st, (const float*)u, (const float*)p, (float*)ustar, (float*)pstar, N, H, W, dx, dy, rho, sd, sp)
+    if (k1 == 3 && k2 == 3) TMG_PF(3, 3);
+    else if (k1 == 3) TMG_PF(3, 5);
+    else if (k2 == 3) TMG_PF(5, 3);
+    else TMG_PF(5, 5);
+#undef TMG_PF
+    TMG_CHECK_LAUNCH();
+    return 0;
+}
+
 // dims = {B, T, 3*H*W}
 extern "C" int tmg_phys_rms(const void* y, const void* trms, void* mean_out, void* coef_out, void* sum_out, const int64_t* dims,
                             hipStream_t st) {

@@ -39,7 +39,7 @@ EXPORTS = [
     "tmg_affine_apply", "tmg_affine_apply_pass", "tmg_bn_finalize", "tmg_affine_bwd", "tmg_lstm_pointwise_fwd", "tmg_lstm_pointwise_bwd", "tmg_gauss_fwd",
     "tmg_gauss_bwd", "tmg_checker", "tmg_upsample_fwd", "tmg_upsample_bwd", "tmg_chan_reduce", "tmg_bn_bwd_apply",
     "tmg_phys_fwd", "tmg_phys_rms", "tmg_phys_bwd", "tmg_conv_wgrad_grouped", "tmg_conv_wgrad_grouped_ws_floats", "tmg_conv_pack_batched", "tmg_masked_add", "tmg_c1x2_fwd", "tmg_c1_fwd", "tmg_c1_bwd", "tmg_dense2_bwd", "tmg_dkappa", "tmg_prof_enable", "tmg_prof_collect", "tmg_mix_f16", "tmg_phys_bwd_dev", "tmg_coupling_fwd", "tmg_coupling_bwd",
-    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_gauss_sample", "tmg_reverse_loss_fwd", "tmg_reverse_loss_bwd", "tmg_sum_terms", "tmg_vec_sum", "tmg_level_pack", "tmg_spread2",
+    "tmg_conv_wino_pack", "tmg_conv_wino_fwd", "tmg_conv_wino_narrow", "tmg_conv_wino_wgrad", "tmg_conv_wino_wgrad_ws_floats", "tmg_mix_f32", "tmg_lu_fold_fwd", "tmg_lu_fold_bwd", "tmg_lu_fold_bwd_split", "tmg_level_finish", "tmg_conv_wgrad_thin_grouped", "tmg_mix_wgrad_grouped", "tmg_layer_planes", "tmg_conv_wino_wgrad_grouped", "tmg_conv_wino_wgrad_grouped_ws_floats", "tmg_adam_step", "tmg_chan_moments", "tmg_bn_finalize64", "tmg_mix_f32_affine_fwd", "tmg_mix_f32_affine_bwd", "tmg_conv_pack_many", "tmg_pad_halves", "tmg_coupling_fwd_halves", "tmg_coupling_bwd_halves", "tmg_fill_i64", "tmg_conv_wino_pack3", "tmg_conv_wino_fwd3", "tmg_mat_inverse", "tmg_gauss_sample", "tmg_reverse_loss_fwd", "tmg_reverse_loss_bwd", "tmg_sum_terms", "tmg_vec_sum", "tmg_level_pack", "tmg_spread2", "tmg_phys_fields",
 ]
 
 
@@ -1071,6 +1071,17 @@ def dense2_bwd(inputs, w1p, w2p, dW1p, dW2p, GD, D, g0, outs, cin_nn, add0=None,
 # ------------------------------------------------------------------------------------------------
 def _flts(vals):
     return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def phys_fields(u, p, ustar, pstar, dx, dy, rho, k1, k2, scale):
+    """Divergence / pressure-Poisson residual fields for 3x3 or 5x5 stencils, scaled or not (tmg_phys_fields).  u: contiguous
+    [N,2,H,W]; p: contiguous [N,1,H,W] or None; ustar [N,1,H,W+2] / pstar [N,1,H,W] (either may be None)."""
+    check_act(u)
+    N, _, Hh, Ww = u.shape
+    rc = lib().tmg_phys_fields(_ptr(u), _ptr(p), _ptr(ustar), _ptr(pstar), _i64(N, Hh, Ww, k1, k2, 1 if scale else 0), _flts([dx, dy, rho]), _stream())
+    if rc == -100:
+        raise ValueError('kernel_size size {:d} is not supported!'.format(k1 if k1 not in (3, 5) else k2))
+    _chk(rc, "tmg_phys_fields")
 
 
 def phys_fwd(y, target, sums, sd, mu, dx, dy, rho=1.0, pstar=None, ustar=None):

@@ -443,6 +443,12 @@ int tmg_spread2(const void* dy, const int64_t* dy_d, void* up, const int64_t* di
  * optional residual fields pstar [N,1,H,W], ustar [N,1,H,W+2].  dims = {N,H,W}; fl = {sd[3], mu[3], dx, dy, rho}. */
 int tmg_phys_fwd(const void* y, const void* target, void* sums, void* pstar_out, void* ustar_out, const int64_t* dims,
                  const float* fl, tmg_stream_t st);
+/* The two residual fields on their own, for every stencil pair and scaling the reference's API accepts
+ * (PhysConstrainedLES.calcDivergence / calcPressurePoisson, physicsConstrained.py:42-94; Grad1Filter2d / Grad2Filter2d with
+ * kernel_size 3 or 5, grad1Filter.py:37-88, grad2Filter.py:28-101; scale = True / False): u [N][2][H][W] planar velocity,
+ * p [N][1][H][W] (may be NULL when pstar is NULL); ustar [N][1][H][W+2] and / or pstar [N][1][H][W], clamped to [-1, 1].
+ * dims = {N, H, W, k1, k2, scale}; fl = {dx, dy, rho}.  k1, k2 outside {3, 5}: -100, nothing launched. */
+int tmg_phys_fields(const void* u, const void* p, void* ustar, void* pstar, const int64_t* dims, const float* fl, tmg_stream_t st);
 /* Per-pixel RMS over the T steps of y = [B,T,3,H,W] against target_rms [B,3,H,W] (trainFlowParallel.py:143-144);
  * writes mean / coefficient maps for the backward pass; sum_out += sum (rms - target_rms)^2.  dims = {B,T,3*H*W}. */
 int tmg_phys_rms(const void* y, const void* trms, void* mean_out, void* coef_out, void* sum_out, const int64_t* dims,

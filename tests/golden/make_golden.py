@@ -321,6 +321,37 @@ def loss_case(fname):
     np.savez_compressed(os.path.join(HERE, fname), **out)
 
 
+def phys_fields_case(fname):
+    """F1, API completeness: PhysConstrainedLES.calcDivergence / calcPressurePoisson with the 3x3 and 5x5 stencils of pc/grad1Filter.py /
+    pc/grad2Filter.py (every combination) and scale = True / False, on a field whose residuals are partly clamped."""
+    import pc.physicsConstrained as rpc
+    out = {}
+    g = torch.Generator().manual_seed(23)
+    B, Hh, Ww = 2, 11, 13
+    dx, dy, rho = 0.05, 0.0625, 1.3
+    u = 0.02 * torch.randn(B, 2, Hh, Ww, generator=g)
+    pr = 0.01 * torch.randn(B, 1, Hh, Ww, generator=g)
+    out.update({"u": u.numpy(), "p": pr.numpy(), "cfg": np.array([dx, dy, rho])})
+    for k1 in (3, 5):
+        for k2 in (3, 5):
+            phys = rpc.PhysConstrainedLES(dx, dy, rho=rho, grad_kernels=[k1, k2])
+            for scale in (True, False):
+                tag = "k%d%d.%s" % (k1, k2, "scaled" if scale else "raw")
+                # (amplitudes that leave part of each residual field inside the clamp, part outside)
+                au, ap = (50.0, 45.0) if scale else (6.0, 0.45)
+                with torch.no_grad():
+                    out[tag + ".ustar"] = phys.calcDivergence(au * u, scale=scale).numpy()
+                    out[tag + ".pstar"] = phys.calcPressurePoisson(ap * u, ap * pr, scale=scale).numpy()
+                out[tag + ".amp"] = np.array([au, ap])
+                print("phys fields", tag, "clamped frac", float((np.abs(out[tag + ".pstar"]) >= 1).mean()), float((np.abs(out[tag + ".ustar"]) >= 1).mean()))
+    try:
+        rpc.PhysConstrainedLES(dx, dy, grad_kernels=[7, 3])
+        out["k7_raises"] = np.array(0)
+    except ValueError:
+        out["k7_raises"] = np.array(1)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
 def loader_case(fname):
     """Row F4: the reference's BackwardStepLoader on synthetic files (tests/common.py writes them again at test time)."""
     import tempfile
@@ -452,6 +483,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "loss" in sys.argv:
         loss_case("phys_loss.npz")
+        sys.exit(0)
+    if "physfields" in sys.argv:
+        phys_fields_case("phys_fields.npz")
         sys.exit(0)
     torch.set_num_threads(8)
     model_case(ref, CFG_TINY, 2, "tiny_model.npz")

@@ -1345,3 +1345,23 @@ def test_fill_i64_writes_host_values_through_kernel_arguments():
     g.replay()
     torch.cuda.synchronize()
     assert out.cpu().tolist() == rows
+
+
+@pytest.mark.parametrize("k1", [3, 5])
+@pytest.mark.parametrize("k2", [3, 5])
+@pytest.mark.parametrize("scale", [True, False])
+def test_residual_fields_for_every_stencil_and_scaling(k1, k2, scale):
+    """PhysConstrainedLES.calcDivergence / calcPressurePoisson on the HIP path with the reference's 3x3 and 5x5 stencils (every
+    combination) and scale = True / False against the fields recorded from the reference (tests/golden/phys_fields.npz, partly clamped);
+    stencil sizes the reference rejects raise ValueError here too."""
+    from pc.physicsConstrained import PhysConstrainedLES
+    d = C.load_npz("phys_fields.npz")
+    dx, dy, rho = (float(v) for v in d["cfg"])
+    tag = "k%d%d.%s" % (k1, k2, "scaled" if scale else "raw")
+    au, ap = (float(v) for v in d[tag + ".amp"])
+    u, p = torch.from_numpy(d["u"]).to(DEV), torch.from_numpy(d["p"]).to(DEV)
+    phys = PhysConstrainedLES(dx, dy, rho=rho, grad_kernels=[k1, k2])
+    C.assert_field(phys.calcDivergence(au * u, scale=scale), d[tag + ".ustar"], tag + " ustar", atol=2e-5)
+    C.assert_field(phys.calcPressurePoisson(ap * u, ap * p, scale=scale), d[tag + ".pstar"], tag + " pstar", atol=2e-5)
+    with pytest.raises(ValueError):
+        PhysConstrainedLES(dx, dy, grad_kernels=[7, 3])

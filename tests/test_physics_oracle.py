@@ -23,3 +23,21 @@ def test_loss_and_gradients_match_reference(tag):
     loss.backward()
     C.assert_grads({"y": y.grad, "logp": logp.grad}, {"y": d[tag + ".dy"], "logp": d[tag + ".dlogp"]}, "loss grads",
                    global_tol=1e-5, tensor_tol=1e-4)
+
+
+@pytest.mark.parametrize("k1", [3, 5])
+@pytest.mark.parametrize("k2", [3, 5])
+@pytest.mark.parametrize("scale", [True, False])
+def test_residual_fields_match_reference_for_every_stencil_and_scaling(k1, k2, scale):
+    """PhysConstrainedLES.calcDivergence / calcPressurePoisson with the 3x3 and 5x5 stencils and scale = True / False
+    (reference pc/physicsConstrained.py:42-94, grad1Filter.py:37-88, grad2Filter.py:28-101): the oracle against phys_fields.npz."""
+    d = C.load_npz("phys_fields.npz")
+    dx, dy, rho = (float(v) for v in d["cfg"])
+    tag = "k%d%d.%s" % (k1, k2, "scaled" if scale else "raw")
+    au, ap = (float(v) for v in d[tag + ".amp"])
+    u, p = torch.from_numpy(d["u"]), torch.from_numpy(d["p"])
+    C.assert_field(PO.divergence(au * u, dx, dy, k1, scale), d[tag + ".ustar"], tag + " ustar", atol=2e-5)
+    C.assert_field(PO.pressure_poisson(ap * u, ap * p, dx, dy, rho, k1, k2, scale), d[tag + ".pstar"], tag + " pstar", atol=2e-5)
+    assert int(d["k7_raises"]) == 1
+    with pytest.raises(ValueError):
+        PO.grad1x(u[:, :1], dx, 7)
