@@ -57,6 +57,7 @@ __device__ __forceinline__ void normal4(uint4 r, float* n) {
 // hz: [npix][2 Ch] = (mean | log-std), clipped as in gauss_fwd_kernel (tmg_pointwise.hip).  One block row per image.
 // eps_in != null: the latents are given; else they are drawn (nonce: two int64 on the device, site: which draw of the call) and,
 // when eps_out != null, stored for the backward pass.  z2 -> out (stride os, offset oo); pass != null: out[.., po + j] = pass[.., j].
+template <bool VEC>
 __global__ __launch_bounds__(256) void gauss_sample_kernel(const float* __restrict__ hz, int hs, const float* __restrict__ eps_in, int es,
                                                            const float* __restrict__ pass, int ps, float* __restrict__ out, int os, int oo,
                                                            int po, float* __restrict__ eps_out, float* __restrict__ logp,
@@ -78,6 +79,31 @@ __global__ __launch_bounds__(256) void gauss_sample_kernel(const float* __restri
         if (!eps_in) {
             const unsigned long long gq = (unsigned long long)b * nquad + q;
             normal4(philox4x32_10(make_uint4((unsigned)gq, (unsigned)(gq >> 32), site, 0x7467u), key), nrm);
+        }
+        if constexpr (VEC) {
+            // Ch % 4 == 0 and every stride / offset a multiple of 4 floats: the quad is four consecutive channels of ONE pixel - one
+            // float4 per operand (the scalar form issued four 4-byte requests per operand and lane: 131 us at the first level of the
+            // metric configuration against 31 us for the round-5 kernel that neither drew nor copied)
+            const unsigned i = 4u * q;
+            const unsigned pl = i / (unsigned)Ch;
+            const size_t pix = base + pl;
+            const int j = (int)(i - pl * (unsigned)Ch);
+            float4 mean = *reinterpret_cast<const float4*>(hz + pix * hs + j);
+            float4 lsd = *reinterpret_cast<const float4*>(hz + pix * hs + Ch + j);
+            if (clip_mean) {
+                mean.x = fminf(fmaxf(mean.x, mlo), mhi); mean.y = fminf(fmaxf(mean.y, mlo), mhi);
+                mean.z = fminf(fmaxf(mean.z, mlo), mhi); mean.w = fminf(fmaxf(mean.w, mlo), mhi);
+            }
+            lsd.x = fminf(fmaxf(lsd.x, slo), shi); lsd.y = fminf(fmaxf(lsd.y, slo), shi);
+            lsd.z = fminf(fmaxf(lsd.z, slo), shi); lsd.w = fminf(fmaxf(lsd.w, slo), shi);
+            float4 v = make_float4(nrm[0], nrm[1], nrm[2], nrm[3]);
+            if (eps_in) v = *reinterpret_cast<const float4*>(eps_in + pix * es + j);
+            lp += -0.5f * (4.f * LOG2PI_G + 2.f * (lsd.x + lsd.y + lsd.z + lsd.w) + v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+            *reinterpret_cast<float4*>(out + pix * os + oo + j) =
+                make_float4(mean.x + expf(lsd.x) * v.x, mean.y + expf(lsd.y) * v.y, mean.z + expf(lsd.z) * v.z, mean.w + expf(lsd.w) * v.w);
+            if (eps_out) *reinterpret_cast<float4*>(eps_out + pix * Ch + j) = v;
+            if (pass) *reinterpret_cast<float4*>(out + pix * os + po + j) = *reinterpret_cast<const float4*>(pass + pix * ps + j);
+            continue;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -115,11 +141,19 @@ extern "C" int tmg_gauss_sample(const void* hz, const int64_t* hz_d, const void*
     if (cap > 256) cap = 256;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(gauss_sample_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)hz + hz_d[1], (int)hz_d[0],
-                       eps_in ? (const float*)eps_in + ei_d[1] : nullptr, eps_in ? (int)ei_d[0] : 0,
-                       pass ? (const float*)pass + p_d[1] : nullptr, pass ? (int)p_d[0] : 0, (float*)out, (int)o_d[0], (int)o_d[1],
-                       (int)pass_off, (float*)eps_out, (float*)logp, (const unsigned long long*)nonce, (unsigned)dims[4], ppi, Ch,
-                       (int)dims[3], fl[0], fl[1], fl[2], fl[3]);
+    const float* hzp = (const float*)hz + hz_d[1];
+    const float* ep = eps_in ? (const float*)eps_in + ei_d[1] : nullptr;
+    const float* pp = pass ? (const float*)pass + p_d[1] : nullptr;
+    bool vec = (Ch & 3) == 0 && (hz_d[0] & 3) == 0 && (o_d[0] & 3) == 0 && (o_d[1] & 3) == 0 && (pass_off & 3) == 0 &&
+               ((((uintptr_t)hzp) | ((uintptr_t)out) | ((uintptr_t)eps_out)) & 15) == 0;
+    if (ep) vec = vec && (ei_d[0] & 3) == 0 && (((uintptr_t)ep) & 15) == 0;
+    if (pp) vec = vec && (p_d[0] & 3) == 0 && (((uintptr_t)pp) & 15) == 0;
+#define TMG_GS_ARGS dim3(gx, B), dim3(256), 0, st, hzp, (int)hz_d[0], ep, eps_in ? (int)ei_d[0] : 0, pp, pass ? (int)p_d[0] : 0, (float*)out, \
+                    (int)o_d[0], (int)o_d[1], (int)pass_off, (float*)eps_out, (float*)logp, (const unsigned long long*)nonce, (unsigned)dims[4], \
+                    ppi, Ch, (int)dims[3], fl[0], fl[1], fl[2], fl[3]
+    if (vec) hipLaunchKernelGGL(gauss_sample_kernel<true>, TMG_GS_ARGS);
+    else hipLaunchKernelGGL(gauss_sample_kernel<false>, TMG_GS_ARGS);
+#undef TMG_GS_ARGS
     TMG_CHECK_LAUNCH();
     return 0;
 }
