@@ -1433,7 +1433,10 @@ def test_trainer_failed_recording_leaves_the_eager_trajectory(monkeypatch):
         if k.endswith("num_batches_tracked"):
             assert torch.equal(got, v), k                 # a leaked statistics update would count twice
         elif "running_" in k:
-            assert float((got - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-7, k
+            # two independent trainings: the float atomics' summation order differs, Adam turns that into parameter differences (the
+            # bound below) and the statistics of the layers downstream follow them (measured: up to 2e-5 of the largest entry).  A
+            # leaked update would move an entry by momentum * 0.9^12 = 3e-2 of it
+            assert float((got - v).abs().max()) <= 3e-4 * float(v.abs().max()) + 1e-6, k
         elif v.dtype.is_floating_point and "log_s_old" not in k:
             assert float((got - v).abs().max()) <= 2e-2 * 4e-3, k
 
