@@ -7,6 +7,19 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 16 bytes through a buffer descriptor: address = descriptor base + scalar byte offset `soff` + per-lane 32-bit byte offset `voff`.
+// The hot loops read their L2-resident packed operands (weights, Winograd U) this way: a flat global load needs a 64-bit VECTOR add
+// per load (v_lshl_add_u64) for the same address, and the fp32 MFMA shares the vector ALUs - measured on wino_fwd_kernel<2>, round 6:
+// 2.31 -> 2.13 ms for the ConvLSTM gate conv.  The descriptor is built from kernel arguments only (wave-uniform: no waterfall loop).
+// (The result must be taken as a whole vector: element-wise __builtin_bit_cast of the builtin's result made hipcc 7.2 load one dword.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tmg_make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 tmg_bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 #define TMG_MAX_IN_SEG 3
 #define TMG_MAX_OUT_SEG 3
 

@@ -239,8 +239,10 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
         abase[i] = ((m >> TWl) * PW + (m & (TW - 1))) * CS4 + q;
         mrc[i] = ((m >> TWl) << 16) | (m & (TW - 1));
     }
-    const int boff0 = li * 16 + 4 * q;  // + n-tile * 256 (scalar); tiles past the end repeat the last (dropped in the epilogue)
-#define TMG_FW_BOFF(J) (boff0 + min(ntile0 + (J), ntiles_total - 1) * 256)
+    // B fragments through a buffer descriptor (tmg_bload4): lane part boff0 (bytes), everything else scalar
+    const unsigned boff0 = 4u * (unsigned)(li * 16 + 4 * q);  // + n-tile * 256 words (scalar); tiles past the end repeat the last (dropped in the epilogue)
+#define TMG_FW_BOFF(J) ((unsigned)(min(ntile0 + (J), ntiles_total - 1) * 1024))
+    const __amdgpu_buffer_rsrc_t wrs = tmg_make_rsrc(p.wpk, (unsigned)(4u * (unsigned)ntaps * (unsigned)KB * (unsigned)p.Cout_pad * 16u));
     const size_t tap_stride = (size_t)KB * p.Cout_pad * 16, kb_stride = (size_t)p.Cout_pad * 16;
 
     // ---- lean staging state ---------------------------------------------------------------------------------------
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
     float4 b0[NTW], b1[NTW];
     if (nst > 0) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) b0[j] = *reinterpret_cast<const float4*>(p.wpk + TMG_FW_BOFF(j));
+        for (int j = 0; j < NTW; ++j) b0[j] = tmg_bload4(wrs, boff0, TMG_FW_BOFF(j));
     }
 
     for (int k = -2; k < nst; ++k) {
@@ -414,7 +416,8 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                     if (txx == p.ksize) { txx = 0; aoffs += a_row_adv; }                                             \
                 }                                                                                                    \
                 const float* wn_ = (tap == ntaps) ? wl_next : wcur;                                                  \
-                _Pragma("unroll") for (int j = 0; j < NTW; ++j) BN[j] = *reinterpret_cast<const float4*>(wn_ + TMG_FW_BOFF(j)); \
+                const unsigned wso_ = (unsigned)((wn_ - p.wpk) * 4);                                               \
+                _Pragma("unroll") for (int j = 0; j < NTW; ++j) BN[j] = tmg_bload4(wrs, boff0, wso_ + TMG_FW_BOFF(j)); \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(BC[j].x, af[i].x, acc[i][j], 0, 0, 0);          \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NTW; ++j)       \
@@ -442,6 +445,41 @@ __global__ __launch_bounds__(512, 1) void conv_fwd_kernel(ConvP p) {
                 // one register per n-tile that the widest instance <4,4,*> - 256 registers - spilled: 8 bytes of scratch per lane)
                 int qe = q;
                 asm volatile("" : "+v"(qe));
+                // STORE-ONLY path (round 6): no load may sit in a conditional block between the stores - the compiler answers such a
+                // load (`add` fetched here, the old output of `accumulate`, a bias quad) with `s_waitcnt vmcnt(0)` in front of EVERY
+                // store, taken or not: each store of the tile then waits for the one before it and for the B fragments / patch loads
+                // prefetched for the next stage (tools/isa_audit.py: 39 of 40 stores of <2,4,*>).  Everything this path needs is
+                // in registers: the bias quads (HB), the `add` operand fetched before the MFMA loop (PREADD).
+                const bool store_only = p.ovec4 && !p.accumulate && (HB || !p.bias) && (PREADD || !p.add.p);
+                if (store_only) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int oy = oy0_ + (mrc[i] >> 16), ox = ox0_ + (mrc[i] & 0xffff);
+                        if (oy < p.Hout && ox < p.Wout) {
+                            const unsigned opx = (unsigned)(__umul24(b_ * p.Hout + oy, p.Wout) + ox);
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j) {
+                                const int n0 = (ntile0 + j) * 16 + 4 * qe;
+                                if (n0 < p.Cout) {
+                                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                                    if (HB) { v[0] += biasq[HB ? j : 0].x; v[1] += biasq[HB ? j : 0].y; v[2] += biasq[HB ? j : 0].z; v[3] += biasq[HB ? j : 0].w; }
+                                    if (PREADD && p.add.p) {
+                                        const float4 a4 = addv[PREADD ? i : 0][PREADD ? j : 0];
+                                        v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+                                    }
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        v[r] *= osc;
+                                        if (p.relu_out) v[r] = fmaxf(v[r], 0.f);
+                                    }
+                                    int nl = n0;
+                                    TMG_PICK_OSEG(p.out, nl, op_, ostride, ooff)
+                                    *reinterpret_cast<float4*>(op_ + (size_t)opx * (unsigned)ostride + ooff + nl) = make_float4(v[0], v[1], v[2], v[3]);
+                                }
+                            }
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int oy = oy0_ + (mrc[i] >> 16), ox = ox0_ + (mrc[i] & 0xffff);

@@ -105,6 +105,11 @@ extern "C" int tmg_wino_stamps(unsigned long long* out, int reset) {
 // NPW: 16-channel output tiles per wave.  2: a block covers up to 256 output channels (wave w: n-tiles 2w, 2w+1).  1: up to 128 -
 // the contractions with 64..128 output channels (the ConvLSTM block's out-conv input gradient, 40 -> 104 at the first level) would leave
 // waves 4-7 of the 2-tile form multiplying repeated tiles; with one tile per wave all eight waves carry live work.
+#ifdef TMG_WINO_FLAT_U
+#define TMG_WN_ULOAD(DST, PTR, BOFF) DST = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(PTR) + (BOFF));
+#else
+#define TMG_WN_ULOAD(DST, PTR, BOFF) DST = tmg_bload4(urs, BOFF, (unsigned)(((PTR) - p.U) * 4));
+#endif
 template <int NPW>
 __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -124,9 +129,9 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
     const int ntile0 = (int)blockIdx.y * (8 * NPW) + NPW * wave;
     const size_t kb_stride = (size_t)p.Npad * 16, pos_stride = (size_t)KB * p.Npad * 16;
     // B-operand (U) lane offsets of this wave's two n-tiles (tiles past the end repeat the last: dropped in the epilogue)
-    int boff[NPW];
+    unsigned boff[NPW];   // BYTE offsets, unsigned: scalar base + 32-bit lane offset selects the saddr form of global_load (no 64-bit vector add per load)
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) boff[n] = li * 16 + 4 * q + min(ntile0 + n, ntt - 1) * 256;
+    for (int n = 0; n < NPW; ++n) boff[n] = 4u * (unsigned)(li * 16 + 4 * q + min(ntile0 + n, ntt - 1) * 256);
 
     // ---- lean staging state: a thread owns channel quad pc4 of every 64th patch pixel -------------------------------------
     const int pc4 = tid & 7, ppix0 = tid >> 3;
@@ -153,13 +158,28 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
     int ci = 0, cc = 0, cm = 0;
     int ti = blockIdx.x, tm = blockIdx.x;
 
+    // U through a buffer descriptor: scalar byte offset (position, channel group) + the lane's constant 32-bit offset - no vector
+    // address arithmetic per load (flat global loads cost a 64-bit vector add each: the fp32 MFMA shares the vector ALUs)
+    const __amdgpu_buffer_rsrc_t urs = tmg_make_rsrc(p.U, 16u * (unsigned)pos_stride * 4u);
+    // The bias of this lane's channels, loaded ONCE and branch-free (no bias / channels past the end: the zero page): a load inside the
+    // epilogue's conditional blocks makes the compiler put `s_waitcnt vmcnt(0)` in front of EVERY store there - each of the 16 stores
+    // of a tile then waits for the one before it and for the whole prefetched U ring (round 6: 6-14 % of the launch).  Y starts at
+    // the bias instead of adding it in the epilogue.
+    f32x4 bvr[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int n0 = (ntile0 + n) * 16 + 4 * q;
+        const float* bp = (p.bias != nullptr && ntile0 + n < ntt && n0 < p.Cout) ? p.bias + n0 : tmg_zero_page;
+        const float4 b4 = *reinterpret_cast<const float4*>(bp);
+        bvr[n] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+    }
     f32x4 Y[4][2][NPW];   // [output pixel of the 2x2 tile][m-tile][n-tile]
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NPW; ++n) Y[o][m][n] = bvr[n];
 
     float4 bfr[4][2][NPW];   // U fragments [ring][16-channel group][n-tile], three positions ahead of the MFMAs
 #ifdef TMG_WINO_STAMP
@@ -259,8 +279,8 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                 {                                                                                                     \
                     const float* up_ = (UB) + (size_t)(POS) * pos_stride;                                             \
                     _Pragma("unroll") for (int n = 0; n < NPW; ++n) {                                                 \
-                        bfr[R][0][n] = *reinterpret_cast<const float4*>(up_ + boff[n]);                               \
-                        bfr[R][1][n] = *reinterpret_cast<const float4*>(up_ + (size_t)((KGN) - 1) * kb_stride + boff[n]); \
+                        TMG_WN_ULOAD(bfr[R][0][n], up_, boff[n])                                                    \
+                        TMG_WN_ULOAD(bfr[R][1][n], up_ + (size_t)((KGN) - 1) * kb_stride, boff[n])                  \
                     }                                                                                                 \
                 }
                 if (k == 0) { TMG_WN_LOADB(0, ub, kgn, 0) TMG_WN_LOADB(1, ub, kgn, 1) TMG_WN_LOADB(2, ub, kgn, 2) }
@@ -342,8 +362,6 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                     for (int n = 0; n < NPW; ++n) {
                         const int n0 = (ntile0 + n) * 16 + 4 * q;
                         if (ntile0 + n < ntt && n0 < p.Cout) {
-                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
                             int nl = n0;
                             TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
 #pragma unroll
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                                 if (oy < p.Hin && ox < p.Win) {
                                     const unsigned opx = ((unsigned)b_ * (unsigned)p.Hin + (unsigned)oy) * (unsigned)p.Win + (unsigned)ox;
                                     *reinterpret_cast<float4*>(optr + (size_t)opx * (unsigned)ostride + ooff + nl) =
-                                        make_float4(Y[o][m][n][0] + bv.x, Y[o][m][n][1] + bv.y, Y[o][m][n][2] + bv.z, Y[o][m][n][3] + bv.w);
+                                        make_float4(Y[o][m][n][0], Y[o][m][n][1], Y[o][m][n][2], Y[o][m][n][3]);
                                 }
                             }
                         }
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int n = 0; n < NPW; ++n) Y[o][m][n] = bvr[n];
                 cm = 0; tm += G;
             } else {
                 ++cm;
