@@ -509,17 +509,26 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
     const int ntt = p.Npad >> 4;
     const int ntile0 = (int)blockIdx.y * (8 * NPW) + NPW * wave;
     const size_t kb_stride = (size_t)p.Npad * 16, pos_stride = (size_t)KB * p.Npad * 16;
-    int boff[NPW];
+    unsigned boff[NPW];   // byte offsets of this lane inside a (position, channel group) slice of U (see wino_fwd_kernel)
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) boff[n] = li * 16 + 4 * q + min(ntile0 + n, ntt - 1) * 256;
+    for (int n = 0; n < NPW; ++n) boff[n] = 4u * (unsigned)(li * 16 + 4 * q + min(ntile0 + n, ntt - 1) * 256);
+    const __amdgpu_buffer_rsrc_t urs = tmg_make_rsrc(p.U, 16u * (unsigned)pos_stride * 4u);
     int cm = 0, tm = blockIdx.x;
+    f32x4 bvr[NPW];       // bias in registers, Y starts from it: no load between the epilogue's stores (see wino_fwd_kernel)
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int n0 = (ntile0 + n) * 16 + 4 * q;
+        const float* bp = (p.bias != nullptr && ntile0 + n < ntt && n0 < p.Cout) ? p.bias + n0 : tmg_zero_page;
+        const float4 b4 = *reinterpret_cast<const float4*>(bp);
+        bvr[n] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+    }
     f32x4 Y[4][2][NPW];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NPW; ++n) Y[o][m][n] = bvr[n];
     float4 bfr[4][2][NPW];
     for (int k = 0; k < nst; ++k) {
         const int c0 = cm * KC;
@@ -529,8 +538,8 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
         {                                                                                                             \
             const float* up_ = (UB) + (size_t)(POS) * pos_stride;                                                     \
             _Pragma("unroll") for (int n = 0; n < NPW; ++n) {                                                         \
-                bfr[R][0][n] = *reinterpret_cast<const float4*>(up_ + boff[n]);                                       \
-                bfr[R][1][n] = *reinterpret_cast<const float4*>(up_ + (size_t)((KGN) - 1) * kb_stride + boff[n]);     \
+                TMG_WN_ULOAD(bfr[R][0][n], up_, boff[n])                                                              \
+                TMG_WN_ULOAD(bfr[R][1][n], up_ + (size_t)((KGN) - 1) * kb_stride, boff[n])                            \
             }                                                                                                         \
         }
         if (k == 0) { TMG_WN_LOADB(0, ub, kgn, 0) TMG_WN_LOADB(1, ub, kgn, 1) TMG_WN_LOADB(2, ub, kgn, 2) }
@@ -601,8 +610,6 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
                 for (int n = 0; n < NPW; ++n) {
                     const int n0 = (ntile0 + n) * 16 + 4 * q;
                     if (ntile0 + n < ntt && n0 < p.Cout) {
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
                         int nl = n0;
                         TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
 #pragma unroll
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
                             if (oy < p.Hin && ox < p.Win) {
                                 const unsigned opx = ((unsigned)b_ * (unsigned)p.Hin + (unsigned)oy) * (unsigned)p.Win + (unsigned)ox;
                                 *reinterpret_cast<float4*>(optr + (size_t)opx * (unsigned)ostride + ooff + nl) =
-                                    make_float4(Y[o][m][n][0] + bv.x, Y[o][m][n][1] + bv.y, Y[o][m][n][2] + bv.z, Y[o][m][n][3] + bv.w);
+                                    make_float4(Y[o][m][n][0], Y[o][m][n][1], Y[o][m][n][2], Y[o][m][n][3]);
                             }
                         }
                     }
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int n = 0; n < NPW; ++n) Y[o][m][n] = bvr[n];
             cm = 0; tm += G;
         } else {
             ++cm;
@@ -1167,7 +1174,8 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
     const size_t kb_stride = (size_t)p.Npad * 16, pos_stride = (size_t)KB * p.Npad * 16;
     const int xi = wave >> 1, par = wave & 1;
     const int pos0 = xi * 4 + 2 * par;
-    const int boff = li * 16 + 4 * q;
+    const unsigned boff = 4u * (unsigned)(li * 16 + 4 * q);   // lane part (bytes) of a U fragment address; the rest is scalar (tmg_bload4)
+    const __amdgpu_buffer_rsrc_t urs = tmg_make_rsrc(p.U, 16u * (unsigned)pos_stride * 4u);
     // row combination of this wave's xi: u = d[ra] + sg d[rb]   (B^T rows: r0 - r2, r1 + r2, r2 - r1, r1 - r3)
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sg = xi == 1 ? 1.f : -1.f;
@@ -1216,8 +1224,8 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
     {                                                                                                                 \
         const int kb_ = min((GI), KB - 1);                                                                            \
         _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                               \
-            const float* up_ = p.U + (size_t)(pos0 + e) * pos_stride + (size_t)kb_ * kb_stride + boff;                \
-            _Pragma("unroll") for (int n = 0; n < NTN; ++n) bq[SLOT][e][n] = *reinterpret_cast<const float4*>(up_ + n * 256); \
+            const unsigned so_ = 4u * (unsigned)((size_t)(pos0 + e) * pos_stride + (size_t)kb_ * kb_stride);         \
+            _Pragma("unroll") for (int n = 0; n < NTN; ++n) bq[SLOT][e][n] = tmg_bload4(urs, boff, so_ + 1024u * n);  \
         }                                                                                                             \
     }
     if (nst > 0) {
@@ -1226,6 +1234,16 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
     }
 
     const bool late = SKEW && wave >= 4;      // stages at the end of the round (see above)
+    // The epilogue item of this thread (Winograd tile, channel quad) is the same for every pixel tile (32 QN <= 512 items): its bias quad
+    // is loaded once, here - a load inside the epilogue is waited for with vmcnt(0), which also drains the U ring and the patch loads
+    // in flight for the next stages.
+    constexpr int QN = NTN * 4;   // channel quads
+    float4 bvq = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int n0 = 4 * (tid % QN);
+        const float* bp = (p.bias != nullptr && tid < 32 * QN && n0 < p.Cout) ? p.bias + n0 : tmg_zero_page;
+        bvq = *reinterpret_cast<const float4*>(bp);
+    }
 #define TMG_WN_STAGE \
         if (k >= -1 && k + 1 < nst) { \
             float* rb_ = lds + ((k + 1) & 1) * RAWW; \
@@ -1337,7 +1355,7 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
                 const int tx_ = t_ % p.tiles_x; t_ /= p.tiles_x;
                 const int ty_ = t_ % p.tiles_y;
                 const int b_ = t_ / p.tiles_y;
-                constexpr int QN = NTN * 4;   // channel quads
+                static_assert(32 * QN <= NT, "one epilogue item per thread");
                 for (int it = tid; it < 32 * QN; it += NT) {
                     const int wt = it / QN, c4 = it - wt * QN;
                     const int n0 = 4 * c4;
@@ -1353,8 +1371,7 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
                         z[0][nu] = make_float4(m0.x + m1.x + m2.x, m0.y + m1.y + m2.y, m0.z + m1.z + m2.z, m0.w + m1.w + m2.w);
                         z[1][nu] = make_float4(m1.x - m2.x - m3.x, m1.y - m2.y - m3.y, m1.z - m2.z - m3.z, m1.w - m2.w - m3.w);
                     }
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
+                    const float4 bv = bvq;
                     int nl = n0;
                     TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
 #pragma unroll

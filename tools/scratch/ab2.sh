@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_ops.py -x -q -m gpu 2>&1 | tail -1
+python tools/bench_wino.py 2>/dev/null | sed 's/bf16x3.*direct/direct/' | cut -c1-90 | sed -n 10,18p
+for i in 1 2 3; do python bench.py --no-cpu-baseline --no-events 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d[\"value\"], d[\"ms_per_step\"])"; done
