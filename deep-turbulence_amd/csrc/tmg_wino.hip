@@ -22,6 +22,7 @@
 //   epilogue   after the last chunk: Y + bias -> NHWC float4 stores (lane = 4 consecutive channels of one Winograd tile).
 #include "tmg_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct WinoP {
     TmgSeg in[TMG_MAX_IN_SEG];
@@ -105,6 +106,65 @@ extern "C" int tmg_wino_stamps(unsigned long long* out, int reset) {
 // NPW: 16-channel output tiles per wave.  2: a block covers up to 256 output channels (wave w: n-tiles 2w, 2w+1).  1: up to 128 -
 // the contractions with 64..128 output channels (the ConvLSTM block's out-conv input gradient, 40 -> 104 at the first level) would leave
 // waves 4-7 of the 2-tile form multiplying repeated tiles; with one tile per wave all eight waves carry live work.
+// One Winograd position (xi, nu) of a 32-channel chunk in the multiply loops of wino_fwd_kernel / wino_fwdp_kernel: the MFMAs of
+// the position and its share of the output transform  Y = A^T M A,  A^T = [[1,1,1,0],[0,1,-1,-1]].  The fp32 MFMA runs on the
+// vector ALUs, so every v_add of the transform is matrix time lost (skipping all of them: -6.7 % of the gate conv, round 6).  Adding
+// every M_pos into the (up to four) Y tiles it belongs to costs 36 tile additions per chunk; this form costs 22:
+//   * the MFMA accumulates by itself: a position that feeds ONE tile with coefficient +-1 is chained straight onto that tile (the
+//     sign is folded into V: the input transform writes -V for nu = 3 and for the row xi = 3, at no cost - a swapped subtraction);
+//   * rows xi = 0 / 3 feed only the output row oy = 0 / 1: nu = 0 -> chained onto Y[oy][0], nu = 3 -> chained onto Y[oy][1],
+//     nu = 1, 2 -> a fresh tile added to both (4 additions per row);
+//   * rows xi = 1, 2 feed both output rows: their column sums T0 = M0 + M1 + M2, T1 = M1 - M2 - M3 are built first (chained / 3
+//     additions) and added to the four Y tiles once (4 additions).
+#define TMG_WN_STEP(D, KG, E)                                                                                         \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n)                       \
+        D[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[R][KG][n].E, af[KG][m].E, D[m][n], 0, 0, 0);
+#define TMG_WN_CHAIN(D)                                                                                               \
+    {                                                                                                                 \
+        TMG_WN_STEP(D, 0, x) TMG_WN_STEP(D, 0, y) TMG_WN_STEP(D, 0, z) TMG_WN_STEP(D, 0, w)                           \
+        if (kgn == 2) { TMG_WN_STEP(D, 1, x) TMG_WN_STEP(D, 1, y) TMG_WN_STEP(D, 1, z) TMG_WN_STEP(D, 1, w) }         \
+    }
+#define TMG_WN_ZERO(D) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n) D[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define TMG_WN_ADD(D, S) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n) D[m][n] += S[m][n];
+#define TMG_WN_SUB(D, S) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n) D[m][n] -= S[m][n];
+// pin an update HERE: left alone the compiler sinks all 16 positions' additions below the last position and keeps 16 x 16
+// accumulator registers alive (300 spilled registers)
+#define TMG_WN_PIN(A)                                                                                                 \
+    {                                                                                                                 \
+        if constexpr (NPW == 2) asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]));        \
+        else asm volatile("" : "+v"(A[0][0]), "+v"(A[1][0]));                                                         \
+    }
+// (pos, R, kgn, bfr, af, Y, T0, T1 of the enclosing loop; pos is a constant after unrolling)
+#define TMG_WN_POSITION                                                                                               \
+    {                                                                                                                 \
+        const int xi = pos >> 2, nu = pos & 3;                                                                        \
+        if (xi == 0 || xi == 3) {                                                                                     \
+            const int o0 = xi == 0 ? 0 : 2;                                                                           \
+            if (nu == 0) { TMG_WN_CHAIN(Y[o0]) }                                                                      \
+            else if (nu == 3) { TMG_WN_CHAIN(Y[o0 + 1]) }                                                             \
+            else {                                                                                                    \
+                f32x4 acc[2][NPW];                                                                                    \
+                TMG_WN_ZERO(acc) TMG_WN_CHAIN(acc)                                                                    \
+                TMG_WN_ADD(Y[o0], acc)                                                                                \
+                if (nu == 1) { TMG_WN_ADD(Y[o0 + 1], acc) } else { TMG_WN_SUB(Y[o0 + 1], acc) }                       \
+                TMG_WN_PIN(Y[o0]) TMG_WN_PIN(Y[o0 + 1])                                                               \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            if (nu == 0) { TMG_WN_ZERO(T0) TMG_WN_CHAIN(T0) }                                                         \
+            else if (nu == 1) { TMG_WN_ZERO(T1) TMG_WN_CHAIN(T1) }                                                    \
+            else if (nu == 2) {                                                                                       \
+                f32x4 acc[2][NPW];                                                                                    \
+                TMG_WN_ZERO(acc) TMG_WN_CHAIN(acc)                                                                    \
+                TMG_WN_ADD(T0, T1) TMG_WN_ADD(T0, acc) TMG_WN_SUB(T1, acc)                                            \
+                TMG_WN_PIN(T0) TMG_WN_PIN(T1)                                                                         \
+            } else {                                                                                                  \
+                TMG_WN_CHAIN(T1)                                                                                      \
+                TMG_WN_ADD(Y[0], T0) TMG_WN_ADD(Y[1], T1)                                                             \
+                if (xi == 1) { TMG_WN_ADD(Y[2], T0) TMG_WN_ADD(Y[3], T1) } else { TMG_WN_SUB(Y[2], T0) TMG_WN_SUB(Y[3], T1) } \
+                TMG_WN_PIN(Y[0]) TMG_WN_PIN(Y[1]) TMG_WN_PIN(Y[2]) TMG_WN_PIN(Y[3])                                   \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
 #ifdef TMG_WINO_FLAT_U
 #define TMG_WN_ULOAD(DST, PTR, BOFF) DST = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(PTR) + (BOFF));
 #else
@@ -174,6 +234,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
         bvr[n] = (f32x4){b4.x, b4.y, b4.z, b4.w};
     }
     f32x4 Y[4][2][NPW];   // [output pixel of the 2x2 tile][m-tile][n-tile]
+    f32x4 T0[2][NPW], T1[2][NPW];   // column sums of a middle row (TMG_WN_POSITION)
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -254,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                     const float4 d1 = *reinterpret_cast<const float4*>(rb + ((th + 1) * PW + c) * CS);
                     const float4 d2 = *reinterpret_cast<const float4*>(rb + ((th + 2) * PW + c) * CS);
                     if (th == 0) { t[0][c] = TMG_W4(-, d0, d2); t[1][c] = TMG_W4(+, d1, d2); }
-                    else         { t[0][c] = TMG_W4(-, d1, d0); t[1][c] = TMG_W4(-, d0, d2); }
+                    else         { t[0][c] = TMG_W4(-, d1, d0); t[1][c] = TMG_W4(-, d2, d0); }   // xi 3 with the sign flipped (TMG_WN_POSITION)
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -262,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                     *reinterpret_cast<float4*>(vb) = TMG_W4(-, t[e][0], t[e][2]);
                     *reinterpret_cast<float4*>(vb + VPL) = TMG_W4(+, t[e][1], t[e][2]);
                     *reinterpret_cast<float4*>(vb + 2 * VPL) = TMG_W4(-, t[e][2], t[e][1]);
-                    *reinterpret_cast<float4*>(vb + 3 * VPL) = TMG_W4(-, t[e][1], t[e][3]);
+                    *reinterpret_cast<float4*>(vb + 3 * VPL) = TMG_W4(-, t[e][3], t[e][1]);      // -V at nu = 3 (TMG_WN_POSITION)
                 }
 #undef TMG_W4
             }
@@ -283,21 +344,29 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                         TMG_WN_ULOAD(bfr[R][1][n], up_ + (size_t)((KGN) - 1) * kb_stride, boff[n])                  \
                     }                                                                                                 \
                 }
-                if (k == 0) { TMG_WN_LOADB(0, ub, kgn, 0) TMG_WN_LOADB(1, ub, kgn, 1) TMG_WN_LOADB(2, ub, kgn, 2) }
+                // LEAD: how many positions ahead of the MFMAs the U fragments are fetched.  One position is 2 x 1 024 matrix cycles on a
+                // SIMD and U is L2-resident.  With two n-tiles per wave a lead of two positions keeps three ring slots live instead of
+                // four: 238 registers against 254 with the column sums of TMG_WN_POSITION; measured equal over the step's shapes (gate
+                // conv 2.045 / 2.081 ms, conditioning contraction 0.663 / 0.642 ms at a lead of 2 / 3).
+                constexpr int LEAD = NPW == 2 ? 2 : 3;
+                if (k == 0) { TMG_WN_LOADB(0, ub, kgn, 0) TMG_WN_LOADB(1, ub, kgn, 1) if (LEAD == 3) TMG_WN_LOADB(2, ub, kgn, 2) }
                 // (every later stage gets its first three fragment sets from the previous stage's last positions)
                 // operand of the next stage (the next chunk of this tile, or chunk 0 of the next tile: every tile uses the same U)
                 const int c0n = (cm + 1 == nchunks) ? 0 : c0 + KC;
                 const int kgn_n = min(KC, p.Cin_pad - c0n) >> 4;
                 const float* ubn = p.U + (size_t)(c0n >> 4) * kb_stride;
-#pragma unroll
-                for (int pos = 0; pos < 16; ++pos) {
-                    const int R = pos & 3;
+                // The 16 positions are written out as 16 calls of one generic lambda (the position is a compile-time constant inside):
+                // as an unrolled loop the two-tile instance was too large for the early full-unroll pass, the loop was unrolled after the
+                // last scalar-replacement pass and the U ring stayed in scratch memory.
+                auto one_position = [&](auto pc_) __attribute__((always_inline)) {
+                    constexpr int pos = decltype(pc_)::value;
+                    constexpr int R = pos & 3;
                     // (without the scheduling fences the compiler hoists all 16 positions' LDS reads to the top and spills)
                     __builtin_amdgcn_sched_barrier(0);
                     // U fragments three positions ahead (a position is only 32 MFMAs per wave: one position of lead does not cover
                     // the L2 latency), V fragments of this position from LDS
-                    if (pos + 3 < 16) TMG_WN_LOADB((pos + 3) & 3, ub, kgn, pos + 3)
-                    else TMG_WN_LOADB((pos + 3) & 3, ubn, kgn_n, pos + 3 - 16)
+                    if (pos + LEAD < 16) TMG_WN_LOADB((pos + LEAD) & 3, ub, kgn, pos + LEAD)
+                    else TMG_WN_LOADB((pos + LEAD) & 3, ubn, kgn_n, pos + LEAD - 16)
                     float4 af[2][2];   // [16-channel group][m-tile]
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
@@ -305,46 +374,12 @@ __global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
                         af[1][m] = v4[(pos * VPL + m * 16 * VS + 16) / 4];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc[2][NPW];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int n = 0; n < NPW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define TMG_WN_STEP(KG, E)                                                                                            \
-                    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n)       \
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[R][KG][n].E, af[KG][m].E, acc[m][n], 0, 0, 0);
-                    TMG_WN_STEP(0, x) TMG_WN_STEP(0, y) TMG_WN_STEP(0, z) TMG_WN_STEP(0, w)
-                    if (kgn == 2) { TMG_WN_STEP(1, x) TMG_WN_STEP(1, y) TMG_WN_STEP(1, z) TMG_WN_STEP(1, w) }
-#undef TMG_WN_STEP
-                    // Y = A^T M A,  A^T = [[1,1,1,0],[0,1,-1,-1]]:  coefficient of position (xi, nu) in output (oy, ox) = a[oy][xi] a[ox][nu]
-                    const int xi = pos >> 2, nu = pos & 3;
-#pragma unroll
-                    for (int oy = 0; oy < 2; ++oy)
-#pragma unroll
-                        for (int ox = 0; ox < 2; ++ox) {
-                            const int ay = oy == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : (xi == 1 ? 1 : -1));
-                            const int ax = ox == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : (nu == 1 ? 1 : -1));
-                            const int cf = ay * ax;
-                            if (cf != 0) {
-                                // fp32 adds / subtracts of the output transform.  (Building this file without the packed-fp32
-                                // instructions - v_pk_add_f32 beside MFMAs is listed as costly in MI355X_MICROARCH.md - was
-                                // measured in round 3: the step moved by 0.6 %, inside the noise.  tmg_hip.NO_PACKED_F32 is
-                                // empty, the file is built with the default flags; TMG_NOPK=wino is the A/B switch.)
-#pragma unroll
-                                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                                    for (int n = 0; n < NPW; ++n) {
-                                        f32x4& y_ = Y[oy * 2 + ox][m][n];
-                                        if (cf > 0) y_ += acc[m][n];
-                                        else y_ -= acc[m][n];
-                                    }
-                                // pin the update HERE: left alone the compiler sinks all 16 positions' additions below the last
-                                // position and keeps 16 x 16 accumulator registers alive (300 spilled registers)
-                                if constexpr (NPW == 2) asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][0][1]), "+v"(Y[oy * 2 + ox][1][0]), "+v"(Y[oy * 2 + ox][1][1]));
-                                else asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][1][0]));
-                            }
-                        }
-                }
+                    TMG_WN_POSITION
+                };
+#define TMG_WN_P(I) one_position(std::integral_constant<int, I>{});
+                TMG_WN_P(0) TMG_WN_P(1) TMG_WN_P(2) TMG_WN_P(3) TMG_WN_P(4) TMG_WN_P(5) TMG_WN_P(6) TMG_WN_P(7)
+                TMG_WN_P(8) TMG_WN_P(9) TMG_WN_P(10) TMG_WN_P(11) TMG_WN_P(12) TMG_WN_P(13) TMG_WN_P(14) TMG_WN_P(15)
+#undef TMG_WN_P
 #undef TMG_WN_LOADB
             }
             TMG_STAMP(4)   // MFMA loop
@@ -489,13 +524,13 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
                     if (xi == 0) t[c] = TMG_W4(-, d[0][c], d[2][c]);
                     else if (xi == 1) t[c] = TMG_W4(+, d[1][c], d[2][c]);
                     else if (xi == 2) t[c] = TMG_W4(-, d[2][c], d[1][c]);
-                    else t[c] = TMG_W4(-, d[1][c], d[3][c]);
+                    else t[c] = TMG_W4(-, d[3][c], d[1][c]);      // xi 3 with the sign flipped (TMG_WN_POSITION)
                 }
                 float* vb = vbuf + (xi * 4) * VPL;
                 *reinterpret_cast<float4*>(vb) = TMG_W4(-, t[0], t[2]);
                 *reinterpret_cast<float4*>(vb + VPL) = TMG_W4(+, t[1], t[2]);
                 *reinterpret_cast<float4*>(vb + 2 * VPL) = TMG_W4(-, t[2], t[1]);
-                *reinterpret_cast<float4*>(vb + 3 * VPL) = TMG_W4(-, t[1], t[3]);
+                *reinterpret_cast<float4*>(vb + 3 * VPL) = TMG_W4(-, t[3], t[1]);                 // -V at nu = 3
             }
 #undef TMG_W4
             if (++ci == nchunks) { ci = 0; ti += G; }
@@ -529,6 +564,7 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < NPW; ++n) Y[o][m][n] = bvr[n];
+    f32x4 T0[2][NPW], T1[2][NPW];
     float4 bfr[4][2][NPW];
     for (int k = 0; k < nst; ++k) {
         const int c0 = cm * KC;
@@ -562,38 +598,7 @@ __global__ __launch_bounds__(768, 1) void wino_fwdp_kernel(WinoP p) {
                     af[1][m] = v4[(pos * VPL + m * 16 * VS + 16) / 4];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 acc[2][NPW];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < NPW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define TMG_WN_STEP(KG, E)                                                                                            \
-                _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < NPW; ++n)           \
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[R][KG][n].E, af[KG][m].E, acc[m][n], 0, 0, 0);
-                TMG_WN_STEP(0, x) TMG_WN_STEP(0, y) TMG_WN_STEP(0, z) TMG_WN_STEP(0, w)
-                if (kgn == 2) { TMG_WN_STEP(1, x) TMG_WN_STEP(1, y) TMG_WN_STEP(1, z) TMG_WN_STEP(1, w) }
-#undef TMG_WN_STEP
-                const int xi = pos >> 2, nu = pos & 3;
-#pragma unroll
-                for (int oy = 0; oy < 2; ++oy)
-#pragma unroll
-                    for (int ox = 0; ox < 2; ++ox) {
-                        const int ay = oy == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : (xi == 1 ? 1 : -1));
-                        const int ax = ox == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : (nu == 1 ? 1 : -1));
-                        const int cf = ay * ax;
-                        if (cf != 0) {
-#pragma unroll
-                            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                                for (int n = 0; n < NPW; ++n) {
-                                    f32x4& y_ = Y[oy * 2 + ox][m][n];
-                                    if (cf > 0) y_ += acc[m][n];
-                                    else y_ -= acc[m][n];
-                                }
-                            if constexpr (NPW == 2) asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][0][1]), "+v"(Y[oy * 2 + ox][1][0]), "+v"(Y[oy * 2 + ox][1][1]));
-                            else asm volatile("" : "+v"(Y[oy * 2 + ox][0][0]), "+v"(Y[oy * 2 + ox][1][0]));
-                        }
-                    }
+                TMG_WN_POSITION
             }
         }
 #undef TMG_WN_LOADB
