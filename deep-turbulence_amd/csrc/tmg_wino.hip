@@ -170,8 +170,11 @@ extern "C" int tmg_wino_stamps(unsigned long long* out, int reset) {
 #else
 #define TMG_WN_ULOAD(DST, PTR, BOFF) DST = tmg_bload4(urs, BOFF, (unsigned)(((PTR) - p.U) * 4));
 #endif
+// (TMG_PACKED_F32: this kernel keeps the packed-fp32 instructions the rest of the file is built without - its float4 input transform and
+// the tile additions of the output transform halve their instruction count: gate conv 2.045 -> 2.023 ms, conditioning contraction
+// 0.663 -> 0.636 ms; wino_fwdp_kernel, wino_nn_kernel (+3 %) and wino_wgrad_kernel (+-0) measured no better with them, round 6)
 template <int NPW>
-__global__ __launch_bounds__(512, 1) void wino_fwd_kernel(WinoP p) {
+__global__ __launch_bounds__(512, 1) TMG_PACKED_F32 void wino_fwd_kernel(WinoP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = 512;
     constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PP = PH * PW;   // output tile, raw patch (halo 1)
