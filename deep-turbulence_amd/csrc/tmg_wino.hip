@@ -1209,6 +1209,14 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
         pyx[u] = ((unsigned)py << 16) | (unsigned)px;
     }
     float4 pv[UPI];
+    // Pixel part of the staging addresses: the same for every 32-channel chunk of a pixel tile (8-60 chunks here), so it is computed when
+    // the issue cursor enters a tile and kept (one register per item + a mask of the zero-padded ones): ~9 vector instructions per load
+    // and chunk less - this kernel issues only 64-96 MFMAs per wave and chunk, and vector cycles add to matrix cycles.
+    // (three n-tiles: the kernel sits at the 256-register limit and measured 1 % slower with the four extra registers live across
+    // the chunks - there the offsets are recomputed per chunk as before)
+    constexpr bool PXC = NTN <= 2;
+    unsigned pxo[UPI];
+    unsigned pzm = 0;
 
     const int G = gridDim.x;
     const int nmine = (int)blockIdx.x < p.ntiles ? (p.ntiles - (int)blockIdx.x + G - 1) / G : 0;
@@ -1288,12 +1296,19 @@ __global__ __launch_bounds__(512, 1) void wino_nn_kernel(WinoNP p) {
                     tss = ss; \
                 } \
             } \
-            const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win); \
+            if (ci == 0 || !PXC) { \
+                const unsigned tbv = (unsigned)b_ * (unsigned)(p.Hin * p.Win); \
+                pzm = 0; \
+                _Pragma("unroll") for (int u = 0; u < UPI; ++u) { \
+                    const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu); \
+                    const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1); \
+                    const bool oob = !p.pad_rep && (iy != iyc || ix != ixc); \
+                    pxo[u] = tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc; \
+                    pzm |= ((oob || ppix0 + u * 64 >= PP) ? 1u : 0u) << u; \
+                } \
+            } \
             _Pragma("unroll") for (int u = 0; u < UPI; ++u) { \
-                const int iy = iy0 + (int)(pyx[u] >> 16), ix = ix0 + (int)(pyx[u] & 0xffffu); \
-                const int iyc = min(max(iy, 0), p.Hin - 1), ixc = min(max(ix, 0), p.Win - 1); \
-                const bool oob = !p.pad_rep && (iy != iyc || ix != ixc); \
-                const float* a_ = (oob || ppix0 + u * 64 >= PP) ? tmg_zero_page : tptr + (size_t)(tbv + (unsigned)iyc * (unsigned)p.Win + (unsigned)ixc) * (unsigned)tss; \
+                const float* a_ = ((pzm >> u) & 1u) ? tmg_zero_page : tptr + (size_t)pxo[u] * (unsigned)tss; \
                 pv[u] = *reinterpret_cast<const float4*>(a_); \
             } \
             if (++ci == nchunks) { ci = 0; ti += G; } \
