@@ -859,13 +859,21 @@ __global__ __launch_bounds__(512, 1) TMG_PACKED_F32 void wino_fwd3_kernel(WinoP 
     int ci = 0, cc = 0, cm = 0;
     int ti = blockIdx.x, tm = blockIdx.x;
 
+    f32x4 bvr[NPW];       // bias in registers, Y starts from it: no load between the epilogue's stores (see wino_fwd_kernel)
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int n0 = (ntile0 + n) * 16 + 4 * q;
+        const float* bp = (p.bias != nullptr && ntile0 + n < ntt && n0 < p.Cout) ? p.bias + n0 : tmg_zero_page;
+        const float4 b4 = *reinterpret_cast<const float4*>(bp);
+        bvr[n] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+    }
     f32x4 Y[4][2][NPW];   // [output pixel of the 2x2 tile][m-tile][n-tile]
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NPW; ++n) Y[o][m][n] = bvr[n];
 
     // U fragments run in STEPS of (position, n-tile) - 32 or 16 per stage, 12 MFMAs each - through a ring of four slots, three steps
     // ahead of their MFMAs (slot = step & 3: the stage length is a multiple of four, one unrolled body).  [A ring of whole positions
@@ -1050,8 +1058,6 @@ __global__ __launch_bounds__(512, 1) TMG_PACKED_F32 void wino_fwd3_kernel(WinoP 
                     for (int n = 0; n < NPW; ++n) {
                         const int n0 = (ntile0 + n) * 16 + 4 * qe;
                         if (ntile0 + n < ntt && n0 < p.Cout) {
-                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0);
                             int nl = n0;
                             TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
 #pragma unroll
@@ -1059,7 +1065,7 @@ __global__ __launch_bounds__(512, 1) TMG_PACKED_F32 void wino_fwd3_kernel(WinoP 
                                 const int oy = oyb + (o >> 1), ox = oxb + (o & 1);
                                 if (oy < p.Hin && ox < p.Win) {
                                     const unsigned opx = ((unsigned)b_ * (unsigned)p.Hin + (unsigned)oy) * (unsigned)p.Win + (unsigned)ox;
-                                    __builtin_nontemporal_store((f32x4){Y[o][m][n][0] + bv.x, Y[o][m][n][1] + bv.y, Y[o][m][n][2] + bv.z, Y[o][m][n][3] + bv.w},
+                                    __builtin_nontemporal_store(Y[o][m][n],
                                                                 reinterpret_cast<f32x4*>(optr + (size_t)opx * (unsigned)ostride + ooff + nl));
                                 }
                             }
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(512, 1) TMG_PACKED_F32 void wino_fwd3_kernel(WinoP 
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int n = 0; n < NPW; ++n) Y[o][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int n = 0; n < NPW; ++n) Y[o][m][n] = bvr[n];
                 cm = 0; tm += G;
             } else {
                 ++cm;
