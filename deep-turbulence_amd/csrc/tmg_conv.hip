@@ -1363,24 +1363,34 @@ __global__ __launch_bounds__(256) void conv_rep_border_mfma_kernel(BorderMP m) {
         }
         if (pv) {
             const size_t opx = ((size_t)b * p.H + qy) * p.W + qx;
+            float* dst[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int n0 = n * 16 + 4 * q;
-                if (n0 < p.Cx) {
-                    int nl = n0;
-                    TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
-                    float* dst = optr + opx * ostride + ooff + nl;
-                    if (S > 1 || v >= 4) {
-                        // the dy channels (or, at a corner, the pairs) of this pixel are split over several waves: hardware float adds
-                        // (a few thousand border pixels)
+                int nl = min(n * 16 + 4 * q, p.Cx - 4);      // (a channel quad past the end: a valid address, never stored)
+                TMG_PICK_OSEG(p.out, nl, optr, ostride, ooff)
+                dst[n] = optr + opx * ostride + ooff + nl;
+            }
+            if (S > 1 || v >= 4) {
+                // the dy channels (or, at a corner, the pairs) of this pixel are split over several waves: hardware float adds
+                // (a few thousand border pixels)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + r, acc[n][r] * osc);
-                    } else {
-                        float4 o = *reinterpret_cast<float4*>(dst);
-                        o.x += acc[n][0] * osc; o.y += acc[n][1] * osc; o.z += acc[n][2] * osc; o.w += acc[n][3] * osc;
-                        *reinterpret_cast<float4*>(dst) = o;
+                for (int n = 0; n < NT; ++n)
+                    if (n * 16 + 4 * q < p.Cx) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst[n] + r, acc[n][r] * osc);
                     }
-                }
+            } else {
+                // read-modify-write of the NT channel quads: all reads first, then all writes (one read + write per quad in turn is a
+                // chain of NT memory round trips - a store behind a load in a conditional block waits for everything in flight)
+                float4 o[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) o[n] = *reinterpret_cast<const float4*>(dst[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    if (n * 16 + 4 * q < p.Cx) {
+                        o[n].x += acc[n][0] * osc; o[n].y += acc[n][1] * osc; o[n].z += acc[n][2] * osc; o[n].w += acc[n][3] * osc;
+                        *reinterpret_cast<float4*>(dst[n]) = o[n];
+                    }
             }
         }
     }

@@ -916,10 +916,14 @@ def test_layer_plane_addends_give_identical_results():
         res[tag] = (xr.detach(), ci.grad.clone(), zi.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
     a, b = res["planes"], res["interleaved"]
     assert torch.equal(a[0], b[0])
-    # (log-det sums and weight gradients meet in float atomics: equal up to summation order)
-    assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-6) and torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-6)
+    # (log-det sums, weight gradients and the corner pixels of the replicate-padding adjoint meet in float atomics: equal up to the
+    # summation order, i.e. to a few ulp OF THE LARGEST TERMS - measured run to run on one layout: 3e-5 on entries of 4e2, 1.4e-6 on an
+    # entry of -0.024 that is the difference of such terms.  The bound is therefore relative to the tensor's scale, not to each entry.)
+    def same(x, y, rel):
+        return float((x - y).abs().max()) <= rel * float(y.abs().max()) + 1e-12
+    assert same(a[1], b[1], 1e-6) and same(a[2], b[2], 1e-6)
     for k in a[3]:
-        assert torch.allclose(a[3][k], b[3][k], rtol=1e-4, atol=1e-5), k
+        assert same(a[3][k], b[3][k], 1e-5), k
 
 
 def test_training_window_capture_matches_reference():
