@@ -6,7 +6,7 @@ OUT=${1:-/dev/stdout}
 TMP=$(mktemp -d)
 # (the matrix-core files are built without the packed-fp32 instructions: tmg_hip.NO_PACKED_F32)
 NOPK=$(python3 -c "import sys; sys.path.insert(0, 'deep-turbulence_amd'); import tmg_hip; print(' '.join(tmg_hip.NO_PACKED_F32))")
-for f in tmg_conv tmg_pointwise tmg_physics tmg_mix16 tmg_coupling tmg_wino tmg_thin; do
+for f in tmg_conv tmg_pointwise tmg_physics tmg_mix16 tmg_coupling tmg_wino tmg_thin tmg_glue; do
   EXTRA=""
   case " $NOPK " in *" $f.hip "*) EXTRA="-Xclang -target-feature -Xclang -packed-fp32-ops";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $EXTRA -I include -c deep-turbulence_amd/csrc/$f.hip -o $TMP/$f.o \
