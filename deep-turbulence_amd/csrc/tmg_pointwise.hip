@@ -254,6 +254,28 @@ __global__ void checker_kernel(const float* __restrict__ src, int ss, int so, fl
     }
 }
 
+// The same move one channel quad (16 bytes) per thread and iteration, 32-bit index arithmetic: C, strides and offsets multiples of 4,
+// 16-byte aligned tensors, fewer than 2^31 quads (the launcher checks).  Cq = C / 4.
+__global__ void checker4_kernel(const float* __restrict__ src, int ss, int so, float* __restrict__ dst, int ds, int dof, int B,
+                                int h, int w, int Cq, int to_small) {
+    const unsigned total = (unsigned)B * (unsigned)h * (unsigned)w * 4u * (unsigned)Cq;
+    const unsigned q4 = 4u * (unsigned)Cq;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned kq = i % q4;
+        unsigned r = i / q4;
+        const unsigned x = r % (unsigned)w;
+        r /= (unsigned)w;
+        const unsigned y = r % (unsigned)h;
+        const unsigned b = r / (unsigned)h;
+        const unsigned k = kq / (unsigned)Cq, c = 4u * (kq - k * (unsigned)Cq);
+        const unsigned ry = (k == 1 || k == 2) ? 1u : 0u, rx = (k >= 2) ? 1u : 0u;
+        const size_t bigpix = ((size_t)b * 2 * h + 2 * y + ry) * (2 * w) + 2 * x + rx;
+        const size_t smallpix = ((size_t)b * h + y) * w + x;
+        if (to_small) *reinterpret_cast<float4*>(dst + smallpix * ds + dof + 4u * kq) = *reinterpret_cast<const float4*>(src + bigpix * ss + so + c);
+        else *reinterpret_cast<float4*>(dst + bigpix * ds + dof + c) = *reinterpret_cast<const float4*>(src + smallpix * ss + so + 4u * kq);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // zero-padded channel halves: compact [npix][2 ch] <-> padded [npix][2 (ch + pad)] = [x1 | 0.. | x2 | 0..]
 // (3-channel fields: ch = 6 on the first level; every kernel of the fast path wants float4-addressable halves)
@@ -1523,6 +1545,14 @@ extern "C" int tmg_fill_i64(void* dst, const int64_t* vals, int64_t n, hipStream
 // dims: [B, h, w, C, to_small]  (h, w: the SMALL spatial size; C: channels of the big tensor)
 extern "C" int tmg_checker(const void* src, const int64_t* s_d, void* dst, const int64_t* d_d, const int64_t* dims, hipStream_t st) {
     const size_t total = (size_t)dims[0] * dims[1] * dims[2] * 4 * dims[3];
+    if (total == 0) return 0;
+    if ((dims[3] & 3) == 0 && ((s_d[0] | s_d[1] | d_d[0] | d_d[1]) & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 &&
+        total / 4 < (1ull << 31)) {
+        hipLaunchKernelGGL(checker4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, (const float*)src, (int)s_d[0], (int)s_d[1], (float*)dst,
+                           (int)d_d[0], (int)d_d[1], (int)dims[0], (int)dims[1], (int)dims[2], (int)(dims[3] / 4), (int)dims[4]);
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(checker_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)src, (int)s_d[0], (int)s_d[1], (float*)dst,
                        (int)d_d[0], (int)d_d[1], (int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4]);
     TMG_CHECK_LAUNCH();
