@@ -133,6 +133,74 @@ __global__ void lstm_pointwise_fwd_kernel(const float* __restrict__ gates, const
     }
 }
 
+// The same, four consecutive hidden channels per thread (float4 loads / stores, 32-bit index arithmetic): R and the c_prev stride /
+// offset multiples of 4, 16-byte aligned tensors, fewer than 2^31 quads (the launcher checks).  Element for element the arithmetic
+// of the scalar kernel.  Rq = R / 4.
+#define TMG_F4(V) {(V).x, (V).y, (V).z, (V).w}
+__global__ void lstm_pointwise_fwd4_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev, int cps, int cpo,
+                                           float* __restrict__ c_next, float* __restrict__ h_next, int Rq, unsigned npix) {
+    const unsigned total = npix * (unsigned)Rq;
+    const int R = 4 * Rq;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pix = i / (unsigned)Rq;
+        const int j = 4 * (int)(i - pix * (unsigned)Rq);
+        const float* gp = gates + (size_t)pix * 4 * R + j;
+        const float4 a4 = *reinterpret_cast<const float4*>(gp), f4 = *reinterpret_cast<const float4*>(gp + R);
+        const float4 o4 = *reinterpret_cast<const float4*>(gp + 2 * R), g4 = *reinterpret_cast<const float4*>(gp + 3 * R);
+        const float4 c4 = c_prev ? *reinterpret_cast<const float4*>(c_prev + (size_t)pix * cps + cpo + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ai[4] = TMG_F4(a4), af[4] = TMG_F4(f4), ao[4] = TMG_F4(o4), ag[4] = TMG_F4(g4), cp[4] = TMG_F4(c4);
+        float cn[4], hn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = sigmoidf_(ai[e]), gf = sigmoidf_(af[e]), go = sigmoidf_(ao[e]), gg = tanhf(ag[e]);
+            cn[e] = gf * cp[e] + gi * gg;
+            hn[e] = go * tanhf(cn[e]);
+        }
+        *reinterpret_cast<float4*>(c_next + (size_t)pix * R + j) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+        *reinterpret_cast<float4*>(h_next + (size_t)pix * R + j) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    }
+}
+
+__global__ void lstm_pointwise_bwd4_kernel(float* __restrict__ acts, const float* __restrict__ c_prev, int cps, int cpo,
+                                           const float* __restrict__ c_next, const float* __restrict__ dh,
+                                           const float* __restrict__ dc_in, float* __restrict__ dc_prev, int Rq, unsigned npix) {
+    const unsigned total = npix * (unsigned)Rq;
+    const int R = 4 * Rq;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pix = i / (unsigned)Rq;
+        const int j = 4 * (int)(i - pix * (unsigned)Rq);
+        float* gp = acts + (size_t)pix * 4 * R + j;
+        const size_t pj = (size_t)pix * R + j;
+        const float4 a4 = *reinterpret_cast<const float4*>(gp), f4 = *reinterpret_cast<const float4*>(gp + R);
+        const float4 o4 = *reinterpret_cast<const float4*>(gp + 2 * R), g4 = *reinterpret_cast<const float4*>(gp + 3 * R);
+        const float4 c4 = c_prev ? *reinterpret_cast<const float4*>(c_prev + (size_t)pix * cps + cpo + j) : z4;
+        const float4 n4 = *reinterpret_cast<const float4*>(c_next + pj);
+        const float4 h4 = dh ? *reinterpret_cast<const float4*>(dh + pj) : z4;
+        const float4 d4 = dc_in ? *reinterpret_cast<const float4*>(dc_in + pj) : z4;
+        const float ai[4] = TMG_F4(a4), af[4] = TMG_F4(f4), ao[4] = TMG_F4(o4), ag[4] = TMG_F4(g4), cp[4] = TMG_F4(c4);
+        const float cnx[4] = TMG_F4(n4), dhv[4] = TMG_F4(h4), dci[4] = TMG_F4(d4);
+        float r0[4], r1[4], r2[4], r3[4], dp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = sigmoidf_(ai[e]), gf = sigmoidf_(af[e]), go = sigmoidf_(ao[e]), gg = tanhf(ag[e]);
+            const float tc = tanhf(cnx[e]);
+            const float dc = dci[e] + dhv[e] * go * (1.f - tc * tc);
+            r0[e] = dc * gg * gi * (1.f - gi);
+            r1[e] = dc * cp[e] * gf * (1.f - gf);
+            r2[e] = dhv[e] * tc * go * (1.f - go);
+            r3[e] = dc * gi * (1.f - gg * gg);
+            dp[e] = dc * gf;
+        }
+        *reinterpret_cast<float4*>(gp) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        *reinterpret_cast<float4*>(gp + R) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+        *reinterpret_cast<float4*>(gp + 2 * R) = make_float4(r2[0], r2[1], r2[2], r2[3]);
+        *reinterpret_cast<float4*>(gp + 3 * R) = make_float4(r3[0], r3[1], r3[2], r3[3]);
+        if (dc_prev) *reinterpret_cast<float4*>(dc_prev + pj) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+    }
+}
+#undef TMG_F4
+
 // acts: the pre-activation gates of the forward pass, overwritten in place by the pre-activation gradients.
 __global__ void lstm_pointwise_bwd_kernel(float* __restrict__ acts, const float* __restrict__ c_prev, int cps, int cpo,
                                           const float* __restrict__ c_next, const float* __restrict__ dh,
@@ -643,6 +711,36 @@ __global__ void masked_add_kernel(const float* __restrict__ src, int ss, int so,
         if (add) v += add[pix * as + ao + c];
         float* d = dst + pix * ds + dof + c;
         *d = accumulate ? (*d + v) : v;
+    }
+}
+
+// The same one channel quad per thread and iteration, 32-bit index arithmetic (n, strides and offsets multiples of 4, 16-byte aligned
+// tensors, fewer than 2^31 quads: checked by the launcher).  nq = n / 4.
+__global__ void masked_add4_kernel(const float* __restrict__ src, int ss, int so, const float* __restrict__ ref, int rs_, int ro,
+                                   const float* __restrict__ add, int as, int ao, float* dst, int ds, int dof, unsigned npix, int nq,
+                                   int accumulate) {
+    const unsigned total = npix * (unsigned)nq;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pix = i / (unsigned)nq;
+        const unsigned c = 4u * (i - pix * (unsigned)nq);
+        float4 v = src ? *reinterpret_cast<const float4*>(src + (size_t)pix * ss + so + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ref) {
+            const float4 r = *reinterpret_cast<const float4*>(ref + (size_t)pix * rs_ + ro + c);
+            if (!(r.x > 0.f)) v.x = 0.f;
+            if (!(r.y > 0.f)) v.y = 0.f;
+            if (!(r.z > 0.f)) v.z = 0.f;
+            if (!(r.w > 0.f)) v.w = 0.f;
+        }
+        if (add) {
+            const float4 a = *reinterpret_cast<const float4*>(add + (size_t)pix * as + ao + c);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)pix * ds + dof + c);
+        if (accumulate) {
+            const float4 o = *d;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *d = v;
     }
 }
 
@@ -1458,6 +1556,14 @@ extern "C" int tmg_lstm_pointwise_fwd(void* gates, const void* c_prev, const int
     const size_t npix = (size_t)dims[0];
     const int R = (int)dims[1];
     TmgProf prof(TMG_PROF_LSTMF, 4.0 * (double)npix * R * (c_prev ? 7 : 6), st);   // gates 4R read, c_prev, c_next, h_next
+    if (npix == 0 || R == 0) return 0;
+    if ((R & 3) == 0 && (!c_prev || ((cprev_d[0] | cprev_d[1]) & 3) == 0) && npix * (size_t)(R / 4) < (1ull << 31) &&
+        ((((uintptr_t)gates) | ((uintptr_t)c_prev) | ((uintptr_t)c_next) | ((uintptr_t)h_next)) & 15) == 0) {
+        hipLaunchKernelGGL(lstm_pointwise_fwd4_kernel, dim3(grid_for(npix * (R / 4))), dim3(256), 0, st, (const float*)gates, (const float*)c_prev,
+                           (int)cprev_d[0], (int)cprev_d[1], (float*)c_next, (float*)h_next, R / 4, (unsigned)npix);
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (const float*)gates, (const float*)c_prev,
                        (int)cprev_d[0], (int)cprev_d[1], (float*)c_next, (float*)h_next, R, npix);
     TMG_CHECK_LAUNCH();
@@ -1469,6 +1575,15 @@ extern "C" int tmg_lstm_pointwise_bwd(void* acts, const void* c_prev, const int6
     const size_t npix = (size_t)dims[0];
     const int R = (int)dims[1];
     TmgProf prof(TMG_PROF_LSTMB, 4.0 * (double)npix * R * (8 + (c_prev ? 1 : 0) + 1 + (dh ? 1 : 0) + (dc_in ? 1 : 0) + (dc_prev ? 1 : 0)), st);
+    if (npix == 0 || R == 0) return 0;
+    if ((R & 3) == 0 && (!c_prev || ((cprev_d[0] | cprev_d[1]) & 3) == 0) && npix * (size_t)(R / 4) < (1ull << 31) &&
+        ((((uintptr_t)acts) | ((uintptr_t)c_prev) | ((uintptr_t)c_next) | ((uintptr_t)dh) | ((uintptr_t)dc_in) | ((uintptr_t)dc_prev)) & 15) == 0) {
+        hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3(grid_for(npix * (R / 4))), dim3(256), 0, st, (float*)acts, (const float*)c_prev,
+                           (int)cprev_d[0], (int)cprev_d[1], (const float*)c_next, (const float*)dh, (const float*)dc_in, (float*)dc_prev, R / 4,
+                           (unsigned)npix);
+        TMG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(grid_for(npix * R)), dim3(256), 0, st, (float*)acts, (const float*)c_prev,
                        (int)cprev_d[0], (int)cprev_d[1], (const float*)c_next, (const float*)dh, (const float*)dc_in, (float*)dc_prev, R,
                        npix);
@@ -1663,6 +1778,22 @@ extern "C" int tmg_masked_add(const void* src, const int64_t* s_d, const void* r
                               const int64_t* a_d, void* dst, const int64_t* d_d, const int64_t* dims, hipStream_t st) {
     const size_t npix = (size_t)dims[0];
     const int n = (int)dims[1];
+    if (npix == 0 || n == 0) return 0;
+    {
+        long long m = n | d_d[0] | d_d[1];
+        uintptr_t al = (uintptr_t)dst;
+        if (src) { m |= s_d[0] | s_d[1]; al |= (uintptr_t)src; }
+        if (ref) { m |= r_d[0] | r_d[1]; al |= (uintptr_t)ref; }
+        if (add) { m |= a_d[0] | a_d[1]; al |= (uintptr_t)add; }
+        if ((m & 3) == 0 && (al & 15) == 0 && npix * (size_t)(n / 4) < (1ull << 31)) {
+            hipLaunchKernelGGL(masked_add4_kernel, dim3(grid_for(npix * (n / 4))), dim3(256), 0, st, (const float*)src, src ? (int)s_d[0] : 0,
+                               src ? (int)s_d[1] : 0, (const float*)ref, ref ? (int)r_d[0] : 0, ref ? (int)r_d[1] : 0, (const float*)add,
+                               add ? (int)a_d[0] : 0, add ? (int)a_d[1] : 0, (float*)dst, (int)d_d[0], (int)d_d[1], (unsigned)npix, n / 4,
+                               (int)dims[2]);
+            TMG_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(masked_add_kernel, dim3(grid_for(npix * n)), dim3(256), 0, st, (const float*)src, src ? (int)s_d[0] : 0,
                        src ? (int)s_d[1] : 0, (const float*)ref, ref ? (int)r_d[0] : 0, ref ? (int)r_d[1] : 0, (const float*)add,
                        add ? (int)a_d[0] : 0, add ? (int)a_d[1] : 0, (float*)dst, (int)d_d[0], (int)d_d[1], npix, n, (int)dims[2]);
