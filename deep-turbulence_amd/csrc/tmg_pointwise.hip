@@ -137,7 +137,21 @@ __global__ void lstm_pointwise_fwd_kernel(const float* __restrict__ gates, const
 // offset multiples of 4, 16-byte aligned tensors, fewer than 2^31 quads (the launcher checks).  Element for element the arithmetic
 // of the scalar kernel.  Rq = R / 4.
 #define TMG_F4(V) {(V).x, (V).y, (V).z, (V).w}
-__global__ void lstm_pointwise_fwd4_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev, int cps, int cpo,
+struct LstmB1 { float r0, r1, r2, r3, dp; };
+// one hidden channel of lstm_pointwise_bwd_kernel: pre-activation gate gradients (i, f, o, g) and the gradient of the previous cell state
+__device__ __forceinline__ LstmB1 lstm_bwd1(float ai, float af, float ao, float ag, float cp, float cnx, float dhv, float dci) {
+    const float gi = sigmoidf_(ai), gf = sigmoidf_(af), go = sigmoidf_(ao), gg = tanhf(ag);
+    const float tc = tanhf(cnx);
+    const float dc = dci + dhv * go * (1.f - tc * tc);
+    LstmB1 o;
+    o.r0 = dc * gg * gi * (1.f - gi);
+    o.r1 = dc * cp * gf * (1.f - gf);
+    o.r2 = dhv * tc * go * (1.f - go);
+    o.r3 = dc * gi * (1.f - gg * gg);
+    o.dp = dc * gf;
+    return o;
+}
+__global__ __launch_bounds__(256) void lstm_pointwise_fwd4_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev, int cps, int cpo,
                                            float* __restrict__ c_next, float* __restrict__ h_next, int Rq, unsigned npix) {
     const unsigned total = npix * (unsigned)Rq;
     const int R = 4 * Rq;
@@ -147,7 +161,7 @@ __global__ void lstm_pointwise_fwd4_kernel(const float* __restrict__ gates, cons
         const float* gp = gates + (size_t)pix * 4 * R + j;
         const float4 a4 = *reinterpret_cast<const float4*>(gp), f4 = *reinterpret_cast<const float4*>(gp + R);
         const float4 o4 = *reinterpret_cast<const float4*>(gp + 2 * R), g4 = *reinterpret_cast<const float4*>(gp + 3 * R);
-        const float4 c4 = c_prev ? *reinterpret_cast<const float4*>(c_prev + (size_t)pix * cps + cpo + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 c4 = *reinterpret_cast<const float4*>(c_prev ? c_prev + (size_t)pix * cps + cpo + j : tmg_zero_page);   // (address select: a struct ternary goes through the stack)
         const float ai[4] = TMG_F4(a4), af[4] = TMG_F4(f4), ao[4] = TMG_F4(o4), ag[4] = TMG_F4(g4), cp[4] = TMG_F4(c4);
         float cn[4], hn[4];
 #pragma unroll
@@ -161,12 +175,11 @@ __global__ void lstm_pointwise_fwd4_kernel(const float* __restrict__ gates, cons
     }
 }
 
-__global__ void lstm_pointwise_bwd4_kernel(float* __restrict__ acts, const float* __restrict__ c_prev, int cps, int cpo,
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd4_kernel(float* __restrict__ acts, const float* __restrict__ c_prev, int cps, int cpo,
                                            const float* __restrict__ c_next, const float* __restrict__ dh,
                                            const float* __restrict__ dc_in, float* __restrict__ dc_prev, int Rq, unsigned npix) {
     const unsigned total = npix * (unsigned)Rq;
     const int R = 4 * Rq;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const unsigned pix = i / (unsigned)Rq;
         const int j = 4 * (int)(i - pix * (unsigned)Rq);
@@ -174,29 +187,17 @@ __global__ void lstm_pointwise_bwd4_kernel(float* __restrict__ acts, const float
         const size_t pj = (size_t)pix * R + j;
         const float4 a4 = *reinterpret_cast<const float4*>(gp), f4 = *reinterpret_cast<const float4*>(gp + R);
         const float4 o4 = *reinterpret_cast<const float4*>(gp + 2 * R), g4 = *reinterpret_cast<const float4*>(gp + 3 * R);
-        const float4 c4 = c_prev ? *reinterpret_cast<const float4*>(c_prev + (size_t)pix * cps + cpo + j) : z4;
+        const float4 c4 = *reinterpret_cast<const float4*>(c_prev ? c_prev + (size_t)pix * cps + cpo + j : tmg_zero_page);
         const float4 n4 = *reinterpret_cast<const float4*>(c_next + pj);
-        const float4 h4 = dh ? *reinterpret_cast<const float4*>(dh + pj) : z4;
-        const float4 d4 = dc_in ? *reinterpret_cast<const float4*>(dc_in + pj) : z4;
-        const float ai[4] = TMG_F4(a4), af[4] = TMG_F4(f4), ao[4] = TMG_F4(o4), ag[4] = TMG_F4(g4), cp[4] = TMG_F4(c4);
-        const float cnx[4] = TMG_F4(n4), dhv[4] = TMG_F4(h4), dci[4] = TMG_F4(d4);
-        float r0[4], r1[4], r2[4], r3[4], dp[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gi = sigmoidf_(ai[e]), gf = sigmoidf_(af[e]), go = sigmoidf_(ao[e]), gg = tanhf(ag[e]);
-            const float tc = tanhf(cnx[e]);
-            const float dc = dci[e] + dhv[e] * go * (1.f - tc * tc);
-            r0[e] = dc * gg * gi * (1.f - gi);
-            r1[e] = dc * cp[e] * gf * (1.f - gf);
-            r2[e] = dhv[e] * tc * go * (1.f - go);
-            r3[e] = dc * gi * (1.f - gg * gg);
-            dp[e] = dc * gf;
-        }
-        *reinterpret_cast<float4*>(gp) = make_float4(r0[0], r0[1], r0[2], r0[3]);
-        *reinterpret_cast<float4*>(gp + R) = make_float4(r1[0], r1[1], r1[2], r1[3]);
-        *reinterpret_cast<float4*>(gp + 2 * R) = make_float4(r2[0], r2[1], r2[2], r2[3]);
-        *reinterpret_cast<float4*>(gp + 3 * R) = make_float4(r3[0], r3[1], r3[2], r3[3]);
-        if (dc_prev) *reinterpret_cast<float4*>(dc_prev + pj) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+        const float4 h4 = *reinterpret_cast<const float4*>(dh ? dh + pj : tmg_zero_page);
+        const float4 d4 = *reinterpret_cast<const float4*>(dc_in ? dc_in + pj : tmg_zero_page);
+        const LstmB1 ex = lstm_bwd1(a4.x, f4.x, o4.x, g4.x, c4.x, n4.x, h4.x, d4.x), ey = lstm_bwd1(a4.y, f4.y, o4.y, g4.y, c4.y, n4.y, h4.y, d4.y);
+        const LstmB1 ez = lstm_bwd1(a4.z, f4.z, o4.z, g4.z, c4.z, n4.z, h4.z, d4.z), ew = lstm_bwd1(a4.w, f4.w, o4.w, g4.w, c4.w, n4.w, h4.w, d4.w);
+        *reinterpret_cast<float4*>(gp) = make_float4(ex.r0, ey.r0, ez.r0, ew.r0);
+        *reinterpret_cast<float4*>(gp + R) = make_float4(ex.r1, ey.r1, ez.r1, ew.r1);
+        *reinterpret_cast<float4*>(gp + 2 * R) = make_float4(ex.r2, ey.r2, ez.r2, ew.r2);
+        *reinterpret_cast<float4*>(gp + 3 * R) = make_float4(ex.r3, ey.r3, ez.r3, ew.r3);
+        if (dc_prev) *reinterpret_cast<float4*>(dc_prev + pj) = make_float4(ex.dp, ey.dp, ez.dp, ew.dp);
     }
 }
 #undef TMG_F4
@@ -324,7 +325,7 @@ __global__ void checker_kernel(const float* __restrict__ src, int ss, int so, fl
 
 // The same move one channel quad (16 bytes) per thread and iteration, 32-bit index arithmetic: C, strides and offsets multiples of 4,
 // 16-byte aligned tensors, fewer than 2^31 quads (the launcher checks).  Cq = C / 4.
-__global__ void checker4_kernel(const float* __restrict__ src, int ss, int so, float* __restrict__ dst, int ds, int dof, int B,
+__global__ __launch_bounds__(256) void checker4_kernel(const float* __restrict__ src, int ss, int so, float* __restrict__ dst, int ds, int dof, int B,
                                 int h, int w, int Cq, int to_small) {
     const unsigned total = (unsigned)B * (unsigned)h * (unsigned)w * 4u * (unsigned)Cq;
     const unsigned q4 = 4u * (unsigned)Cq;
@@ -716,7 +717,7 @@ __global__ void masked_add_kernel(const float* __restrict__ src, int ss, int so,
 
 // The same one channel quad per thread and iteration, 32-bit index arithmetic (n, strides and offsets multiples of 4, 16-byte aligned
 // tensors, fewer than 2^31 quads: checked by the launcher).  nq = n / 4.
-__global__ void masked_add4_kernel(const float* __restrict__ src, int ss, int so, const float* __restrict__ ref, int rs_, int ro,
+__global__ __launch_bounds__(256) void masked_add4_kernel(const float* __restrict__ src, int ss, int so, const float* __restrict__ ref, int rs_, int ro,
                                    const float* __restrict__ add, int as, int ao, float* dst, int ds, int dof, unsigned npix, int nq,
                                    int accumulate) {
     const unsigned total = npix * (unsigned)nq;

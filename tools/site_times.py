@@ -2,7 +2,7 @@
 """Launch sites of one step from a rocprofv3 kernel trace: kernels aggregated by (name, grid size, LDS size) - the grid tells the
 launch sites of one kernel apart (level, direction) - with launches and time per step, VGPR / AGPR / LDS of the code object, and
 the share of the step.  Also the busy time per phase of the step (encoder / level k forward / level k backward) cut at the
-checker_kernel launches that open and close a level.
+checker_kernel / checker4_kernel launches that open and close a level.
 
   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-events
   python tools/site_times.py gpurun_out/trace [--steps 3 --skip 2] [--out profiles/r4_sites_config_M.txt]
@@ -76,7 +76,7 @@ def main():
     # ---- phases of one step (the last selected one): the level boundaries are the checker launches
     s0 = ends[skip + steps - 2] + 1
     one = rows[s0:hi]
-    cuts = [i for i, r in enumerate(one) if "checker_kernel" in r["Kernel_Name"]]
+    cuts = [i for i, r in enumerate(one) if "checker_kernel" in r["Kernel_Name"] or "checker4_kernel" in r["Kernel_Name"]]
     nlev = len(cuts) // 2
     lines.append("")
     lines.append("busy time between the level boundaries of one step (forward: a level ends with its un-squeeze, backward: it starts with the")
